@@ -1,0 +1,145 @@
+// Named root circuits: the BASELINE.json configs and the shapes of the reference's own tests, as
+// (n_inputs, closure) pairs that any CircuitMode can be run under.
+//   u254_add            BASELINE config 1   (src/gadgets/bigint/add.rs:9-26 on 254-bit operands)
+//   fq_mul              BASELINE config 2   (src/gadgets/bn254/fp254impl.rs:219-230)
+//   fq12_mul            BASELINE config 3   (tests/fq12_mul_e2e.rs:166-173)
+//   fq12_mul_chain:K    Groth16-shaped SYNTHETIC for config 4: r <- Fq12::mul(r, b), K times
+//   fq_complex          tests/streaming_evaluate.rs:401-407  ((a^2)*b + a)
+//   gate:T              tests/streaming_evaluate.rs:136-213  (one gate of discriminant T at the root)
+//   driver_mix          credits / dead-gate / pass-through / constant edge cases (circuit/mod.rs:419-836 shapes)
+#pragma once
+#include <string>
+
+#include "bn254.hpp"
+
+namespace gsv {
+
+struct NamedCircuit {
+  size_t n_inputs = 0;
+  size_t n_outputs = 0;
+  CircuitFn fn;
+};
+
+namespace detail {
+inline Wires driver_mix(CircuitContext& c, const Wires& in) {
+  // in: 6 wires.  Exercises: a dead gate (zero fan-out output), a constant-input AND (not folded),
+  // a component whose outputs are {input pass-through, constant, internal}, same wire as a and b,
+  // a child that ignores one of its inputs, nested children.
+  using namespace gadgets;
+  WireId dead = c.issue_wire();
+  c.add_gate(Gate::and_(in[0], in[1], dead));  // never read: credits 0 -> UNREACHABLE, gate_id still consumed
+  WireId k = c.issue_wire();
+  c.add_gate(Gate::and_(in[0], FALSE_WIRE, k));  // AND with constant still costs a ciphertext
+  WireId sq = c.issue_wire();
+  c.add_gate(Gate::or_(in[2], in[2], sq));  // same wire twice: two credits
+  Wires child_in = {in[3], in[4], in[5], k};
+  Wires ch = component(c, KeyBuilder("test::mixed_outputs"), child_in, 4, [](CircuitContext& cc, const Wires& x) -> Wires {
+    WireId t = cc.issue_wire();
+    cc.add_gate(Gate::nimp(x[0], x[1], t));  // x[2] is never read by the child
+    WireId u = cc.issue_wire();
+    cc.add_gate(Gate::xnor(t, x[3], u));
+    Wires inner = component(cc, KeyBuilder("test::inner"), Wires{t, u}, 2, [](CircuitContext& c3, const Wires& y) -> Wires {
+      WireId p = c3.issue_wire(), q = c3.issue_wire();
+      c3.add_gate(Gate::and_variant(y[0], y[1], p, true, true, false));
+      c3.add_gate(Gate::xor_(y[0], TRUE_WIRE, q));  // q is dropped by the caller below -> dead inside the child
+      return {p, q};
+    });
+    return {x[0], TRUE_WIRE, u, inner[0]};
+  });
+  Wires sum = add(c, Wires{ch[0], ch[2], sq}, Wires{ch[3], in[1], k});
+  Wires nocarry = add_without_carry(c, Wires{sum[0], sum[1]}, Wires{sum[2], sum[3]});  // top carry dead
+  WireId sel = selector(c, nocarry[0], nocarry[1], ch[1]);
+  return {sel, ch[1], in[5], sum[3]};
+}
+}  // namespace detail
+
+inline NamedCircuit make_circuit(const std::string& spec) {
+  using namespace gadgets;
+  std::string name = spec;
+  uint64_t param = 0;
+  bool has_param = false;
+  size_t colon = spec.find(':');
+  if (colon != std::string::npos) {
+    name = spec.substr(0, colon);
+    param = std::stoull(spec.substr(colon + 1));
+    has_param = true;
+  }
+  NamedCircuit nc;
+  auto two_fq = [&](std::function<Wires(CircuitContext&, const Wires&, const Wires&)> op) {
+    nc.n_inputs = 508; nc.n_outputs = 254;
+    nc.fn = [op](CircuitContext& c, const Wires& in) { return op(c, slice(in, 0, 254), slice(in, 254, 508)); };
+  };
+  auto one_fq = [&](std::function<Wires(CircuitContext&, const Wires&)> op) {
+    nc.n_inputs = 254; nc.n_outputs = 254;
+    nc.fn = [op](CircuitContext& c, const Wires& in) { return op(c, in); };
+  };
+  if (name == "u254_add" || name == "bigint_add") {
+    size_t n = (name == "u254_add") ? 254 : size_t(param);
+    nc.n_inputs = 2 * n; nc.n_outputs = n + 1;
+    nc.fn = [n](CircuitContext& c, const Wires& in) { return add(c, slice(in, 0, n), slice(in, n, 2 * n)); };
+  } else if (name == "bigint_sub") {
+    size_t n = size_t(param);
+    nc.n_inputs = 2 * n; nc.n_outputs = n + 1;
+    nc.fn = [n](CircuitContext& c, const Wires& in) { return sub(c, slice(in, 0, n), slice(in, n, 2 * n)); };
+  } else if (name == "bigint_mul") {
+    size_t n = size_t(param);
+    nc.n_inputs = 2 * n; nc.n_outputs = 2 * n;
+    nc.fn = [n](CircuitContext& c, const Wires& in) { return mul(c, slice(in, 0, n), slice(in, n, 2 * n)); };
+  } else if (name == "fq_add") { two_fq([](CircuitContext& c, const Wires& a, const Wires& b) { return fq::add(c, a, b); });
+  } else if (name == "fq_sub") { two_fq([](CircuitContext& c, const Wires& a, const Wires& b) { return fq::sub(c, a, b); });
+  } else if (name == "fq_mul") { two_fq([](CircuitContext& c, const Wires& a, const Wires& b) { return fq::mul_montgomery(c, a, b); });
+  } else if (name == "fq_neg") { one_fq([](CircuitContext& c, const Wires& a) { return fq::neg(c, a); });
+  } else if (name == "fq_double") { one_fq([](CircuitContext& c, const Wires& a) { return fq::double_(c, a); });
+  } else if (name == "fq_half") { one_fq([](CircuitContext& c, const Wires& a) { return fq::half(c, a); });
+  } else if (name == "fq_triple") { one_fq([](CircuitContext& c, const Wires& a) { return fq::triple(c, a); });
+  } else if (name == "fq_div6") { one_fq([](CircuitContext& c, const Wires& a) { return fq::div6(c, a); });
+  } else if (name == "fq_complex") {
+    two_fq([](CircuitContext& c, const Wires& a, const Wires& b) {
+      Wires a2 = fq::square_montgomery(c, a);
+      Wires a2b = fq::mul_montgomery(c, a2, b);
+      return fq::add(c, a2b, a);
+    });
+  } else if (name == "fq2_mul") {
+    nc.n_inputs = 1016; nc.n_outputs = 508;
+    nc.fn = [](CircuitContext& c, const Wires& in) {
+      return fq2::mul_montgomery(c, Fq2::from_wires(slice(in, 0, 508)), Fq2::from_wires(slice(in, 508, 1016))).to_wires();
+    };
+  } else if (name == "fq6_mul") {
+    nc.n_inputs = 3048; nc.n_outputs = 1524;
+    nc.fn = [](CircuitContext& c, const Wires& in) {
+      return fq6::mul_montgomery(c, Fq6::from_wires(slice(in, 0, 1524)), Fq6::from_wires(slice(in, 1524, 3048))).to_wires();
+    };
+  } else if (name == "fq12_mul" || name == "fq12_mul_chain") {
+    size_t k = (name == "fq12_mul") ? 1 : size_t(param);
+    if (k == 0) gsv_panic("fq12_mul_chain: K must be >= 1");
+    nc.n_inputs = 6096; nc.n_outputs = 3048;
+    nc.fn = [k](CircuitContext& c, const Wires& in) {
+      Fq12 r = Fq12::from_wires(slice(in, 0, 3048));
+      Fq12 b = Fq12::from_wires(slice(in, 3048, 6096));
+      for (size_t i = 0; i < k; ++i) r = fq12::mul_montgomery(c, r, b);
+      return r.to_wires();
+    };
+  } else if (name == "gate") {
+    if (!has_param || param > 10) gsv_panic("gate:T needs T in 0..10");
+    GateType t = static_cast<GateType>(param);
+    nc.n_inputs = 2; nc.n_outputs = 1;
+    if (t == GateType::Not) {
+      // Gate::not is in place (a == b == c), gate.rs:139-147; used only by the reference's tests.
+      nc.fn = [](CircuitContext& c, const Wires& in) { c.add_gate(Gate::not_(in[0])); return Wires{in[0]}; };
+    } else {
+      nc.fn = [t](CircuitContext& c, const Wires& in) {
+        WireId o = c.issue_wire();
+        c.add_gate(Gate::make(t, in[0], in[1], o));
+        return Wires{o};
+      };
+    }
+  } else if (name == "driver_mix") {
+    nc.n_inputs = 6; nc.n_outputs = 4;
+    nc.fn = detail::driver_mix;
+  } else {
+    gsv_panic("unknown circuit: " + spec);
+  }
+  return nc;
+}
+
+}  // namespace gsv

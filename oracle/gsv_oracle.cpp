@@ -1,0 +1,653 @@
+// =====================================================================================
+// CPU ORACLE — TEST INFRASTRUCTURE ONLY.
+//
+// A sequential CPU restatement of the reference's hot path (BitVM/garbled-snark-verifier
+// v0.4.0): label algebra, gate-id tweak, fixed-key AES-128 hash, privacy-free half-gate
+// garble/degarble, AES CBC-MAC ciphertext commitment, credit-counted wire storage and the
+// Execute / Garble / Evaluate modes, run under the mode-generic streaming driver.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+// The product (garbled_snark_verifier_amd/) never links, imports or calls it.
+//
+// PARITY UNPINNED: the reference is Rust, there is no cargo/rustc in the build image and the
+// reference holds no golden ciphertext/label/hash literal.  What pins this file:
+//   * FIPS-197 C.1 AES-128 known-answer vector, the standard ChaCha20 zero-key keystream;
+//   * SURVEY.md Appendix B vectors (derived from the reference's formulas with OpenSSL);
+//   * the reference's own property tests restated in tests/ (halfgates_garbling.rs:81-157,
+//     tests/streaming_evaluate.rs:136-213, tests/fq12_mul_e2e.rs:217-235, ciphertext counts
+//     of garble_test.rs / garble_integration_test.rs);
+//   * Execute-mode gadget results against Python integer arithmetic.
+//
+// Each function cites the reference file:line it follows (paths relative to /root/reference).
+// The gate-stream producers (driver + gadgets, reference layers L2/L3, which are mode-generic in
+// the reference too) are shared with the product as headers under
+// garbled_snark_verifier_amd/csrc/{circuit,gadgets}; everything label-/AES-related is restated here
+// independently of the product's device and host code.
+// =====================================================================================
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <optional>
+
+#if defined(__AES__) && defined(__SSE2__)
+#include <immintrin.h>
+#define GSVO_HAVE_AESNI 1
+#else
+#define GSVO_HAVE_AESNI 0
+#endif
+
+#include "../garbled_snark_verifier_amd/csrc/gadgets/circuits.hpp"
+
+namespace oracle {
+using namespace gsv;
+
+// ---------------------------------------------------------------------------------------
+// src/core/s.rs:14,25-31 — S(u128); to_bytes() = big-endian.  We hold the 16 BE bytes.
+struct S {
+  uint8_t b[16];
+  static S zero() { S s; std::memset(s.b, 0, 16); return s; }
+  S operator^(const S& o) const { S r; for (int i = 0; i < 16; ++i) r.b[i] = b[i] ^ o.b[i]; return r; }
+  bool operator==(const S& o) const { return std::memcmp(b, o.b, 16) == 0; }
+};
+
+// ---------------------------------------------------------------------------------------
+// AES-128, FIPS-197.  Portable byte-wise implementation (the reference's non-x86 fallback is the
+// `aes` crate, src/hashers/aes_ni.rs:291-373) and an AES-NI path (aes_ni.rs:39-120,179-216).
+static const uint8_t SBOX[256] = {
+    0x63, 0x7c, 0x77, 0x7b, 0xf2, 0x6b, 0x6f, 0xc5, 0x30, 0x01, 0x67, 0x2b, 0xfe, 0xd7, 0xab, 0x76, 0xca, 0x82, 0xc9, 0x7d, 0xfa, 0x59,
+    0x47, 0xf0, 0xad, 0xd4, 0xa2, 0xaf, 0x9c, 0xa4, 0x72, 0xc0, 0xb7, 0xfd, 0x93, 0x26, 0x36, 0x3f, 0xf7, 0xcc, 0x34, 0xa5, 0xe5, 0xf1,
+    0x71, 0xd8, 0x31, 0x15, 0x04, 0xc7, 0x23, 0xc3, 0x18, 0x96, 0x05, 0x9a, 0x07, 0x12, 0x80, 0xe2, 0xeb, 0x27, 0xb2, 0x75, 0x09, 0x83,
+    0x2c, 0x1a, 0x1b, 0x6e, 0x5a, 0xa0, 0x52, 0x3b, 0xd6, 0xb3, 0x29, 0xe3, 0x2f, 0x84, 0x53, 0xd1, 0x00, 0xed, 0x20, 0xfc, 0xb1, 0x5b,
+    0x6a, 0xcb, 0xbe, 0x39, 0x4a, 0x4c, 0x58, 0xcf, 0xd0, 0xef, 0xaa, 0xfb, 0x43, 0x4d, 0x33, 0x85, 0x45, 0xf9, 0x02, 0x7f, 0x50, 0x3c,
+    0x9f, 0xa8, 0x51, 0xa3, 0x40, 0x8f, 0x92, 0x9d, 0x38, 0xf5, 0xbc, 0xb6, 0xda, 0x21, 0x10, 0xff, 0xf3, 0xd2, 0xcd, 0x0c, 0x13, 0xec,
+    0x5f, 0x97, 0x44, 0x17, 0xc4, 0xa7, 0x7e, 0x3d, 0x64, 0x5d, 0x19, 0x73, 0x60, 0x81, 0x4f, 0xdc, 0x22, 0x2a, 0x90, 0x88, 0x46, 0xee,
+    0xb8, 0x14, 0xde, 0x5e, 0x0b, 0xdb, 0xe0, 0x32, 0x3a, 0x0a, 0x49, 0x06, 0x24, 0x5c, 0xc2, 0xd3, 0xac, 0x62, 0x91, 0x95, 0xe4, 0x79,
+    0xe7, 0xc8, 0x37, 0x6d, 0x8d, 0xd5, 0x4e, 0xa9, 0x6c, 0x56, 0xf4, 0xea, 0x65, 0x7a, 0xae, 0x08, 0xba, 0x78, 0x25, 0x2e, 0x1c, 0xa6,
+    0xb4, 0xc6, 0xe8, 0xdd, 0x74, 0x1f, 0x4b, 0xbd, 0x8b, 0x8a, 0x70, 0x3e, 0xb5, 0x66, 0x48, 0x03, 0xf6, 0x0e, 0x61, 0x35, 0x57, 0xb9,
+    0x86, 0xc1, 0x1d, 0x9e, 0xe1, 0xf8, 0x98, 0x11, 0x69, 0xd9, 0x8e, 0x94, 0x9b, 0x1e, 0x87, 0xe9, 0xce, 0x55, 0x28, 0xdf, 0x8c, 0xa1,
+    0x89, 0x0d, 0xbf, 0xe6, 0x42, 0x68, 0x41, 0x99, 0x2d, 0x0f, 0xb0, 0x54, 0xbb, 0x16};
+
+static inline uint8_t xtime(uint8_t x) { return uint8_t((x << 1) ^ ((x >> 7) * 0x1b)); }
+
+struct Aes128 {
+  uint8_t rk[11][16];
+#if GSVO_HAVE_AESNI
+  __m128i rkx[11];
+#endif
+  explicit Aes128(const uint8_t key[16]) {  // FIPS-197 §5.2 key expansion (aes_ni.rs:179-216)
+    std::memcpy(rk[0], key, 16);
+    uint8_t rcon = 1;
+    for (int r = 1; r <= 10; ++r) {
+      const uint8_t* p = rk[r - 1];
+      uint8_t t[4] = {uint8_t(SBOX[p[13]] ^ rcon), SBOX[p[14]], SBOX[p[15]], SBOX[p[12]]};
+      for (int i = 0; i < 4; ++i) rk[r][i] = p[i] ^ t[i];
+      for (int i = 4; i < 16; ++i) rk[r][i] = p[i] ^ rk[r][i - 4];
+      rcon = xtime(rcon);
+    }
+#if GSVO_HAVE_AESNI
+    for (int r = 0; r <= 10; ++r) rkx[r] = _mm_loadu_si128(reinterpret_cast<const __m128i*>(rk[r]));
+#endif
+  }
+  void encrypt_portable(const uint8_t in[16], uint8_t out[16]) const {  // FIPS-197 §5.1
+    uint8_t s[16];
+    for (int i = 0; i < 16; ++i) s[i] = in[i] ^ rk[0][i];
+    for (int r = 1; r <= 10; ++r) {
+      uint8_t t[16];
+      for (int c = 0; c < 4; ++c)       // SubBytes + ShiftRows: state[row][col] = s[4*col+row]
+        for (int row = 0; row < 4; ++row) t[4 * c + row] = SBOX[s[4 * ((c + row) & 3) + row]];
+      if (r < 10) {
+        for (int c = 0; c < 4; ++c) {  // MixColumns
+          uint8_t a0 = t[4 * c], a1 = t[4 * c + 1], a2 = t[4 * c + 2], a3 = t[4 * c + 3];
+          s[4 * c + 0] = xtime(a0) ^ (xtime(a1) ^ a1) ^ a2 ^ a3;
+          s[4 * c + 1] = a0 ^ xtime(a1) ^ (xtime(a2) ^ a2) ^ a3;
+          s[4 * c + 2] = a0 ^ a1 ^ xtime(a2) ^ (xtime(a3) ^ a3);
+          s[4 * c + 3] = (xtime(a0) ^ a0) ^ a1 ^ a2 ^ xtime(a3);
+        }
+      } else {
+        std::memcpy(s, t, 16);
+      }
+      for (int i = 0; i < 16; ++i) s[i] ^= rk[r][i];
+    }
+    std::memcpy(out, s, 16);
+  }
+#if GSVO_HAVE_AESNI
+  inline __m128i encrypt_ni(__m128i st) const {  // aes_ni.rs:39-54
+    st = _mm_xor_si128(st, rkx[0]);
+    for (int r = 1; r < 10; ++r) st = _mm_aesenc_si128(st, rkx[r]);
+    return _mm_aesenclast_si128(st, rkx[10]);
+  }
+#endif
+};
+
+static bool g_use_aesni = GSVO_HAVE_AESNI;
+
+// aes_ni.rs:165 — static key [0x42; 16], expanded once.
+static const Aes128& static_cipher() {
+  static const uint8_t key[16] = {0x42, 0x42, 0x42, 0x42, 0x42, 0x42, 0x42, 0x42, 0x42, 0x42, 0x42, 0x42, 0x42, 0x42, 0x42, 0x42};
+  static const Aes128 c(key);
+  return c;
+}
+
+static inline S aes_static(const S& in) {  // aes128_encrypt_block_static, aes_ni.rs:240-244
+  S out;
+#if GSVO_HAVE_AESNI
+  if (g_use_aesni) {
+    __m128i st = _mm_loadu_si128(reinterpret_cast<const __m128i*>(in.b));
+    _mm_storeu_si128(reinterpret_cast<__m128i*>(out.b), static_cipher().encrypt_ni(st));
+    return out;
+  }
+#endif
+  static_cipher().encrypt_portable(in.b, out.b);
+  return out;
+}
+
+// src/hashers/mod.rs:57-64,90-96 — tweak mask: bytes[0..8) = LE64(g ^ C0), bytes[8..16) = LE64(g * C1).
+static inline S to_tweak(uint64_t gate_id) {
+  uint64_t t0 = gate_id ^ 0x123456789ABCDEF0ull;
+  uint64_t t1 = gate_id * 0xDEADBEEFCAFEBABEull;  // wrapping
+  S m;
+  for (int i = 0; i < 8; ++i) { m.b[i] = uint8_t(t0 >> (8 * i)); m.b[8 + i] = uint8_t(t1 >> (8 * i)); }
+  return m;
+}
+// hashers/mod.rs:66-86 + aes_ni.rs:261-282 — H(x, g) = AES_K(x_bytes XOR tweak(g)); no feed-forward.
+static inline S hash_with_gate(const S& label, uint64_t gate_id) { return aes_static(label ^ to_tweak(gate_id)); }
+
+static inline void hash2_with_gate(const S& l0, const S& l1, uint64_t gate_id, S& h0, S& h1) {
+#if GSVO_HAVE_AESNI
+  if (g_use_aesni) {  // aes_ni.rs:68-94 two blocks interleaved
+    const Aes128& c = static_cipher();
+    S tw = to_tweak(gate_id);
+    __m128i t = _mm_loadu_si128(reinterpret_cast<const __m128i*>(tw.b));
+    __m128i s0 = _mm_xor_si128(_mm_loadu_si128(reinterpret_cast<const __m128i*>(l0.b)), t);
+    __m128i s1 = _mm_xor_si128(_mm_loadu_si128(reinterpret_cast<const __m128i*>(l1.b)), t);
+    s0 = _mm_xor_si128(s0, c.rkx[0]); s1 = _mm_xor_si128(s1, c.rkx[0]);
+    for (int r = 1; r < 10; ++r) { s0 = _mm_aesenc_si128(s0, c.rkx[r]); s1 = _mm_aesenc_si128(s1, c.rkx[r]); }
+    s0 = _mm_aesenclast_si128(s0, c.rkx[10]); s1 = _mm_aesenclast_si128(s1, c.rkx[10]);
+    _mm_storeu_si128(reinterpret_cast<__m128i*>(h0.b), s0);
+    _mm_storeu_si128(reinterpret_cast<__m128i*>(h1.b), s1);
+    return;
+  }
+#endif
+  h0 = hash_with_gate(l0, gate_id);
+  h1 = hash_with_gate(l1, gate_id);
+}
+
+// src/core/gate_type.rs:20-37 alphas_const
+static inline void alphas(GateType t, bool& aa, bool& ab, bool& ac) {
+  int v = int(t);
+  if (v >= 8) { aa = ab = ac = false; return; }
+  aa = v & 4; ab = v & 2; ac = v & 1;
+}
+
+// src/circuit/modes/garble_mode/halfgates_garbling.rs:5-38
+static inline bool garble_gate(GateType t, const S& a0, const S& b0, const S& delta, uint64_t gate_id, S& c0, S& ct) {
+  switch (t) {
+    case GateType::Xor: c0 = a0 ^ b0; return false;
+    case GateType::Xnor: c0 = a0 ^ b0 ^ delta; return false;
+    case GateType::Not: c0 = a0 ^ delta; return false;
+    default: {
+      bool aa, ab, ac;
+      alphas(t, aa, ab, ac);
+      S selected = aa ? (a0 ^ delta) : a0;
+      S other = aa ? a0 : (a0 ^ delta);
+      S h0, h1;
+      hash2_with_gate(selected, other, gate_id, h0, h1);
+      S b_sel = ab ? (b0 ^ delta) : b0;
+      ct = h0 ^ h1 ^ b_sel;
+      c0 = ac ? (h0 ^ delta) : h0;
+      return true;
+    }
+  }
+}
+
+// halfgates_garbling.rs:41-69.  `ct` is only read for AND-family gates (lazy in the reference).
+template <class NextCt>
+static inline S degarble_gate(GateType t, NextCt&& next_ct, const S& a, bool a_value, const S& b, uint64_t gate_id) {
+  switch (t) {
+    case GateType::Xor: return a ^ b;
+    case GateType::Xnor: return a ^ b;
+    case GateType::Not: return a;
+    default: {
+      S ct = next_ct();
+      S h = hash_with_gate(a, gate_id);
+      bool aa, ab, ac;
+      alphas(t, aa, ab, ac);
+      if (a_value != aa) return ct ^ h ^ b;
+      return h;
+    }
+  }
+}
+
+// src/ciphertext_hasher.rs:4-33 — h <- AES_K(h XOR ct), from h = 0.
+struct AESAccumulatingHash {
+  S h = S::zero();
+  void update(const S& ct) { h = aes_static(h ^ ct); }
+};
+
+// ---------------------------------------------------------------------------------------
+// rand_core 0.6.4 SeedableRng::seed_from_u64 (PCG32 expansion) + rand_chacha 0.3.1 ChaCha20Rng
+// (64-bit block counter from 0, stream 0) + rand 0.8.5 Standard for u128 (low u64 first).
+// Call sites: garble_mode.rs:81-85,116-118; core/s.rs:57-59.  Libraries are not vendored in
+// /root/reference; versions pinned by its Cargo.lock.
+struct ChaCha20Rng {
+  uint32_t key[8];
+  uint64_t counter = 0;
+  uint32_t buf[16];
+  int idx = 16;
+  static ChaCha20Rng seed_from_u64(uint64_t state) {
+    ChaCha20Rng r;
+    for (int i = 0; i < 8; ++i) {
+      state = state * 6364136223846793005ull + 11634580027462260723ull;
+      uint32_t xorshifted = uint32_t(((state >> 18) ^ state) >> 27);
+      uint32_t rot = uint32_t(state >> 59);
+      r.key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));  // rotate_right; value = LE word
+    }
+    return r;
+  }
+  static inline uint32_t rotl(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
+  void block() {
+    uint32_t st[16] = {0x61707865, 0x3320646e, 0x79622d32, 0x6b206574, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                       uint32_t(counter), uint32_t(counter >> 32), 0, 0};
+    uint32_t x[16];
+    std::memcpy(x, st, sizeof x);
+#define GSVO_QR(a, b, c, d) \
+  x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16); x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12); \
+  x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);  x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+    for (int i = 0; i < 10; ++i) {
+      GSVO_QR(0, 4, 8, 12) GSVO_QR(1, 5, 9, 13) GSVO_QR(2, 6, 10, 14) GSVO_QR(3, 7, 11, 15)
+      GSVO_QR(0, 5, 10, 15) GSVO_QR(1, 6, 11, 12) GSVO_QR(2, 7, 8, 13) GSVO_QR(3, 4, 9, 14)
+    }
+#undef GSVO_QR
+    for (int i = 0; i < 16; ++i) buf[i] = x[i] + st[i];
+    ++counter;
+    idx = 0;
+  }
+  uint32_t next_u32() { if (idx >= 16) block(); return buf[idx++]; }
+  uint64_t next_u64() { uint64_t lo = next_u32(); uint64_t hi = next_u32(); return lo | (hi << 32); }
+  S gen_s() {  // S::random = rng.gen::<u128>(): x = next_u64 (low), y = next_u64 (high); bytes = BE(u128)
+    uint64_t lo = next_u64(), hi = next_u64();
+    S s;
+    for (int i = 0; i < 8; ++i) { s.b[i] = uint8_t(hi >> (56 - 8 * i)); s.b[8 + i] = uint8_t(lo >> (56 - 8 * i)); }
+    return s;
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// src/storage.rs:39-198 — slab keyed WireId-2 with u16 credits.  Slot reuse is LIFO like slab 0.4.
+template <class T>
+class Storage {
+ public:
+  explicit Storage(size_t capacity) { entries_.reserve(capacity); }
+  WireId allocate(T data, Credits credits) {  // :119-133
+    if (credits == 0) return UNREACHABLE;
+    size_t index;
+    if (next_ == entries_.size()) {
+      index = entries_.size();
+      entries_.push_back(Entry{true, credits, std::move(data), 0});
+      next_ = entries_.size();
+    } else {
+      index = next_;
+      next_ = entries_[index].next_free;
+      entries_[index] = Entry{true, credits, std::move(data), 0};
+    }
+    ++len_;
+    if (len_ > peak_) peak_ = len_;
+    return WireId(index) + 2;
+  }
+  bool add_credits(WireId key, Credits credits) {  // :137-152
+    Entry* e = find(key);
+    if (!e) return false;
+    uint32_t v = uint32_t(e->credits) + credits;
+    if (v > 0xFFFF) gsv_panic("Your credits overflow capacity");
+    e->credits = Credits(v);
+    return true;
+  }
+  // :158-179 — returns false on NotFound; removes the entry when the last credit is spent.
+  bool get(WireId key, T& out) {
+    Entry* e = find(key);
+    if (!e) return false;
+    if (e->credits == 1) {
+      out = std::move(e->data);
+      e->occupied = false;
+      e->next_free = next_;
+      next_ = size_t(key - 2);
+      --len_;
+    } else {
+      e->credits -= 1;
+      out = e->data;
+    }
+    return true;
+  }
+  template <class F>
+  bool set(WireId key, F&& f) {  // :185-198
+    Entry* e = find(key);
+    if (!e) return false;
+    f(e->data);
+    return true;
+  }
+  size_t len() const { return len_; }
+  size_t peak() const { return peak_; }
+
+ private:
+  struct Entry { bool occupied; Credits credits; T data; size_t next_free; };
+  Entry* find(WireId key) {
+    if (key < 2) gsv_panic("storage: key below index offset");
+    size_t idx = size_t(key - 2);
+    if (idx >= entries_.size() || !entries_[idx].occupied) return nullptr;
+    return &entries_[idx];
+  }
+  std::vector<Entry> entries_;
+  size_t next_ = 0, len_ = 0, peak_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------
+// src/circuit/modes/execute_mode.rs:21-125
+class ExecuteMode final : public CircuitMode {
+ public:
+  explicit ExecuteMode(size_t cap) : storage_(cap) {}
+  WireId allocate_wire(Credits c) override { return storage_.allocate(std::nullopt, c); }
+  bool lookup(WireId w, bool& v) {
+    if (w == TRUE_WIRE) { v = true; return true; }
+    if (w == FALSE_WIRE) { v = false; return true; }
+    std::optional<bool> o;
+    if (!storage_.get(w, o)) return false;
+    if (!o) gsv_panic("lookup_wire: wire created but not initialized");
+    v = *o;
+    return true;
+  }
+  void feed(WireId w, bool v) {
+    if (w == TRUE_WIRE || w == FALSE_WIRE || w == UNREACHABLE) return;
+    if (!storage_.set(w, [&](std::optional<bool>& d) { d = v; })) gsv_panic("feed_wire: NotFound");
+  }
+  bool consume_wire(WireId w) override { bool v; return lookup(w, v); }
+  void add_credits(const WireId* ws, size_t n, Credits c) override {
+    for (size_t i = 0; i < n; ++i) if (!storage_.add_credits(ws[i], c)) gsv_panic("add_credits: NotFound");
+  }
+  void evaluate_gate(const Gate& g) override {  // :56-90
+    bool a, b;
+    if (!lookup(g.a, a)) gsv_panic("Can't find wire_a");
+    if (!lookup(g.b, b)) gsv_panic("Can't find wire_b");
+    if (g.c == UNREACHABLE) return;
+    feed(g.c, gate_f(g.t, a, b));
+  }
+  size_t peak() const { return storage_.peak(); }
+ private:
+  Storage<std::optional<bool>> storage_;
+};
+
+// src/circuit/modes/garble_mode.rs:65-267
+struct GarbledWire { S label0, label1; };
+class GarbleMode final : public CircuitMode {
+ public:
+  GarbleMode(size_t cap, uint64_t seed) : storage_(cap), rng_(ChaCha20Rng::seed_from_u64(seed)) {  // :80-97
+    delta = rng_.gen_s();
+    false_wire = random_wire();
+    true_wire = random_wire();
+  }
+  GarbledWire issue_garbled_wire() { return random_wire(); }  // :116-118
+  WireId allocate_wire(Credits c) override { return storage_.allocate(std::nullopt, c); }
+  bool lookup(WireId w, GarbledWire& gw) {  // :238-258
+    if (w == TRUE_WIRE) { gw = true_wire; return true; }
+    if (w == FALSE_WIRE) { gw = false_wire; return true; }
+    std::optional<S> o;
+    if (!storage_.get(w, o)) return false;
+    if (!o) gsv_panic("lookup_wire: wire created but not initialized");
+    gw.label0 = *o; gw.label1 = *o ^ delta;
+    return true;
+  }
+  void feed(WireId w, const GarbledWire& gw) {  // :224-236
+    if (w == TRUE_WIRE || w == FALSE_WIRE || w == UNREACHABLE) return;
+    if (!storage_.set(w, [&](std::optional<S>& d) { d = gw.label0; })) gsv_panic("feed_wire: NotFound");
+  }
+  bool consume_wire(WireId w) override { GarbledWire gw; return lookup(w, gw); }
+  void add_credits(const WireId* ws, size_t n, Credits c) override {
+    for (size_t i = 0; i < n; ++i) if (!storage_.add_credits(ws[i], c)) gsv_panic("add_credits: NotFound");
+  }
+  S read_label0(WireId w, const char* which) {  // :167-191 — constants contribute label0 for both FALSE and TRUE
+    if (w == FALSE_WIRE) return false_wire.label0;
+    if (w == TRUE_WIRE) return true_wire.label0;
+    std::optional<S> o;
+    if (!storage_.get(w, o)) gsv_panic(std::string("Can't find ") + which);
+    if (!o) gsv_panic("evaluate_gate: wire created but not initialized");
+    return *o;
+  }
+  void evaluate_gate(const Gate& g) override {  // :160-222
+    S a0 = read_label0(g.a, "wire_a");
+    S b0 = read_label0(g.b, "wire_b");
+    uint64_t gate_id = gate_index++;           // :192 — before the UNREACHABLE test
+    if (g.c == UNREACHABLE) return;            // :195-197
+    S c0, ct;
+    if (garble_gate(g.t, a0, b0, delta, gate_id, c0, ct)) {  // :201-210
+      hash.update(ct);
+      ++n_ciphertexts;
+      if (ct_capture && n_ciphertexts <= ct_capture_cap) std::memcpy(ct_capture + 16 * (n_ciphertexts - 1), ct.b, 16);
+    }
+    if (g.c == FALSE_WIRE || g.c == TRUE_WIRE) gsv_panic("gate output is a constant wire");
+    if (!storage_.set(g.c, [&](std::optional<S>& d) { d = c0; })) gsv_panic("evaluate_gate: output wire NotFound");
+  }
+  S delta;
+  GarbledWire false_wire, true_wire;
+  uint64_t gate_index = 0, n_ciphertexts = 0;
+  AESAccumulatingHash hash;  // CiphertextHandler = AESAccumulatingHash (circuit/mod.rs:148-158)
+  uint8_t* ct_capture = nullptr;
+  uint64_t ct_capture_cap = 0;
+  size_t peak() const { return storage_.peak(); }
+ private:
+  GarbledWire random_wire() { GarbledWire w; w.label0 = rng_.gen_s(); w.label1 = w.label0 ^ delta; return w; }  // :37-44
+  Storage<std::optional<S>> storage_;
+  ChaCha20Rng rng_;
+};
+
+// src/circuit/modes/evaluate_mode.rs:59-196
+struct EvaluatedWire { S active_label; bool value; };
+class EvaluateMode final : public CircuitMode {
+ public:
+  EvaluateMode(size_t cap, const S& true_w, const S& false_w, const uint8_t* cts, uint64_t n_ct)
+      : storage_(cap), false_wire_(false_w), true_wire_(true_w), cts_(cts), n_ct_(n_ct) {}
+  WireId allocate_wire(Credits c) override { return storage_.allocate(std::nullopt, c); }
+  bool lookup(WireId w, EvaluatedWire& ew) {  // :172-185
+    if (w == TRUE_WIRE) { ew = {true_wire_, true}; return true; }
+    if (w == FALSE_WIRE) { ew = {false_wire_, false}; return true; }
+    std::optional<EvaluatedWire> o;
+    if (!storage_.get(w, o)) return false;
+    if (!o) gsv_panic("lookup_wire: wire created but not initialized");
+    ew = *o;
+    return true;
+  }
+  void feed(WireId w, const EvaluatedWire& ew) {  // :160-170
+    if (w == TRUE_WIRE || w == FALSE_WIRE || w == UNREACHABLE) return;
+    if (!storage_.set(w, [&](std::optional<EvaluatedWire>& d) { d = ew; })) gsv_panic("feed_wire: NotFound");
+  }
+  bool consume_wire(WireId w) override { EvaluatedWire e; return lookup(w, e); }
+  void add_credits(const WireId* ws, size_t n, Credits c) override {
+    for (size_t i = 0; i < n; ++i) if (!storage_.add_credits(ws[i], c)) gsv_panic("add_credits: NotFound");
+  }
+  void evaluate_gate(const Gate& g) override {  // :123-158
+    EvaluatedWire a, b;
+    if (!lookup(g.a, a)) gsv_panic("evaluate: wire_a missing");
+    if (!lookup(g.b, b)) gsv_panic("evaluate: wire_b missing");
+    uint64_t gate_id = gate_index++;
+    if (g.c == UNREACHABLE) return;
+    S label = degarble_gate(g.t, [&]() -> S {
+      // FileSource::recv (ciphertext_source.rs:60-101): next 16-byte record, CBC-MAC'd as it is read.
+      if (consumed >= n_ct_) gsv_panic("Ciphertext source exhausted at gate " + std::to_string(gate_id));
+      S ct;
+      std::memcpy(ct.b, cts_ + 16 * consumed, 16);
+      ++consumed;
+      hash.update(ct);
+      return ct;
+    }, a.active_label, a.value, b.active_label, gate_id);
+    feed(g.c, EvaluatedWire{label, gate_f(g.t, a.value, b.value)});
+  }
+  uint64_t gate_index = 0, consumed = 0;
+  AESAccumulatingHash hash;
+ private:
+  Storage<std::optional<EvaluatedWire>> storage_;
+  S false_wire_, true_wire_;
+  const uint8_t* cts_;
+  uint64_t n_ct_;
+};
+
+static thread_local std::string g_err;
+static inline void copy_counts(const GateCount& gc, uint64_t* out) { if (out) for (int i = 0; i < GATE_TYPE_COUNT; ++i) out[i] = gc.n[i]; }
+
+}  // namespace oracle
+
+using namespace oracle;
+
+extern "C" {
+
+const char* gsvo_last_error() { return g_err.c_str(); }
+int gsvo_have_aesni() { return GSVO_HAVE_AESNI; }
+void gsvo_set_use_aesni(int on) { g_use_aesni = GSVO_HAVE_AESNI && on; }
+
+int gsvo_circuit_info(const char* circuit, uint64_t* n_in, uint64_t* n_out) {
+  try { NamedCircuit nc = make_circuit(circuit); *n_in = nc.n_inputs; *n_out = nc.n_outputs; return 0; }
+  catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// ---- primitives (known-answer tests)
+void gsvo_aes128_encrypt(const uint8_t key[16], const uint8_t in[16], uint8_t out[16], int force_portable) {
+  Aes128 c(key);
+#if GSVO_HAVE_AESNI
+  if (!force_portable) { _mm_storeu_si128(reinterpret_cast<__m128i*>(out), c.encrypt_ni(_mm_loadu_si128(reinterpret_cast<const __m128i*>(in)))); return; }
+#endif
+  c.encrypt_portable(in, out);
+}
+void gsvo_tweak(uint64_t gate_id, uint8_t out[16]) { S t = to_tweak(gate_id); std::memcpy(out, t.b, 16); }
+void gsvo_hash(const uint8_t label[16], uint64_t gate_id, uint8_t out[16]) {
+  S l; std::memcpy(l.b, label, 16);
+  S h = hash_with_gate(l, gate_id);
+  std::memcpy(out, h.b, 16);
+}
+int gsvo_garble_gate(uint8_t type, const uint8_t a0[16], const uint8_t b0[16], const uint8_t delta[16], uint64_t gate_id, uint8_t c0[16], uint8_t ct[16]) {
+  S a, b, d, c, t = S::zero();
+  std::memcpy(a.b, a0, 16); std::memcpy(b.b, b0, 16); std::memcpy(d.b, delta, 16);
+  bool has = garble_gate(GateType(type), a, b, d, gate_id, c, t);
+  std::memcpy(c0, c.b, 16); std::memcpy(ct, t.b, 16);
+  return has ? 1 : 0;
+}
+void gsvo_degarble_gate(uint8_t type, const uint8_t ct[16], const uint8_t a[16], int a_value, const uint8_t b[16], uint64_t gate_id, uint8_t out[16]) {
+  S sa, sb, sct;
+  std::memcpy(sa.b, a, 16); std::memcpy(sb.b, b, 16); std::memcpy(sct.b, ct, 16);
+  S r = degarble_gate(GateType(type), [&]() { return sct; }, sa, a_value != 0, sb, gate_id);
+  std::memcpy(out, r.b, 16);
+}
+void gsvo_cbcmac(const uint8_t* cts, uint64_t n, uint8_t out[16]) {
+  AESAccumulatingHash h;
+  for (uint64_t i = 0; i < n; ++i) { S c; std::memcpy(c.b, cts + 16 * i, 16); h.update(c); }
+  std::memcpy(out, h.h.b, 16);
+}
+void gsvo_chacha_labels(uint64_t seed, uint64_t n, uint8_t* out) {
+  ChaCha20Rng r = ChaCha20Rng::seed_from_u64(seed);
+  for (uint64_t i = 0; i < n; ++i) { S s = r.gen_s(); std::memcpy(out + 16 * i, s.b, 16); }
+}
+void gsvo_chacha_words_from_key(const uint8_t key[32], uint64_t n, uint32_t* out) {
+  ChaCha20Rng r;
+  for (int i = 0; i < 8; ++i) r.key[i] = uint32_t(key[4 * i]) | uint32_t(key[4 * i + 1]) << 8 | uint32_t(key[4 * i + 2]) << 16 | uint32_t(key[4 * i + 3]) << 24;
+  for (uint64_t i = 0; i < n; ++i) out[i] = r.next_u32();
+}
+
+// ---- CircuitBuilder::streaming_execute (circuit/mod.rs:124-137)
+int gsvo_execute(const char* circuit, uint64_t capacity, const uint8_t* input_bits, uint8_t* output_bits, uint64_t* gate_counts, uint64_t* peak_live) {
+  try {
+    NamedCircuit nc = make_circuit(circuit);
+    ExecuteMode mode(capacity);
+    StreamingRunner run(mode, nc.n_inputs, nc.fn);
+    const Wires& in = run.prepare();
+    for (size_t i = 0; i < in.size(); ++i) mode.feed(in[i], input_bits[i] != 0);
+    for (WireId w : in) { bool v; if (!mode.lookup(w, v)) gsv_panic("input lookup failed"); }
+    const Wires& out = run.execute();
+    for (size_t i = 0; i < out.size(); ++i) { bool v; if (!mode.lookup(out[i], v)) gsv_panic("Can't find output wire"); output_bits[i] = v; }
+    copy_counts(run.ctx().gate_count, gate_counts);
+    if (peak_live) *peak_live = mode.peak();
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// ---- CircuitBuilder::streaming_garbling with AESAccumulatingHash (circuit/mod.rs:180-203).
+// Input labels: one issue_garbled_wire() per input wire in allocation order (tests/fq12_mul_e2e.rs:82-96,
+// garbled_groth16.rs:156-176).  Outputs: label0 of every output wire (label1 = label0 ^ delta).
+int gsvo_garble(const char* circuit, uint64_t capacity, uint64_t seed, uint8_t delta[16], uint8_t false_label0[16], uint8_t true_label0[16],
+                uint8_t* input_label0, uint8_t* output_label0, uint8_t ct_hash[16], uint64_t* n_ciphertexts, uint64_t* gate_counts,
+                uint8_t* ct_out, uint64_t ct_cap, uint64_t* peak_live) {
+  try {
+    NamedCircuit nc = make_circuit(circuit);
+    GarbleMode mode(capacity, seed);
+    mode.ct_capture = ct_out; mode.ct_capture_cap = ct_out ? ct_cap : 0;
+    StreamingRunner run(mode, nc.n_inputs, nc.fn);
+    const Wires& in = run.prepare();
+    for (size_t i = 0; i < in.size(); ++i) mode.feed(in[i], mode.issue_garbled_wire());
+    for (size_t i = 0; i < in.size(); ++i) {
+      GarbledWire gw;
+      if (!mode.lookup(in[i], gw)) gsv_panic("input lookup failed");
+      if (input_label0) std::memcpy(input_label0 + 16 * i, gw.label0.b, 16);
+    }
+    const Wires& out = run.execute();
+    for (size_t i = 0; i < out.size(); ++i) {
+      GarbledWire gw;
+      if (!mode.lookup(out[i], gw)) gsv_panic("Can't find output wire");
+      if (output_label0) std::memcpy(output_label0 + 16 * i, gw.label0.b, 16);
+    }
+    std::memcpy(delta, mode.delta.b, 16);
+    std::memcpy(false_label0, mode.false_wire.label0.b, 16);
+    std::memcpy(true_label0, mode.true_wire.label0.b, 16);
+    std::memcpy(ct_hash, mode.hash.h.b, 16);
+    *n_ciphertexts = mode.n_ciphertexts;
+    copy_counts(run.ctx().gate_count, gate_counts);
+    if (peak_live) *peak_live = mode.peak();
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// ---- CircuitBuilder::streaming_evaluation over a ciphertext byte stream (circuit/mod.rs:225-249,
+// ciphertext_source.rs:36-107: raw 16-byte big-endian records, no framing).
+int gsvo_evaluate(const char* circuit, uint64_t capacity, const uint8_t true_active[16], const uint8_t false_active[16],
+                  const uint8_t* input_active, const uint8_t* input_bits, const uint8_t* cts, uint64_t n_ct,
+                  uint8_t* output_active, uint8_t* output_bits, uint8_t ct_hash[16], uint64_t* n_consumed) {
+  try {
+    NamedCircuit nc = make_circuit(circuit);
+    S t, f;
+    std::memcpy(t.b, true_active, 16); std::memcpy(f.b, false_active, 16);
+    EvaluateMode mode(capacity, t, f, cts, n_ct);
+    StreamingRunner run(mode, nc.n_inputs, nc.fn);
+    const Wires& in = run.prepare();
+    for (size_t i = 0; i < in.size(); ++i) {
+      EvaluatedWire ew; std::memcpy(ew.active_label.b, input_active + 16 * i, 16); ew.value = input_bits[i] != 0;
+      mode.feed(in[i], ew);
+    }
+    for (WireId w : in) { EvaluatedWire ew; if (!mode.lookup(w, ew)) gsv_panic("input lookup failed"); }
+    const Wires& out = run.execute();
+    for (size_t i = 0; i < out.size(); ++i) {
+      EvaluatedWire ew;
+      if (!mode.lookup(out[i], ew)) gsv_panic("Can't find output wire");
+      std::memcpy(output_active + 16 * i, ew.active_label.b, 16);
+      output_bits[i] = ew.value;
+    }
+    std::memcpy(ct_hash, mode.hash.h.b, 16);
+    *n_consumed = mode.consumed;
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// ---- cpu_baseline leg of bench.py: time one garbling instance (single thread), inline CBC-MAC.
+int gsvo_bench_garble(const char* circuit, uint64_t capacity, uint64_t seed, double* seconds, uint64_t* gates, uint8_t ct_hash[16]) {
+  try {
+    NamedCircuit nc = make_circuit(circuit);
+    auto t0 = std::chrono::steady_clock::now();
+    GarbleMode mode(capacity, seed);
+    StreamingRunner run(mode, nc.n_inputs, nc.fn);
+    const Wires& in = run.prepare();
+    for (size_t i = 0; i < in.size(); ++i) mode.feed(in[i], mode.issue_garbled_wire());
+    for (WireId w : in) { GarbledWire gw; mode.lookup(w, gw); }
+    const Wires& out = run.execute();
+    for (WireId w : out) { GarbledWire gw; mode.lookup(w, gw); }
+    auto t1 = std::chrono::steady_clock::now();
+    *seconds = std::chrono::duration<double>(t1 - t0).count();
+    *gates = run.ctx().gate_count.total();
+    std::memcpy(ct_hash, mode.hash.h.b, 16);
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+}  // extern "C"
