@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Headline benchmark: gates/s (garble) on the Groth16/BN254-verifier-sized circuit, one rank per GPU.
+
+Workload (BASELINE.json configs[3]): one garbling instance = 11.17 B gates.  The full verifier's gate
+stream producer (pairing / MSM gadgets) is SURVEY.md §8(f1) "next"; until it lands the circuit is the
+Groth16-SHAPED SYNTHETIC named in SURVEY.md §8(d): a chain of R = 551 `Fq12::mul_montgomery`
+components (r <- r*b), 20,284,982 gates each = 11,177,025,082 gates, garbled exactly as the reference
+would stream it (gate ids and ciphertext indices run through the whole chain; verified bit-exactly
+against the CPU oracle on a short chain in tests/ and below).  Every GPU garbles `--instances`
+independent cut-and-choose instances (own seed => own delta / labels / ciphertext stream) per step.
+
+One "step" = one pass of the hot path: garble all instances of this rank's batch, ciphertexts written to
+each instance's device-resident stream (ring of `--ct-ring` replays), output labels gathered.
+`value` = total gates garbled by all ranks per second (weak scaling: per-GPU work fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+VERIFIER_GATES = 11_174_708_821  # README.md:12 of the reference
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--instances", type=int, default=16, help="cut-and-choose instances per GPU per step")
+    ap.add_argument("--replays", type=int, default=0, help="Fq12-mul components per instance (0 = enough for 11.17 B gates)")
+    ap.add_argument("--ct-ring", type=int, default=2, help="replays of ciphertexts kept per instance in HBM")
+    ap.add_argument("--cpu-baseline-chain", type=int, default=8, help="Fq12 muls garbled by the CPU oracle for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-check", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+    import garbled_snark_verifier_amd as gsv
+
+    engine = gsv.Engine(local_rank)  # raises without a HIP device: no CPU fallback
+    t0 = time.time()
+    prog = gsv.Program.from_circuit("fq12_mul", chain_feedback=True)
+    compile_s = time.time() - t0
+    info = prog.info
+    gates_per_replay = info["n_gates"]
+    replays = args.replays or -(-VERIFIER_GATES // gates_per_replay)
+    B = args.instances
+    n_in = info["n_inputs"]
+    f_nf = info["n_ciphertexts"] / gates_per_replay
+    bytes_per_gate = 64.0 + 16.0 * f_nf  # 16 B record + 2x16 B label reads + 16 B write + 16 B*f_nf ciphertext
+
+    seeds = [1_000_003 * (rank + 1) + i for i in range(B)]
+    delta = np.zeros((B, 16), np.uint8)
+    consts = np.zeros((B, 2, 16), np.uint8)
+    inputs = np.zeros((B, n_in, 16), np.uint8)
+    for i, s in enumerate(seeds):
+        delta[i], consts[i, 0], consts[i, 1], inputs[i] = gsv.labels_from_seed(s, n_in)
+    sess = gsv.Session(engine, prog, B, replays, min(args.ct_ring, replays))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    out_dev = torch.empty((B, info["n_outputs"], 16), dtype=torch.uint8, device="cuda")
+    gathered = [torch.empty_like(out_dev) for _ in range(world)] if world > 1 else None
+
+    def step():
+        sess.set_garble_inputs(delta, consts, inputs)  # fresh labels resident in HBM before the kernel starts
+        sess.garble(0)
+        sess.sync()
+        if world > 1:  # the one exchange of the path: all-gather of the instances' output labels (RCCL over xGMI)
+            out_dev.copy_(torch.from_numpy(sess.read_outputs()).to("cuda"))
+            dist.all_gather(gathered, out_dev)
+        return sess.last_kernel_ms()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        kernel_ms.append(step())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    gates_per_step_rank = gates_per_replay * replays * B
+    total_gates = gates_per_step_rank * world * args.steps
+    value = total_gates / elapsed
+
+    result = None
+    if rank == 0:
+        avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
+        achieved_gbs = gates_per_step_rank * bytes_per_gate / avg_kernel_s / 1e9
+        result = {
+            "metric": "gates/sec (garble) on Groth16/BN254 verifier; ciphertext-hash match",
+            "value": value, "unit": "gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u128 labels (u32 lanes)", "data": "synthetic",
+            "config": {"workload": "Groth16-shaped synthetic: chain of %d Fq12::mul_montgomery components = %d gates per instance "
+                                   "(>= 11,174,708,821-gate verifier); %d cut-and-choose instances per GPU" % (replays, gates_per_replay * replays, B),
+                       "instances_per_gpu": B, "replays": replays, "gates_per_instance": gates_per_replay * replays,
+                       "nonfree_fraction": f_nf, "program_steps": info["n_steps"], "and_depth": info["and_depth"],
+                       "wire_slots": info["n_slots"], "program_image_bytes": info["device_bytes"], "compile_s": compile_s},
+            "per_instance_gates_per_s": gates_per_replay * replays / avg_kernel_s,
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "run_program_kernel<false>", "kernel_ms_avg": avg_kernel_s * 1e3,
+                         "bytes_per_gate": bytes_per_gate},
+        }
+        if not args.no_check:
+            import oracle_lib as o
+            # bit-exactness of this very program against the CPU oracle on the chain's first two components
+            chk = gsv.CircuitBuilder.streaming_garbling("fq12_mul", [seeds[0]], engine=engine, program=prog, replays=2, keep_ciphertexts=False)
+            ref = o.garble("fq12_mul_chain:2", seeds[0], capture_ct=False)
+            result["ciphertext_hash_match"] = bool(chk.ciphertext_hash[0] == ref.ct_hash.tobytes() and (chk.output_label0[0] == ref.output_label0).all())
+            result["hash_check"] = {"circuit": "fq12_mul_chain:2", "seed": seeds[0], "gpu": chk.ciphertext_hash[0].hex(), "oracle": ref.ct_hash.tobytes().hex()}
+        if args.cpu_baseline_chain and world == 1:
+            import oracle_lib as o
+            spec = "fq12_mul_chain:%d" % args.cpu_baseline_chain
+            sec, gates, _ = o.bench_garble(spec, seed=0)
+            result["cpu_baseline"] = {"value": gates / sec, "unit": "gates/s", "cores": 1, "kind": "port",
+                                      "sample": "%s (%d gates) garbled once by the C++ oracle, AES-NI hash + inline CBC-MAC, 1 thread, %.1f s" % (spec, gates, sec)}
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

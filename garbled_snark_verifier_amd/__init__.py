@@ -1,0 +1,339 @@
+"""MI355X-native garbling / evaluation engine for the streaming Free-XOR / half-gates gate loop of
+BitVM/garbled-snark-verifier.
+
+This module is the thin Python host layer over the C ABI in ``include/gsv_engine.h``
+(``libgsv_engine.so``: hand-written HIP kernels for gfx950 + C++ host runtime).  It mirrors the
+reference's entry points for the hot path
+
+    CircuitBuilder::streaming_garbling    src/circuit/mod.rs:180-203   ->  CircuitBuilder.streaming_garbling
+    CircuitBuilder::streaming_evaluation  src/circuit/mod.rs:225-249   ->  CircuitBuilder.streaming_evaluation
+    AESAccumulatingHash                   src/ciphertext_hasher.rs     ->  StreamingResult.ciphertext_hash
+
+There is no CPU fallback: every garble/evaluate call runs on a HIP device or raises ``GsvError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+__all__ = ["GsvError", "lib", "Program", "Engine", "Session", "CircuitBuilder", "StreamingResult", "labels_from_seed", "GATE_NAMES"]
+
+GATE_NAMES = ["And", "Nand", "Nimp", "Imp", "Ncimp", "Cimp", "Nor", "Or", "Xor", "Xnor", "Not"]
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+class GsvError(RuntimeError):
+    pass
+
+
+class _ProgramInfo(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_inputs", "n_outputs", "n_gates", "n_ciphertexts", "n_dead")] + [("gate_count", C.c_uint64 * 11)] + [
+        (n, C.c_uint64) for n in ("n_steps", "and_depth", "n_and_steps", "max_step_width", "n_slots", "peak_live", "device_bytes")]
+
+
+class _Gate(C.Structure):
+    _fields_ = [("wire_a", C.c_uint64), ("wire_b", C.c_uint64), ("wire_c", C.c_uint64), ("gate_type", C.c_uint8), ("pad", C.c_uint8 * 7)]
+
+
+EXPORTS = [
+    "gsv_last_error", "gsv_recorder_create", "gsv_recorder_destroy", "gsv_recorder_allocate_wire", "gsv_recorder_declare_input",
+    "gsv_recorder_push_gates", "gsv_recorder_declare_outputs", "gsv_recorder_record_circuit", "gsv_recorder_counts", "gsv_program_compile", "gsv_program_destroy",
+    "gsv_program_get_info", "gsv_engine_create", "gsv_engine_destroy", "gsv_labels_from_seed", "gsv_session_create", "gsv_session_destroy",
+    "gsv_session_set_garble_inputs", "gsv_session_garble", "gsv_session_set_evaluate_inputs", "gsv_session_upload_ciphertexts",
+    "gsv_session_evaluate", "gsv_session_sync", "gsv_session_last_kernel_ms", "gsv_session_read_outputs", "gsv_session_read_ciphertexts",
+    "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_commit_labels",
+]
+
+
+def lib():
+    """Loads (building in-tree if needed) libgsv_engine.so.  Raises if the library cannot be built/loaded."""
+    global _lib
+    if _lib is None:
+        so = _build.build()
+        L = C.CDLL(so)
+        u8p, vp = C.POINTER(C.c_uint8), C.c_void_p
+        L.gsv_last_error.restype = C.c_char_p
+        L.gsv_recorder_create.argtypes = [C.POINTER(vp)]
+        L.gsv_recorder_destroy.argtypes = [vp]
+        L.gsv_recorder_destroy.restype = None
+        L.gsv_recorder_allocate_wire.argtypes = [vp, C.c_uint16, C.POINTER(C.c_uint64)]
+        L.gsv_recorder_declare_input.argtypes = [vp, C.c_uint64]
+        L.gsv_recorder_push_gates.argtypes = [vp, C.POINTER(_Gate), C.c_size_t]
+        L.gsv_recorder_declare_outputs.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t]
+        L.gsv_recorder_record_circuit.argtypes = [vp, C.c_char_p]
+        L.gsv_recorder_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.gsv_program_compile.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(vp)]
+        L.gsv_program_destroy.argtypes = [vp]
+        L.gsv_program_destroy.restype = None
+        L.gsv_program_get_info.argtypes = [vp, C.POINTER(_ProgramInfo)]
+        L.gsv_engine_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.gsv_engine_destroy.argtypes = [vp]
+        L.gsv_engine_destroy.restype = None
+        L.gsv_labels_from_seed.argtypes = [C.c_uint64, C.c_size_t, u8p, u8p, u8p, u8p]
+        L.gsv_session_create.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.c_uint64, C.POINTER(vp)]
+        L.gsv_session_destroy.argtypes = [vp]
+        L.gsv_session_destroy.restype = None
+        L.gsv_session_set_garble_inputs.argtypes = [vp, u8p, u8p, u8p]
+        L.gsv_session_garble.argtypes = [vp, C.c_uint64]
+        L.gsv_session_set_evaluate_inputs.argtypes = [vp, u8p, u8p, u8p]
+        L.gsv_session_upload_ciphertexts.argtypes = [vp, C.c_size_t, u8p, C.c_uint64]
+        L.gsv_session_evaluate.argtypes = [vp, C.c_uint64]
+        L.gsv_session_sync.argtypes = [vp]
+        L.gsv_session_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_double)]
+        L.gsv_session_read_outputs.argtypes = [vp, u8p, u8p]
+        L.gsv_session_read_ciphertexts.argtypes = [vp, C.c_size_t, C.c_uint64, C.c_uint64, u8p]
+        L.gsv_session_ciphertext_hash.argtypes = [vp, C.c_size_t, u8p]
+        L.gsv_cbcmac_update.argtypes = [u8p, u8p, C.c_uint64]
+        L.gsv_commit_labels.argtypes = [u8p, C.c_uint64, u8p]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise GsvError("gsv status %d: %s" % (rc, lib().gsv_last_error().decode(errors="replace")))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8)) if a is not None else None
+
+
+def _u8(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a if shape is None else a.reshape(shape)
+
+
+def labels_from_seed(seed, n_inputs):
+    """(delta, false_label0, true_label0, input_label0[n_inputs,16]) as GarbleMode::new draws them
+    (src/circuit/modes/garble_mode.rs:80-97,116-118)."""
+    d, f, t = (np.zeros(16, np.uint8) for _ in range(3))
+    inp = np.zeros((n_inputs, 16), np.uint8)
+    _chk(lib().gsv_labels_from_seed(seed, n_inputs, _p(d), _p(f), _p(t), _p(inp)))
+    return d, f, t, inp
+
+
+def cbcmac(cts, state=None):
+    """AESAccumulatingHash over 16-byte records (src/ciphertext_hasher.rs:23-29)."""
+    st = np.zeros(16, np.uint8) if state is None else _u8(state).copy()
+    a = _u8(cts).reshape(-1)
+    _chk(lib().gsv_cbcmac_update(_p(st), _p(a) if a.size else None, a.size // 16))
+    return st.tobytes()
+
+
+class Program:
+    """A recorded circuit compiled to device steps (gsv_recorder + gsv_program)."""
+
+    def __init__(self, handle):
+        self.h = handle
+        info = _ProgramInfo()
+        _chk(lib().gsv_program_get_info(self.h, C.byref(info)))
+        self.info = {n: (list(getattr(info, n)) if n == "gate_count" else int(getattr(info, n))) for n, _ in _ProgramInfo._fields_}
+
+    @classmethod
+    def from_circuit(cls, spec, chain_feedback=False):
+        """Record one of the built-in restated circuits through the two-pass credit driver and compile it.
+        chain_feedback: output i is copied to input i after every replay (component chains)."""
+        L = lib()
+        r = C.c_void_p()
+        _chk(L.gsv_recorder_create(C.byref(r)))
+        try:
+            _chk(L.gsv_recorder_record_circuit(r, spec.encode()))
+            return cls._compile(r, chain_feedback)
+        finally:
+            L.gsv_recorder_destroy(r)
+
+    @classmethod
+    def from_gates(cls, n_inputs, gates, outputs, credits=None):
+        """Record an explicit gate list through the CircuitMode-shaped recorder API.
+        gates: iterable of (gate_type, a, b, c) with wire ids: 0/1 constants, inputs 2..2+n_inputs-1, further
+        wires in first-write order; c == None marks a dead gate (UNREACHABLE)."""
+        L = lib()
+        r = C.c_void_p()
+        _chk(L.gsv_recorder_create(C.byref(r)))
+        try:
+            known = set()
+            for _ in range(n_inputs):
+                w = C.c_uint64()
+                _chk(L.gsv_recorder_allocate_wire(r, 1, C.byref(w)))
+                _chk(L.gsv_recorder_declare_input(r, w.value))
+                known.add(w.value)
+            arr = (_Gate * max(1, len(gates)))()
+            for i, (t, a, b, c) in enumerate(gates):
+                if c is not None and c not in known and c >= 2:
+                    w = C.c_uint64()
+                    _chk(L.gsv_recorder_allocate_wire(r, 1, C.byref(w)))
+                    if w.value != c:
+                        raise GsvError("from_gates: wires must be numbered in first-write order (expected %d, got %d)" % (w.value, c))
+                    known.add(c)
+                arr[i].wire_a, arr[i].wire_b, arr[i].gate_type = a, b, t
+                arr[i].wire_c = 0xFFFFFFFFFFFFFFFF if c is None else c
+            _chk(L.gsv_recorder_push_gates(r, arr, len(gates)))
+            outs = (C.c_uint64 * max(1, len(outputs)))(*outputs)
+            _chk(L.gsv_recorder_declare_outputs(r, outs, len(outputs)))
+            return cls._compile(r, False)
+        finally:
+            L.gsv_recorder_destroy(r)
+
+    @classmethod
+    def _compile(cls, r, chain_feedback):
+        L = lib()
+        h = C.c_void_p()
+        if chain_feedback:
+            no = C.c_uint64()
+            _chk(L.gsv_recorder_counts(r, None, C.byref(no), None))
+            n_out = no.value
+            idx = (C.c_uint32 * n_out)(*range(n_out))
+            _chk(L.gsv_program_compile(r, idx, idx, n_out, C.byref(h)))
+        else:
+            _chk(L.gsv_program_compile(r, None, None, 0, C.byref(h)))
+        return cls(h)
+
+    def __del__(self):
+        if getattr(self, "h", None) is not None and _lib is not None:
+            _lib.gsv_program_destroy(self.h)
+            self.h = None
+
+
+class Engine:
+    """One GPU (gsv_engine).  Creation fails loudly when no HIP device is present."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _chk(lib().gsv_engine_create(device, C.byref(self.h)))
+        self.device = device
+
+    def __del__(self):
+        if getattr(self, "h", None) is not None and _lib is not None and self.h:
+            _lib.gsv_engine_destroy(self.h)
+            self.h = None
+
+
+class Session:
+    """A batch of instances on one program (gsv_session)."""
+
+    def __init__(self, engine, program, n_instances=1, replays=1, ct_capacity_replays=None):
+        self.engine, self.program = engine, program
+        self.n, self.replays = n_instances, replays
+        self.ct_cap = replays if ct_capacity_replays is None else ct_capacity_replays
+        self.h = C.c_void_p()
+        _chk(lib().gsv_session_create(engine.h, program.h, n_instances, replays, self.ct_cap, C.byref(self.h)))
+        self.n_in, self.n_out = program.info["n_inputs"], program.info["n_outputs"]
+
+    def set_garble_inputs(self, delta, const_label0, input_label0):
+        d = _u8(delta, (self.n, 16))
+        c = _u8(const_label0, (self.n, 32))
+        i = _u8(input_label0, (self.n, self.n_in * 16))
+        _chk(lib().gsv_session_set_garble_inputs(self.h, _p(d), _p(c), _p(i) if self.n_in else None))
+
+    def garble(self, gate_id_base=0):
+        _chk(lib().gsv_session_garble(self.h, gate_id_base))
+
+    def set_evaluate_inputs(self, const_active, input_active, input_bits):
+        c = _u8(const_active, (self.n, 32))
+        a = _u8(input_active, (self.n, self.n_in * 16))
+        b = _u8(input_bits, (self.n, self.n_in))
+        _chk(lib().gsv_session_set_evaluate_inputs(self.h, _p(c), _p(a) if self.n_in else None, _p(b) if self.n_in else None))
+
+    def upload_ciphertexts(self, instance, cts):
+        a = _u8(cts).reshape(-1)
+        _chk(lib().gsv_session_upload_ciphertexts(self.h, instance, _p(a) if a.size else None, a.size // 16))
+
+    def evaluate(self, gate_id_base=0):
+        _chk(lib().gsv_session_evaluate(self.h, gate_id_base))
+
+    def sync(self):
+        _chk(lib().gsv_session_sync(self.h))
+
+    def last_kernel_ms(self):
+        ms = C.c_double()
+        _chk(lib().gsv_session_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def read_outputs(self, with_bits=False):
+        lab = np.zeros((self.n, self.n_out, 16), np.uint8)
+        bits = np.zeros((self.n, self.n_out), np.uint8) if with_bits else None
+        _chk(lib().gsv_session_read_outputs(self.h, _p(lab), _p(bits)))
+        return (lab, bits) if with_bits else lab
+
+    def read_ciphertexts(self, instance, first=0, n=None):
+        if n is None:
+            n = self.ct_cap * self.program.info["n_ciphertexts"] - first
+        out = np.zeros((n, 16), np.uint8)
+        _chk(lib().gsv_session_read_ciphertexts(self.h, instance, first, n, _p(out) if n else None))
+        return out
+
+    def ciphertext_hash(self, instance):
+        h = np.zeros(16, np.uint8)
+        _chk(lib().gsv_session_ciphertext_hash(self.h, instance, _p(h)))
+        return h.tobytes()
+
+    def close(self):
+        if getattr(self, "h", None) is not None and _lib is not None and self.h:
+            _lib.gsv_session_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+class StreamingResult:
+    """Fields of the reference's StreamingResult that exist for this path (src/circuit/mod.rs:81-107)."""
+    pass
+
+
+class CircuitBuilder:
+    """Host-side mirror of the reference's CircuitBuilder entry points for the garble/evaluate path."""
+
+    @staticmethod
+    def streaming_garbling(circuit, seeds, engine=None, program=None, replays=1, keep_ciphertexts=True):
+        """Garble `circuit` once per seed (one instance per seed, all on `engine`'s GPU).
+        Mirrors CircuitBuilder::streaming_garbling(inputs, cap, seed, AESAccumulatingHash, f) per instance
+        (src/circuit/mod.rs:185-203): labels from the seed's ChaCha stream, ciphertext hash = CBC-MAC."""
+        seeds = [seeds] if np.isscalar(seeds) else list(seeds)
+        engine = engine or Engine(0)
+        program = program or Program.from_circuit(circuit)
+        n_in = program.info["n_inputs"]
+        B = len(seeds)
+        delta = np.zeros((B, 16), np.uint8)
+        consts = np.zeros((B, 2, 16), np.uint8)
+        inputs = np.zeros((B, n_in, 16), np.uint8)
+        for i, s in enumerate(seeds):
+            delta[i], consts[i, 0], consts[i, 1], inputs[i] = labels_from_seed(s, n_in)
+        sess = Session(engine, program, B, replays)
+        sess.set_garble_inputs(delta, consts, inputs)
+        sess.garble(0)
+        sess.sync()
+        r = StreamingResult()
+        r.session, r.program = sess, program
+        r.delta, r.false_label0, r.true_label0, r.input_label0 = delta, consts[:, 0], consts[:, 1], inputs
+        r.output_label0 = sess.read_outputs()
+        r.kernel_ms = sess.last_kernel_ms()
+        r.n_ciphertexts = program.info["n_ciphertexts"] * replays
+        r.gate_count = [g * replays for g in program.info["gate_count"]]
+        r.ciphertext_hash = [sess.ciphertext_hash(i) for i in range(B)]
+        r.ciphertexts = [sess.read_ciphertexts(i) for i in range(B)] if keep_ciphertexts else None
+        return r
+
+    @staticmethod
+    def streaming_evaluation(circuit, true_active, false_active, input_active, input_bits, ciphertexts, engine=None, program=None, replays=1):
+        """Evaluate instances from their ciphertext streams (src/circuit/mod.rs:225-249).  Arrays carry a
+        leading instance dimension; `ciphertexts` is a list of [n,16] uint8 arrays (gc_{i}.bin bytes)."""
+        engine = engine or Engine(0)
+        program = program or Program.from_circuit(circuit)
+        ta, fa = _u8(true_active).reshape(-1, 16), _u8(false_active).reshape(-1, 16)
+        B = ta.shape[0]
+        consts = np.stack([fa, ta], axis=1)
+        sess = Session(engine, program, B, replays)
+        sess.set_evaluate_inputs(consts, input_active, input_bits)
+        for i in range(B):
+            sess.upload_ciphertexts(i, ciphertexts[i])
+        sess.evaluate(0)
+        sess.sync()
+        r = StreamingResult()
+        r.session, r.program = sess, program
+        r.output_active, r.output_bits = sess.read_outputs(with_bits=True)
+        r.kernel_ms = sess.last_kernel_ms()
+        r.ciphertext_hash = [sess.ciphertext_hash(i) for i in range(B)]
+        return r

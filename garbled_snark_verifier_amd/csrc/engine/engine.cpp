@@ -1,0 +1,425 @@
+// Host runtime + C ABI (include/gsv_engine.h) of the MI355X garbling engine.
+// Device memory, streams and events are plain HIP runtime calls; there is NO CPU execution path for
+// garble/evaluate — without a HIP device gsv_engine_create fails with GSV_ERR_DEVICE.
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../../include/gsv_engine.h"
+#include "../gadgets/circuits.hpp"
+#include "host_crypto.hpp"
+#include "kernel_api.h"
+#include "program.hpp"
+
+using namespace gsv;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define GSV_TRY try {
+#define GSV_CATCH                                                                 \
+  }                                                                               \
+  catch (const std::exception& e) { return fail(GSV_ERR_CIRCUIT, e.what()); }     \
+  catch (...) { return fail(GSV_ERR_CIRCUIT, "unknown exception"); }
+
+#define HIPCHK(expr)                                                                                         \
+  do {                                                                                                       \
+    hipError_t _e = (expr);                                                                                  \
+    if (_e != hipSuccess) return fail(GSV_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+  } while (0)
+
+struct gsv_recorder {
+  RecordMode mode;
+  std::vector<uint32_t> inputs, outputs;  // SSA ids
+  bool outputs_declared = false;
+};
+
+struct DevProgram {
+  void *steps = nullptr, *ands = nullptr, *xors = nullptr, *fb_src = nullptr, *fb_dst = nullptr, *out_slots = nullptr;
+  size_t bytes = 0;
+};
+
+struct gsv_program {
+  Program prog;
+  std::mutex mu;
+  std::map<int, DevProgram> dev;  // per device
+  size_t image_bytes() const {
+    return prog.steps.size() * sizeof(StepDesc) + prog.ands.size() * sizeof(AndRec) + prog.xors.size() * sizeof(XorRec) +
+           (prog.fb_src_slot.size() * 2 + prog.output_slots.size()) * sizeof(uint32_t);
+  }
+};
+
+struct gsv_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  void* te = nullptr;  // device T-tables
+};
+
+struct gsv_session {
+  gsv_engine* e = nullptr;
+  gsv_program* p = nullptr;
+  DevProgram dp;
+  size_t n_inst = 0;
+  uint64_t replays = 1, ct_cap = 1;
+  void *W = nullptr, *VB = nullptr, *CT = nullptr, *delta = nullptr, *out = nullptr, *out_bits = nullptr, *in_bits = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ran = false, last_eval = false;
+  uint64_t ct_stride() const { return ct_cap * p->prog.n_ct; }
+};
+
+extern "C" {
+
+const char* gsv_last_error(void) { return g_err.c_str(); }
+
+// ---------------------------------------------------------------- recorder
+int gsv_recorder_create(gsv_recorder** out) {
+  if (!out) return fail(GSV_ERR_INVALID, "null out");
+  *out = new gsv_recorder();
+  return GSV_OK;
+}
+void gsv_recorder_destroy(gsv_recorder* r) { delete r; }
+
+int gsv_recorder_allocate_wire(gsv_recorder* r, uint16_t credits, uint64_t* wire_out) {
+  if (!r || !wire_out) return fail(GSV_ERR_INVALID, "null argument");
+  GSV_TRY
+  *wire_out = r->mode.allocate_wire(credits);
+  return GSV_OK;
+  GSV_CATCH
+}
+int gsv_recorder_declare_input(gsv_recorder* r, uint64_t wire) {
+  if (!r) return fail(GSV_ERR_INVALID, "null recorder");
+  GSV_TRY
+  r->inputs.push_back(r->mode.define_input(wire));
+  return GSV_OK;
+  GSV_CATCH
+}
+int gsv_recorder_push_gates(gsv_recorder* r, const gsv_gate* gates, size_t n) {
+  if (!r || (!gates && n)) return fail(GSV_ERR_INVALID, "null argument");
+  GSV_TRY
+  for (size_t i = 0; i < n; ++i) {
+    if (gates[i].gate_type > 10) return fail(GSV_ERR_INVALID, "gate_type out of range");
+    r->mode.evaluate_gate(Gate{gates[i].wire_a, gates[i].wire_b, gates[i].wire_c, GateType(gates[i].gate_type)});
+  }
+  return GSV_OK;
+  GSV_CATCH
+}
+int gsv_recorder_declare_outputs(gsv_recorder* r, const uint64_t* wires, size_t n) {
+  if (!r || (!wires && n)) return fail(GSV_ERR_INVALID, "null argument");
+  GSV_TRY
+  r->outputs.clear();
+  for (size_t i = 0; i < n; ++i) r->outputs.push_back(r->mode.current(wires[i]));
+  r->outputs_declared = true;
+  return GSV_OK;
+  GSV_CATCH
+}
+int gsv_recorder_record_circuit(gsv_recorder* r, const char* spec) {
+  if (!r || !spec) return fail(GSV_ERR_INVALID, "null argument");
+  GSV_TRY
+  if (!r->inputs.empty() || r->mode.trace().size()) return fail(GSV_ERR_INVALID, "recorder already holds a circuit");
+  NamedCircuit nc = make_circuit(spec);
+  StreamingRunner run(r->mode, nc.n_inputs, nc.fn);  // two-pass credit driver, circuit/mod.rs:253-301
+  const Wires& in = run.prepare();
+  for (WireId w : in) r->inputs.push_back(r->mode.define_input(w));
+  const Wires& out = run.execute();
+  for (WireId w : out) r->outputs.push_back(r->mode.current(w));
+  r->outputs_declared = true;
+  return GSV_OK;
+  GSV_CATCH
+}
+
+int gsv_recorder_counts(const gsv_recorder* r, uint64_t* n_inputs, uint64_t* n_outputs, uint64_t* n_gates) {
+  if (!r) return fail(GSV_ERR_INVALID, "null recorder");
+  if (n_inputs) *n_inputs = r->inputs.size();
+  if (n_outputs) *n_outputs = r->outputs.size();
+  if (n_gates) *n_gates = const_cast<gsv_recorder*>(r)->mode.trace().size();
+  return GSV_OK;
+}
+
+// ---------------------------------------------------------------- program
+int gsv_program_compile(gsv_recorder* r, const uint32_t* fb_out_idx, const uint32_t* fb_in_idx, size_t n_feedback, gsv_program** out) {
+  if (!r || !out) return fail(GSV_ERR_INVALID, "null argument");
+  if (!r->outputs_declared) return fail(GSV_ERR_INVALID, "outputs not declared");
+  GSV_TRY
+  std::vector<std::pair<uint32_t, uint32_t>> fb;
+  for (size_t i = 0; i < n_feedback; ++i) fb.push_back({fb_out_idx[i], fb_in_idx[i]});
+  std::unique_ptr<gsv_program> p(new gsv_program());
+  p->prog = compile_program(r->mode.trace(), r->inputs, r->outputs, fb);
+  for (size_t i = 0; i < p->prog.input_slots.size(); ++i)
+    if (p->prog.input_slots[i] != 2 + i) return fail(GSV_ERR_CIRCUIT, "internal: inputs are not slot-contiguous");
+  *out = p.release();
+  return GSV_OK;
+  GSV_CATCH
+}
+void gsv_program_destroy(gsv_program* p) {
+  if (!p) return;
+  for (auto& kv : p->dev) {
+    (void)hipSetDevice(kv.first);
+    for (void* q : {kv.second.steps, kv.second.ands, kv.second.xors, kv.second.fb_src, kv.second.fb_dst, kv.second.out_slots})
+      if (q) (void)hipFree(q);
+  }
+  delete p;
+}
+int gsv_program_get_info(const gsv_program* p, gsv_program_info* info) {
+  if (!p || !info) return fail(GSV_ERR_INVALID, "null argument");
+  const Program& g = p->prog;
+  std::memset(info, 0, sizeof *info);
+  info->n_inputs = g.input_slots.size(); info->n_outputs = g.output_slots.size();
+  info->n_gates = g.n_gates; info->n_ciphertexts = g.n_ct; info->n_dead = g.n_dead;
+  for (int i = 0; i < 11; ++i) info->gate_count[i] = g.gate_count[i];
+  info->n_steps = g.steps.size(); info->and_depth = g.and_depth; info->n_and_steps = g.n_and_steps; info->max_step_width = g.max_step_width;
+  info->n_slots = g.n_slots; info->peak_live = g.peak_live; info->device_bytes = p->image_bytes();
+  return GSV_OK;
+}
+
+// ---------------------------------------------------------------- engine
+int gsv_engine_create(int device, gsv_engine** out) {
+  if (!out) return fail(GSV_ERR_INVALID, "null out");
+  int n = 0;
+  hipError_t er = hipGetDeviceCount(&n);
+  if (er != hipSuccess || n <= 0) return fail(GSV_ERR_DEVICE, "no HIP device available: the garbling engine has no CPU fallback");
+  if (device < 0 || device >= n) return fail(GSV_ERR_DEVICE, "device index out of range");
+  HIPCHK(hipSetDevice(device));
+  std::unique_ptr<gsv_engine> e(new gsv_engine());
+  e->device = device;
+  HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  const AesTables& t = AesTables::fixed_key();
+  HIPCHK(hipMalloc(&e->te, sizeof t.te));
+  HIPCHK(hipMemcpy(e->te, t.te, sizeof t.te, hipMemcpyHostToDevice));
+  if (gsvk_upload_round_keys(t.rk) != 0) return fail(GSV_ERR_DEVICE, "round key upload failed");
+  *out = e.release();
+  return GSV_OK;
+}
+void gsv_engine_destroy(gsv_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->te) (void)hipFree(e->te);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int gsv_labels_from_seed(uint64_t seed, size_t n_inputs, uint8_t delta[16], uint8_t false_label0[16], uint8_t true_label0[16], uint8_t* input_label0) {
+  if (!delta || !false_label0 || !true_label0 || (!input_label0 && n_inputs)) return fail(GSV_ERR_INVALID, "null argument");
+  ChaCha20Seed rng(seed);
+  rng.next_label(delta);
+  rng.next_label(false_label0);
+  rng.next_label(true_label0);
+  for (size_t i = 0; i < n_inputs; ++i) rng.next_label(input_label0 + 16 * i);
+  return GSV_OK;
+}
+
+// ---------------------------------------------------------------- sessions
+static int upload_program(gsv_engine* e, gsv_program* p, DevProgram* out) {
+  std::lock_guard<std::mutex> lk(p->mu);
+  auto it = p->dev.find(e->device);
+  if (it != p->dev.end()) { *out = it->second; return GSV_OK; }
+  DevProgram d;
+  const Program& g = p->prog;
+  auto up = [&](void** dst, const void* src, size_t bytes) -> int {
+    if (bytes == 0) { *dst = nullptr; return GSV_OK; }
+    HIPCHK(hipMalloc(dst, bytes));
+    HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    d.bytes += bytes;
+    return GSV_OK;
+  };
+  int rc;
+  if ((rc = up(&d.steps, g.steps.data(), g.steps.size() * sizeof(StepDesc)))) return rc;
+  if ((rc = up(&d.ands, g.ands.data(), g.ands.size() * sizeof(AndRec)))) return rc;
+  if ((rc = up(&d.xors, g.xors.data(), g.xors.size() * sizeof(XorRec)))) return rc;
+  if ((rc = up(&d.fb_src, g.fb_src_slot.data(), g.fb_src_slot.size() * 4))) return rc;
+  if ((rc = up(&d.fb_dst, g.fb_dst_slot.data(), g.fb_dst_slot.size() * 4))) return rc;
+  if ((rc = up(&d.out_slots, g.output_slots.data(), g.output_slots.size() * 4))) return rc;
+  p->dev[e->device] = d;
+  *out = d;
+  return GSV_OK;
+}
+
+int gsv_session_create(gsv_engine* e, const gsv_program* cp, size_t n_instances, uint64_t replays, uint64_t ct_capacity_replays, gsv_session** out) {
+  if (!e || !cp || !out || n_instances == 0 || replays == 0) return fail(GSV_ERR_INVALID, "bad argument");
+  gsv_program* p = const_cast<gsv_program*>(cp);
+  if (ct_capacity_replays == 0 || ct_capacity_replays > replays) ct_capacity_replays = replays;
+  if (replays > 0xFFFFFFFFull) return fail(GSV_ERR_INVALID, "too many replays");
+  HIPCHK(hipSetDevice(e->device));
+  std::unique_ptr<gsv_session> s(new gsv_session());
+  s->e = e; s->p = p; s->n_inst = n_instances; s->replays = replays; s->ct_cap = ct_capacity_replays;
+  int rc = upload_program(e, p, &s->dp);
+  if (rc) return rc;
+  const Program& g = p->prog;
+  HIPCHK(hipMalloc(&s->W, n_instances * size_t(g.n_slots) * 16));
+  HIPCHK(hipMalloc(&s->VB, n_instances * size_t(g.n_slots)));
+  HIPCHK(hipMemset(s->VB, 0, n_instances * size_t(g.n_slots)));
+  size_t ct_bytes = n_instances * size_t(s->ct_stride()) * 16;
+  HIPCHK(hipMalloc(&s->CT, ct_bytes ? ct_bytes : 16));
+  HIPCHK(hipMalloc(&s->delta, n_instances * 16));
+  HIPCHK(hipMalloc(&s->out, n_instances * g.output_slots.size() * 16 + 16));
+  HIPCHK(hipMalloc(&s->out_bits, n_instances * g.output_slots.size() + 16));
+  HIPCHK(hipMalloc(&s->in_bits, n_instances * g.input_slots.size() + 16));
+  HIPCHK(hipEventCreate(&s->ev0));
+  HIPCHK(hipEventCreate(&s->ev1));
+  *out = s.release();
+  return GSV_OK;
+}
+void gsv_session_destroy(gsv_session* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->e->device);
+  (void)hipStreamSynchronize(s->e->stream);
+  for (void* q : {s->W, s->VB, s->CT, s->delta, s->out, s->out_bits, s->in_bits}) if (q) (void)hipFree(q);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  delete s;
+}
+
+static int stage_labels(gsv_session* s, const uint8_t* consts, const uint8_t* inputs) {
+  // Per instance the wire file starts [const0, const1, input0, input1, ...]: one strided copy.
+  const Program& g = s->p->prog;
+  const size_t n_in = g.input_slots.size();
+  const size_t row = (2 + n_in) * 16;
+  std::vector<uint8_t> host(s->n_inst * row);
+  for (size_t i = 0; i < s->n_inst; ++i) {
+    std::memcpy(&host[i * row], consts + 32 * i, 32);
+    if (n_in) std::memcpy(&host[i * row + 32], inputs + i * n_in * 16, n_in * 16);
+  }
+  HIPCHK(hipMemcpy2D(s->W, size_t(g.n_slots) * 16, host.data(), row, row, s->n_inst, hipMemcpyHostToDevice));
+  return GSV_OK;
+}
+
+int gsv_session_set_garble_inputs(gsv_session* s, const uint8_t* delta, const uint8_t* const_label0, const uint8_t* input_label0) {
+  if (!s || !delta || !const_label0 || (!input_label0 && !s->p->prog.input_slots.empty())) return fail(GSV_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(s->e->device));
+  HIPCHK(hipMemcpy(s->delta, delta, s->n_inst * 16, hipMemcpyHostToDevice));
+  return stage_labels(s, const_label0, input_label0);
+}
+int gsv_session_set_evaluate_inputs(gsv_session* s, const uint8_t* const_active, const uint8_t* input_active, const uint8_t* input_bits) {
+  if (!s || !const_active || ((!input_active || !input_bits) && !s->p->prog.input_slots.empty())) return fail(GSV_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(s->e->device));
+  int rc = stage_labels(s, const_active, input_active);
+  if (rc) return rc;
+  const Program& g = s->p->prog;
+  const size_t n_in = g.input_slots.size();
+  // plaintext bits: constants FALSE=0 / TRUE=1 (evaluate_mode.rs:104-121), then the input bits
+  HIPCHK(hipMemset(s->VB, 0, s->n_inst * size_t(g.n_slots)));
+  std::vector<uint8_t> two(s->n_inst * 2);
+  for (size_t i = 0; i < s->n_inst; ++i) { two[2 * i] = 0; two[2 * i + 1] = 1; }
+  HIPCHK(hipMemcpy2D(s->VB, g.n_slots, two.data(), 2, 2, s->n_inst, hipMemcpyHostToDevice));
+  if (n_in) {
+    std::vector<uint8_t> nb(s->n_inst * n_in);
+    for (size_t i = 0; i < nb.size(); ++i) nb[i] = input_bits[i] ? 1 : 0;
+    HIPCHK(hipMemcpy(s->in_bits, nb.data(), nb.size(), hipMemcpyHostToDevice));
+    if (gsvk_scatter_bits(s->VB, g.n_slots, 2, s->in_bits, uint32_t(n_in), uint32_t(s->n_inst), nullptr) != 0) return fail(GSV_ERR_DEVICE, "scatter_bits launch failed");
+    HIPCHK(hipDeviceSynchronize());
+  }
+  return GSV_OK;
+}
+int gsv_session_upload_ciphertexts(gsv_session* s, size_t instance, const uint8_t* cts, uint64_t n_records) {
+  if (!s || instance >= s->n_inst || (!cts && n_records)) return fail(GSV_ERR_INVALID, "bad argument");
+  if (n_records > s->ct_stride()) return fail(GSV_ERR_INVALID, "more ciphertexts than the session's stream capacity");
+  HIPCHK(hipSetDevice(s->e->device));
+  if (n_records) HIPCHK(hipMemcpy(static_cast<uint8_t*>(s->CT) + instance * s->ct_stride() * 16, cts, n_records * 16, hipMemcpyHostToDevice));
+  return GSV_OK;
+}
+
+static int launch(gsv_session* s, uint64_t gate_id_base, bool eval) {
+  const Program& g = s->p->prog;
+  HIPCHK(hipSetDevice(s->e->device));
+  dev::KernelArgs ka{};
+  ka.steps = s->dp.steps; ka.ands = s->dp.ands; ka.xors = s->dp.xors;
+  ka.W = static_cast<uint4*>(s->W); ka.VB = static_cast<uint8_t*>(s->VB); ka.CT = static_cast<uint4*>(s->CT);
+  ka.delta = static_cast<const uint4*>(s->delta); ka.te = static_cast<const uint32_t*>(s->e->te);
+  ka.fb_src = static_cast<const uint32_t*>(s->dp.fb_src); ka.fb_dst = static_cast<const uint32_t*>(s->dp.fb_dst);
+  ka.ct_stride = s->ct_stride(); ka.gid_base = gate_id_base; ka.n_gates = g.n_gates; ka.n_ct = g.n_ct;
+  ka.n_steps = uint32_t(g.steps.size()); ka.n_slots = g.n_slots; ka.replays = uint32_t(s->replays); ka.ct_cap_replays = uint32_t(s->ct_cap);
+  ka.n_fb = uint32_t(g.fb_src_slot.size()); ka.fb_stage_base = g.fb_stage_base;
+  HIPCHK(hipEventRecord(s->ev0, s->e->stream));
+  if (ka.n_steps) {
+    if (gsvk_launch_program(&ka, uint32_t(s->n_inst), eval ? 1 : 0, s->e->stream) != 0) return fail(GSV_ERR_DEVICE, "kernel launch failed");
+  }
+  HIPCHK(hipEventRecord(s->ev1, s->e->stream));
+  if (!g.output_slots.empty()) {
+    if (gsvk_gather_outputs(s->W, s->VB, g.n_slots, static_cast<const uint32_t*>(s->dp.out_slots), uint32_t(g.output_slots.size()),
+                            uint32_t(s->n_inst), s->out, eval ? s->out_bits : nullptr, s->e->stream) != 0)
+      return fail(GSV_ERR_DEVICE, "gather launch failed");
+  }
+  s->ran = true; s->last_eval = eval;
+  return GSV_OK;
+}
+int gsv_session_garble(gsv_session* s, uint64_t gate_id_base) { return s ? launch(s, gate_id_base, false) : fail(GSV_ERR_INVALID, "null session"); }
+int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base) { return s ? launch(s, gate_id_base, true) : fail(GSV_ERR_INVALID, "null session"); }
+
+int gsv_session_sync(gsv_session* s) {
+  if (!s) return fail(GSV_ERR_INVALID, "null session");
+  HIPCHK(hipSetDevice(s->e->device));
+  HIPCHK(hipStreamSynchronize(s->e->stream));
+  return GSV_OK;
+}
+int gsv_session_last_kernel_ms(gsv_session* s, double* ms) {
+  if (!s || !ms || !s->ran) return fail(GSV_ERR_INVALID, "no launch recorded");
+  HIPCHK(hipEventSynchronize(s->ev1));
+  float f = 0;
+  HIPCHK(hipEventElapsedTime(&f, s->ev0, s->ev1));
+  *ms = f;
+  return GSV_OK;
+}
+int gsv_session_read_outputs(gsv_session* s, uint8_t* labels, uint8_t* bits) {
+  if (!s || !labels || !s->ran) return fail(GSV_ERR_INVALID, "bad argument / nothing ran");
+  HIPCHK(hipSetDevice(s->e->device));
+  HIPCHK(hipStreamSynchronize(s->e->stream));
+  const size_t n = s->n_inst * s->p->prog.output_slots.size();
+  if (n) HIPCHK(hipMemcpy(labels, s->out, n * 16, hipMemcpyDeviceToHost));
+  if (bits) {
+    if (!s->last_eval) return fail(GSV_ERR_INVALID, "plaintext bits exist only after evaluate");
+    if (n) HIPCHK(hipMemcpy(bits, s->out_bits, n, hipMemcpyDeviceToHost));
+  }
+  return GSV_OK;
+}
+int gsv_session_read_ciphertexts(gsv_session* s, size_t instance, uint64_t first, uint64_t n_records, uint8_t* out) {
+  if (!s || instance >= s->n_inst || (!out && n_records)) return fail(GSV_ERR_INVALID, "bad argument");
+  if (first + n_records > s->ct_stride()) return fail(GSV_ERR_INVALID, "range exceeds the retained ciphertext stream");
+  HIPCHK(hipSetDevice(s->e->device));
+  HIPCHK(hipStreamSynchronize(s->e->stream));
+  if (n_records) HIPCHK(hipMemcpy(out, static_cast<uint8_t*>(s->CT) + (instance * s->ct_stride() + first) * 16, n_records * 16, hipMemcpyDeviceToHost));
+  return GSV_OK;
+}
+int gsv_session_ciphertext_hash(gsv_session* s, size_t instance, uint8_t hash[16]) {
+  if (!s || instance >= s->n_inst || !hash) return fail(GSV_ERR_INVALID, "bad argument");
+  if (s->ct_cap != s->replays) return fail(GSV_ERR_INVALID, "the session retains only part of the stream (ct_capacity_replays < replays)");
+  HIPCHK(hipSetDevice(s->e->device));
+  HIPCHK(hipStreamSynchronize(s->e->stream));
+  const uint64_t total = s->ct_stride();
+  const uint64_t chunk = 1ull << 20;  // 16 MiB of records per D2H
+  std::vector<uint8_t> buf(size_t(std::min<uint64_t>(chunk, total ? total : 1)) * 16);
+  CbcMacHost mac;
+  for (uint64_t off = 0; off < total; off += chunk) {
+    uint64_t n = std::min(chunk, total - off);
+    HIPCHK(hipMemcpy(buf.data(), static_cast<uint8_t*>(s->CT) + (instance * total + off) * 16, n * 16, hipMemcpyDeviceToHost));
+    mac.update(buf.data(), n);
+  }
+  mac.digest(hash);
+  return GSV_OK;
+}
+int gsv_cbcmac_update(uint8_t state[16], const uint8_t* cts, uint64_t n_records) {
+  if (!state || (!cts && n_records)) return fail(GSV_ERR_INVALID, "null argument");
+  // CbcMacHost starts from zero; chain by XOR-ing the state into the first block (h ^ ct).
+  CbcMacHost mac;
+  if (n_records == 0) return GSV_OK;
+  uint8_t first[16];
+  for (int i = 0; i < 16; ++i) first[i] = cts[i] ^ state[i];
+  mac.update(first, 1);
+  mac.update(cts + 16, n_records - 1);
+  mac.digest(state);
+  return GSV_OK;
+}
+int gsv_commit_labels(const uint8_t* labels, uint64_t n, uint8_t* out) {
+  if ((!labels || !out) && n) return fail(GSV_ERR_INVALID, "null argument");
+  for (uint64_t i = 0; i < n; ++i) {  // AES_K(label): one-block CBC-MAC from zero state
+    CbcMacHost mac;
+    mac.update(labels + 16 * i, 1);
+    mac.digest(out + 16 * i);
+  }
+  return GSV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,147 @@
+// Per-gate label arithmetic of the MI355X engine: fixed-key AES-128 (T-table form for LDS),
+// gate-id tweak, privacy-free half-gate garble / degarble.
+//
+// Written for the gfx950 kernels in garble_kernels.hip; the functions are also compilable as plain
+// host C++ (GSV_HD expands to nothing) so that tests/hostsim can unit-test exactly this code on a
+// machine without a GPU.  The product's C-ABI never takes the host route.
+//
+// Data convention: a label is the 16 bytes of the reference's `S::to_bytes()` (big-endian u128,
+// src/core/s.rs:25-31) = the AES block, held as four little-endian 32-bit words w[0..3] of those
+// bytes, i.e. w[i] is AES state column i with row 0 in the low byte.  XOR is layout-agnostic.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define GSV_HD __host__ __device__ __forceinline__
+#else
+#define GSV_HD inline
+#endif
+
+namespace gsv {
+namespace dev {
+
+struct Label {
+  uint32_t w[4];
+};
+GSV_HD Label lxor(const Label& a, const Label& b) { return Label{{a.w[0] ^ b.w[0], a.w[1] ^ b.w[1], a.w[2] ^ b.w[2], a.w[3] ^ b.w[3]}}; }
+// XOR with delta iff `on` (branch-free: mask is 0 or ~0).
+GSV_HD Label lxor_if(const Label& a, const Label& d, uint32_t on) {
+  uint32_t m = 0u - (on & 1u);
+  return Label{{a.w[0] ^ (d.w[0] & m), a.w[1] ^ (d.w[1] & m), a.w[2] ^ (d.w[2] & m), a.w[3] ^ (d.w[3] & m)}};
+}
+
+// Gate discriminants = reference `GateType` repr(C) values (src/core/gate_type.rs:3-15).
+enum : uint32_t { GT_AND = 0, GT_XOR = 8, GT_XNOR = 9, GT_NOT = 10 };
+// alphas_const (gate_type.rs:20-37): for discriminant t<8, (alpha_a, alpha_b, alpha_c) = bits (4,2,1) of t.
+GSV_HD uint32_t alpha_a(uint32_t t) { return (t >> 2) & 1u; }
+GSV_HD uint32_t alpha_b(uint32_t t) { return (t >> 1) & 1u; }
+GSV_HD uint32_t alpha_c(uint32_t t) { return t & 1u; }
+// Plain truth function ((a^aa)&(b^ab))^ac for t<8; Xor/Xnor/Not otherwise (gate_type.rs:39-61).
+GSV_HD uint32_t gate_eval_bit(uint32_t t, uint32_t a, uint32_t b) {
+  if (t < 8) return (((a ^ alpha_a(t)) & (b ^ alpha_b(t))) ^ alpha_c(t)) & 1u;
+  if (t == GT_XOR) return (a ^ b) & 1u;
+  if (t == GT_XNOR) return (a ^ b ^ 1u) & 1u;
+  return (a ^ 1u) & 1u;
+}
+
+// Tweak (src/hashers/mod.rs:57-64,90-96): bytes[0..8) = LE64(g ^ C0), bytes[8..16) = LE64(g * C1).
+GSV_HD Label tweak_of(uint64_t gate_id) {
+  uint64_t t0 = gate_id ^ 0x123456789ABCDEF0ull;
+  uint64_t t1 = gate_id * 0xDEADBEEFCAFEBABEull;
+  return Label{{uint32_t(t0), uint32_t(t0 >> 32), uint32_t(t1), uint32_t(t1 >> 32)}};
+}
+
+// AES context as the kernels see it: four 256-entry T-tables (in LDS on the device) and the 44
+// round-key words of the fixed key 0x42*16 (src/hashers/aes_ni.rs:165).
+//   Te0[x] = (2s, s, s, 3s)   Te1[x] = (3s, 2s, s, s)   Te2[x] = (s, 3s, 2s, s)   Te3[x] = (s, s, 3s, 2s)
+// as little-endian words (byte k = state row k), s = SBOX[x].
+struct AesCtx {
+  const uint32_t* te0;
+  const uint32_t* te1;
+  const uint32_t* te2;
+  const uint32_t* te3;
+  const uint32_t* rk;  // 44 words
+};
+
+// One full AES-128 encryption of `in` (FIPS-197; equals _mm_aesenc x9 + _mm_aesenclast, aes_ni.rs:39-54).
+GSV_HD Label aes128_encrypt(const AesCtx& c, const Label& in) {
+  uint32_t s0 = in.w[0] ^ c.rk[0], s1 = in.w[1] ^ c.rk[1], s2 = in.w[2] ^ c.rk[2], s3 = in.w[3] ^ c.rk[3];
+#pragma unroll
+  for (int r = 1; r < 10; ++r) {
+    uint32_t t0 = c.te0[s0 & 0xff] ^ c.te1[(s1 >> 8) & 0xff] ^ c.te2[(s2 >> 16) & 0xff] ^ c.te3[s3 >> 24] ^ c.rk[4 * r + 0];
+    uint32_t t1 = c.te0[s1 & 0xff] ^ c.te1[(s2 >> 8) & 0xff] ^ c.te2[(s3 >> 16) & 0xff] ^ c.te3[s0 >> 24] ^ c.rk[4 * r + 1];
+    uint32_t t2 = c.te0[s2 & 0xff] ^ c.te1[(s3 >> 8) & 0xff] ^ c.te2[(s0 >> 16) & 0xff] ^ c.te3[s1 >> 24] ^ c.rk[4 * r + 2];
+    uint32_t t3 = c.te0[s3 & 0xff] ^ c.te1[(s0 >> 8) & 0xff] ^ c.te2[(s1 >> 16) & 0xff] ^ c.te3[s2 >> 24] ^ c.rk[4 * r + 3];
+    s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+  }
+  // final round: SubBytes + ShiftRows + AddRoundKey; plain S-box bytes sit in Te2 byte0, Te3 byte1, Te0 byte2, Te1 byte3.
+  Label o;
+  o.w[0] = (c.te2[s0 & 0xff] & 0x000000ffu) ^ (c.te3[(s1 >> 8) & 0xff] & 0x0000ff00u) ^ (c.te0[(s2 >> 16) & 0xff] & 0x00ff0000u) ^ (c.te1[s3 >> 24] & 0xff000000u) ^ c.rk[40];
+  o.w[1] = (c.te2[s1 & 0xff] & 0x000000ffu) ^ (c.te3[(s2 >> 8) & 0xff] & 0x0000ff00u) ^ (c.te0[(s3 >> 16) & 0xff] & 0x00ff0000u) ^ (c.te1[s0 >> 24] & 0xff000000u) ^ c.rk[41];
+  o.w[2] = (c.te2[s2 & 0xff] & 0x000000ffu) ^ (c.te3[(s3 >> 8) & 0xff] & 0x0000ff00u) ^ (c.te0[(s0 >> 16) & 0xff] & 0x00ff0000u) ^ (c.te1[s1 >> 24] & 0xff000000u) ^ c.rk[42];
+  o.w[3] = (c.te2[s3 & 0xff] & 0x000000ffu) ^ (c.te3[(s0 >> 8) & 0xff] & 0x0000ff00u) ^ (c.te0[(s1 >> 16) & 0xff] & 0x00ff0000u) ^ (c.te1[s2 >> 24] & 0xff000000u) ^ c.rk[43];
+  return o;
+}
+
+// Two independent blocks interleaved (the reference's encrypt2_blocks, aes_ni.rs:68-94): gives the
+// compiler two dependency chains to overlap LDS latency with.
+GSV_HD void aes128_encrypt2(const AesCtx& c, const Label& in0, const Label& in1, Label& out0, Label& out1) {
+  uint32_t a0 = in0.w[0] ^ c.rk[0], a1 = in0.w[1] ^ c.rk[1], a2 = in0.w[2] ^ c.rk[2], a3 = in0.w[3] ^ c.rk[3];
+  uint32_t b0 = in1.w[0] ^ c.rk[0], b1 = in1.w[1] ^ c.rk[1], b2 = in1.w[2] ^ c.rk[2], b3 = in1.w[3] ^ c.rk[3];
+#pragma unroll
+  for (int r = 1; r < 10; ++r) {
+    uint32_t k0 = c.rk[4 * r], k1 = c.rk[4 * r + 1], k2 = c.rk[4 * r + 2], k3 = c.rk[4 * r + 3];
+    uint32_t t0 = c.te0[a0 & 0xff] ^ c.te1[(a1 >> 8) & 0xff] ^ c.te2[(a2 >> 16) & 0xff] ^ c.te3[a3 >> 24] ^ k0;
+    uint32_t u0 = c.te0[b0 & 0xff] ^ c.te1[(b1 >> 8) & 0xff] ^ c.te2[(b2 >> 16) & 0xff] ^ c.te3[b3 >> 24] ^ k0;
+    uint32_t t1 = c.te0[a1 & 0xff] ^ c.te1[(a2 >> 8) & 0xff] ^ c.te2[(a3 >> 16) & 0xff] ^ c.te3[a0 >> 24] ^ k1;
+    uint32_t u1 = c.te0[b1 & 0xff] ^ c.te1[(b2 >> 8) & 0xff] ^ c.te2[(b3 >> 16) & 0xff] ^ c.te3[b0 >> 24] ^ k1;
+    uint32_t t2 = c.te0[a2 & 0xff] ^ c.te1[(a3 >> 8) & 0xff] ^ c.te2[(a0 >> 16) & 0xff] ^ c.te3[a1 >> 24] ^ k2;
+    uint32_t u2 = c.te0[b2 & 0xff] ^ c.te1[(b3 >> 8) & 0xff] ^ c.te2[(b0 >> 16) & 0xff] ^ c.te3[b1 >> 24] ^ k2;
+    uint32_t t3 = c.te0[a3 & 0xff] ^ c.te1[(a0 >> 8) & 0xff] ^ c.te2[(a1 >> 16) & 0xff] ^ c.te3[a2 >> 24] ^ k3;
+    uint32_t u3 = c.te0[b3 & 0xff] ^ c.te1[(b0 >> 8) & 0xff] ^ c.te2[(b1 >> 16) & 0xff] ^ c.te3[b2 >> 24] ^ k3;
+    a0 = t0; a1 = t1; a2 = t2; a3 = t3;
+    b0 = u0; b1 = u1; b2 = u2; b3 = u3;
+  }
+  out0.w[0] = (c.te2[a0 & 0xff] & 0x000000ffu) ^ (c.te3[(a1 >> 8) & 0xff] & 0x0000ff00u) ^ (c.te0[(a2 >> 16) & 0xff] & 0x00ff0000u) ^ (c.te1[a3 >> 24] & 0xff000000u) ^ c.rk[40];
+  out0.w[1] = (c.te2[a1 & 0xff] & 0x000000ffu) ^ (c.te3[(a2 >> 8) & 0xff] & 0x0000ff00u) ^ (c.te0[(a3 >> 16) & 0xff] & 0x00ff0000u) ^ (c.te1[a0 >> 24] & 0xff000000u) ^ c.rk[41];
+  out0.w[2] = (c.te2[a2 & 0xff] & 0x000000ffu) ^ (c.te3[(a3 >> 8) & 0xff] & 0x0000ff00u) ^ (c.te0[(a0 >> 16) & 0xff] & 0x00ff0000u) ^ (c.te1[a1 >> 24] & 0xff000000u) ^ c.rk[42];
+  out0.w[3] = (c.te2[a3 & 0xff] & 0x000000ffu) ^ (c.te3[(a0 >> 8) & 0xff] & 0x0000ff00u) ^ (c.te0[(a1 >> 16) & 0xff] & 0x00ff0000u) ^ (c.te1[a2 >> 24] & 0xff000000u) ^ c.rk[43];
+  out1.w[0] = (c.te2[b0 & 0xff] & 0x000000ffu) ^ (c.te3[(b1 >> 8) & 0xff] & 0x0000ff00u) ^ (c.te0[(b2 >> 16) & 0xff] & 0x00ff0000u) ^ (c.te1[b3 >> 24] & 0xff000000u) ^ c.rk[40];
+  out1.w[1] = (c.te2[b1 & 0xff] & 0x000000ffu) ^ (c.te3[(b2 >> 8) & 0xff] & 0x0000ff00u) ^ (c.te0[(b3 >> 16) & 0xff] & 0x00ff0000u) ^ (c.te1[b0 >> 24] & 0xff000000u) ^ c.rk[41];
+  out1.w[2] = (c.te2[b2 & 0xff] & 0x000000ffu) ^ (c.te3[(b3 >> 8) & 0xff] & 0x0000ff00u) ^ (c.te0[(b0 >> 16) & 0xff] & 0x00ff0000u) ^ (c.te1[b1 >> 24] & 0xff000000u) ^ c.rk[42];
+  out1.w[3] = (c.te2[b3 & 0xff] & 0x000000ffu) ^ (c.te3[(b0 >> 8) & 0xff] & 0x0000ff00u) ^ (c.te0[(b1 >> 16) & 0xff] & 0x00ff0000u) ^ (c.te1[b2 >> 24] & 0xff000000u) ^ c.rk[43];
+}
+
+// H(x, g) = AES_K(x ^ tweak(g)), no feed-forward (src/hashers/mod.rs:66-86).
+GSV_HD Label hash_with_gate(const AesCtx& c, const Label& x, uint64_t gate_id) { return aes128_encrypt(c, lxor(x, tweak_of(gate_id))); }
+
+// garble_gate, AND-family arm (halfgates_garbling.rs:17-35).  t < 8.
+GSV_HD void garble_and(const AesCtx& c, uint32_t t, const Label& a0, const Label& b0, const Label& delta, uint64_t gate_id,
+                       Label& c0, Label& ct) {
+  Label tw = tweak_of(gate_id);
+  Label sel = lxor_if(a0, delta, alpha_a(t));  // selected_a
+  Label oth = lxor(sel, delta);                // other_a
+  Label hs, ho;
+  aes128_encrypt2(c, lxor(sel, tw), lxor(oth, tw), hs, ho);
+  Label bsel = lxor_if(b0, delta, alpha_b(t));
+  ct = lxor(lxor(hs, ho), bsel);
+  c0 = lxor_if(hs, delta, alpha_c(t));
+}
+// garble_gate, free arm (halfgates_garbling.rs:14-16).  t in {Xor, Xnor, Not}.
+GSV_HD Label garble_free(uint32_t t, const Label& a0, const Label& b0, const Label& delta) {
+  Label r = (t == GT_NOT) ? a0 : lxor(a0, b0);
+  return lxor_if(r, delta, (t != GT_XOR) ? 1u : 0u);
+}
+// degarble_gate, AND-family arm (halfgates_garbling.rs:57-67).
+GSV_HD Label degarble_and(const AesCtx& c, uint32_t t, const Label& ct, const Label& a, uint32_t a_value, const Label& b, uint64_t gate_id) {
+  Label h = hash_with_gate(c, a, gate_id);
+  uint32_t use_ct = (a_value ^ alpha_a(t)) & 1u;
+  Label z{{0, 0, 0, 0}};
+  Label m = lxor(ct, b);
+  return lxor(h, lxor_if(z, m, use_ct));
+}
+// degarble_gate, free arm (halfgates_garbling.rs:49-55).
+GSV_HD Label degarble_free(uint32_t t, const Label& a, const Label& b) { return (t == GT_NOT) ? a : lxor(a, b); }
+
+}  // namespace dev
+}  // namespace gsv

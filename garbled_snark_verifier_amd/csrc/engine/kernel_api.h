@@ -1,0 +1,45 @@
+// Internal launch interface between engine.cpp (host runtime, built with g++) and kernels.hip
+// (device code, built with hipcc for gfx950).  Not part of the public C ABI.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
+#include <stdint.h>
+
+#define GSV_BLOCK_THREADS 1024
+
+namespace gsv {
+namespace dev {
+
+struct KernelArgs {
+  const void* steps;   // StepDesc[n_steps]   {and_off, and_cnt, xor_off, xor_cnt}
+  const void* ands;    // AndRec[]            32 B
+  const void* xors;    // XorRec[]            16 B
+  uint4* W;            // [n_instances][n_slots] labels
+  uint8_t* VB;         // [n_instances][n_slots] plaintext bits (evaluate only)
+  uint4* CT;           // [n_instances][ct_stride] ciphertext streams
+  const uint4* delta;  // [n_instances] (garble only)
+  const uint32_t* te;  // 4*256 T-table words
+  const uint32_t* fb_src;
+  const uint32_t* fb_dst;
+  uint64_t ct_stride;  // records per instance = ct_cap_replays * n_ct
+  uint64_t gid_base;   // gate_id of the first gate of replay 0
+  uint64_t n_gates;    // gate_ids consumed per replay
+  uint64_t n_ct;       // ciphertexts per replay
+  uint32_t n_steps;
+  uint32_t n_slots;
+  uint32_t replays;
+  uint32_t ct_cap_replays;
+  uint32_t n_fb;
+  uint32_t fb_stage_base;
+};
+
+}  // namespace dev
+}  // namespace gsv
+
+extern "C" {
+int gsvk_upload_round_keys(const uint32_t rk[44]);
+int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, int evaluate, hipStream_t stream);
+int gsvk_gather_outputs(const void* W, const void* VB, uint32_t n_slots, const uint32_t* slots, uint32_t n_out, uint32_t n_instances,
+                        void* out, void* out_bits, hipStream_t stream);
+int gsvk_scatter_bits(void* VB, uint32_t n_slots, uint32_t first_slot, const void* bits, uint32_t n, uint32_t n_instances, hipStream_t stream);
+}

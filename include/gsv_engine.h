@@ -1,0 +1,145 @@
+/* gsv_engine.h — C ABI of the MI355X (gfx950) garbling / evaluation engine.
+ *
+ * This is the drop-in boundary for the reference's hot path (BitVM/garbled-snark-verifier v0.4.0).
+ * The reference has no FFI; its seam is the Rust trait trio
+ *     CircuitMode        src/circuit/modes.rs:26-51
+ *     CiphertextHandler  src/circuit/mod.rs:140-178
+ *     CiphertextSource   src/circuit/ciphertext_source.rs:14-21
+ * A `GpuGarbleMode` / `GpuEvaluateMode` (`impl CircuitMode`) placed next to garble_mode.rs forwards
+ * to the functions below (binding shown in INTEGRATION.md).  Plain pointers and sizes only; every
+ * function returns 0 on success and a non-zero gsv_status otherwise (the C side never unwinds; the
+ * Rust shim turns non-zero into panic! to keep the reference's error behaviour).  All label buffers
+ * are arrays of 16-byte records in `S::to_bytes()` order (big-endian u128, src/core/s.rs:25-31) —
+ * the same bytes the reference writes to gc_{i}.bin (src/cut_and_choose/ciphertext_repository.rs:94-106).
+ *
+ * Object model
+ *   gsv_recorder  one per circuit: records the gate stream that `CircuitMode::evaluate_gate`
+ *                 receives (or a built-in restated gadget circuit) — replaces GarbleMode's per-gate
+ *                 loop body (garble_mode.rs:160-222) with "enqueue".
+ *   gsv_program   the recorded stream compiled into dependency-levelled device steps; shared by all
+ *                 instances of a cut-and-choose run (cut_and_choose/garbler.rs:206-234 garbles the SAME
+ *                 circuit once per seed).
+ *   gsv_engine    one per GPU / per host thread; owns the HIP stream, device tables and buffers.
+ *   gsv_session   one batch of instances garbled or evaluated on a program: wire files, ciphertext
+ *                 streams, outputs.
+ */
+#ifndef GSV_ENGINE_H
+#define GSV_ENGINE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gsv_status {
+  GSV_OK = 0,
+  GSV_ERR_INVALID = 1,   /* bad argument / state */
+  GSV_ERR_CIRCUIT = 2,   /* what the reference would panic! on (missing wire, arity mismatch, ...) */
+  GSV_ERR_DEVICE = 3,    /* HIP failure or no gfx950 device: the engine has NO CPU fallback */
+  GSV_ERR_EXHAUSTED = 4  /* ciphertext source exhausted (evaluate_mode.rs:141) */
+} gsv_status;
+
+/* Gate record = reference `Gate` (src/core/gate.rs:7-12) with u64 wire ids; `gate_type` is the
+ * `GateType` repr(C) discriminant (src/core/gate_type.rs:3-15): And 0, Nand 1, Nimp 2, Imp 3,
+ * Ncimp 4, Cimp 5, Nor 6, Or 7, Xor 8, Xnor 9, Not 10. */
+typedef struct gsv_gate {
+  uint64_t wire_a, wire_b, wire_c; /* wire_c == GSV_WIRE_UNREACHABLE: dead gate (gate_id still consumed) */
+  uint8_t gate_type;
+  uint8_t pad[7];
+} gsv_gate;
+#define GSV_WIRE_FALSE 0ull             /* circuit_context_trait.rs:2 */
+#define GSV_WIRE_TRUE 1ull              /* circuit_context_trait.rs:3 */
+#define GSV_WIRE_UNREACHABLE (~0ull)    /* src/core/wire.rs:8 */
+
+typedef struct gsv_recorder gsv_recorder;
+typedef struct gsv_program gsv_program;
+typedef struct gsv_engine gsv_engine;
+typedef struct gsv_session gsv_session;
+
+const char* gsv_last_error(void); /* thread-local message for the last non-zero status */
+
+/* ---- recording: the CircuitMode seam ------------------------------------------------------- */
+int gsv_recorder_create(gsv_recorder** out);
+void gsv_recorder_destroy(gsv_recorder* r);
+/* CircuitMode::allocate_wire (modes.rs:38; storage.rs:119-133): credits == 0 -> GSV_WIRE_UNREACHABLE. */
+int gsv_recorder_allocate_wire(gsv_recorder* r, uint16_t credits, uint64_t* wire_out);
+/* CircuitMode::feed_wire for a root input (EncodeInput::encode): declares `wire` as the next circuit input. */
+int gsv_recorder_declare_input(gsv_recorder* r, uint64_t wire);
+/* CircuitMode::evaluate_gate (modes.rs:36), batched: n gates in stream order. */
+int gsv_recorder_push_gates(gsv_recorder* r, const gsv_gate* gates, size_t n);
+/* CircuitOutput::decode wire list (circuit/mod.rs:283): declares the circuit's output wires, in order. */
+int gsv_recorder_declare_outputs(gsv_recorder* r, const uint64_t* wires, size_t n);
+/* Record one of the built-in restated circuits (host mirror of src/gadgets, driven through the
+ * two-pass credit driver of src/circuit/streaming_mode.rs) e.g. "u254_add", "fq_mul", "fq12_mul". */
+int gsv_recorder_record_circuit(gsv_recorder* r, const char* circuit_spec);
+/* What has been recorded so far: declared inputs / outputs and gates pushed (dead ones included). */
+int gsv_recorder_counts(const gsv_recorder* r, uint64_t* n_inputs, uint64_t* n_outputs, uint64_t* n_gates);
+
+/* ---- compile -------------------------------------------------------------------------------- */
+/* feedback pairs (output index -> input index) are copied at the end of every replay, so that a
+ * program garbled with `replays = K` equals K chained calls of the component (gate ids and the
+ * ciphertext stream continue across replays). n_feedback may be 0. */
+int gsv_program_compile(gsv_recorder* r, const uint32_t* fb_out_idx, const uint32_t* fb_in_idx, size_t n_feedback, gsv_program** out);
+void gsv_program_destroy(gsv_program* p);
+typedef struct gsv_program_info {
+  uint64_t n_inputs, n_outputs;
+  uint64_t n_gates;        /* per replay, dead gates included (= GateCount total, gate_type.rs:123-148) */
+  uint64_t n_ciphertexts;  /* per replay */
+  uint64_t n_dead;
+  uint64_t gate_count[11]; /* by GateType discriminant */
+  uint64_t n_steps, and_depth, n_and_steps, max_step_width; /* device steps; AND-depth of the DAG; steps holding AES work */
+  uint64_t n_slots, peak_live;
+  uint64_t device_bytes;   /* size of the program image in HBM */
+} gsv_program_info;
+int gsv_program_get_info(const gsv_program* p, gsv_program_info* info);
+
+/* ---- engine --------------------------------------------------------------------------------- */
+int gsv_engine_create(int device, gsv_engine** out); /* fails with GSV_ERR_DEVICE if no HIP device */
+void gsv_engine_destroy(gsv_engine* e);
+
+/* Seed -> labels exactly as GarbleMode::new + issue_garbled_wire draw them (garble_mode.rs:80-97,
+ * 116-118): delta, false.label0, true.label0, then n_inputs input label0s.  Host-only helper for the
+ * stand-alone harness; a Rust host passes its own labels. */
+int gsv_labels_from_seed(uint64_t seed, size_t n_inputs, uint8_t delta[16], uint8_t false_label0[16], uint8_t true_label0[16], uint8_t* input_label0);
+
+/* ---- sessions: one batch of instances on one program ---------------------------------------- */
+/* ct_capacity_replays: how many replays' worth of ciphertexts each instance's device stream holds
+ * (a ring indexed by replay); pass `replays` to keep the whole stream. */
+int gsv_session_create(gsv_engine* e, const gsv_program* p, size_t n_instances, uint64_t replays, uint64_t ct_capacity_replays, gsv_session** out);
+void gsv_session_destroy(gsv_session* s);
+
+/* Garble (GarbleMode): per instance i: delta[16i..], const_label0 = {false.label0, true.label0}
+ * (32 B per instance), input_label0 (n_inputs*16 B per instance).  Asynchronous on the engine stream. */
+int gsv_session_set_garble_inputs(gsv_session* s, const uint8_t* delta, const uint8_t* const_label0, const uint8_t* input_label0);
+int gsv_session_garble(gsv_session* s, uint64_t gate_id_base);
+/* Evaluate (EvaluateMode): const_active = {false active label, true active label} (evaluate_mode.rs:70),
+ * input_active labels + plaintext bits (evaluate_mode.rs:15-18).  Ciphertexts come from the session's
+ * device stream: either uploaded with gsv_session_upload_ciphertexts (CiphertextSource / gc_{i}.bin
+ * bytes) or left there by a previous gsv_session_garble on the same session. */
+int gsv_session_set_evaluate_inputs(gsv_session* s, const uint8_t* const_active, const uint8_t* input_active, const uint8_t* input_bits);
+int gsv_session_upload_ciphertexts(gsv_session* s, size_t instance, const uint8_t* cts, uint64_t n_records);
+int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base);
+
+int gsv_session_sync(gsv_session* s);
+/* seconds of device time of the last garble/evaluate launch (HIP events on the engine stream) */
+int gsv_session_last_kernel_ms(gsv_session* s, double* ms);
+
+/* Outputs after sync.  Garble: label0 per output wire (label1 = label0 ^ delta).  Evaluate: active
+ * label + plaintext bit per output wire. */
+int gsv_session_read_outputs(gsv_session* s, uint8_t* labels /* n_inst*n_out*16 */, uint8_t* bits /* n_inst*n_out or NULL */);
+/* CiphertextHandler side: copy `n_records` 16-byte ciphertexts of one instance, starting at stream
+ * index `first`, to host memory (gate order, no framing). */
+int gsv_session_read_ciphertexts(gsv_session* s, size_t instance, uint64_t first, uint64_t n_records, uint8_t* out);
+/* AESAccumulatingHash over the instance's full retained stream (ciphertext_hasher.rs:23-29):
+ * D2H in chunks + AES-NI CBC-MAC on the calling host thread. */
+int gsv_session_ciphertext_hash(gsv_session* s, size_t instance, uint8_t hash[16]);
+/* Stand-alone host CBC-MAC (AESAccumulatingHash) over a byte stream, chaining from `state`. */
+int gsv_cbcmac_update(uint8_t state[16], const uint8_t* cts, uint64_t n_records);
+/* AesLabelCommitHasher: AES_K(label) for n labels (cut_and_choose/mod.rs:41-48). */
+int gsv_commit_labels(const uint8_t* labels, uint64_t n, uint8_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSV_ENGINE_H */

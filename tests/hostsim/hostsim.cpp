@@ -1,0 +1,168 @@
+// TEST-ONLY host interpreter of the engine's compiled gate programs.
+//
+// Purpose: exercise, on a machine WITHOUT a GPU, exactly the pieces the gfx950 kernel is built from —
+// RecordMode + compile_program (csrc/engine/program.hpp), the T-table AES / half-gate math of
+// csrc/engine/gate_math.hpp and the table/seed code of csrc/engine/host_crypto.hpp — by walking the
+// device schedule step by step the way run_program_kernel does.  Gates inside a step are visited in
+// REVERSE order so that any dependency between gates of one step (a scheduling bug) shows up as a
+// mismatch against the oracle.  This file is linked only into tests/hostsim/libgsv_hostsim.so; the
+// product library (libgsv_engine.so) has no CPU execution path.
+#include <cstring>
+#include <memory>
+
+#include "../../garbled_snark_verifier_amd/csrc/engine/gate_math.hpp"
+#include "../../garbled_snark_verifier_amd/csrc/engine/host_crypto.hpp"
+#include "../../garbled_snark_verifier_amd/csrc/engine/program.hpp"
+#include "../../garbled_snark_verifier_amd/csrc/gadgets/circuits.hpp"
+
+using namespace gsv;
+using gsv::dev::Label;
+
+static thread_local std::string g_err;
+
+static Label load(const uint8_t* p) { Label l; std::memcpy(l.w, p, 16); return l; }
+static void store(uint8_t* p, const Label& l) { std::memcpy(p, l.w, 16); }
+
+struct SimProgram {
+  Program prog;
+};
+
+extern "C" {
+
+const char* hostsim_last_error() { return g_err.c_str(); }
+
+int hostsim_compile(const char* spec, int chain_feedback, SimProgram** out, uint64_t* info /* 12 */) {
+  try {
+    NamedCircuit nc = make_circuit(spec);
+    RecordMode mode;
+    StreamingRunner run(mode, nc.n_inputs, nc.fn);
+    std::vector<uint32_t> in_ssa, out_ssa;
+    for (WireId w : run.prepare()) in_ssa.push_back(mode.define_input(w));
+    for (WireId w : run.execute()) out_ssa.push_back(mode.current(w));
+    std::vector<std::pair<uint32_t, uint32_t>> fb;
+    if (chain_feedback) for (uint32_t i = 0; i < out_ssa.size(); ++i) fb.push_back({i, i});  // output i -> input i
+    auto sp = std::make_unique<SimProgram>();
+    sp->prog = compile_program(mode.trace(), in_ssa, out_ssa, fb);
+    const Program& g = sp->prog;
+    if (info) {
+      info[0] = g.input_slots.size(); info[1] = g.output_slots.size(); info[2] = g.n_gates; info[3] = g.n_ct; info[4] = g.n_dead;
+      info[5] = g.steps.size(); info[6] = g.and_depth; info[7] = g.n_and_steps; info[8] = g.max_step_width; info[9] = g.n_slots;
+      info[10] = g.peak_live; info[11] = run.ctx().component_calls;
+    }
+    *out = sp.release();
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+void hostsim_free(SimProgram* p) { delete p; }
+
+// mode 0 = garble, 1 = evaluate.  Buffers as in include/gsv_engine.h (16-byte records).
+int hostsim_run(SimProgram* sp, int evaluate, uint32_t replays, uint64_t gid_base, const uint8_t delta[16], const uint8_t consts[32],
+                const uint8_t* inputs, const uint8_t* input_bits, uint8_t* cts /* in (evaluate) / out (garble): replays*n_ct*16 */,
+                uint8_t* out_labels, uint8_t* out_bits) {
+  try {
+    const Program& g = sp->prog;
+    const AesTables& T = AesTables::fixed_key();
+    dev::AesCtx aes{T.te[0], T.te[1], T.te[2], T.te[3], T.rk};
+    std::vector<uint8_t> W(size_t(g.n_slots) * 16, 0xA5);  // poison: reading a never-written slot is visible
+    std::vector<uint8_t> VB(g.n_slots, 0);
+    std::memcpy(&W[0], consts, 32);
+    VB[0] = 0; VB[1] = 1;
+    for (size_t i = 0; i < g.input_slots.size(); ++i) {
+      std::memcpy(&W[size_t(g.input_slots[i]) * 16], inputs + 16 * i, 16);
+      if (evaluate) VB[g.input_slots[i]] = input_bits[i] ? 1 : 0;
+    }
+    Label d = evaluate ? Label{{0, 0, 0, 0}} : load(delta);
+    for (uint32_t rep = 0; rep < replays; ++rep) {
+      const uint64_t gb = gid_base + uint64_t(rep) * g.n_gates;
+      uint8_t* ct = cts + size_t(rep) * g.n_ct * 16;
+      for (const StepDesc& sd : g.steps) {
+        // snapshot semantics: all reads of a step see the state before the step (as on the GPU,
+        // where every lane loads its operands before anyone's store is guaranteed visible)
+        std::vector<std::pair<uint32_t, Label>> wr;
+        std::vector<std::pair<uint32_t, uint8_t>> wb;
+        wr.reserve(sd.and_cnt + sd.xor_cnt);
+        for (uint32_t k = sd.xor_cnt; k-- > 0;) {
+          const XorRec& r = g.xors[sd.xor_off + k];
+          Label a = load(&W[size_t(r.a) * 16]), b = load(&W[size_t(r.b) * 16]);
+          if (!evaluate) wr.push_back({r.c, dev::garble_free(r.type, a, b, d)});
+          else {
+            wr.push_back({r.c, dev::degarble_free(r.type, a, b)});
+            wb.push_back({r.c, uint8_t(dev::gate_eval_bit(r.type, VB[r.a], VB[r.b]))});
+          }
+        }
+        for (uint32_t k = sd.and_cnt; k-- > 0;) {
+          const AndRec& r = g.ands[sd.and_off + k];
+          Label a = load(&W[size_t(r.a) * 16]), b = load(&W[size_t(r.b) * 16]);
+          if (!evaluate) {
+            Label c0, c;
+            dev::garble_and(aes, r.type, a, b, d, gb + r.gid, c0, c);
+            wr.push_back({r.c, c0});
+            store(ct + size_t(r.ct) * 16, c);
+          } else {
+            Label c = load(ct + size_t(r.ct) * 16);
+            wr.push_back({r.c, dev::degarble_and(aes, r.type, c, a, VB[r.a], b, gb + r.gid)});
+            wb.push_back({r.c, uint8_t(dev::gate_eval_bit(r.type, VB[r.a], VB[r.b]))});
+          }
+        }
+        for (auto& x : wr) store(&W[size_t(x.first) * 16], x.second);
+        for (auto& x : wb) VB[x.first] = x.second;
+      }
+      if (!g.fb_src_slot.empty()) {
+        std::vector<uint8_t> tmp(g.fb_src_slot.size() * 16), tb(g.fb_src_slot.size());
+        for (size_t i = 0; i < g.fb_src_slot.size(); ++i) { std::memcpy(&tmp[16 * i], &W[size_t(g.fb_src_slot[i]) * 16], 16); tb[i] = VB[g.fb_src_slot[i]]; }
+        for (size_t i = 0; i < g.fb_dst_slot.size(); ++i) { std::memcpy(&W[size_t(g.fb_dst_slot[i]) * 16], &tmp[16 * i], 16); VB[g.fb_dst_slot[i]] = tb[i]; }
+      }
+    }
+    for (size_t i = 0; i < g.output_slots.size(); ++i) {
+      std::memcpy(out_labels + 16 * i, &W[size_t(g.output_slots[i]) * 16], 16);
+      if (out_bits) out_bits[i] = VB[g.output_slots[i]];
+    }
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// raw trace export (type, a, b, c as SSA ids; c = 0xFFFFFFFF for dead gates) for schedule experiments
+int hostsim_trace(const char* spec, uint64_t cap, uint8_t* type, uint32_t* a, uint32_t* b, uint32_t* c, uint64_t* n_out, uint32_t* n_wires,
+                  uint32_t* in_ssa, uint32_t* out_ssa) {
+  try {
+    NamedCircuit nc = make_circuit(spec);
+    RecordMode mode;
+    StreamingRunner run(mode, nc.n_inputs, nc.fn);
+    size_t k = 0;
+    for (WireId w : run.prepare()) in_ssa[k++] = mode.define_input(w);
+    k = 0;
+    for (WireId w : run.execute()) out_ssa[k++] = mode.current(w);
+    const Trace& t = mode.trace();
+    *n_out = t.size(); *n_wires = t.n_wires;
+    if (t.size() > cap) return 2;
+    std::memcpy(type, t.type.data(), t.size()); std::memcpy(a, t.a.data(), 4 * t.size());
+    std::memcpy(b, t.b.data(), 4 * t.size()); std::memcpy(c, t.c.data(), 4 * t.size());
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// host crypto of the product, for known-answer tests
+void hostsim_labels_from_seed(uint64_t seed, uint64_t n, uint8_t* out) {
+  ChaCha20Seed r(seed);
+  for (uint64_t i = 0; i < n; ++i) r.next_label(out + 16 * i);
+}
+void hostsim_cbcmac(const uint8_t* cts, uint64_t n, uint8_t out[16]) {
+  CbcMacHost m;
+  m.update(cts, n);
+  m.digest(out);
+}
+void hostsim_aes_ttable(const uint8_t in[16], uint8_t out[16]) {
+  const AesTables& T = AesTables::fixed_key();
+  dev::AesCtx aes{T.te[0], T.te[1], T.te[2], T.te[3], T.rk};
+  Label o = dev::aes128_encrypt(aes, load(in));
+  store(out, o);
+}
+void hostsim_aes_portable(const uint8_t in[16], uint8_t out[16]) { CbcMacHost::encrypt_portable(AesTables::fixed_key(), in, out); }
+void hostsim_hash(const uint8_t label[16], uint64_t gid, uint8_t out[16]) {
+  const AesTables& T = AesTables::fixed_key();
+  dev::AesCtx aes{T.te[0], T.te[1], T.te[2], T.te[3], T.rk};
+  store(out, dev::hash_with_gate(aes, load(label), gid));
+}
+void hostsim_sbox(uint8_t out[256]) { std::memcpy(out, AesTables::fixed_key().sbox, 256); }
+
+}  // extern "C"

@@ -1,0 +1,115 @@
+"""ctypes binding for tests/hostsim (TEST-ONLY host interpreter of compiled engine programs)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "hostsim", "libgsv_hostsim.so")
+_lib = None
+INFO_FIELDS = ["n_inputs", "n_outputs", "n_gates", "n_ct", "n_dead", "n_steps", "and_depth", "n_and_steps", "max_step_width", "n_slots",
+               "peak_live", "component_calls"]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "hostsim")], stdout=subprocess.DEVNULL)
+        L = C.CDLL(_SO)
+        L.hostsim_last_error.restype = C.c_char_p
+        u8p = C.POINTER(C.c_uint8)
+        L.hostsim_compile.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.hostsim_free.argtypes = [C.c_void_p]
+        L.hostsim_run.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
+        L.hostsim_labels_from_seed.argtypes = [C.c_uint64, C.c_uint64, u8p]
+        L.hostsim_cbcmac.argtypes = [u8p, C.c_uint64, u8p]
+        L.hostsim_aes_ttable.argtypes = [u8p, u8p]
+        L.hostsim_aes_portable.argtypes = [u8p, u8p]
+        L.hostsim_hash.argtypes = [u8p, C.c_uint64, u8p]
+        L.hostsim_sbox.argtypes = [u8p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8)) if a is not None else None
+
+
+class SimProgram:
+    def __init__(self, spec, chain_feedback=False):
+        h = C.c_void_p()
+        info = np.zeros(12, np.uint64)
+        if lib().hostsim_compile(spec.encode(), int(chain_feedback), C.byref(h), info.ctypes.data_as(C.POINTER(C.c_uint64))):
+            raise RuntimeError(lib().hostsim_last_error().decode())
+        self.h = h
+        self.info = dict(zip(INFO_FIELDS, (int(x) for x in info)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().hostsim_free(self.h)
+            self.h = None
+
+    def garble(self, delta, consts, inputs, replays=1, gid_base=0):
+        n_out, n_ct = self.info["n_outputs"], self.info["n_ct"]
+        cts = np.zeros((replays * n_ct, 16), np.uint8)
+        out = np.zeros((n_out, 16), np.uint8)
+        inputs = np.ascontiguousarray(inputs, np.uint8)
+        consts = np.ascontiguousarray(consts, np.uint8)
+        delta = np.ascontiguousarray(delta, np.uint8)
+        if lib().hostsim_run(self.h, 0, replays, gid_base, _p(delta), _p(consts), _p(inputs), None, _p(cts), _p(out), None):
+            raise RuntimeError(lib().hostsim_last_error().decode())
+        return out, cts
+
+    def evaluate(self, consts_active, inputs_active, input_bits, cts, replays=1, gid_base=0):
+        n_out = self.info["n_outputs"]
+        out = np.zeros((n_out, 16), np.uint8)
+        bits = np.zeros(n_out, np.uint8)
+        cts = np.ascontiguousarray(cts, np.uint8).copy()
+        ia = np.ascontiguousarray(inputs_active, np.uint8)
+        ib = np.ascontiguousarray(input_bits, np.uint8)
+        ca = np.ascontiguousarray(consts_active, np.uint8)
+        z = np.zeros(16, np.uint8)
+        if lib().hostsim_run(self.h, 1, replays, gid_base, _p(z), _p(ca), _p(ia), _p(ib), _p(cts), _p(out), _p(bits)):
+            raise RuntimeError(lib().hostsim_last_error().decode())
+        return out, bits
+
+
+def labels_from_seed(seed, n):
+    out = np.zeros((n, 16), np.uint8)
+    lib().hostsim_labels_from_seed(seed, n, _p(out))
+    return out
+
+
+def cbcmac(cts):
+    a = np.ascontiguousarray(cts, np.uint8).reshape(-1)
+    out = np.zeros(16, np.uint8)
+    lib().hostsim_cbcmac(_p(a) if a.size else None, a.size // 16, _p(out))
+    return out.tobytes()
+
+
+def aes_ttable(block):
+    i = np.frombuffer(bytes(block), np.uint8).copy()
+    o = np.zeros(16, np.uint8)
+    lib().hostsim_aes_ttable(_p(i), _p(o))
+    return o.tobytes()
+
+
+def aes_portable(block):
+    i = np.frombuffer(bytes(block), np.uint8).copy()
+    o = np.zeros(16, np.uint8)
+    lib().hostsim_aes_portable(_p(i), _p(o))
+    return o.tobytes()
+
+
+def hash_with_gate(label, gid):
+    i = np.frombuffer(bytes(label), np.uint8).copy()
+    o = np.zeros(16, np.uint8)
+    lib().hostsim_hash(_p(i), gid, _p(o))
+    return o.tobytes()
+
+
+def sbox():
+    o = np.zeros(256, np.uint8)
+    lib().hostsim_sbox(_p(o))
+    return o
