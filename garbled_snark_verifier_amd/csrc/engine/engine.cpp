@@ -333,6 +333,7 @@ static int launch(gsv_session* s, uint64_t gate_id_base, bool eval) {
   ka.ct_stride = s->ct_stride(); ka.gid_base = gate_id_base; ka.n_gates = g.n_gates; ka.n_ct = g.n_ct;
   ka.n_steps = uint32_t(g.steps.size()); ka.n_slots = g.n_slots; ka.replays = uint32_t(s->replays); ka.ct_cap_replays = uint32_t(s->ct_cap);
   ka.n_fb = uint32_t(g.fb_src_slot.size()); ka.fb_stage_base = g.fb_stage_base;
+  if (const char* dg = getenv("GSV_DIAG")) ka.diag = uint32_t(atoi(dg));  // timing experiments: outputs are wrong when set
   HIPCHK(hipEventRecord(s->ev0, s->e->stream));
   if (ka.n_steps) {
     if (gsvk_launch_program(&ka, uint32_t(s->n_inst), eval ? 1 : 0, s->e->stream) != 0) return fail(GSV_ERR_DEVICE, "kernel launch failed");
