@@ -150,7 +150,7 @@ int gsv_program_compile(gsv_recorder* r, const uint32_t* fb_out_idx, const uint3
   std::unique_ptr<gsv_program> p(new gsv_program());
   p->prog = compile_program(r->mode.trace(), r->inputs, r->outputs, fb);
   for (size_t i = 0; i < p->prog.input_slots.size(); ++i)
-    if (p->prog.input_slots[i] != 2 + i) return fail(GSV_ERR_CIRCUIT, "internal: inputs are not slot-contiguous");
+    if (p->prog.input_slots[i] != SLOT_FIRST_INPUT + i) return fail(GSV_ERR_CIRCUIT, "internal: inputs are not slot-contiguous");
   *out = p.release();
   return GSV_OK;
   GSV_CATCH
@@ -173,6 +173,7 @@ int gsv_program_get_info(const gsv_program* p, gsv_program_info* info) {
   for (int i = 0; i < 11; ++i) info->gate_count[i] = g.gate_count[i];
   info->n_steps = g.steps.size(); info->and_depth = g.and_depth; info->n_and_steps = g.n_and_steps; info->max_step_width = g.max_step_width;
   info->n_slots = g.n_slots; info->peak_live = g.peak_live; info->device_bytes = p->image_bytes();
+  info->n_lds_slots = g.n_lds_slots; info->reads_lds = g.reads_lds; info->reads_hbm = g.reads_hbm; info->writes_lds = g.writes_lds; info->writes_hbm = g.writes_hbm;
   return GSV_OK;
 }
 
@@ -274,14 +275,14 @@ void gsv_session_destroy(gsv_session* s) {
 }
 
 static int stage_labels(gsv_session* s, const uint8_t* consts, const uint8_t* inputs) {
-  // Per instance the wire file starts [const0, const1, input0, input1, ...]: one strided copy.
+  // Per instance the wire file starts [FALSE, TRUE, ZERO, input0, input1, ...]: one strided copy.
   const Program& g = s->p->prog;
   const size_t n_in = g.input_slots.size();
-  const size_t row = (2 + n_in) * 16;
-  std::vector<uint8_t> host(s->n_inst * row);
+  const size_t row = (SLOT_FIRST_INPUT + n_in) * 16;
+  std::vector<uint8_t> host(s->n_inst * row, 0);
   for (size_t i = 0; i < s->n_inst; ++i) {
     std::memcpy(&host[i * row], consts + 32 * i, 32);
-    if (n_in) std::memcpy(&host[i * row + 32], inputs + i * n_in * 16, n_in * 16);
+    if (n_in) std::memcpy(&host[i * row + SLOT_FIRST_INPUT * 16], inputs + i * n_in * 16, n_in * 16);
   }
   HIPCHK(hipMemcpy2D(s->W, size_t(g.n_slots) * 16, host.data(), row, row, s->n_inst, hipMemcpyHostToDevice));
   return GSV_OK;
@@ -309,7 +310,7 @@ int gsv_session_set_evaluate_inputs(gsv_session* s, const uint8_t* const_active,
     std::vector<uint8_t> nb(s->n_inst * n_in);
     for (size_t i = 0; i < nb.size(); ++i) nb[i] = input_bits[i] ? 1 : 0;
     HIPCHK(hipMemcpy(s->in_bits, nb.data(), nb.size(), hipMemcpyHostToDevice));
-    if (gsvk_scatter_bits(s->VB, g.n_slots, 2, s->in_bits, uint32_t(n_in), uint32_t(s->n_inst), nullptr) != 0) return fail(GSV_ERR_DEVICE, "scatter_bits launch failed");
+    if (gsvk_scatter_bits(s->VB, g.n_slots, SLOT_FIRST_INPUT, s->in_bits, uint32_t(n_in), uint32_t(s->n_inst), nullptr) != 0) return fail(GSV_ERR_DEVICE, "scatter_bits launch failed");
     HIPCHK(hipDeviceSynchronize());
   }
   return GSV_OK;

@@ -5,10 +5,10 @@
 // width a few hundred gates), so a step is latency-bound, not throughput-bound: the workgroup walks
 // the program's steps with `s_barrier` between them — no grid-wide synchronisation, no inter-CU
 // traffic — and independent cut-and-choose instances fill the other CUs.
-//   * wire file W[instance][slot] : 16-byte labels in HBM, L2-resident working set, 128-bit
-//     coalescable loads/stores (global_load_dwordx4)
-//   * AES T-tables: 128 KiB in LDS per workgroup, bank-replicated so lookups never conflict;
-//     round keys scalar (constant address space)
+//   * two-level wire file: short-lived labels (most of them) in a 120 KiB LDS window chosen by the
+//     compiler's fan-out/lifetime pass, long-lived ones in W[instance][slot] in HBM (128-bit accesses,
+//     next-fit slot order so that a step's stores coalesce)
+//   * AES table Te0: 32 KiB in LDS, bank-replicated so lookups never conflict; round keys scalar
 //   * within a step the AND-family records and the free-gate records are two contiguous runs, so
 //     only one wave per step diverges on the gate kind (no per-lane ballot/compaction needed);
 //     records of the NEXT step are prefetched into registers before the barrier
@@ -24,45 +24,91 @@ namespace dev {
 
 __constant__ uint32_t c_rk[44];
 
-__device__ __forceinline__ Label ld_label(const uint4* p) {
-  uint4 v = *p;
-  return Label{{v.x, v.y, v.z, v.w}};
-}
-__device__ __forceinline__ void st_label(uint4* p, const Label& l) { *p = make_uint4(l.w[0], l.w[1], l.w[2], l.w[3]); }
+// Native 128-bit / 64-bit vectors (copyable across address spaces, one dwordx4 / dwordx2 access each).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-// T-tables in LDS, every entry replicated once per LDS bank: dword index = K*8192 + x*32 + (lane & 31).
-// A wave's ds_read_b32 is served in two 32-lane groups (MI355X_MICROARCH.md §LDS); inside a group lane j
-// only ever touches bank j, so 64 data-dependent lookups cost the conflict-free 2 cycles instead of the
-// ~3.5x of a shared 1 KiB table.  4 tables x 256 entries x 32 banks x 4 B = 128 KiB of the CU's 160 KiB.
-struct LdsBankedTables {
-  const char* base;   // LDS
-  uint32_t off[4];    // (lane & 31) * 4 + K * 32768, bytes
+// LDS map of a workgroup (163,328 of the CU's 163,840 bytes):
+//   [0, 32 KiB)            AES table Te0, every entry replicated once per LDS bank: dword x*32 + (lane & 31).
+//                          A wave's ds_read_b32 is served in two 32-lane groups (MI355X_MICROARCH.md §LDS);
+//                          inside a group lane j only touches bank j, so 64 data-dependent lookups cost the
+//                          conflict-free 2 cycles (SQ_LDS_BANK_CONFLICT = 0 in profiles/).  Te1..Te3 are byte
+//                          rotations of Te0 (one v_alignbit each).
+//   [32 KiB, +120 KiB)     label window: GSV_LDS_SLOTS x 16 B, the short-lived wires chosen by the compiler
+//   [.., +7.5 KiB)         plaintext bits of window wires (evaluate mode)
+#define GSV_LDS_SLOTS 7680u
+#define GSV_LDS_TABLE_BYTES 32768u
+#define GSV_LDS_BYTES (GSV_LDS_TABLE_BYTES + GSV_LDS_SLOTS * 16u + GSV_LDS_SLOTS)
+#define GSV_SLOT_LDS_FLAG (1u << 20)
+#define GSV_SLOT_INDEX_MASK (GSV_SLOT_LDS_FLAG - 1u)
+#define GSV_SLOT_MASK ((1u << 21) - 1u)
+
+// Address-space-qualified pointers keep every access a plain ds_* or global_* instruction (no
+// generic/flat pointers, which would also need a null-checked LDS->flat cast).
+#define GSV_LDS __attribute__((address_space(3)))
+#define GSV_GLB __attribute__((address_space(1)))
+typedef uint32_t GSV_LDS lds_u32;
+typedef u32x4 GSV_LDS lds_u128;
+typedef uint8_t GSV_LDS lds_u8;
+typedef u32x4 GSV_GLB glb_u128;
+typedef u32x2 GSV_GLB glb_u64;
+typedef uint8_t GSV_GLB glb_u8;
+
+struct LdsBankedTable {
+  uint32_t lane4;  // (lane & 31) * 4; the table starts at LDS byte 0
   template <int K, int BYTE>
   __device__ __forceinline__ uint32_t lk(uint32_t s) const {
     // byte BYTE of s, times 128 (32 banks x 4 B), as bits 7..14
-    uint32_t x = BYTE == 0 ? (s << 7) : BYTE == 1 ? (s >> 1) : BYTE == 2 ? (s >> 9) : (s >> 17);
-    return *reinterpret_cast<const uint32_t*>(base + ((x & 0x7f80u) | off[K]));
+    const uint32_t x = BYTE == 0 ? (s << 7) : BYTE == 1 ? (s >> 1) : BYTE == 2 ? (s >> 9) : (s >> 17);
+    const uint32_t v = *reinterpret_cast<const lds_u32*>(uintptr_t((x & 0x7f80u) | lane4));
+    return K == 0 ? v : __builtin_amdgcn_alignbit(v, v, 32 - 8 * K);  // rotl(v, 8K): Te_K from Te0
   }
 };
-#define GSV_TE_LDS_WORDS (4 * 256 * 32)
+
+struct WireFile {
+  glb_u128* hbm;      // this instance's wire file
+  glb_u8* hbm_bits;   // evaluate: plaintext bits
+  __device__ __forceinline__ static lds_u128* win(uint32_t idx) { return reinterpret_cast<lds_u128*>(uintptr_t(GSV_LDS_TABLE_BYTES + idx * 16u)); }
+  __device__ __forceinline__ static lds_u8* win_bit(uint32_t idx) { return reinterpret_cast<lds_u8*>(uintptr_t(GSV_LDS_TABLE_BYTES + GSV_LDS_SLOTS * 16u + idx)); }
+  __device__ __forceinline__ Label ld(uint32_t slot) const {
+    u32x4 v;
+    if (slot & GSV_SLOT_LDS_FLAG) v = *win(slot & GSV_SLOT_INDEX_MASK); else v = hbm[slot];
+    return Label{{v.x, v.y, v.z, v.w}};
+  }
+  __device__ __forceinline__ void st(uint32_t slot, const Label& l) const {
+    const u32x4 v = {l.w[0], l.w[1], l.w[2], l.w[3]};
+    if (slot & GSV_SLOT_LDS_FLAG) *win(slot & GSV_SLOT_INDEX_MASK) = v; else hbm[slot] = v;
+  }
+  __device__ __forceinline__ uint32_t ld_bit(uint32_t slot) const {
+    uint32_t b;
+    if (slot & GSV_SLOT_LDS_FLAG) b = *win_bit(slot & GSV_SLOT_INDEX_MASK); else b = hbm_bits[slot];
+    return b;
+  }
+  __device__ __forceinline__ void st_bit(uint32_t slot, uint32_t b) const {
+    if (slot & GSV_SLOT_LDS_FLAG) *win_bit(slot & GSV_SLOT_INDEX_MASK) = uint8_t(b); else hbm_bits[slot] = uint8_t(b);
+  }
+};
 
 template <bool EVAL>
 __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelArgs ka) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t s_te[];  // GSV_TE_LDS_WORDS
+  extern __shared__ __attribute__((aligned(16))) char s_mem[];
   const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < GSV_TE_LDS_WORDS; i += GSV_BLOCK_THREADS) s_te[i] = ka.te[((i >> 13) << 8) | ((i >> 5) & 255u)];
+  (void)s_mem;  // the dynamic LDS block starts at LDS address 0 (no static __shared__ in this kernel)
+  for (uint32_t i = tid; i < GSV_LDS_TABLE_BYTES / 4; i += GSV_BLOCK_THREADS) *reinterpret_cast<lds_u32*>(uintptr_t(i * 4u)) = ka.te[i >> 5];
   __syncthreads();
-  const uint32_t lane4 = (tid & 31u) * 4u;
-  const LdsBankedTables aes{reinterpret_cast<const char*>(s_te), {lane4, lane4 + 32768u, lane4 + 65536u, lane4 + 98304u}};
+  const LdsBankedTable aes{(tid & 31u) * 4u};
   const uint32_t* rk = c_rk;
 
   const uint32_t inst = blockIdx.x;
-  uint4* __restrict__ W = ka.W + size_t(inst) * ka.n_slots;
-  uint8_t* __restrict__ VB = EVAL ? ka.VB + size_t(inst) * ka.n_slots : nullptr;
-  uint4* __restrict__ CT = ka.CT + size_t(inst) * ka.ct_stride;
-  const Label delta = EVAL ? Label{{0, 0, 0, 0}} : ld_label(ka.delta + inst);
-  const uint4* __restrict__ and_q = reinterpret_cast<const uint4*>(ka.ands);
-  const uint4* __restrict__ xor_q = reinterpret_cast<const uint4*>(ka.xors);
+  WireFile wf;
+  wf.hbm = (glb_u128*)(ka.W + size_t(inst) * ka.n_slots);      // C-style cast: generic -> global address space
+  wf.hbm_bits = (glb_u8*)(ka.VB + size_t(inst) * ka.n_slots);
+  glb_u128* __restrict__ CT = (glb_u128*)(ka.CT + size_t(inst) * ka.ct_stride);
+  Label delta{{0, 0, 0, 0}};
+  if (!EVAL) { const u32x4 d = ((const glb_u128*)ka.delta)[inst]; delta = Label{{d.x, d.y, d.z, d.w}}; }
+  const glb_u128* __restrict__ and_q = (const glb_u128*)ka.ands;  // 16 B records
+  const glb_u64* __restrict__ xor_q = (const glb_u64*)ka.xors;    // 8 B records
+  const glb_u128* __restrict__ step_q = (const glb_u128*)ka.steps;
 
   for (uint32_t rep = 0; rep < ka.replays; ++rep) {
     const uint64_t gid_base = ka.gid_base + uint64_t(rep) * ka.n_gates;
@@ -70,77 +116,78 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
 
     // step descriptor {and_off, and_cnt, xor_off, xor_cnt}: lanes [0, and_cnt) take AND-family gates,
     // lanes [and_cnt, and_cnt + xor_cnt) take free gates, so only the boundary wave diverges.
-    uint4 sd = reinterpret_cast<const uint4*>(ka.steps)[0];
-    // prefetched records for this thread's first gate of the step
-    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = make_uint4(0, 0, 0, 0);
-    if (tid < sd.y) { r0 = and_q[2 * size_t(sd.x + tid)]; r1 = and_q[2 * size_t(sd.x + tid) + 1]; }
-    else if (tid < sd.y + sd.w) r0 = xor_q[size_t(sd.z + (tid - sd.y))];
+    u32x4 sd = step_q[0];
+    // prefetched record for this thread's first gate of the step
+    u32x4 r0 = {0, 0, 0, 0};
+    if (tid < sd.y) r0 = and_q[size_t(sd.x + tid)];
+    else if (tid < sd.y + sd.w) { const u32x2 x = xor_q[size_t(sd.z + (tid - sd.y))]; r0.x = x.x; r0.y = x.y; }
     for (uint32_t s = 0; s < ka.n_steps; ++s) {
       const uint32_t and_off = sd.x, and_cnt = sd.y, xor_off = sd.z, total = sd.y + sd.w;
       // issue next step's descriptor + record loads early; they complete while this step computes
-      uint4 nsd = sd, n0 = r0, n1 = r1;
-      if (s + 1 < ka.n_steps && !(ka.diag & 2u)) {
-        nsd = reinterpret_cast<const uint4*>(ka.steps)[s + 1];
-        if (tid < nsd.y) { n0 = and_q[2 * size_t(nsd.x + tid)]; n1 = and_q[2 * size_t(nsd.x + tid) + 1]; }
-        else if (tid < nsd.y + nsd.w) n0 = xor_q[size_t(nsd.z + (tid - nsd.y))];
+      u32x4 nsd = sd, n0 = r0;
+      if (s + 1 < ka.n_steps) {
+        nsd = step_q[s + 1];
+        if (tid < nsd.y) n0 = and_q[size_t(nsd.x + tid)];
+        else if (tid < nsd.y + nsd.w) { const u32x2 x = xor_q[size_t(nsd.z + (tid - nsd.y))]; n0.x = x.x; n0.y = x.y; }
       }
       for (uint32_t i = tid; i < total; i += GSV_BLOCK_THREADS) {
+        u32x4 q = r0;
         if (i < and_cnt) {
-          uint4 q0 = r0, q1 = r1;
-          if (i != tid) { q0 = and_q[2 * size_t(and_off + i)]; q1 = and_q[2 * size_t(and_off + i) + 1]; }
-          const uint32_t t = q0.w;
-          const uint64_t gid = gid_base + q1.x;
-          Label a = delta, b = delta;
-          if (!(ka.diag & 4u)) { a = ld_label(W + q0.x); b = ld_label(W + q0.y); }
+          if (i != tid) q = and_q[size_t(and_off + i)];
+        } else if (i != tid) { const u32x2 x = xor_q[size_t(xor_off + (i - and_cnt))]; q.x = x.x; q.y = x.y; }
+        // common slot fields: a = bits 0..20, b = 21..41, c = 42..62 of the low 64 bits
+        const uint32_t sa = q.x & GSV_SLOT_MASK;
+        const uint32_t sb = ((q.x >> 21) | (q.y << 11)) & GSV_SLOT_MASK;
+        const uint32_t sc = (q.y >> 10) & GSV_SLOT_MASK;
+        Label a = delta, b = delta;
+        if (!(ka.diag & 4u)) { a = wf.ld(sa); b = wf.ld(sb); }
+        if (i < and_cnt) {
+          const uint32_t t = (q.y >> 31) | ((q.z & 3u) << 1);
+          const uint64_t hi = (uint64_t(q.w) << 32) | q.z;
+          const uint64_t gid = gid_base + ((hi >> 2) & 0x7FFFFFFFull);
+          const uint32_t cti = uint32_t(hi >> 33);
           if (!EVAL) {
             Label c0, ct;
             if (ka.diag & 1u) { c0 = lxor(a, b); ct = lxor(a, tweak_of(gid)); }
             else garble_and(aes, rk, t, a, b, delta, gid, c0, ct);
             if (!(ka.diag & 8u)) {
-              st_label(W + q0.z, c0);
-              st_label(CT + ct_base + q1.y, ct);
-            } else if (c0.w[0] == 0x12345678u && ct.w[1] == 0x9abcdef0u) st_label(W + q0.z, c0);
+              wf.st(sc, c0);
+              CT[ct_base + cti] = u32x4{ct.w[0], ct.w[1], ct.w[2], ct.w[3]};
+            } else if (c0.w[0] == 0x12345678u && ct.w[1] == 0x9abcdef0u) wf.st(sc, c0);
           } else {
-            const uint32_t va = VB[q0.x], vb = VB[q0.y];
-            const Label ct = ld_label(CT + ct_base + q1.y);
-            st_label(W + q0.z, degarble_and(aes, rk, t, ct, a, va, b, gid));
-            VB[q0.z] = uint8_t(gate_eval_bit(t, va, vb));
+            const uint32_t va = wf.ld_bit(sa), vb = wf.ld_bit(sb);
+            const u32x4 cv = CT[ct_base + cti];
+            const Label ct{{cv.x, cv.y, cv.z, cv.w}};
+            wf.st(sc, degarble_and(aes, rk, t, ct, a, va, b, gid));
+            wf.st_bit(sc, gate_eval_bit(t, va, vb));
           }
         } else {
-          uint4 q0 = r0;
-          if (i != tid) q0 = xor_q[size_t(xor_off + (i - and_cnt))];
-          const uint32_t t = q0.w;
-          Label a = delta, b = delta;
-          if (!(ka.diag & 4u)) { a = ld_label(W + q0.x); b = ld_label(W + q0.y); }
+          const uint32_t xnor = q.y >> 31;
+          const Label x = lxor(a, b);
           if (!EVAL) {
-            const Label c0 = garble_free(t, a, b, delta);
-            if (!(ka.diag & 8u) || c0.w[0] == 0x12345678u) st_label(W + q0.z, c0);
+            const Label c0 = lxor_if(x, delta, xnor);
+            if (!(ka.diag & 8u) || c0.w[0] == 0x12345678u) wf.st(sc, c0);
           } else {
-            st_label(W + q0.z, degarble_free(t, a, b));
-            VB[q0.z] = uint8_t(gate_eval_bit(t, VB[q0.x], VB[q0.y]));
+            wf.st(sc, x);
+            wf.st_bit(sc, (wf.ld_bit(sa) ^ wf.ld_bit(sb) ^ xnor) & 1u);
           }
         }
       }
-      __syncthreads();  // workgroup-scope release/acquire: this step's W stores are visible to every wave
-      if (ka.diag & 2u) {
-        if (s + 1 < ka.n_steps) {
-          nsd = reinterpret_cast<const uint4*>(ka.steps)[s + 1];
-          if (tid < nsd.y) { n0 = and_q[2 * size_t(nsd.x + tid)]; n1 = and_q[2 * size_t(nsd.x + tid) + 1]; }
-          else if (tid < nsd.y + nsd.w) n0 = xor_q[size_t(nsd.z + (tid - nsd.y))];
-        }
-      }
-      sd = nsd; r0 = n0; r1 = n1;
+      __syncthreads();  // workgroup-scope release/acquire: this step's LDS + HBM stores are visible to every wave
+      sd = nsd; r0 = n0;
     }
-    // replay epilogue: feedback copies through staging slots (sources may alias destinations)
+    // replay epilogue: feedback copies through staging slots (sources may alias destinations; all in HBM)
     if (ka.n_fb) {
       for (uint32_t i = tid; i < ka.n_fb; i += GSV_BLOCK_THREADS) {
-        W[ka.fb_stage_base + i] = W[ka.fb_src[i]];
-        if (EVAL) VB[ka.fb_stage_base + i] = VB[ka.fb_src[i]];
+        const u32x4 v = wf.hbm[ka.fb_src[i]];
+        wf.hbm[ka.fb_stage_base + i] = v;
+        if (EVAL) { const uint8_t bv = wf.hbm_bits[ka.fb_src[i]]; wf.hbm_bits[ka.fb_stage_base + i] = bv; }
       }
       __syncthreads();
       for (uint32_t i = tid; i < ka.n_fb; i += GSV_BLOCK_THREADS) {
-        W[ka.fb_dst[i]] = W[ka.fb_stage_base + i];
-        if (EVAL) VB[ka.fb_dst[i]] = VB[ka.fb_stage_base + i];
+        const u32x4 v = wf.hbm[ka.fb_stage_base + i];
+        wf.hbm[ka.fb_dst[i]] = v;
+        if (EVAL) { const uint8_t bv = wf.hbm_bits[ka.fb_stage_base + i]; wf.hbm_bits[ka.fb_dst[i]] = bv; }
       }
       __syncthreads();
     }
@@ -175,7 +222,7 @@ int gsvk_upload_round_keys(const uint32_t rk[44]) {
   return int(hipMemcpyToSymbol(HIP_SYMBOL(gsv::dev::c_rk), rk, 44 * sizeof(uint32_t)));
 }
 int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, int evaluate, hipStream_t stream) {
-  const size_t lds = GSV_TE_LDS_WORDS * sizeof(uint32_t);
+  const size_t lds = GSV_LDS_BYTES;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));

@@ -10,8 +10,10 @@
 // compile_program() turns a trace into the device schedule:
 //   * gates are levelised ASAP over the dataflow DAG; one level = one device step holding that
 //     level's AND-family gates (AES work) and free gates (XOR work) as two homogeneous record runs;
-//   * wire slots are assigned by a linear scan over steps (a slot is recycled one step after its
-//     last reader), which keeps the live window L2-resident instead of one slot per wire.
+//   * wire slots are assigned by a scan over steps (a slot is recycled one step after its last
+//     reader) from two next-fit pools: short-lived wires (the large majority: a ripple-carry bit is
+//     read one or two steps after it is produced) live in the workgroup's LDS label window, the rest
+//     in the instance's HBM wire file.  This is the "active-wire window sized by the fan-out pass".
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -84,10 +86,29 @@ class RecordMode final : public CircuitMode {
   std::vector<uint8_t> written_;
 };
 
-// ---- device-facing program format (all little-endian u32; uploaded verbatim) ----------------------
-struct XorRec { uint32_t a, b, c, type; };                       // 16 B: slots + GateType (8, 9, 10)
-struct AndRec { uint32_t a, b, c, type, gid, ct, pad0, pad1; };  // 32 B: + gate_id and ciphertext index, both
-                                                                 //       relative to the replay's bases
+// ---- device-facing program format (little-endian; uploaded verbatim) -----------------------------
+// A wire location ("slot") is 21 bits: bit 20 set = entry of the workgroup's LDS label window,
+// clear = entry of the instance's wire file in HBM.  HBM slots 0/1/2 hold the FALSE constant, the TRUE
+// constant and the all-zero label (lets the in-place NOT gate be encoded as XNOR(a, ZERO)).
+constexpr uint32_t SLOT_BITS = 21;
+constexpr uint32_t SLOT_LDS_FLAG = 1u << 20;
+constexpr uint32_t SLOT_INDEX_MASK = SLOT_LDS_FLAG - 1;
+constexpr uint32_t SLOT_MASK = (1u << SLOT_BITS) - 1;
+constexpr uint32_t SLOT_FALSE = 0, SLOT_TRUE = 1, SLOT_ZERO = 2, SLOT_FIRST_INPUT = 3;
+constexpr uint32_t LDS_WINDOW_SLOTS = 7680;  // 120 KiB of the CU's 160 KiB (32 KiB go to the banked AES table)
+
+// Free gate, 8 bytes:   bits 0..20 a | 21..41 b | 42..62 c | 63 xnor
+struct XorRec { uint64_t v; };
+inline XorRec pack_xor(uint32_t a, uint32_t b, uint32_t c, bool xnor) {
+  return XorRec{uint64_t(a) | (uint64_t(b) << 21) | (uint64_t(c) << 42) | (uint64_t(xnor ? 1 : 0) << 63)};
+}
+// AND-family gate, 16 bytes: lo = a | b<<21 | c<<42 | (type&1)<<63 ; hi = type>>1 (2 bits) | gid<<2 (31 bits) | ct<<33 (31 bits)
+// gid / ct are relative to the replay's gate-id and ciphertext bases.
+struct AndRec { uint64_t lo, hi; };
+inline AndRec pack_and(uint32_t a, uint32_t b, uint32_t c, uint32_t type, uint32_t gid, uint32_t ct) {
+  return AndRec{uint64_t(a) | (uint64_t(b) << 21) | (uint64_t(c) << 42) | (uint64_t(type & 1u) << 63),
+                uint64_t(type >> 1) | (uint64_t(gid) << 2) | (uint64_t(ct) << 33)};
+}
 struct StepDesc { uint32_t and_off, and_cnt, xor_off, xor_cnt; };  // one dependency level: AND-family + free gates
 
 struct Program {
@@ -95,7 +116,8 @@ struct Program {
   std::vector<AndRec> ands;
   std::vector<XorRec> xors;
   std::vector<uint32_t> input_slots, output_slots;
-  uint32_t n_slots = 0;        // wire-file entries per instance (incl. constants, inputs, feedback staging)
+  uint32_t n_slots = 0;        // HBM wire-file entries per instance (constants, inputs, long-lived wires, feedback staging)
+  uint32_t n_lds_slots = 0;    // LDS window entries used
   uint32_t fb_stage_base = 0;  // first staging slot for feedback copies
   std::vector<uint32_t> fb_src_slot, fb_dst_slot;  // replay epilogue: W[dst] <- W[src]
   uint64_t n_gates = 0;        // gates in stream order INCLUDING dead ones (= gate_ids consumed per replay)
@@ -104,17 +126,53 @@ struct Program {
   uint64_t gate_count[GATE_TYPE_COUNT] = {0};
   uint32_t and_depth = 0, n_and_steps = 0, max_step_width = 0;
   uint32_t peak_live = 0;
+  uint64_t reads_lds = 0, reads_hbm = 0, writes_lds = 0, writes_hbm = 0;  // label accesses per replay by location
+};
+
+struct CompileOptions {
+  uint32_t lds_slots = LDS_WINDOW_SLOTS;  // 0 = keep every wire in HBM
+  uint32_t lds_max_lifetime = 8;          // a wire goes to the LDS window only if it dies within this many steps
+};
+
+// next-fit slot pool over a bitmap: consecutive allocations get ascending (mostly consecutive) slots, so the
+// stores of one step coalesce and the operands of neighbouring gates sit in neighbouring lines.
+class SlotPool {
+ public:
+  explicit SlotPool(uint32_t fixed_capacity = 0) : fixed_(fixed_capacity != 0) { if (fixed_) used_.assign(fixed_capacity, 0); }
+  // returns DEAD_WIRE when a fixed pool is full
+  uint32_t alloc() {
+    if (n_free_ == 0) {
+      if (fixed_ && high_ >= used_.size()) return DEAD_WIRE;
+      if (!fixed_ && high_ >= used_.size()) used_.resize(std::max<size_t>(1024, used_.size() * 2), 0);
+      used_[high_] = 1;
+      cursor_ = high_ + 1;
+      return high_++;
+    }
+    uint32_t i = cursor_ < high_ ? cursor_ : 0;
+    while (used_[i]) { if (++i >= high_) i = 0; }
+    used_[i] = 1; --n_free_;
+    cursor_ = i + 1;
+    return i;
+  }
+  void release(uint32_t i) { used_[i] = 0; ++n_free_; }
+  void reserve_low(uint32_t n) { if (used_.size() < n) used_.resize(n, 0); for (uint32_t i = high_; i < n; ++i) used_[i] = 1; high_ = std::max(high_, n); cursor_ = high_; }
+  uint32_t high() const { return high_; }
+ private:
+  std::vector<uint8_t> used_;
+  uint32_t high_ = 0, cursor_ = 0, n_free_ = 0;
+  bool fixed_;
 };
 
 // inputs / outputs: SSA ids of the circuit's input and output wires.
 // feedback: pairs (output index -> input index) copied at the end of every replay (chained circuits).
 inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inputs, const std::vector<uint32_t>& outputs,
-                               const std::vector<std::pair<uint32_t, uint32_t>>& feedback = {}) {
+                               const std::vector<std::pair<uint32_t, uint32_t>>& feedback = {}, const CompileOptions& opt = CompileOptions()) {
   const size_t n = t.size();
   const uint32_t nw = t.n_wires;
   Program p;
   p.n_gates = n;
-  if (n >= 0xFFFFFFFFull) gsv_panic("program too large: gate index must fit 32 bits per replay");
+  if (n >= 0x7FFFFFFFull) gsv_panic("program too large: gate index must fit 31 bits per replay");
+  if (opt.lds_slots > SLOT_INDEX_MASK) gsv_panic("LDS window larger than the slot encoding");
 
   // 1. ASAP dependency level per wire (inputs / constants = 0) and AND-depth (statistic).
   std::vector<uint32_t> lev(nw, 0), ad(nw, 0);
@@ -151,12 +209,13 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
   last_use[0] = last_use[1] = NEVER;
   for (uint32_t w : inputs) last_use[w] = NEVER;
   for (uint32_t w : outputs) last_use[w] = NEVER;
-  // 4. slots: constants 0,1; inputs 2..; then a linear scan over steps
+  // 4. slots: HBM 0,1,2 = FALSE, TRUE, ZERO; inputs 3..; then a scan over steps with two next-fit pools
   std::vector<uint32_t> slot(nw, DEAD_WIRE);
-  slot[0] = 0; slot[1] = 1;
-  uint32_t next_slot = 2;
-  for (uint32_t w : inputs) { if (slot[w] == DEAD_WIRE) slot[w] = next_slot++; }
-  std::vector<uint32_t> free_stack;
+  slot[0] = SLOT_FALSE; slot[1] = SLOT_TRUE;
+  uint32_t next_in = SLOT_FIRST_INPUT;
+  for (uint32_t w : inputs) { if (slot[w] == DEAD_WIRE) slot[w] = next_in++; }
+  SlotPool hbm, lds(opt.lds_slots);
+  hbm.reserve_low(next_in);
   auto dies_at = [&](uint32_t w, uint32_t def_step) -> uint32_t { return last_use[w] == UNUSED ? def_step : last_use[w]; };
   std::vector<uint32_t> die_cnt(size_t(n_steps) + 1, 0);
   for (size_t k = 0; k < n_live; ++k) {
@@ -186,7 +245,7 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
     }
     p.n_ct = k;
   }
-  uint32_t live = next_slot, peak = next_slot;
+  uint32_t live = next_in, peak = next_in;
   p.steps.reserve(n_steps);
   for (uint32_t s = 0; s < n_steps; ++s) {
     StepDesc sd{uint32_t(p.ands.size()), cnt[2 * size_t(s) + 1] - cnt[2 * size_t(s)], uint32_t(p.xors.size()),
@@ -194,35 +253,52 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
     for (uint32_t k = cnt[2 * size_t(s)]; k < cnt[2 * size_t(s) + 2]; ++k) {
       size_t i = order[k];
       uint32_t c = t.c[i];
-      uint32_t sl;
-      if (!free_stack.empty()) { sl = free_stack.back(); free_stack.pop_back(); }
-      else sl = next_slot++;
+      uint32_t sl = DEAD_WIRE;
+      if (opt.lds_slots && last_use[c] != NEVER && dies_at(c, s) - s <= opt.lds_max_lifetime) {
+        uint32_t l = lds.alloc();
+        if (l != DEAD_WIRE) sl = l | SLOT_LDS_FLAG;
+      }
+      if (sl == DEAD_WIRE) {
+        sl = hbm.alloc();
+        if (sl > SLOT_INDEX_MASK) gsv_panic("program needs more than 2^20 HBM wire slots per instance");
+      }
       slot[c] = sl;
       ++live;
       uint32_t sa = slot[t.a[i]], sb = slot[t.b[i]];
       if (sa == DEAD_WIRE || sb == DEAD_WIRE) gsv_panic("internal: operand without slot");
-      if (t.type[i] < 8) p.ands.push_back(AndRec{sa, sb, sl, t.type[i], uint32_t(i), ct_index[i], 0, 0});
-      else p.xors.push_back(XorRec{sa, sb, sl, t.type[i]});
+      const uint8_t ty = t.type[i];
+      if (ty == uint8_t(GateType::Not)) sb = SLOT_ZERO;  // NOT(a) == XNOR(a, ZERO)
+      ((sa & SLOT_LDS_FLAG) ? p.reads_lds : p.reads_hbm)++;
+      ((sb & SLOT_LDS_FLAG) ? p.reads_lds : p.reads_hbm)++;
+      ((sl & SLOT_LDS_FLAG) ? p.writes_lds : p.writes_hbm)++;
+      if (ty < 8) p.ands.push_back(pack_and(sa, sb, sl, ty, uint32_t(i), ct_index[i]));
+      else p.xors.push_back(pack_xor(sa, sb, sl, ty != uint8_t(GateType::Xor)));
     }
     peak = std::max(peak, live);
-    for (uint32_t k = die_cnt[s]; k < die_cnt[s + 1]; ++k) { free_stack.push_back(slot[die_list[k]]); --live; }
+    for (uint32_t k = die_cnt[s]; k < die_cnt[s + 1]; ++k) {
+      uint32_t sl = slot[die_list[k]];
+      if (sl & SLOT_LDS_FLAG) lds.release(sl & SLOT_INDEX_MASK); else hbm.release(sl);
+      --live;
+    }
     p.steps.push_back(sd);
     p.max_step_width = std::max(p.max_step_width, sd.and_cnt + sd.xor_cnt);
     if (sd.and_cnt) p.n_and_steps++;
   }
   p.peak_live = peak;
+  p.n_lds_slots = lds.high();
   for (uint32_t w : inputs) p.input_slots.push_back(slot[w]);
   for (uint32_t w : outputs) {
     if (slot[w] == DEAD_WIRE) gsv_panic("output wire was never produced");
     p.output_slots.push_back(slot[w]);
   }
-  p.fb_stage_base = next_slot;
+  p.fb_stage_base = std::max(hbm.high(), next_in);
   for (auto& fb : feedback) {
     if (fb.first >= outputs.size() || fb.second >= inputs.size()) gsv_panic("feedback index out of range");
     p.fb_src_slot.push_back(p.output_slots[fb.first]);
     p.fb_dst_slot.push_back(p.input_slots[fb.second]);
   }
-  p.n_slots = next_slot + uint32_t(feedback.size());
+  p.n_slots = p.fb_stage_base + uint32_t(feedback.size());
+  if (p.n_slots > SLOT_INDEX_MASK) gsv_panic("program needs more than 2^20 HBM wire slots per instance");
   return p;
 }
 

@@ -91,6 +91,8 @@ typedef struct gsv_program_info {
   uint64_t n_steps, and_depth, n_and_steps, max_step_width; /* device steps; AND-depth of the DAG; steps holding AES work */
   uint64_t n_slots, peak_live;
   uint64_t device_bytes;   /* size of the program image in HBM */
+  uint64_t n_lds_slots;    /* entries of the per-workgroup LDS label window in use */
+  uint64_t reads_lds, reads_hbm, writes_lds, writes_hbm; /* label accesses per replay, by location */
 } gsv_program_info;
 int gsv_program_get_info(const gsv_program* p, gsv_program_info* info);
 

@@ -31,7 +31,7 @@ extern "C" {
 
 const char* hostsim_last_error() { return g_err.c_str(); }
 
-int hostsim_compile(const char* spec, int chain_feedback, SimProgram** out, uint64_t* info /* 12 */) {
+int hostsim_compile(const char* spec, int chain_feedback, SimProgram** out, uint64_t* info /* 17 */) {
   try {
     NamedCircuit nc = make_circuit(spec);
     RecordMode mode;
@@ -48,6 +48,7 @@ int hostsim_compile(const char* spec, int chain_feedback, SimProgram** out, uint
       info[0] = g.input_slots.size(); info[1] = g.output_slots.size(); info[2] = g.n_gates; info[3] = g.n_ct; info[4] = g.n_dead;
       info[5] = g.steps.size(); info[6] = g.and_depth; info[7] = g.n_and_steps; info[8] = g.max_step_width; info[9] = g.n_slots;
       info[10] = g.peak_live; info[11] = run.ctx().component_calls;
+      info[12] = g.n_lds_slots; info[13] = g.reads_lds; info[14] = g.reads_hbm; info[15] = g.writes_lds; info[16] = g.writes_hbm;
     }
     *out = sp.release();
     return 0;
@@ -66,8 +67,12 @@ int hostsim_run(SimProgram* sp, int evaluate, uint32_t replays, uint64_t gid_bas
     const uint32_t* rk = T.rk;
     std::vector<uint8_t> W(size_t(g.n_slots) * 16, 0xA5);  // poison: reading a never-written slot is visible
     std::vector<uint8_t> VB(g.n_slots, 0);
+    std::vector<uint8_t> LW(size_t(LDS_WINDOW_SLOTS) * 16, 0x5A), LB(LDS_WINDOW_SLOTS, 0);  // LDS window image
+    auto lab = [&](uint32_t slot) -> uint8_t* { return (slot & SLOT_LDS_FLAG) ? &LW[size_t(slot & SLOT_INDEX_MASK) * 16] : &W[size_t(slot) * 16]; };
+    auto bit = [&](uint32_t slot) -> uint8_t& { return (slot & SLOT_LDS_FLAG) ? LB[slot & SLOT_INDEX_MASK] : VB[slot]; };
     std::memcpy(&W[0], consts, 32);
-    VB[0] = 0; VB[1] = 1;
+    std::memset(&W[size_t(SLOT_ZERO) * 16], 0, 16);
+    VB[0] = 0; VB[1] = 1; VB[SLOT_ZERO] = 0;
     for (size_t i = 0; i < g.input_slots.size(); ++i) {
       std::memcpy(&W[size_t(g.input_slots[i]) * 16], inputs + 16 * i, 16);
       if (evaluate) VB[g.input_slots[i]] = input_bits[i] ? 1 : 0;
@@ -83,40 +88,42 @@ int hostsim_run(SimProgram* sp, int evaluate, uint32_t replays, uint64_t gid_bas
         std::vector<std::pair<uint32_t, uint8_t>> wb;
         wr.reserve(sd.and_cnt + sd.xor_cnt);
         for (uint32_t k = sd.xor_cnt; k-- > 0;) {
-          const XorRec& r = g.xors[sd.xor_off + k];
-          Label a = load(&W[size_t(r.a) * 16]), b = load(&W[size_t(r.b) * 16]);
-          if (!evaluate) wr.push_back({r.c, dev::garble_free(r.type, a, b, d)});
-          else {
-            wr.push_back({r.c, dev::degarble_free(r.type, a, b)});
-            wb.push_back({r.c, uint8_t(dev::gate_eval_bit(r.type, VB[r.a], VB[r.b]))});
-          }
+          const uint64_t v = g.xors[sd.xor_off + k].v;
+          const uint32_t sa = uint32_t(v) & SLOT_MASK, sb = uint32_t(v >> 21) & SLOT_MASK, sc = uint32_t(v >> 42) & SLOT_MASK, xnor = uint32_t(v >> 63);
+          Label x = dev::lxor(load(lab(sa)), load(lab(sb)));
+          if (!evaluate) wr.push_back({sc, dev::lxor_if(x, d, xnor)});
+          else { wr.push_back({sc, x}); wb.push_back({sc, uint8_t((bit(sa) ^ bit(sb) ^ xnor) & 1u)}); }
         }
         for (uint32_t k = sd.and_cnt; k-- > 0;) {
           const AndRec& r = g.ands[sd.and_off + k];
-          Label a = load(&W[size_t(r.a) * 16]), b = load(&W[size_t(r.b) * 16]);
+          const uint32_t sa = uint32_t(r.lo) & SLOT_MASK, sb = uint32_t(r.lo >> 21) & SLOT_MASK, sc = uint32_t(r.lo >> 42) & SLOT_MASK;
+          const uint32_t ty = uint32_t(r.lo >> 63) | (uint32_t(r.hi & 3u) << 1);
+          const uint64_t gid = gb + ((r.hi >> 2) & 0x7FFFFFFFull);
+          const uint32_t cti = uint32_t(r.hi >> 33);
+          Label a = load(lab(sa)), b = load(lab(sb));
           if (!evaluate) {
             Label c0, c;
-            dev::garble_and(aes, rk, r.type, a, b, d, gb + r.gid, c0, c);
-            wr.push_back({r.c, c0});
-            store(ct + size_t(r.ct) * 16, c);
+            dev::garble_and(aes, rk, ty, a, b, d, gid, c0, c);
+            wr.push_back({sc, c0});
+            store(ct + size_t(cti) * 16, c);
           } else {
-            Label c = load(ct + size_t(r.ct) * 16);
-            wr.push_back({r.c, dev::degarble_and(aes, rk, r.type, c, a, VB[r.a], b, gb + r.gid)});
-            wb.push_back({r.c, uint8_t(dev::gate_eval_bit(r.type, VB[r.a], VB[r.b]))});
+            Label c = load(ct + size_t(cti) * 16);
+            wr.push_back({sc, dev::degarble_and(aes, rk, ty, c, a, bit(sa), b, gid)});
+            wb.push_back({sc, uint8_t(dev::gate_eval_bit(ty, bit(sa), bit(sb)))});
           }
         }
-        for (auto& x : wr) store(&W[size_t(x.first) * 16], x.second);
-        for (auto& x : wb) VB[x.first] = x.second;
+        for (auto& x : wr) store(lab(x.first), x.second);
+        for (auto& x : wb) bit(x.first) = x.second;
       }
       if (!g.fb_src_slot.empty()) {
         std::vector<uint8_t> tmp(g.fb_src_slot.size() * 16), tb(g.fb_src_slot.size());
-        for (size_t i = 0; i < g.fb_src_slot.size(); ++i) { std::memcpy(&tmp[16 * i], &W[size_t(g.fb_src_slot[i]) * 16], 16); tb[i] = VB[g.fb_src_slot[i]]; }
-        for (size_t i = 0; i < g.fb_dst_slot.size(); ++i) { std::memcpy(&W[size_t(g.fb_dst_slot[i]) * 16], &tmp[16 * i], 16); VB[g.fb_dst_slot[i]] = tb[i]; }
+        for (size_t i = 0; i < g.fb_src_slot.size(); ++i) { std::memcpy(&tmp[16 * i], lab(g.fb_src_slot[i]), 16); tb[i] = bit(g.fb_src_slot[i]); }
+        for (size_t i = 0; i < g.fb_dst_slot.size(); ++i) { std::memcpy(lab(g.fb_dst_slot[i]), &tmp[16 * i], 16); bit(g.fb_dst_slot[i]) = tb[i]; }
       }
     }
     for (size_t i = 0; i < g.output_slots.size(); ++i) {
-      std::memcpy(out_labels + 16 * i, &W[size_t(g.output_slots[i]) * 16], 16);
-      if (out_bits) out_bits[i] = VB[g.output_slots[i]];
+      std::memcpy(out_labels + 16 * i, lab(g.output_slots[i]), 16);
+      if (out_bits) out_bits[i] = bit(g.output_slots[i]);
     }
     return 0;
   } catch (const std::exception& e) { g_err = e.what(); return 1; }
