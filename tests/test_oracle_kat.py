@@ -1,0 +1,149 @@
+"""Pins the CPU oracle: public known-answer vectors, SURVEY.md Appendix B (derived from the reference's
+formulas with OpenSSL), and the reference's own property tests restated.
+
+The reference holds no golden ciphertext / label / hash literal ("parity unpinned"); these
+are the anchors that exist.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as o
+
+K42 = bytes([0x42] * 16)
+
+
+def hx(b):
+    return bytes(b).hex()
+
+
+def test_fips197_c1_both_paths():
+    key = bytes(range(16))
+    pt = bytes.fromhex("00112233445566778899aabbccddeeff")
+    assert hx(o.aes128_encrypt(key, pt)) == "69c4e0d86a7b0430d8cdb78070b4c55a"
+    assert hx(o.aes128_encrypt(key, pt, portable=True)) == "69c4e0d86a7b0430d8cdb78070b4c55a"
+    for _ in range(64):
+        k, b = os.urandom(16), os.urandom(16)
+        assert o.aes128_encrypt(k, b) == o.aes128_encrypt(k, b, portable=True)
+
+
+def test_appendix_b_static_key_and_tweaks():
+    assert hx(o.aes128_encrypt(K42, bytes(16))) == "73446bba4a5a60c9410cf3d8805b910a"  # = commit_label(S::ZERO)
+    assert hx(o.tweak(0)) == "f0debc9a785634120000000000000000"
+    assert hx(o.tweak(1)) == "f1debc9a78563412bebafecaefbeadde"
+    assert hx(o.tweak(2)) == "f2debc9a785634127c75fd95df7d5bbd"
+    assert hx(o.tweak(50_000_000)) == "702e469878563412007ffb276c80a28f"
+    assert hx(o.tweak(11_174_708_820)) == "a458ac007a56341258ba34e9ad8c0bc8"
+
+
+def test_appendix_b_hash_and_cbcmac():
+    assert hx(o.hash_with_gate(bytes(16), 0)) == "e88f57b46473c37f4f78602e11256ec9"
+    assert hx(o.hash_with_gate((1).to_bytes(16, "big"), 1)) == "bcbc3cacb27be77badfc7921cc7b41a9"
+    assert hx(o.hash_with_gate(bytes.fromhex("0123456789abcdef0fedcba987654321"), 11174708820)) == "dd9ba5a1d15b06b9d34c484870d95e96"
+    one, two = (1).to_bytes(16, "big"), (2).to_bytes(16, "big")
+    assert hx(o.cbcmac(one)) == "b79a4ed1b63f3449a97dba67284adb90"
+    assert hx(o.cbcmac(one + two)) == "2fea5cabc4145f474abfe8ff478af374"
+    assert o.cbcmac(b"") == bytes(16)  # running hash starts at S::ZERO (ciphertext_hasher.rs:8-14)
+
+
+def test_appendix_b_gate_vectors():
+    a0 = bytes.fromhex("00112233445566778899aabbccddeeff")
+    b0 = bytes.fromhex("0f0e0d0c0b0a09080706050403020100")
+    d = bytes.fromhex("8000000000000000000000000000abcd")
+    c0, ct = o.garble_gate(0, a0, b0, d, 7)
+    assert hx(ct) == "4a2b7771692a652c17503a91e3cc34a9" and hx(c0) == "80fe8897edfa70ef620f0d7b9f3a9ce0"
+    c0, ct = o.garble_gate(7, a0, b0, d, 7)
+    assert hx(ct) == "ca2b7771692a652c17503a91e3cc9f64" and hx(c0) == "45dbf2ea8fda1ccb725932ee7ff40284"
+
+
+def test_chacha20_zero_key_keystream_and_seed_expansion():
+    w = o.chacha_words_from_key(bytes(32), 16)
+    # RFC 7539 / original ChaCha20 zero key, zero nonce, counter 0: 76 b8 e0 ad a0 f1 3d 90 ...
+    assert [hex(int(x)) for x in w[:4]] == ["0xade0b876", "0x903df1a0", "0xe56a5d40", "0x28bd8653"]
+    # label = big-endian bytes of u128 = w0 | w1<<32 | w2<<64 | w3<<96 (rand 0.8.5 gen::<u128>, core/s.rs:57-59)
+    labs = o.chacha_labels(0, 2)
+    assert labs.shape == (2, 16) and (labs[0] != labs[1]).any()
+    assert (o.chacha_labels(0, 5)[:2] == labs).all()
+    assert (o.chacha_labels(1, 1) != labs[:1]).any()
+
+
+@pytest.mark.parametrize("t", range(8))
+def test_halfgate_garble_degarble_consistency(t):
+    """halfgates_garbling.rs:81-157: garble once, degarble all four input combinations."""
+    rng = np.random.default_rng(t)
+    delta, a0, b0 = (rng.integers(0, 256, 16, dtype=np.uint8).tobytes() for _ in range(3))
+    x = lambda p, q: bytes(i ^ j for i, j in zip(p, q))
+    for gid in (0, 1, 2**40 + 12345):
+        c0, ct = o.garble_gate(t, a0, b0, delta, gid)
+        assert ct is not None
+        aa, ab, ac = (t >> 2) & 1, (t >> 1) & 1, t & 1
+        for va in (0, 1):
+            for vb in (0, 1):
+                a = x(a0, delta) if va else a0
+                b = x(b0, delta) if vb else b0
+                got = o.degarble_gate(t, ct, a, va, b, gid)
+                f = ((va ^ aa) & (vb ^ ab)) ^ ac
+                assert got == (x(c0, delta) if f else c0)
+
+
+def test_free_gates():
+    rng = np.random.default_rng(1)
+    delta, a0, b0 = (rng.integers(0, 256, 16, dtype=np.uint8).tobytes() for _ in range(3))
+    x = lambda p, q: bytes(i ^ j for i, j in zip(p, q))
+    assert o.garble_gate(8, a0, b0, delta, 5) == (x(a0, b0), None)
+    assert o.garble_gate(9, a0, b0, delta, 5) == (x(x(a0, b0), delta), None)
+    assert o.garble_gate(10, a0, a0, delta, 5) == (x(a0, delta), None)
+    assert o.degarble_gate(8, None, a0, 0, b0, 5) == x(a0, b0)
+    assert o.degarble_gate(10, None, a0, 0, a0, 5) == a0
+
+
+@pytest.mark.parametrize("t", range(11))
+def test_streaming_every_gate_type_all_inputs(t):
+    """tests/streaming_evaluate.rs:136-213: eval.active_label == garble.select(f(a,b))."""
+    spec = "gate:%d" % t
+    g = o.garble(spec, 42)
+    assert g.n_ciphertexts == (1 if t < 8 else 0)  # garble_test.rs:82,129-133,181
+    for a in (0, 1):
+        for b in (0, 1):
+            bits = np.array([a, b], np.uint8)
+            act = np.where(bits[:, None] == 1, g.input_label0 ^ g.delta[None, :], g.input_label0)
+            e = o.evaluate(spec, (g.true_label0 ^ g.delta).tobytes(), g.false_label0.tobytes(), act, bits, g.ciphertexts)
+            ob, _, _ = o.execute(spec, bits)
+            assert (e.output_bits == ob).all()
+            assert (e.output_active == np.where(ob[:, None] == 1, g.output_label0 ^ g.delta[None, :], g.output_label0)).all()
+            assert e.ct_hash.tobytes() == g.ct_hash.tobytes()
+
+
+def test_constants_differ_and_dead_gates():
+    g = o.garble("driver_mix", 5)
+    assert (g.false_label0 != g.true_label0).any()
+    assert int(g.gate_counts.sum()) == 29 and g.n_ciphertexts == 12 and int(g.gate_counts[:8].sum()) == 13
+    for bits in range(64):
+        b = np.array([(bits >> i) & 1 for i in range(6)], np.uint8)
+        act = np.where(b[:, None] == 1, g.input_label0 ^ g.delta[None, :], g.input_label0)
+        e = o.evaluate("driver_mix", (g.true_label0 ^ g.delta).tobytes(), g.false_label0.tobytes(), act, b, g.ciphertexts)
+        ob, _, _ = o.execute("driver_mix", b)
+        assert (e.output_bits == ob).all()
+        assert (e.output_active == np.where(ob[:, None] == 1, g.output_label0 ^ g.delta[None, :], g.output_label0)).all()
+
+
+def test_evaluate_source_exhausted_panics():
+    g = o.garble("gate:0", 1)
+    bits = np.array([1, 1], np.uint8)
+    act = np.where(bits[:, None] == 1, g.input_label0 ^ g.delta[None, :], g.input_label0)
+    with pytest.raises(RuntimeError, match="exhausted"):
+        o.evaluate("gate:0", (g.true_label0 ^ g.delta).tobytes(), g.false_label0.tobytes(), act, bits, np.zeros((0, 16), np.uint8))
+
+
+def test_fq12_mul_e2e_shape():
+    """tests/fq12_mul_e2e.rs:175-236 with AesNiHasher: every output gw.select(value) == active_label."""
+    spec = "fq12_mul"
+    g = o.garble(spec, 0, capacity=15_000)
+    assert g.peak_live <= 15_000
+    rng = np.random.default_rng(0)
+    bits = rng.integers(0, 2, g.n_in).astype(np.uint8)
+    act = np.where(bits[:, None] == 1, g.input_label0 ^ g.delta[None, :], g.input_label0)
+    e = o.evaluate(spec, (g.true_label0 ^ g.delta).tobytes(), g.false_label0.tobytes(), act, bits, g.ciphertexts, capacity=15_000)
+    assert (e.output_active == np.where(e.output_bits[:, None] == 1, g.output_label0 ^ g.delta[None, :], g.output_label0)).all()
+    assert e.n_consumed == g.n_ciphertexts and e.ct_hash.tobytes() == g.ct_hash.tobytes()
