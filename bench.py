@@ -30,9 +30,9 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--instances", type=int, default=16, help="cut-and-choose instances per GPU per step")
+    ap.add_argument("--instances", type=int, default=256, help="cut-and-choose instances per GPU per step (one workgroup = one CU each)")
     ap.add_argument("--replays", type=int, default=0, help="Fq12-mul components per instance (0 = enough for 11.17 B gates)")
     ap.add_argument("--ct-ring", type=int, default=2, help="replays of ciphertexts kept per instance in HBM")
     ap.add_argument("--cpu-baseline-chain", type=int, default=8, help="Fq12 muls garbled by the CPU oracle for cpu_baseline (0 = skip)")
@@ -109,6 +109,9 @@ def main():
     total_gates = gates_per_step_rank * world * args.steps
     value = total_gates / elapsed
 
+    traffic = None
+    if os.environ.get("GSV_BENCH_TRAFFIC_BYTES"):  # measured separately with rocprofv3 --pmc (see profiles/), passed in for the record
+        traffic = float(os.environ["GSV_BENCH_TRAFFIC_BYTES"])
     result = None
     if rank == 0:
         avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3
@@ -125,8 +128,10 @@ def main():
                        "wire_slots": info["n_slots"], "program_image_bytes": info["device_bytes"], "compile_s": compile_s},
             "per_instance_gates_per_s": gates_per_replay * replays / avg_kernel_s,
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "run_program_kernel<false>", "kernel_ms_avg": avg_kernel_s * 1e3,
-                         "bytes_per_gate": bytes_per_gate},
+                         "traffic": traffic, "kernel": "run_program_kernel<false>", "kernel_ms_avg": avg_kernel_s * 1e3,
+                         "bytes_per_gate": bytes_per_gate, "algorithmic_bytes_per_launch": gates_per_step_rank * bytes_per_gate,
+                         "lds_label_reads_frac": info["reads_lds"] / max(1, info["reads_lds"] + info["reads_hbm"]),
+                         "lds_label_writes_frac": info["writes_lds"] / max(1, info["writes_lds"] + info["writes_hbm"])},
         }
         if not args.no_check:
             import oracle_lib as o
