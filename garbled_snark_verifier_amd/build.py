@@ -38,7 +38,7 @@ def build(force=False, verbose=False):
     k_o = os.path.join(ENG, "kernels.o")
     e_o = os.path.join(ENG, "engine.o")
     cmds = [
-        [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(ENG, "kernels.hip"), "-o", k_o],
+        [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-promote-alloca-to-lds", "-c", os.path.join(ENG, "kernels.hip"), "-o", k_o],
         ["g++", "-O2", "-std=c++17", "-fPIC", "-maes", "-msse2", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include"),
          "-Wall", "-Wno-unused-parameter", "-c", os.path.join(ENG, "engine.cpp"), "-o", e_o],
         [hipcc, "-shared", "-o", OUT, k_o, e_o],

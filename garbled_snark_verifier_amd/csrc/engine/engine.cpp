@@ -337,7 +337,8 @@ static int launch(gsv_session* s, uint64_t gate_id_base, bool eval) {
   if (const char* dg = getenv("GSV_DIAG")) ka.diag = uint32_t(atoi(dg));  // timing experiments: outputs are wrong when set
   HIPCHK(hipEventRecord(s->ev0, s->e->stream));
   if (ka.n_steps) {
-    if (gsvk_launch_program(&ka, uint32_t(s->n_inst), eval ? 1 : 0, s->e->stream) != 0) return fail(GSV_ERR_DEVICE, "kernel launch failed");
+    int lrc = gsvk_launch_program(&ka, uint32_t(s->n_inst), eval ? 1 : 0, s->e->stream);
+    if (lrc != 0) return fail(GSV_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipError_t(lrc)));
   }
   HIPCHK(hipEventRecord(s->ev1, s->e->stream));
   if (!g.output_slots.empty()) {

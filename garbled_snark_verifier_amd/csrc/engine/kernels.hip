@@ -65,10 +65,13 @@ struct LdsBankedTable {
   }
 };
 
+typedef uint32_t GSV_GLB glb_u32;
+
 struct WireFile {
   glb_u128* hbm;      // this instance's wire file
   glb_u8* hbm_bits;   // evaluate: plaintext bits
   __device__ __forceinline__ static lds_u128* win(uint32_t idx) { return reinterpret_cast<lds_u128*>(uintptr_t(GSV_LDS_TABLE_BYTES + idx * 16u)); }
+  __device__ __forceinline__ static lds_u32* win_word(uint32_t idx, uint32_t c) { return reinterpret_cast<lds_u32*>(uintptr_t(GSV_LDS_TABLE_BYTES + idx * 16u + c * 4u)); }
   __device__ __forceinline__ static lds_u8* win_bit(uint32_t idx) { return reinterpret_cast<lds_u8*>(uintptr_t(GSV_LDS_TABLE_BYTES + GSV_LDS_SLOTS * 16u + idx)); }
   __device__ __forceinline__ Label ld(uint32_t slot) const {
     u32x4 v;
@@ -78,6 +81,15 @@ struct WireFile {
   __device__ __forceinline__ void st(uint32_t slot, const Label& l) const {
     const u32x4 v = {l.w[0], l.w[1], l.w[2], l.w[3]};
     if (slot & GSV_SLOT_LDS_FLAG) *win(slot & GSV_SLOT_INDEX_MASK) = v; else hbm[slot] = v;
+  }
+  // one 32-bit column of a label (narrow-step mode: a label is spread over the 4 lanes of a quad)
+  __device__ __forceinline__ uint32_t ld_word(uint32_t slot, uint32_t c) const {
+    uint32_t v;
+    if (slot & GSV_SLOT_LDS_FLAG) v = *win_word(slot & GSV_SLOT_INDEX_MASK, c); else v = ((const glb_u32*)hbm)[slot * 4u + c];
+    return v;
+  }
+  __device__ __forceinline__ void st_word(uint32_t slot, uint32_t c, uint32_t v) const {
+    if (slot & GSV_SLOT_LDS_FLAG) *win_word(slot & GSV_SLOT_INDEX_MASK, c) = v; else ((glb_u32*)hbm)[slot * 4u + c] = v;
   }
   __device__ __forceinline__ uint32_t ld_bit(uint32_t slot) const {
     uint32_t b;
@@ -89,6 +101,36 @@ struct WireFile {
   }
 };
 
+// ---- AES-128 with ONE BLOCK SPREAD OVER THE 4 LANES OF A QUAD (lane c holds state column c). -------------
+// A lone wave needs ~5 us for the per-lane two-block AES (~1400 dependent-ish VALU + 320 LDS ops), and most
+// steps of the circuit hold fewer AND gates than one wave has lanes.  Spreading a block over a quad cuts the
+// per-lane instruction stream ~6x: every lane looks up the four T-table terms of ITS OWN column and the
+// ShiftRows routing becomes three quad_perm DPP moves:
+//   new s_c = Te0[b0(s_c)] ^ Te1[b1(s_c+1)] ^ Te2[b2(s_c+2)] ^ Te3[b3(s_c+3)] ^ rk[4r+c]
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_from(uint32_t v) {  // lane 4k+i reads lane 4k+perm[i]
+  return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, 0xF, 0xF, false));
+}
+#define GSV_QP_NEXT1 0x39  // quad_perm [1,2,3,0]
+#define GSV_QP_NEXT2 0x4E  // quad_perm [2,3,0,1]
+#define GSV_QP_NEXT3 0x93  // quad_perm [3,0,1,2]
+__device__ __forceinline__ uint32_t aes128_quad(const LdsBankedTable& T, const uint32_t (&rkc)[11], uint32_t s) {
+  s ^= rkc[0];
+#pragma unroll
+  for (int r = 1; r < 10; ++r) {
+    const uint32_t u0 = T.lk<0, 0>(s), u1 = T.lk<1, 1>(s), u2 = T.lk<2, 2>(s), u3 = T.lk<3, 3>(s);
+    s = u0 ^ quad_from<GSV_QP_NEXT1>(u1) ^ quad_from<GSV_QP_NEXT2>(u2) ^ quad_from<GSV_QP_NEXT3>(u3) ^ rkc[r];
+  }
+  const uint32_t m0 = T.lk<2, 0>(s) & 0x000000ffu, m1 = T.lk<3, 1>(s) & 0x0000ff00u;
+  const uint32_t m2 = T.lk<0, 2>(s) & 0x00ff0000u, m3 = T.lk<1, 3>(s) & 0xff000000u;
+  return m0 ^ quad_from<GSV_QP_NEXT1>(m1) ^ quad_from<GSV_QP_NEXT2>(m2) ^ quad_from<GSV_QP_NEXT3>(m3) ^ rkc[10];
+}
+__device__ __forceinline__ uint32_t tweak_word(uint64_t gate_id, uint32_t c) {  // column c of tweak_of(gate_id)
+  const uint64_t t0 = gate_id ^ 0x123456789ABCDEF0ull, t1 = gate_id * 0xDEADBEEFCAFEBABEull;
+  const uint64_t t = (c & 2u) ? t1 : t0;
+  return (c & 1u) ? uint32_t(t >> 32) : uint32_t(t);
+}
+
 template <bool EVAL>
 __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelArgs ka) {
   extern __shared__ __attribute__((aligned(16))) char s_mem[];
@@ -98,84 +140,172 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   __syncthreads();
   const LdsBankedTable aes{(tid & 31u) * 4u};
   const uint32_t* rk = c_rk;
+  // narrow-step mode: LPG lanes per AND gate (garble: two blocks x 4 columns; evaluate: one block x 4 columns)
+  constexpr uint32_t LPG = EVAL ? 4u : 8u;
+  const uint32_t col = tid & 3u, blk = (tid >> 2) & 1u;
+  uint32_t rkc[11];
+#pragma unroll
+  for (int r = 0; r < 11; ++r) rkc[r] = c_rk[4 * r + col];
 
   const uint32_t inst = blockIdx.x;
   WireFile wf;
   wf.hbm = (glb_u128*)(ka.W + size_t(inst) * ka.n_slots);      // C-style cast: generic -> global address space
   wf.hbm_bits = (glb_u8*)(ka.VB + size_t(inst) * ka.n_slots);
   glb_u128* __restrict__ CT = (glb_u128*)(ka.CT + size_t(inst) * ka.ct_stride);
+  glb_u32* __restrict__ CTw = (glb_u32*)CT;
   Label delta{{0, 0, 0, 0}};
   if (!EVAL) { const u32x4 d = ((const glb_u128*)ka.delta)[inst]; delta = Label{{d.x, d.y, d.z, d.w}}; }
+  // this lane's column of delta (selects, not a runtime-indexed array: that would be promoted to static LDS)
+  const uint32_t dq = col == 0 ? delta.w[0] : col == 1 ? delta.w[1] : col == 2 ? delta.w[2] : delta.w[3];
   const glb_u128* __restrict__ and_q = (const glb_u128*)ka.ands;  // 16 B records
   const glb_u64* __restrict__ xor_q = (const glb_u64*)ka.xors;    // 8 B records
   const glb_u128* __restrict__ step_q = (const glb_u128*)ka.steps;
+  const bool no_store = (ka.diag & 8u) != 0, no_load = (ka.diag & 4u) != 0, no_aes = (ka.diag & 1u) != 0, no_narrow = (ka.diag & 16u) != 0;
 
   for (uint32_t rep = 0; rep < ka.replays; ++rep) {
     const uint64_t gid_base = ka.gid_base + uint64_t(rep) * ka.n_gates;
     const uint64_t ct_base = uint64_t(rep % ka.ct_cap_replays) * ka.n_ct;
 
-    // step descriptor {and_off, and_cnt, xor_off, xor_cnt}: lanes [0, and_cnt) take AND-family gates,
-    // lanes [and_cnt, and_cnt + xor_cnt) take free gates, so only the boundary wave diverges.
-    u32x4 sd = step_q[0];
-    // prefetched record for this thread's first gate of the step
-    u32x4 r0 = {0, 0, 0, 0};
-    if (tid < sd.y) r0 = and_q[size_t(sd.x + tid)];
-    else if (tid < sd.y + sd.w) { const u32x2 x = xor_q[size_t(sd.z + (tid - sd.y))]; r0.x = x.x; r0.y = x.y; }
+    // A step descriptor is {and_off, and_cnt, xor_off, xor_cnt}.  Lane -> gate mapping of a step:
+    //   wide   (default)                : lane i takes AND gate i for i < and_cnt, else free gate i - and_cnt;
+    //                                     more than 1024 gates => several passes.
+    //   narrow (and_cnt*LPG + xor_cnt <= 1024): LPG consecutive lanes share AND gate i/LPG, free gates follow.
+    // Either way AND work and XOR work are contiguous lane ranges: only a boundary wave diverges on the gate kind.
+    //
+    // Software pipeline, two steps deep: while step s computes, the descriptor + this lane's first record of
+    // step s+2 are in flight (program records stream from HBM).  The step barrier must only wait for what other
+    // waves will read — this step's label stores — so it is a hand-counted `s_waitcnt vmcnt(N)`: vector-memory
+    // ops retire in issue order and the N youngest ops of the wave are, by construction (compiler barriers pin
+    // the order), the record prefetch load and, when the wave's last pass held AND gates, the ciphertext store.
+    const uint32_t last_step = ka.n_steps - 1;
+    const uint32_t vtid = tid >> 31;  // always 0, but not provably uniform: keeps descriptor loads on the vector path
+    auto is_narrow = [&](const u32x4& d) -> bool { return !no_narrow && d.y != 0 && d.y * LPG + d.w <= GSV_BLOCK_THREADS; };
+    auto load_desc = [&](uint32_t s) -> u32x4 { return step_q[(s < last_step ? s : last_step) + vtid]; };
+    auto load_rec = [&](const u32x4& d) -> u32x4 {  // record of this lane's first (or only) gate of step d
+      u32x4 r = {0, 0, 0, 0};
+      const uint32_t na = is_narrow(d) ? d.y * LPG : d.y;
+      if (tid < na) r = and_q[size_t(d.x + (is_narrow(d) ? tid / LPG : tid))];
+      else if (tid < na + d.w) { const u32x2 x = xor_q[size_t(d.z + (tid - na))]; r.x = x.x; r.y = x.y; }
+      return r;
+    };
+    u32x4 sd = load_desc(0), r0 = load_rec(sd);
+    u32x4 nsd = load_desc(1), n0 = load_rec(nsd);
+    const uint32_t wave_first = __builtin_amdgcn_readfirstlane(tid);
     for (uint32_t s = 0; s < ka.n_steps; ++s) {
       const uint32_t and_off = sd.x, and_cnt = sd.y, xor_off = sd.z, total = sd.y + sd.w;
-      // issue next step's descriptor + record loads early; they complete while this step computes
-      u32x4 nsd = sd, n0 = r0;
-      if (s + 1 < ka.n_steps) {
-        nsd = step_q[s + 1];
-        if (tid < nsd.y) n0 = and_q[size_t(nsd.x + tid)];
-        else if (tid < nsd.y + nsd.w) { const u32x2 x = xor_q[size_t(nsd.z + (tid - nsd.y))]; n0.x = x.x; n0.y = x.y; }
-      }
-      for (uint32_t i = tid; i < total; i += GSV_BLOCK_THREADS) {
-        u32x4 q = r0;
-        if (i < and_cnt) {
-          if (i != tid) q = and_q[size_t(and_off + i)];
-        } else if (i != tid) { const u32x2 x = xor_q[size_t(xor_off + (i - and_cnt))]; q.x = x.x; q.y = x.y; }
-        // common slot fields: a = bits 0..20, b = 21..41, c = 42..62 of the low 64 bits
+      const u32x4 n2sd = load_desc(s + 2);  // lands during this step; its record load is issued at the end
+      bool young_ct = false;                 // did this wave issue a ciphertext store AFTER its last label store?
+      if (is_narrow(sd)) {
+        // ------------------------------------------------------------------ narrow step: one pass
+        const uint32_t na = and_cnt * LPG;
+        const u32x4 q = r0;
         const uint32_t sa = q.x & GSV_SLOT_MASK;
         const uint32_t sb = ((q.x >> 21) | (q.y << 11)) & GSV_SLOT_MASK;
         const uint32_t sc = (q.y >> 10) & GSV_SLOT_MASK;
-        Label a = delta, b = delta;
-        if (!(ka.diag & 4u)) { a = wf.ld(sa); b = wf.ld(sb); }
-        if (i < and_cnt) {
-          const uint32_t t = (q.y >> 31) | ((q.z & 3u) << 1);
+        const uint32_t top = q.y >> 31;
+        if (tid < na) {
+          const uint32_t t = top | ((q.z & 3u) << 1);
           const uint64_t hi = (uint64_t(q.w) << 32) | q.z;
           const uint64_t gid = gid_base + ((hi >> 2) & 0x7FFFFFFFull);
           const uint32_t cti = uint32_t(hi >> 33);
+          uint32_t a_c = dq, b_c = dq;
+          if (!no_load) { a_c = wf.ld_word(sa, col); b_c = wf.ld_word(sb, col); }
+          const uint32_t twc = tweak_word(gid, col);
           if (!EVAL) {
-            Label c0, ct;
-            if (ka.diag & 1u) { c0 = lxor(a, b); ct = lxor(a, tweak_of(gid)); }
-            else garble_and(aes, rk, t, a, b, delta, gid, c0, ct);
-            if (!(ka.diag & 8u)) {
-              wf.st(sc, c0);
-              CT[ct_base + cti] = u32x4{ct.w[0], ct.w[1], ct.w[2], ct.w[3]};
-            } else if (c0.w[0] == 0x12345678u && ct.w[1] == 0x9abcdef0u) wf.st(sc, c0);
+            uint32_t x = a_c ^ (alpha_a(t) ? dq : 0u);  // selected_a ; lanes of the second quad take other_a
+            if (blk) x ^= dq;
+            const uint32_t h = no_aes ? (x ^ twc) : aes128_quad(aes, rkc, x ^ twc);
+            const uint32_t o = uint32_t(__shfl_xor(int(h), 4));  // the other block's column c
+            const uint32_t c0_c = h ^ (alpha_c(t) ? dq : 0u);
+            const uint32_t ct_c = h ^ o ^ b_c ^ (alpha_b(t) ? dq : 0u);
+            if (!blk && !no_store) wf.st_word(sc, col, c0_c);
+            asm volatile("" ::: "memory");
+            if (!blk && !no_store) CTw[(ct_base + cti) * 4u + col] = ct_c;
           } else {
             const uint32_t va = wf.ld_bit(sa), vb = wf.ld_bit(sb);
-            const u32x4 cv = CT[ct_base + cti];
-            const Label ct{{cv.x, cv.y, cv.z, cv.w}};
-            wf.st(sc, degarble_and(aes, rk, t, ct, a, va, b, gid));
-            wf.st_bit(sc, gate_eval_bit(t, va, vb));
+            const uint32_t ct_c = CTw[(ct_base + cti) * 4u + col];
+            const uint32_t h = no_aes ? (a_c ^ twc) : aes128_quad(aes, rkc, a_c ^ twc);
+            const uint32_t use_ct = (va ^ alpha_a(t)) & 1u;
+            wf.st_word(sc, col, h ^ (use_ct ? (ct_c ^ b_c) : 0u));
+            if (col == 0) wf.st_bit(sc, gate_eval_bit(t, va, vb));
           }
-        } else {
-          const uint32_t xnor = q.y >> 31;
-          const Label x = lxor(a, b);
-          if (!EVAL) {
-            const Label c0 = lxor_if(x, delta, xnor);
-            if (!(ka.diag & 8u) || c0.w[0] == 0x12345678u) wf.st(sc, c0);
-          } else {
-            wf.st(sc, x);
-            wf.st_bit(sc, (wf.ld_bit(sa) ^ wf.ld_bit(sb) ^ xnor) & 1u);
+        } else if (tid < na + sd.w) {
+          Label a = delta, b = delta;
+          if (!no_load) { a = wf.ld(sa); b = wf.ld(sb); }
+          Label c0 = lxor(a, b);
+          if (!EVAL) c0 = lxor_if(c0, delta, top);
+          if (!no_store || c0.w[0] == 0x12345678u) {
+            wf.st(sc, c0);
+            if (EVAL) wf.st_bit(sc, (wf.ld_bit(sa) ^ wf.ld_bit(sb) ^ top) & 1u);
           }
         }
+        // the AND lanes come first, so a wave holding any AND lane issued its ciphertext store last... unless it
+        // also holds free-gate lanes (boundary wave), whose label store is issued after it in program order.
+        young_ct = !EVAL && !no_store && wave_first + 64u <= na;
+      } else {
+        // ------------------------------------------------------------------ wide step: passes of 1024 gates
+        // the record of pass k+1 is requested before pass k computes
+        auto load_pass_rec = [&](uint32_t i) -> u32x4 {
+          u32x4 r = {0, 0, 0, 0};
+          if (i < and_cnt) r = and_q[size_t(and_off + i)];
+          else if (i < total) { const u32x2 x = xor_q[size_t(xor_off + (i - and_cnt))]; r.x = x.x; r.y = x.y; }
+          return r;
+        };
+        u32x4 qnext = r0;
+        for (uint32_t i = tid; i < total; i += GSV_BLOCK_THREADS) {
+          const u32x4 q = qnext;
+          if (i + GSV_BLOCK_THREADS < total) qnext = load_pass_rec(i + GSV_BLOCK_THREADS);
+          const bool is_and = i < and_cnt;
+          // common slot fields: a = bits 0..20, b = 21..41, c = 42..62 of the low 64 bits; bit 63 = xnor / type bit 0
+          const uint32_t sa = q.x & GSV_SLOT_MASK;
+          const uint32_t sb = ((q.x >> 21) | (q.y << 11)) & GSV_SLOT_MASK;
+          const uint32_t sc = (q.y >> 10) & GSV_SLOT_MASK;
+          const uint32_t top = q.y >> 31;
+          Label a = delta, b = delta;
+          if (!no_load) { a = wf.ld(sa); b = wf.ld(sb); }
+          Label c0, ct{{0, 0, 0, 0}};
+          uint32_t cti = 0, vc = 0;
+          if (is_and) {
+            const uint32_t t = top | ((q.z & 3u) << 1);
+            const uint64_t hi = (uint64_t(q.w) << 32) | q.z;
+            const uint64_t gid = gid_base + ((hi >> 2) & 0x7FFFFFFFull);
+            cti = uint32_t(hi >> 33);
+            if (!EVAL) {
+              if (no_aes) { c0 = lxor(a, b); ct = lxor(a, tweak_of(gid)); }
+              else garble_and(aes, rk, t, a, b, delta, gid, c0, ct);
+            } else {
+              const uint32_t va = wf.ld_bit(sa), vb = wf.ld_bit(sb);
+              const u32x4 cv = CT[ct_base + cti];
+              c0 = degarble_and(aes, rk, t, Label{{cv.x, cv.y, cv.z, cv.w}}, a, va, b, gid);
+              vc = gate_eval_bit(t, va, vb);
+            }
+          } else {
+            c0 = lxor(a, b);
+            if (!EVAL) c0 = lxor_if(c0, delta, top);
+            else vc = (wf.ld_bit(sa) ^ wf.ld_bit(sb) ^ top) & 1u;
+          }
+          if (!no_store || c0.w[0] == 0x12345678u) {
+            wf.st(sc, c0);
+            if (EVAL) wf.st_bit(sc, vc);
+          }
+          asm volatile("" ::: "memory");  // label stores stay older than the ciphertext store
+          if (!EVAL && is_and && !no_store) CT[ct_base + cti] = u32x4{ct.w[0], ct.w[1], ct.w[2], ct.w[3]};
+          asm volatile("" ::: "memory");
+        }
+        if (!EVAL && wave_first < total && !no_store) {
+          const uint32_t i_last = wave_first + ((total - 1u - wave_first) / GSV_BLOCK_THREADS) * GSV_BLOCK_THREADS;
+          young_ct = i_last < and_cnt;
+        }
       }
-      __syncthreads();  // workgroup-scope release/acquire: this step's LDS + HBM stores are visible to every wave
+      asm volatile("" ::: "memory");
+      const u32x4 n2r = load_rec(n2sd);  // the wave's youngest load: may stay in flight across the barrier
+      asm volatile("" ::: "memory");
+      if (young_ct) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       sd = nsd; r0 = n0;
+      nsd = n2sd; n0 = n2r;
     }
+    __syncthreads();
     // replay epilogue: feedback copies through staging slots (sources may alias destinations; all in HBM)
     if (ka.n_fb) {
       for (uint32_t i = tid; i < ka.n_fb; i += GSV_BLOCK_THREADS) {
@@ -225,6 +355,10 @@ int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, in
   const size_t lds = GSV_LDS_BYTES;
   static bool attr_done = false;
   if (!attr_done) {
+    // the kernels address LDS from byte 0: there must be no static LDS in front of the dynamic block
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false>)) != hipSuccess || fa.sharedSizeBytes != 0) return int(hipErrorInvalidValue);
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true>)) != hipSuccess || fa.sharedSizeBytes != 0) return int(hipErrorInvalidValue);
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e1 != hipSuccess || e2 != hipSuccess) return int(e1 != hipSuccess ? e1 : e2);
