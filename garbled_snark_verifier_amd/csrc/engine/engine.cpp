@@ -148,7 +148,10 @@ int gsv_program_compile(gsv_recorder* r, const uint32_t* fb_out_idx, const uint3
   std::vector<std::pair<uint32_t, uint32_t>> fb;
   for (size_t i = 0; i < n_feedback; ++i) fb.push_back({fb_out_idx[i], fb_in_idx[i]});
   std::unique_ptr<gsv_program> p(new gsv_program());
-  p->prog = compile_program(r->mode.trace(), r->inputs, r->outputs, fb);
+  CompileOptions opt;
+  if (const char* e = getenv("GSV_LDS_LIFETIME")) opt.lds_max_lifetime = uint32_t(atoi(e));  // tuning knobs (defaults are the measured best)
+  if (const char* e = getenv("GSV_LDS_SLOTS")) opt.lds_slots = std::min<uint32_t>(uint32_t(atoi(e)), LDS_WINDOW_SLOTS);
+  p->prog = compile_program(r->mode.trace(), r->inputs, r->outputs, fb, opt);
   for (size_t i = 0; i < p->prog.input_slots.size(); ++i)
     if (p->prog.input_slots[i] != SLOT_FIRST_INPUT + i) return fail(GSV_ERR_CIRCUIT, "internal: inputs are not slot-contiguous");
   *out = p.release();

@@ -59,6 +59,15 @@ GSV_HD Label tweak_of(uint64_t gate_id) {
 // Two accessors exist: PlainTables (host / tests: four 256-entry arrays) and, in kernels.hip,
 // LdsBankedTables (each entry replicated once per LDS bank so that a wave's 64 random lookups
 // never conflict).
+// three-input XOR: one V_BITOP3_B32 (truth table 0x96) on gfx950
+GSV_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+  return a ^ b ^ c;
+#endif
+}
+
 struct PlainTables {
   const uint32_t* te[4];
   template <int K, int BYTE>
@@ -68,14 +77,14 @@ struct PlainTables {
 // One middle round for one column: T0[b0 of x0] ^ T1[b1 of x1] ^ T2[b2 of x2] ^ T3[b3 of x3] ^ k
 template <class Tab>
 GSV_HD uint32_t aes_col(const Tab& T, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t k) {
-  return T.template lk<0, 0>(x0) ^ T.template lk<1, 1>(x1) ^ T.template lk<2, 2>(x2) ^ T.template lk<3, 3>(x3) ^ k;
+  return xor3(xor3(T.template lk<0, 0>(x0), T.template lk<1, 1>(x1), T.template lk<2, 2>(x2)), T.template lk<3, 3>(x3), k);
 }
 // Final round column: SubBytes + ShiftRows + AddRoundKey; the plain S-box byte sits in Te2 byte0,
 // Te3 byte1, Te0 byte2, Te1 byte3.
 template <class Tab>
 GSV_HD uint32_t aes_last_col(const Tab& T, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t k) {
-  return (T.template lk<2, 0>(x0) & 0x000000ffu) ^ (T.template lk<3, 1>(x1) & 0x0000ff00u) ^ (T.template lk<0, 2>(x2) & 0x00ff0000u) ^
-         (T.template lk<1, 3>(x3) & 0xff000000u) ^ k;
+  return xor3(xor3(T.template lk<2, 0>(x0) & 0x000000ffu, T.template lk<3, 1>(x1) & 0x0000ff00u, T.template lk<0, 2>(x2) & 0x00ff0000u),
+              T.template lk<1, 3>(x3) & 0xff000000u, k);
 }
 
 // One full AES-128 encryption of `in` (FIPS-197; equals _mm_aesenc x9 + _mm_aesenclast, aes_ni.rs:39-54).

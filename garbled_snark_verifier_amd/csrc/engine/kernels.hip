@@ -183,9 +183,11 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     auto load_desc = [&](uint32_t s) -> u32x4 { return step_q[(s < last_step ? s : last_step) + vtid]; };
     auto load_rec = [&](const u32x4& d) -> u32x4 {  // record of this lane's first (or only) gate of step d
       u32x4 r = {0, 0, 0, 0};
-      const uint32_t na = is_narrow(d) ? d.y * LPG : d.y;
-      if (tid < na) r = and_q[size_t(d.x + (is_narrow(d) ? tid / LPG : tid))];
-      else if (tid < na + d.w) { const u32x2 x = xor_q[size_t(d.z + (tid - na))]; r.x = x.x; r.y = x.y; }
+      if (is_narrow(d)) {
+        const uint32_t na = d.y * LPG;
+        if (tid < na) r = and_q[size_t(d.x + tid / LPG)];
+        else if (tid < na + d.w) { const u32x2 x = xor_q[size_t(d.z + (tid - na))]; r.x = x.x; r.y = x.y; }
+      } else if (tid < d.y) r = and_q[size_t(d.x + tid)];  // wide: free-gate records are fetched inside the step
       return r;
     };
     u32x4 sd = load_desc(0), r0 = load_rec(sd);
@@ -243,59 +245,83 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         // also holds free-gate lanes (boundary wave), whose label store is issued after it in program order.
         young_ct = !EVAL && !no_store && wave_first + 64u <= na;
       } else {
-        // ------------------------------------------------------------------ wide step: passes of 1024 gates
-        // the record of pass k+1 is requested before pass k computes
-        auto load_pass_rec = [&](uint32_t i) -> u32x4 {
-          u32x4 r = {0, 0, 0, 0};
-          if (i < and_cnt) r = and_q[size_t(and_off + i)];
-          else if (i < total) { const u32x2 x = xor_q[size_t(xor_off + (i - and_cnt))]; r.x = x.x; r.y = x.y; }
+        // ------------------------------------------------------------------ wide step
+        // AND-family gates: passes of 1024 gates, one per lane (two interleaved AES blocks each).
+        // Free gates: batches of 4 per lane with all eight operand loads of a batch issued together; the first
+        // batch's loads are issued BEFORE the AES passes so their HBM/LDS latency hides behind the AES work.
+        const uint32_t xor_cnt = sd.w;
+        auto load_xor_rec = [&](uint32_t j) -> u32x2 {
+          u32x2 r = {0, 0};
+          if (j < xor_cnt) r = xor_q[size_t(xor_off + j)];
           return r;
         };
+        constexpr int XB = 4;
+        u32x2 xr[XB];
+        Label xa[XB], xb[XB];
+        auto issue_xor_batch = [&](uint32_t base) {
+#pragma unroll
+          for (int j = 0; j < XB; ++j) xr[j] = load_xor_rec(base + uint32_t(j) * GSV_BLOCK_THREADS + tid);
+#pragma unroll
+          for (int j = 0; j < XB; ++j) {
+            const uint32_t sa = xr[j].x & GSV_SLOT_MASK, sb = ((xr[j].x >> 21) | (xr[j].y << 11)) & GSV_SLOT_MASK;
+            xa[j] = delta; xb[j] = delta;
+            if (!no_load && base + uint32_t(j) * GSV_BLOCK_THREADS + tid < xor_cnt) { xa[j] = wf.ld(sa); xb[j] = wf.ld(sb); }
+          }
+        };
+        auto finish_xor_batch = [&](uint32_t base) {
+#pragma unroll
+          for (int j = 0; j < XB; ++j) {
+            if (base + uint32_t(j) * GSV_BLOCK_THREADS + tid < xor_cnt) {
+              const uint32_t sa = xr[j].x & GSV_SLOT_MASK, sb = ((xr[j].x >> 21) | (xr[j].y << 11)) & GSV_SLOT_MASK;
+              const uint32_t sc = (xr[j].y >> 10) & GSV_SLOT_MASK, top = xr[j].y >> 31;
+              Label c0 = lxor(xa[j], xb[j]);
+              if (!EVAL) c0 = lxor_if(c0, delta, top);
+              if (!no_store || c0.w[0] == 0x12345678u) {
+                wf.st(sc, c0);
+                if (EVAL) wf.st_bit(sc, (wf.ld_bit(sa) ^ wf.ld_bit(sb) ^ top) & 1u);
+              }
+            }
+          }
+        };
+        issue_xor_batch(0);
+        // ---- AND passes; the record of pass k+1 is requested before pass k computes
         u32x4 qnext = r0;
-        for (uint32_t i = tid; i < total; i += GSV_BLOCK_THREADS) {
+        for (uint32_t i = tid; i < and_cnt; i += GSV_BLOCK_THREADS) {
           const u32x4 q = qnext;
-          if (i + GSV_BLOCK_THREADS < total) qnext = load_pass_rec(i + GSV_BLOCK_THREADS);
-          const bool is_and = i < and_cnt;
-          // common slot fields: a = bits 0..20, b = 21..41, c = 42..62 of the low 64 bits; bit 63 = xnor / type bit 0
+          if (i + GSV_BLOCK_THREADS < and_cnt) qnext = and_q[size_t(and_off + i + GSV_BLOCK_THREADS)];
           const uint32_t sa = q.x & GSV_SLOT_MASK;
           const uint32_t sb = ((q.x >> 21) | (q.y << 11)) & GSV_SLOT_MASK;
           const uint32_t sc = (q.y >> 10) & GSV_SLOT_MASK;
-          const uint32_t top = q.y >> 31;
+          const uint32_t t = (q.y >> 31) | ((q.z & 3u) << 1);
+          const uint64_t hi = (uint64_t(q.w) << 32) | q.z;
+          const uint64_t gid = gid_base + ((hi >> 2) & 0x7FFFFFFFull);
+          const uint32_t cti = uint32_t(hi >> 33);
           Label a = delta, b = delta;
           if (!no_load) { a = wf.ld(sa); b = wf.ld(sb); }
           Label c0, ct{{0, 0, 0, 0}};
-          uint32_t cti = 0, vc = 0;
-          if (is_and) {
-            const uint32_t t = top | ((q.z & 3u) << 1);
-            const uint64_t hi = (uint64_t(q.w) << 32) | q.z;
-            const uint64_t gid = gid_base + ((hi >> 2) & 0x7FFFFFFFull);
-            cti = uint32_t(hi >> 33);
-            if (!EVAL) {
-              if (no_aes) { c0 = lxor(a, b); ct = lxor(a, tweak_of(gid)); }
-              else garble_and(aes, rk, t, a, b, delta, gid, c0, ct);
-            } else {
-              const uint32_t va = wf.ld_bit(sa), vb = wf.ld_bit(sb);
-              const u32x4 cv = CT[ct_base + cti];
-              c0 = degarble_and(aes, rk, t, Label{{cv.x, cv.y, cv.z, cv.w}}, a, va, b, gid);
-              vc = gate_eval_bit(t, va, vb);
-            }
+          uint32_t vc = 0;
+          if (!EVAL) {
+            if (no_aes) { c0 = lxor(a, b); ct = lxor(a, tweak_of(gid)); }
+            else garble_and(aes, rk, t, a, b, delta, gid, c0, ct);
           } else {
-            c0 = lxor(a, b);
-            if (!EVAL) c0 = lxor_if(c0, delta, top);
-            else vc = (wf.ld_bit(sa) ^ wf.ld_bit(sb) ^ top) & 1u;
+            const uint32_t va = wf.ld_bit(sa), vb = wf.ld_bit(sb);
+            const u32x4 cv = CT[ct_base + cti];
+            c0 = degarble_and(aes, rk, t, Label{{cv.x, cv.y, cv.z, cv.w}}, a, va, b, gid);
+            vc = gate_eval_bit(t, va, vb);
           }
           if (!no_store || c0.w[0] == 0x12345678u) {
             wf.st(sc, c0);
             if (EVAL) wf.st_bit(sc, vc);
           }
-          asm volatile("" ::: "memory");  // label stores stay older than the ciphertext store
-          if (!EVAL && is_and && !no_store) CT[ct_base + cti] = u32x4{ct.w[0], ct.w[1], ct.w[2], ct.w[3]};
-          asm volatile("" ::: "memory");
+          if (!EVAL && !no_store) CT[ct_base + cti] = u32x4{ct.w[0], ct.w[1], ct.w[2], ct.w[3]};
         }
-        if (!EVAL && wave_first < total && !no_store) {
-          const uint32_t i_last = wave_first + ((total - 1u - wave_first) / GSV_BLOCK_THREADS) * GSV_BLOCK_THREADS;
-          young_ct = i_last < and_cnt;
+        // ---- free-gate batches (their label stores are the wave's youngest stores: no young ciphertext store)
+        for (uint32_t base = 0; base < xor_cnt; base += XB * GSV_BLOCK_THREADS) {
+          if (base) issue_xor_batch(base);
+          finish_xor_batch(base);
         }
+        young_ct = !EVAL && !no_store && xor_cnt == 0 && wave_first < and_cnt &&
+                   (wave_first + ((and_cnt - 1u - wave_first) / GSV_BLOCK_THREADS) * GSV_BLOCK_THREADS) < and_cnt;
       }
       asm volatile("" ::: "memory");
       const u32x4 n2r = load_rec(n2sd);  // the wave's youngest load: may stay in flight across the barrier

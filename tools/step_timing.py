@@ -9,10 +9,13 @@ import numpy as np
 import garbled_snark_verifier_amd as gsv
 
 eng = gsv.Engine(0)
-for spec, reps in (("u254_add", 2000), ("fq_mul", 200), ("fq12_mul", 2)):
+SPECS = (("u254_add", 2000), ("fq_mul", 200), ("fq12_mul", 2))
+if os.environ.get("GSV_ONLY"):
+    SPECS = tuple(x for x in SPECS if x[0] == os.environ["GSV_ONLY"])
+for spec, reps in SPECS:
     prog = gsv.Program.from_circuit(spec, chain_feedback=True)
     n_in = prog.info["n_inputs"]
-    for B in (1, 64):
+    for B in ((1,) if os.environ.get("GSV_ONLY") else (1, 64)):
         d, f, t, inp = gsv.labels_from_seed(1, n_in)
         sess = gsv.Session(eng, prog, B, reps, 1)
         sess.set_garble_inputs(np.tile(d, (B, 1)), np.tile(np.stack([f, t]), (B, 1, 1)), np.tile(inp, (B, 1, 1)))
