@@ -151,6 +151,8 @@ int gsv_program_compile(gsv_recorder* r, const uint32_t* fb_out_idx, const uint3
   CompileOptions opt;
   if (const char* e = getenv("GSV_LDS_LIFETIME")) opt.lds_max_lifetime = uint32_t(atoi(e));  // tuning knobs (defaults are the measured best)
   if (const char* e = getenv("GSV_LDS_SLOTS")) opt.lds_slots = std::min<uint32_t>(uint32_t(atoi(e)), LDS_WINDOW_SLOTS);
+  // two instances per workgroup (set before compiling): each gets half of the LDS label window
+  if (const char* e = getenv("GSV_INSTANCES_PER_WG")) if (atoi(e) == 2) opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / 2);
   p->prog = compile_program(r->mode.trace(), r->inputs, r->outputs, fb, opt);
   for (size_t i = 0; i < p->prog.input_slots.size(); ++i)
     if (p->prog.input_slots[i] != SLOT_FIRST_INPUT + i) return fail(GSV_ERR_CIRCUIT, "internal: inputs are not slot-contiguous");
@@ -337,6 +339,11 @@ static int launch(gsv_session* s, uint64_t gate_id_base, bool eval) {
   ka.ct_stride = s->ct_stride(); ka.gid_base = gate_id_base; ka.n_gates = g.n_gates; ka.n_ct = g.n_ct;
   ka.n_steps = uint32_t(g.steps.size()); ka.n_slots = g.n_slots; ka.replays = uint32_t(s->replays); ka.ct_cap_replays = uint32_t(s->ct_cap);
   ka.n_fb = uint32_t(g.fb_src_slot.size()); ka.fb_stage_base = g.fb_stage_base;
+  ka.n_instances = uint32_t(s->n_inst);
+  {
+    const char* e = getenv("GSV_INSTANCES_PER_WG");
+    ka.instances_per_wg = (e && atoi(e) == 2 && g.lds_slots_limit <= LDS_WINDOW_SLOTS / 2 && s->n_inst >= 2) ? 2u : 1u;
+  }
   if (const char* dg = getenv("GSV_DIAG")) ka.diag = uint32_t(atoi(dg));  // timing experiments: outputs are wrong when set
   HIPCHK(hipEventRecord(s->ev0, s->e->stream));
   if (ka.n_steps) {

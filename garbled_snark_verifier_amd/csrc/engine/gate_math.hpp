@@ -53,7 +53,8 @@ GSV_HD Label tweak_of(uint64_t gate_id) {
 
 // AES tables as the kernels see them.  A table accessor `Tab` provides
 //     template <int K, int BYTE> uint32_t lk(uint32_t s) const   = Te_K[ byte BYTE of s ]
-// and `rk` points to the 44 round-key words of the fixed key 0x42*16 (src/hashers/aes_ni.rs:165).
+//     uint32_t rk(int i) const                                   = round-key word i (0..43) of the fixed key
+//                                                                  0x42*16 (src/hashers/aes_ni.rs:165)
 //   Te0[x] = (2s, s, s, 3s)   Te1[x] = (3s, 2s, s, s)   Te2[x] = (s, 3s, 2s, s)   Te3[x] = (s, s, 3s, 2s)
 // as little-endian words (byte k = state row k), s = SBOX[x].
 // Two accessors exist: PlainTables (host / tests: four 256-entry arrays) and, in kernels.hip,
@@ -70,8 +71,10 @@ GSV_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
 
 struct PlainTables {
   const uint32_t* te[4];
+  const uint32_t* rkp;  // 44 round-key words
   template <int K, int BYTE>
   GSV_HD uint32_t lk(uint32_t s) const { return te[K][(s >> (8 * BYTE)) & 0xff]; }
+  GSV_HD uint32_t rk(int i) const { return rkp[i]; }
 };
 
 // One middle round for one column: T0[b0 of x0] ^ T1[b1 of x1] ^ T2[b2 of x2] ^ T3[b3 of x3] ^ k
@@ -89,33 +92,33 @@ GSV_HD uint32_t aes_last_col(const Tab& T, uint32_t x0, uint32_t x1, uint32_t x2
 
 // One full AES-128 encryption of `in` (FIPS-197; equals _mm_aesenc x9 + _mm_aesenclast, aes_ni.rs:39-54).
 template <class Tab>
-GSV_HD Label aes128_encrypt(const Tab& T, const uint32_t* rk, const Label& in) {
-  uint32_t s0 = in.w[0] ^ rk[0], s1 = in.w[1] ^ rk[1], s2 = in.w[2] ^ rk[2], s3 = in.w[3] ^ rk[3];
+GSV_HD Label aes128_encrypt(const Tab& T, const Label& in) {
+  uint32_t s0 = in.w[0] ^ T.rk(0), s1 = in.w[1] ^ T.rk(1), s2 = in.w[2] ^ T.rk(2), s3 = in.w[3] ^ T.rk(3);
 #pragma unroll
   for (int r = 1; r < 10; ++r) {
-    uint32_t t0 = aes_col(T, s0, s1, s2, s3, rk[4 * r + 0]);
-    uint32_t t1 = aes_col(T, s1, s2, s3, s0, rk[4 * r + 1]);
-    uint32_t t2 = aes_col(T, s2, s3, s0, s1, rk[4 * r + 2]);
-    uint32_t t3 = aes_col(T, s3, s0, s1, s2, rk[4 * r + 3]);
+    uint32_t t0 = aes_col(T, s0, s1, s2, s3, T.rk(4 * r + 0));
+    uint32_t t1 = aes_col(T, s1, s2, s3, s0, T.rk(4 * r + 1));
+    uint32_t t2 = aes_col(T, s2, s3, s0, s1, T.rk(4 * r + 2));
+    uint32_t t3 = aes_col(T, s3, s0, s1, s2, T.rk(4 * r + 3));
     s0 = t0; s1 = t1; s2 = t2; s3 = t3;
   }
   Label o;
-  o.w[0] = aes_last_col(T, s0, s1, s2, s3, rk[40]);
-  o.w[1] = aes_last_col(T, s1, s2, s3, s0, rk[41]);
-  o.w[2] = aes_last_col(T, s2, s3, s0, s1, rk[42]);
-  o.w[3] = aes_last_col(T, s3, s0, s1, s2, rk[43]);
+  o.w[0] = aes_last_col(T, s0, s1, s2, s3, T.rk(40));
+  o.w[1] = aes_last_col(T, s1, s2, s3, s0, T.rk(41));
+  o.w[2] = aes_last_col(T, s2, s3, s0, s1, T.rk(42));
+  o.w[3] = aes_last_col(T, s3, s0, s1, s2, T.rk(43));
   return o;
 }
 
 // Two independent blocks interleaved (the reference's encrypt2_blocks, aes_ni.rs:68-94): two
 // dependency chains to overlap LDS latency with.
 template <class Tab>
-GSV_HD void aes128_encrypt2(const Tab& T, const uint32_t* rk, const Label& in0, const Label& in1, Label& out0, Label& out1) {
-  uint32_t a0 = in0.w[0] ^ rk[0], a1 = in0.w[1] ^ rk[1], a2 = in0.w[2] ^ rk[2], a3 = in0.w[3] ^ rk[3];
-  uint32_t b0 = in1.w[0] ^ rk[0], b1 = in1.w[1] ^ rk[1], b2 = in1.w[2] ^ rk[2], b3 = in1.w[3] ^ rk[3];
+GSV_HD void aes128_encrypt2(const Tab& T, const Label& in0, const Label& in1, Label& out0, Label& out1) {
+  uint32_t a0 = in0.w[0] ^ T.rk(0), a1 = in0.w[1] ^ T.rk(1), a2 = in0.w[2] ^ T.rk(2), a3 = in0.w[3] ^ T.rk(3);
+  uint32_t b0 = in1.w[0] ^ T.rk(0), b1 = in1.w[1] ^ T.rk(1), b2 = in1.w[2] ^ T.rk(2), b3 = in1.w[3] ^ T.rk(3);
 #pragma unroll
   for (int r = 1; r < 10; ++r) {
-    const uint32_t k0 = rk[4 * r], k1 = rk[4 * r + 1], k2 = rk[4 * r + 2], k3 = rk[4 * r + 3];
+    const uint32_t k0 = T.rk(4 * r), k1 = T.rk(4 * r + 1), k2 = T.rk(4 * r + 2), k3 = T.rk(4 * r + 3);
     uint32_t t0 = aes_col(T, a0, a1, a2, a3, k0), u0 = aes_col(T, b0, b1, b2, b3, k0);
     uint32_t t1 = aes_col(T, a1, a2, a3, a0, k1), u1 = aes_col(T, b1, b2, b3, b0, k1);
     uint32_t t2 = aes_col(T, a2, a3, a0, a1, k2), u2 = aes_col(T, b2, b3, b0, b1, k2);
@@ -123,25 +126,25 @@ GSV_HD void aes128_encrypt2(const Tab& T, const uint32_t* rk, const Label& in0, 
     a0 = t0; a1 = t1; a2 = t2; a3 = t3;
     b0 = u0; b1 = u1; b2 = u2; b3 = u3;
   }
-  out0.w[0] = aes_last_col(T, a0, a1, a2, a3, rk[40]); out1.w[0] = aes_last_col(T, b0, b1, b2, b3, rk[40]);
-  out0.w[1] = aes_last_col(T, a1, a2, a3, a0, rk[41]); out1.w[1] = aes_last_col(T, b1, b2, b3, b0, rk[41]);
-  out0.w[2] = aes_last_col(T, a2, a3, a0, a1, rk[42]); out1.w[2] = aes_last_col(T, b2, b3, b0, b1, rk[42]);
-  out0.w[3] = aes_last_col(T, a3, a0, a1, a2, rk[43]); out1.w[3] = aes_last_col(T, b3, b0, b1, b2, rk[43]);
+  out0.w[0] = aes_last_col(T, a0, a1, a2, a3, T.rk(40)); out1.w[0] = aes_last_col(T, b0, b1, b2, b3, T.rk(40));
+  out0.w[1] = aes_last_col(T, a1, a2, a3, a0, T.rk(41)); out1.w[1] = aes_last_col(T, b1, b2, b3, b0, T.rk(41));
+  out0.w[2] = aes_last_col(T, a2, a3, a0, a1, T.rk(42)); out1.w[2] = aes_last_col(T, b2, b3, b0, b1, T.rk(42));
+  out0.w[3] = aes_last_col(T, a3, a0, a1, a2, T.rk(43)); out1.w[3] = aes_last_col(T, b3, b0, b1, b2, T.rk(43));
 }
 
 // H(x, g) = AES_K(x ^ tweak(g)), no feed-forward (src/hashers/mod.rs:66-86).
 template <class Tab>
-GSV_HD Label hash_with_gate(const Tab& T, const uint32_t* rk, const Label& x, uint64_t gate_id) { return aes128_encrypt(T, rk, lxor(x, tweak_of(gate_id))); }
+GSV_HD Label hash_with_gate(const Tab& T, const Label& x, uint64_t gate_id) { return aes128_encrypt(T, lxor(x, tweak_of(gate_id))); }
 
 // garble_gate, AND-family arm (halfgates_garbling.rs:17-35).  t < 8.
 template <class Tab>
-GSV_HD void garble_and(const Tab& T, const uint32_t* rk, uint32_t t, const Label& a0, const Label& b0, const Label& delta, uint64_t gate_id,
+GSV_HD void garble_and(const Tab& T, uint32_t t, const Label& a0, const Label& b0, const Label& delta, uint64_t gate_id,
                        Label& c0, Label& ct) {
   Label tw = tweak_of(gate_id);
   Label sel = lxor_if(a0, delta, alpha_a(t));  // selected_a
   Label oth = lxor(sel, delta);                // other_a
   Label hs, ho;
-  aes128_encrypt2(T, rk, lxor(sel, tw), lxor(oth, tw), hs, ho);
+  aes128_encrypt2(T, lxor(sel, tw), lxor(oth, tw), hs, ho);
   Label bsel = lxor_if(b0, delta, alpha_b(t));
   ct = lxor(lxor(hs, ho), bsel);
   c0 = lxor_if(hs, delta, alpha_c(t));
@@ -153,8 +156,8 @@ GSV_HD Label garble_free(uint32_t t, const Label& a0, const Label& b0, const Lab
 }
 // degarble_gate, AND-family arm (halfgates_garbling.rs:57-67).
 template <class Tab>
-GSV_HD Label degarble_and(const Tab& T, const uint32_t* rk, uint32_t t, const Label& ct, const Label& a, uint32_t a_value, const Label& b, uint64_t gate_id) {
-  Label h = hash_with_gate(T, rk, a, gate_id);
+GSV_HD Label degarble_and(const Tab& T, uint32_t t, const Label& ct, const Label& a, uint32_t a_value, const Label& b, uint64_t gate_id) {
+  Label h = hash_with_gate(T, a, gate_id);
   uint32_t use_ct = (a_value ^ alpha_a(t)) & 1u;
   Label z{{0, 0, 0, 0}};
   Label m = lxor(ct, b);

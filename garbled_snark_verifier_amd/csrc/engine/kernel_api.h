@@ -31,6 +31,8 @@ struct KernelArgs {
   uint32_t ct_cap_replays;
   uint32_t n_fb;
   uint32_t fb_stage_base;
+  uint32_t n_instances;
+  uint32_t instances_per_wg;  // 1 or 2 (2 needs a program compiled for half the LDS window)
   uint32_t diag;  // timing experiments only (GSV_DIAG env): 1 = skip AES, 2 = no record prefetch, 4 = skip label loads, 8 = skip stores
 };
 

@@ -36,9 +36,12 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 //                          rotations of Te0 (one v_alignbit each).
 //   [32 KiB, +120 KiB)     label window: GSV_LDS_SLOTS x 16 B, the short-lived wires chosen by the compiler
 //   [.., +7.5 KiB)         plaintext bits of window wires (evaluate mode)
+//   [.., +176 B)           the 44 round-key words (read with a wave-uniform address = LDS broadcast; keeping them
+//                          in SGPRs instead spilled ~60 SGPRs and put v_readlane/v_writelane into every step)
 #define GSV_LDS_SLOTS 7680u
 #define GSV_LDS_TABLE_BYTES 32768u
-#define GSV_LDS_BYTES (GSV_LDS_TABLE_BYTES + GSV_LDS_SLOTS * 16u + GSV_LDS_SLOTS)
+#define GSV_LDS_RK_BASE (GSV_LDS_TABLE_BYTES + GSV_LDS_SLOTS * 16u + GSV_LDS_SLOTS)  // 44 round-key words
+#define GSV_LDS_BYTES (GSV_LDS_RK_BASE + 176u)
 #define GSV_SLOT_LDS_FLAG (1u << 20)
 #define GSV_SLOT_INDEX_MASK (GSV_SLOT_LDS_FLAG - 1u)
 #define GSV_SLOT_MASK ((1u << 21) - 1u)
@@ -63,6 +66,7 @@ struct LdsBankedTable {
     const uint32_t v = *reinterpret_cast<const lds_u32*>(uintptr_t((x & 0x7f80u) | lane4));
     return K == 0 ? v : __builtin_amdgcn_alignbit(v, v, 32 - 8 * K);  // rotl(v, 8K): Te_K from Te0
   }
+  __device__ __forceinline__ uint32_t rk(int i) const { return *reinterpret_cast<const lds_u32*>(uintptr_t(GSV_LDS_RK_BASE + 4u * uint32_t(i))); }
 };
 
 typedef uint32_t GSV_GLB glb_u32;
@@ -70,9 +74,11 @@ typedef uint32_t GSV_GLB glb_u32;
 struct WireFile {
   glb_u128* hbm;      // this instance's wire file
   glb_u8* hbm_bits;   // evaluate: plaintext bits
-  __device__ __forceinline__ static lds_u128* win(uint32_t idx) { return reinterpret_cast<lds_u128*>(uintptr_t(GSV_LDS_TABLE_BYTES + idx * 16u)); }
-  __device__ __forceinline__ static lds_u32* win_word(uint32_t idx, uint32_t c) { return reinterpret_cast<lds_u32*>(uintptr_t(GSV_LDS_TABLE_BYTES + idx * 16u + c * 4u)); }
-  __device__ __forceinline__ static lds_u8* win_bit(uint32_t idx) { return reinterpret_cast<lds_u8*>(uintptr_t(GSV_LDS_TABLE_BYTES + GSV_LDS_SLOTS * 16u + idx)); }
+  uint32_t win_base;  // LDS byte address of this instance's label window
+  uint32_t bit_base;  // LDS byte address of this instance's window plaintext bits
+  __device__ __forceinline__ lds_u128* win(uint32_t idx) const { return reinterpret_cast<lds_u128*>(uintptr_t(win_base + idx * 16u)); }
+  __device__ __forceinline__ lds_u32* win_word(uint32_t idx, uint32_t c) const { return reinterpret_cast<lds_u32*>(uintptr_t(win_base + idx * 16u + c * 4u)); }
+  __device__ __forceinline__ lds_u8* win_bit(uint32_t idx) const { return reinterpret_cast<lds_u8*>(uintptr_t(bit_base + idx)); }
   __device__ __forceinline__ Label ld(uint32_t slot) const {
     u32x4 v;
     if (slot & GSV_SLOT_LDS_FLAG) v = *win(slot & GSV_SLOT_INDEX_MASK); else v = hbm[slot];
@@ -131,24 +137,33 @@ __device__ __forceinline__ uint32_t tweak_word(uint64_t gate_id, uint32_t c) {  
   return (c & 1u) ? uint32_t(t >> 32) : uint32_t(t);
 }
 
-template <bool EVAL>
+// NI = instances per workgroup.  NI = 2 splits the 1024 threads into two halves that garble two instances of the
+// same program in lockstep (they share the step barrier and the AES table; each has half of the label window):
+// the many steps that are narrower than half a workgroup then cost their fixed latency once for two instances.
+template <bool EVAL, int NI>
 __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelArgs ka) {
   extern __shared__ __attribute__((aligned(16))) char s_mem[];
-  const uint32_t tid = threadIdx.x;
   (void)s_mem;  // the dynamic LDS block starts at LDS address 0 (no static __shared__ in this kernel)
-  for (uint32_t i = tid; i < GSV_LDS_TABLE_BYTES / 4; i += GSV_BLOCK_THREADS) *reinterpret_cast<lds_u32*>(uintptr_t(i * 4u)) = ka.te[i >> 5];
+  for (uint32_t i = threadIdx.x; i < GSV_LDS_TABLE_BYTES / 4; i += GSV_BLOCK_THREADS) *reinterpret_cast<lds_u32*>(uintptr_t(i * 4u)) = ka.te[i >> 5];
+  if (threadIdx.x < 44) *reinterpret_cast<lds_u32*>(uintptr_t(GSV_LDS_RK_BASE + 4u * threadIdx.x)) = c_rk[threadIdx.x];
   __syncthreads();
+  constexpr uint32_t BT = GSV_BLOCK_THREADS / NI;  // threads per instance
+  const uint32_t sub = threadIdx.x / BT;            // which instance of this workgroup
+  const uint32_t tid = threadIdx.x % BT;            // lane index inside the instance's thread group
   const LdsBankedTable aes{(tid & 31u) * 4u};
-  const uint32_t* rk = c_rk;
   // narrow-step mode: LPG lanes per AND gate (garble: two blocks x 4 columns; evaluate: one block x 4 columns)
   constexpr uint32_t LPG = EVAL ? 4u : 8u;
   const uint32_t col = tid & 3u, blk = (tid >> 2) & 1u;
   uint32_t rkc[11];
 #pragma unroll
-  for (int r = 0; r < 11; ++r) rkc[r] = c_rk[4 * r + col];
+  for (int r = 0; r < 11; ++r) rkc[r] = *reinterpret_cast<const lds_u32*>(uintptr_t(GSV_LDS_RK_BASE + 4u * (4u * uint32_t(r) + col)));
 
-  const uint32_t inst = blockIdx.x;
+  uint32_t inst = blockIdx.x * NI + sub;
+  const bool inst_active = inst < ka.n_instances;  // an odd batch leaves the last half idle (it still joins every barrier)
+  if (!inst_active) inst = ka.n_instances - 1;     // harmless addresses; every gate loop below is masked off
   WireFile wf;
+  wf.win_base = GSV_LDS_TABLE_BYTES + sub * (GSV_LDS_SLOTS / NI) * 16u;
+  wf.bit_base = GSV_LDS_TABLE_BYTES + GSV_LDS_SLOTS * 16u + sub * (GSV_LDS_SLOTS / NI);
   wf.hbm = (glb_u128*)(ka.W + size_t(inst) * ka.n_slots);      // C-style cast: generic -> global address space
   wf.hbm_bits = (glb_u8*)(ka.VB + size_t(inst) * ka.n_slots);
   glb_u128* __restrict__ CT = (glb_u128*)(ka.CT + size_t(inst) * ka.ct_stride);
@@ -172,15 +187,19 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     //   narrow (and_cnt*LPG + xor_cnt <= 1024): LPG consecutive lanes share AND gate i/LPG, free gates follow.
     // Either way AND work and XOR work are contiguous lane ranges: only a boundary wave diverges on the gate kind.
     //
-    // Software pipeline, two steps deep: while step s computes, the descriptor + this lane's first record of
-    // step s+2 are in flight (program records stream from HBM).  The step barrier must only wait for what other
+    // Software pipeline, two steps deep: while step s computes, the descriptor (scalar load: the whole
+    // step bookkeeping stays on the scalar unit, which matters because all 16 waves run it even when only one
+    // has gates) + this lane's first record of step s+2 are in flight (program records stream from HBM).  The step barrier must only wait for what other
     // waves will read — this step's label stores — so it is a hand-counted `s_waitcnt vmcnt(N)`: vector-memory
     // ops retire in issue order and the N youngest ops of the wave are, by construction (compiler barriers pin
     // the order), the record prefetch load and, when the wave's last pass held AND gates, the ciphertext store.
     const uint32_t last_step = ka.n_steps - 1;
-    const uint32_t vtid = tid >> 31;  // always 0, but not provably uniform: keeps descriptor loads on the vector path
-    auto is_narrow = [&](const u32x4& d) -> bool { return !no_narrow && d.y != 0 && d.y * LPG + d.w <= GSV_BLOCK_THREADS; };
-    auto load_desc = [&](uint32_t s) -> u32x4 { return step_q[(s < last_step ? s : last_step) + vtid]; };
+    auto is_narrow = [&](const u32x4& d) -> bool { return !no_narrow && d.y != 0 && d.y * LPG + d.w <= BT; };
+    auto load_desc = [&](uint32_t s) -> u32x4 {
+      u32x4 d = step_q[s < last_step ? s : last_step];  // wave-uniform address: a scalar (SMEM) load, two steps ahead of its use
+      if (!inst_active) { d.y = 0; d.w = 0; }
+      return d;
+    };
     auto load_rec = [&](const u32x4& d) -> u32x4 {  // record of this lane's first (or only) gate of step d
       u32x4 r = {0, 0, 0, 0};
       if (is_narrow(d)) {
@@ -192,7 +211,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     };
     u32x4 sd = load_desc(0), r0 = load_rec(sd);
     u32x4 nsd = load_desc(1), n0 = load_rec(nsd);
-    const uint32_t wave_first = __builtin_amdgcn_readfirstlane(tid);
+    const uint32_t wave_first = __builtin_amdgcn_readfirstlane(tid);  // index of the wave's first lane inside its instance group
     for (uint32_t s = 0; s < ka.n_steps; ++s) {
       const uint32_t and_off = sd.x, and_cnt = sd.y, xor_off = sd.z, total = sd.y + sd.w;
       const u32x4 n2sd = load_desc(s + 2);  // lands during this step; its record load is issued at the end
@@ -255,23 +274,23 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           if (j < xor_cnt) r = xor_q[size_t(xor_off + j)];
           return r;
         };
-        constexpr int XB = 4;
+        constexpr int XB = 2;
         u32x2 xr[XB];
         Label xa[XB], xb[XB];
         auto issue_xor_batch = [&](uint32_t base) {
 #pragma unroll
-          for (int j = 0; j < XB; ++j) xr[j] = load_xor_rec(base + uint32_t(j) * GSV_BLOCK_THREADS + tid);
+          for (int j = 0; j < XB; ++j) xr[j] = load_xor_rec(base + uint32_t(j) * BT + tid);
 #pragma unroll
           for (int j = 0; j < XB; ++j) {
             const uint32_t sa = xr[j].x & GSV_SLOT_MASK, sb = ((xr[j].x >> 21) | (xr[j].y << 11)) & GSV_SLOT_MASK;
             xa[j] = delta; xb[j] = delta;
-            if (!no_load && base + uint32_t(j) * GSV_BLOCK_THREADS + tid < xor_cnt) { xa[j] = wf.ld(sa); xb[j] = wf.ld(sb); }
+            if (!no_load && base + uint32_t(j) * BT + tid < xor_cnt) { xa[j] = wf.ld(sa); xb[j] = wf.ld(sb); }
           }
         };
         auto finish_xor_batch = [&](uint32_t base) {
 #pragma unroll
           for (int j = 0; j < XB; ++j) {
-            if (base + uint32_t(j) * GSV_BLOCK_THREADS + tid < xor_cnt) {
+            if (base + uint32_t(j) * BT + tid < xor_cnt) {
               const uint32_t sa = xr[j].x & GSV_SLOT_MASK, sb = ((xr[j].x >> 21) | (xr[j].y << 11)) & GSV_SLOT_MASK;
               const uint32_t sc = (xr[j].y >> 10) & GSV_SLOT_MASK, top = xr[j].y >> 31;
               Label c0 = lxor(xa[j], xb[j]);
@@ -286,9 +305,9 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         issue_xor_batch(0);
         // ---- AND passes; the record of pass k+1 is requested before pass k computes
         u32x4 qnext = r0;
-        for (uint32_t i = tid; i < and_cnt; i += GSV_BLOCK_THREADS) {
+        for (uint32_t i = tid; i < and_cnt; i += BT) {
           const u32x4 q = qnext;
-          if (i + GSV_BLOCK_THREADS < and_cnt) qnext = and_q[size_t(and_off + i + GSV_BLOCK_THREADS)];
+          if (i + BT < and_cnt) qnext = and_q[size_t(and_off + i + BT)];
           const uint32_t sa = q.x & GSV_SLOT_MASK;
           const uint32_t sb = ((q.x >> 21) | (q.y << 11)) & GSV_SLOT_MASK;
           const uint32_t sc = (q.y >> 10) & GSV_SLOT_MASK;
@@ -302,11 +321,11 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           uint32_t vc = 0;
           if (!EVAL) {
             if (no_aes) { c0 = lxor(a, b); ct = lxor(a, tweak_of(gid)); }
-            else garble_and(aes, rk, t, a, b, delta, gid, c0, ct);
+            else garble_and(aes, t, a, b, delta, gid, c0, ct);
           } else {
             const uint32_t va = wf.ld_bit(sa), vb = wf.ld_bit(sb);
             const u32x4 cv = CT[ct_base + cti];
-            c0 = degarble_and(aes, rk, t, Label{{cv.x, cv.y, cv.z, cv.w}}, a, va, b, gid);
+            c0 = degarble_and(aes, t, Label{{cv.x, cv.y, cv.z, cv.w}}, a, va, b, gid);
             vc = gate_eval_bit(t, va, vb);
           }
           if (!no_store || c0.w[0] == 0x12345678u) {
@@ -316,12 +335,12 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           if (!EVAL && !no_store) CT[ct_base + cti] = u32x4{ct.w[0], ct.w[1], ct.w[2], ct.w[3]};
         }
         // ---- free-gate batches (their label stores are the wave's youngest stores: no young ciphertext store)
-        for (uint32_t base = 0; base < xor_cnt; base += XB * GSV_BLOCK_THREADS) {
+        for (uint32_t base = 0; base < xor_cnt; base += XB * BT) {
           if (base) issue_xor_batch(base);
           finish_xor_batch(base);
         }
         young_ct = !EVAL && !no_store && xor_cnt == 0 && wave_first < and_cnt &&
-                   (wave_first + ((and_cnt - 1u - wave_first) / GSV_BLOCK_THREADS) * GSV_BLOCK_THREADS) < and_cnt;
+                   (wave_first + ((and_cnt - 1u - wave_first) / BT) * BT) < and_cnt;
       }
       asm volatile("" ::: "memory");
       const u32x4 n2r = load_rec(n2sd);  // the wave's youngest load: may stay in flight across the barrier
@@ -334,13 +353,14 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     __syncthreads();
     // replay epilogue: feedback copies through staging slots (sources may alias destinations; all in HBM)
     if (ka.n_fb) {
-      for (uint32_t i = tid; i < ka.n_fb; i += GSV_BLOCK_THREADS) {
+      const uint32_t nfb = inst_active ? ka.n_fb : 0u;
+      for (uint32_t i = tid; i < nfb; i += BT) {
         const u32x4 v = wf.hbm[ka.fb_src[i]];
         wf.hbm[ka.fb_stage_base + i] = v;
         if (EVAL) { const uint8_t bv = wf.hbm_bits[ka.fb_src[i]]; wf.hbm_bits[ka.fb_stage_base + i] = bv; }
       }
       __syncthreads();
-      for (uint32_t i = tid; i < ka.n_fb; i += GSV_BLOCK_THREADS) {
+      for (uint32_t i = tid; i < nfb; i += BT) {
         const u32x4 v = wf.hbm[ka.fb_stage_base + i];
         wf.hbm[ka.fb_dst[i]] = v;
         if (EVAL) { const uint8_t bv = wf.hbm_bits[ka.fb_stage_base + i]; wf.hbm_bits[ka.fb_dst[i]] = bv; }
@@ -383,15 +403,24 @@ int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, in
   if (!attr_done) {
     // the kernels address LDS from byte 0: there must be no static LDS in front of the dynamic block
     hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false>)) != hipSuccess || fa.sharedSizeBytes != 0) return int(hipErrorInvalidValue);
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true>)) != hipSuccess || fa.sharedSizeBytes != 0) return int(hipErrorInvalidValue);
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    if (e1 != hipSuccess || e2 != hipSuccess) return int(e1 != hipSuccess ? e1 : e2);
+    const void* kernels[4] = {reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 1>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 1>),
+                              reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 2>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 2>)};
+    for (const void* k : kernels) {
+      if (hipFuncGetAttributes(&fa, k) != hipSuccess || fa.sharedSizeBytes != 0) return int(hipErrorInvalidValue);
+      hipError_t e0 = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+      if (e0 != hipSuccess) return int(e0);
+    }
     attr_done = true;
   }
-  if (evaluate) hipLaunchKernelGGL(gsv::dev::run_program_kernel<true>, dim3(n_instances), dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
-  else hipLaunchKernelGGL(gsv::dev::run_program_kernel<false>, dim3(n_instances), dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
+  const uint32_t ni = ka->instances_per_wg == 2 ? 2u : 1u;
+  const dim3 grid((n_instances + ni - 1) / ni);
+  if (ni == 2) {
+    if (evaluate) hipLaunchKernelGGL((gsv::dev::run_program_kernel<true, 2>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
+    else hipLaunchKernelGGL((gsv::dev::run_program_kernel<false, 2>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
+  } else {
+    if (evaluate) hipLaunchKernelGGL((gsv::dev::run_program_kernel<true, 1>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
+    else hipLaunchKernelGGL((gsv::dev::run_program_kernel<false, 1>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
+  }
   return int(hipGetLastError());
 }
 int gsvk_gather_outputs(const void* W, const void* VB, uint32_t n_slots, const uint32_t* slots, uint32_t n_out, uint32_t n_instances,

@@ -118,6 +118,7 @@ struct Program {
   std::vector<uint32_t> input_slots, output_slots;
   uint32_t n_slots = 0;        // HBM wire-file entries per instance (constants, inputs, long-lived wires, feedback staging)
   uint32_t n_lds_slots = 0;    // LDS window entries used
+  uint32_t lds_slots_limit = 0; // window size the program was compiled for (decides how many instances share a workgroup)
   uint32_t fb_stage_base = 0;  // first staging slot for feedback copies
   std::vector<uint32_t> fb_src_slot, fb_dst_slot;  // replay epilogue: W[dst] <- W[src]
   uint64_t n_gates = 0;        // gates in stream order INCLUDING dead ones (= gate_ids consumed per replay)
@@ -286,6 +287,7 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
   }
   p.peak_live = peak;
   p.n_lds_slots = lds.high();
+  p.lds_slots_limit = opt.lds_slots;
   for (uint32_t w : inputs) p.input_slots.push_back(slot[w]);
   for (uint32_t w : outputs) {
     if (slot[w] == DEAD_WIRE) gsv_panic("output wire was never produced");

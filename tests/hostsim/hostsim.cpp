@@ -63,8 +63,7 @@ int hostsim_run(SimProgram* sp, int evaluate, uint32_t replays, uint64_t gid_bas
   try {
     const Program& g = sp->prog;
     const AesTables& T = AesTables::fixed_key();
-    dev::PlainTables aes{{T.te[0], T.te[1], T.te[2], T.te[3]}};
-    const uint32_t* rk = T.rk;
+    dev::PlainTables aes{{T.te[0], T.te[1], T.te[2], T.te[3]}, T.rk};
     std::vector<uint8_t> W(size_t(g.n_slots) * 16, 0xA5);  // poison: reading a never-written slot is visible
     std::vector<uint8_t> VB(g.n_slots, 0);
     std::vector<uint8_t> LW(size_t(LDS_WINDOW_SLOTS) * 16, 0x5A), LB(LDS_WINDOW_SLOTS, 0);  // LDS window image
@@ -103,12 +102,12 @@ int hostsim_run(SimProgram* sp, int evaluate, uint32_t replays, uint64_t gid_bas
           Label a = load(lab(sa)), b = load(lab(sb));
           if (!evaluate) {
             Label c0, c;
-            dev::garble_and(aes, rk, ty, a, b, d, gid, c0, c);
+            dev::garble_and(aes, ty, a, b, d, gid, c0, c);
             wr.push_back({sc, c0});
             store(ct + size_t(cti) * 16, c);
           } else {
             Label c = load(ct + size_t(cti) * 16);
-            wr.push_back({sc, dev::degarble_and(aes, rk, ty, c, a, bit(sa), b, gid)});
+            wr.push_back({sc, dev::degarble_and(aes, ty, c, a, bit(sa), b, gid)});
             wb.push_back({sc, uint8_t(dev::gate_eval_bit(ty, bit(sa), bit(sb)))});
           }
         }
@@ -161,15 +160,15 @@ void hostsim_cbcmac(const uint8_t* cts, uint64_t n, uint8_t out[16]) {
 }
 void hostsim_aes_ttable(const uint8_t in[16], uint8_t out[16]) {
   const AesTables& T = AesTables::fixed_key();
-  dev::PlainTables aes{{T.te[0], T.te[1], T.te[2], T.te[3]}};
-  Label o = dev::aes128_encrypt(aes, T.rk, load(in));
+  dev::PlainTables aes{{T.te[0], T.te[1], T.te[2], T.te[3]}, T.rk};
+  Label o = dev::aes128_encrypt(aes, load(in));
   store(out, o);
 }
 void hostsim_aes_portable(const uint8_t in[16], uint8_t out[16]) { CbcMacHost::encrypt_portable(AesTables::fixed_key(), in, out); }
 void hostsim_hash(const uint8_t label[16], uint64_t gid, uint8_t out[16]) {
   const AesTables& T = AesTables::fixed_key();
-  dev::PlainTables aes{{T.te[0], T.te[1], T.te[2], T.te[3]}};
-  store(out, dev::hash_with_gate(aes, T.rk, load(label), gid));
+  dev::PlainTables aes{{T.te[0], T.te[1], T.te[2], T.te[3]}, T.rk};
+  store(out, dev::hash_with_gate(aes, load(label), gid));
 }
 void hostsim_sbox(uint8_t out[256]) { std::memcpy(out, AesTables::fixed_key().sbox, 256); }
 
