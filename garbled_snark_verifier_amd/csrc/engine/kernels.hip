@@ -206,12 +206,45 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         const uint32_t na = d.y * LPG;
         if (tid < na) r = and_q[size_t(d.x + tid / LPG)];
         else if (tid < na + d.w) { const u32x2 x = xor_q[size_t(d.z + (tid - na))]; r.x = x.x; r.y = x.y; }
-      } else if (tid < d.y) r = and_q[size_t(d.x + tid)];  // wide: free-gate records are fetched inside the step
+      } else if (d.y >= BT) { r = and_q[size_t(d.x + tid)]; }  // wide: first whole pass; free-gate records are fetched inside the step
+      else if (tid / LPG < d.y) r = and_q[size_t(d.x + tid / LPG)];  // wide without a whole pass: first multi-lane remainder pass
       return r;
     };
     u32x4 sd = load_desc(0), r0 = load_rec(sd);
     u32x4 nsd = load_desc(1), n0 = load_rec(nsd);
     const uint32_t wave_first = __builtin_amdgcn_readfirstlane(tid);  // index of the wave's first lane inside its instance group
+    // One AND-family gate spread over LPG lanes (garble: two AES blocks x 4 columns, evaluate: one block x 4 columns).
+    // Called with LPG-aligned groups of active lanes; `q` is the gate's 16-byte record (same in all lanes of the group).
+    auto and_multilane = [&](const u32x4& q) {
+      const uint32_t sa = q.x & GSV_SLOT_MASK;
+      const uint32_t sb = ((q.x >> 21) | (q.y << 11)) & GSV_SLOT_MASK;
+      const uint32_t sc = (q.y >> 10) & GSV_SLOT_MASK;
+      const uint32_t t = (q.y >> 31) | ((q.z & 3u) << 1);
+      const uint64_t hi = (uint64_t(q.w) << 32) | q.z;
+      const uint64_t gid = gid_base + ((hi >> 2) & 0x7FFFFFFFull);
+      const uint32_t cti = uint32_t(hi >> 33);
+      uint32_t a_c = dq, b_c = dq;
+      if (!no_load) { a_c = wf.ld_word(sa, col); b_c = wf.ld_word(sb, col); }
+      const uint32_t twc = tweak_word(gid, col);
+      if (!EVAL) {
+        uint32_t x = a_c ^ (alpha_a(t) ? dq : 0u);  // selected_a ; lanes of the second quad take other_a
+        if (blk) x ^= dq;
+        const uint32_t h = no_aes ? (x ^ twc) : aes128_quad(aes, rkc, x ^ twc);
+        const uint32_t o = uint32_t(__shfl_xor(int(h), 4));  // the other block's column c
+        const uint32_t c0_c = h ^ (alpha_c(t) ? dq : 0u);
+        const uint32_t ct_c = h ^ o ^ b_c ^ (alpha_b(t) ? dq : 0u);
+        if (!blk && !no_store) wf.st_word(sc, col, c0_c);
+        asm volatile("" ::: "memory");
+        if (!blk && !no_store) CTw[(ct_base + cti) * 4u + col] = ct_c;
+      } else {
+        const uint32_t va = wf.ld_bit(sa), vb = wf.ld_bit(sb);
+        const uint32_t ct_c = CTw[(ct_base + cti) * 4u + col];
+        const uint32_t h = no_aes ? (a_c ^ twc) : aes128_quad(aes, rkc, a_c ^ twc);
+        const uint32_t use_ct = (va ^ alpha_a(t)) & 1u;
+        wf.st_word(sc, col, h ^ (use_ct ? (ct_c ^ b_c) : 0u));
+        if (col == 0) wf.st_bit(sc, gate_eval_bit(t, va, vb));
+      }
+    };
     for (uint32_t s = 0; s < ka.n_steps; ++s) {
       const uint32_t and_off = sd.x, and_cnt = sd.y, xor_off = sd.z, total = sd.y + sd.w;
       const u32x4 n2sd = load_desc(s + 2);  // lands during this step; its record load is issued at the end
@@ -225,31 +258,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         const uint32_t sc = (q.y >> 10) & GSV_SLOT_MASK;
         const uint32_t top = q.y >> 31;
         if (tid < na) {
-          const uint32_t t = top | ((q.z & 3u) << 1);
-          const uint64_t hi = (uint64_t(q.w) << 32) | q.z;
-          const uint64_t gid = gid_base + ((hi >> 2) & 0x7FFFFFFFull);
-          const uint32_t cti = uint32_t(hi >> 33);
-          uint32_t a_c = dq, b_c = dq;
-          if (!no_load) { a_c = wf.ld_word(sa, col); b_c = wf.ld_word(sb, col); }
-          const uint32_t twc = tweak_word(gid, col);
-          if (!EVAL) {
-            uint32_t x = a_c ^ (alpha_a(t) ? dq : 0u);  // selected_a ; lanes of the second quad take other_a
-            if (blk) x ^= dq;
-            const uint32_t h = no_aes ? (x ^ twc) : aes128_quad(aes, rkc, x ^ twc);
-            const uint32_t o = uint32_t(__shfl_xor(int(h), 4));  // the other block's column c
-            const uint32_t c0_c = h ^ (alpha_c(t) ? dq : 0u);
-            const uint32_t ct_c = h ^ o ^ b_c ^ (alpha_b(t) ? dq : 0u);
-            if (!blk && !no_store) wf.st_word(sc, col, c0_c);
-            asm volatile("" ::: "memory");
-            if (!blk && !no_store) CTw[(ct_base + cti) * 4u + col] = ct_c;
-          } else {
-            const uint32_t va = wf.ld_bit(sa), vb = wf.ld_bit(sb);
-            const uint32_t ct_c = CTw[(ct_base + cti) * 4u + col];
-            const uint32_t h = no_aes ? (a_c ^ twc) : aes128_quad(aes, rkc, a_c ^ twc);
-            const uint32_t use_ct = (va ^ alpha_a(t)) & 1u;
-            wf.st_word(sc, col, h ^ (use_ct ? (ct_c ^ b_c) : 0u));
-            if (col == 0) wf.st_bit(sc, gate_eval_bit(t, va, vb));
-          }
+          and_multilane(q);
         } else if (tid < na + sd.w) {
           Label a = delta, b = delta;
           if (!no_load) { a = wf.ld(sa); b = wf.ld(sb); }
@@ -303,11 +312,14 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           }
         };
         issue_xor_batch(0);
-        // ---- AND passes; the record of pass k+1 is requested before pass k computes
+        // ---- AND-family gates: whole passes of BT gates in the one-gate-per-lane form (two interleaved AES blocks
+        // per lane), then the remainder in the LPG-lanes-per-gate form: a partly filled one-gate-per-lane pass would
+        // cost the full ~5 us AES latency for a handful of waves, the multi-lane form ~1 us per BT/LPG gates.
+        const uint32_t and_full = (and_cnt / BT) * BT;
         u32x4 qnext = r0;
-        for (uint32_t i = tid; i < and_cnt; i += BT) {
+        for (uint32_t i = tid; i < and_full; i += BT) {
           const u32x4 q = qnext;
-          if (i + BT < and_cnt) qnext = and_q[size_t(and_off + i + BT)];
+          if (i + BT < and_full) qnext = and_q[size_t(and_off + i + BT)];
           const uint32_t sa = q.x & GSV_SLOT_MASK;
           const uint32_t sb = ((q.x >> 21) | (q.y << 11)) & GSV_SLOT_MASK;
           const uint32_t sc = (q.y >> 10) & GSV_SLOT_MASK;
@@ -334,13 +346,17 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           }
           if (!EVAL && !no_store) CT[ct_base + cti] = u32x4{ct.w[0], ct.w[1], ct.w[2], ct.w[3]};
         }
+        for (uint32_t g = and_full + tid / LPG; g < and_cnt; g += BT / LPG) {
+          // the first remainder record was prefetched two steps ago when the step has no whole pass
+          const u32x4 q = (and_full == 0 && g == tid / LPG) ? r0 : u32x4(and_q[size_t(and_off + g)]);
+          and_multilane(q);
+        }
         // ---- free-gate batches (their label stores are the wave's youngest stores: no young ciphertext store)
         for (uint32_t base = 0; base < xor_cnt; base += XB * BT) {
           if (base) issue_xor_batch(base);
           finish_xor_batch(base);
         }
-        young_ct = !EVAL && !no_store && xor_cnt == 0 && wave_first < and_cnt &&
-                   (wave_first + ((and_cnt - 1u - wave_first) / BT) * BT) < and_cnt;
+        young_ct = !EVAL && !no_store && xor_cnt == 0 && and_full == and_cnt && wave_first < and_cnt;
       }
       asm volatile("" ::: "memory");
       const u32x4 n2r = load_rec(n2sd);  // the wave's youngest load: may stay in flight across the barrier
