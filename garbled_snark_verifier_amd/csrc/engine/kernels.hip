@@ -206,8 +206,8 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         const uint32_t na = d.y * LPG;
         if (tid < na) r = and_q[size_t(d.x + tid / LPG)];
         else if (tid < na + d.w) { const u32x2 x = xor_q[size_t(d.z + (tid - na))]; r.x = x.x; r.y = x.y; }
-      } else if (d.y >= BT) { r = and_q[size_t(d.x + tid)]; }  // wide: first whole pass; free-gate records are fetched inside the step
-      else if (tid / LPG < d.y) r = and_q[size_t(d.x + tid / LPG)];  // wide without a whole pass: first multi-lane remainder pass
+      } else if (d.y >= BT || d.y % BT > 2u * (BT / LPG)) { if (tid < d.y) r = and_q[size_t(d.x + tid)]; }  // wide: first one-per-lane pass
+      else if (tid / LPG < d.y) r = and_q[size_t(d.x + tid / LPG)];  // wide with only a small remainder: first multi-lane pass
       return r;
     };
     u32x4 sd = load_desc(0), r0 = load_rec(sd);
@@ -315,7 +315,9 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         // ---- AND-family gates: whole passes of BT gates in the one-gate-per-lane form (two interleaved AES blocks
         // per lane), then the remainder in the LPG-lanes-per-gate form: a partly filled one-gate-per-lane pass would
         // cost the full ~5 us AES latency for a handful of waves, the multi-lane form ~1 us per BT/LPG gates.
-        const uint32_t and_full = (and_cnt / BT) * BT;
+        // (remainders larger than two multi-lane passes are cheaper as one partly filled one-per-lane pass)
+        const uint32_t and_rem = and_cnt % BT;
+        const uint32_t and_full = (and_rem <= 2u * (BT / LPG)) ? and_cnt - and_rem : and_cnt;
         u32x4 qnext = r0;
         for (uint32_t i = tid; i < and_full; i += BT) {
           const u32x4 q = qnext;
@@ -356,7 +358,8 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           if (base) issue_xor_batch(base);
           finish_xor_batch(base);
         }
-        young_ct = !EVAL && !no_store && xor_cnt == 0 && and_full == and_cnt && wave_first < and_cnt;
+        young_ct = !EVAL && !no_store && xor_cnt == 0 && and_full == and_cnt && wave_first < and_cnt &&
+                   (wave_first + ((and_cnt - 1u - wave_first) / BT) * BT) < and_cnt;
       }
       asm volatile("" ::: "memory");
       const u32x4 n2r = load_rec(n2sd);  // the wave's youngest load: may stay in flight across the barrier
