@@ -109,9 +109,14 @@ def main():
     total_gates = gates_per_step_rank * world * args.steps
     value = total_gates / elapsed
 
+    # HBM bytes per launch from the PMC counters: collected in separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+    # passes of this same command and committed under profiles/ (a run cannot read its own counters); only reported
+    # when the committed measurement was taken on the configuration being run.
     traffic = None
-    if os.environ.get("GSV_BENCH_TRAFFIC_BYTES"):  # measured separately with rocprofv3 --pmc (see profiles/), passed in for the record
-        traffic = float(os.environ["GSV_BENCH_TRAFFIC_BYTES"])
+    tpath = os.path.join(ROOT, "profiles", "r01_v3_full", "traffic.json")
+    if os.path.exists(tpath) and B == 256 and replays == -(-VERIFIER_GATES // gates_per_replay) and world == 1:
+        with open(tpath) as f:
+            traffic = float(json.load(f)["hbm_bytes_raw"])
     result = None
     if rank == 0:
         avg_kernel_s = (sum(kernel_ms) / len(kernel_ms)) / 1e3

@@ -18,7 +18,8 @@ import numpy as np
 
 from . import build as _build
 
-__all__ = ["GsvError", "lib", "Program", "Engine", "Session", "CircuitBuilder", "StreamingResult", "labels_from_seed", "GATE_NAMES"]
+__all__ = ["GsvError", "lib", "Program", "Engine", "Session", "CircuitBuilder", "StreamingResult", "labels_from_seed", "GATE_NAMES", "cbcmac",
+           "write_gc_file", "read_gc_file", "gc_file_name"]
 
 GATE_NAMES = ["And", "Nand", "Nimp", "Imp", "Ncimp", "Cimp", "Nor", "Or", "Xor", "Xnor", "Not"]
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -338,3 +339,28 @@ class CircuitBuilder:
         r.kernel_ms = sess.last_kernel_ms()
         r.ciphertext_hash = [sess.ciphertext_hash(i) for i in range(B)]
         return r
+
+
+# ---- ciphertext files: the reference's gc_{index}.bin format ---------------------------------------------------
+# src/cut_and_choose/ciphertext_repository.rs:29,94-106,157 writes, and FileSource (src/circuit/ciphertext_source.rs:36-107)
+# reads, a bare concatenation of 16-byte S::to_bytes() records in gate order, no header.  FileSource CBC-MACs what it
+# reads, so evaluation re-derives the commitment; read_gc_file returns the same pair.
+def gc_file_name(index):
+    return "gc_%d.bin" % index
+
+
+def write_gc_file(path, ciphertexts):
+    """Writes a ciphertext stream ([n,16] uint8) as gc_{i}.bin bytes and returns its AESAccumulatingHash."""
+    a = _u8(ciphertexts).reshape(-1, 16)
+    with open(path, "wb") as f:
+        f.write(a.tobytes())
+    return cbcmac(a)
+
+
+def read_gc_file(path):
+    """Returns ([n,16] uint8 ciphertexts, AESAccumulatingHash) of a gc_{i}.bin file; rejects a trailing partial record."""
+    data = np.fromfile(path, dtype=np.uint8)
+    if data.size % 16:
+        raise GsvError("%s: length %d is not a multiple of 16-byte ciphertext records" % (path, data.size))
+    cts = data.reshape(-1, 16)
+    return cts, cbcmac(cts)

@@ -122,3 +122,24 @@ def test_compiled_chain_replay_matches_streamed_chain():
     inputs_b[:508] = out_a
     out_b, cts_b = sp1.garble(delta, consts, inputs_b, replays=1, gid_base=sp.info["n_gates"])
     assert (out2 == out_b).all() and (cts2 == np.concatenate([cts_a, cts_b])).all()
+
+
+def test_gc_file_format_roundtrip(tmp_path):
+    """gc_{i}.bin = bare 16-byte records (ciphertext_repository.rs:94-106); reading re-derives the CBC-MAC."""
+    import garbled_snark_verifier_amd as gsv
+    g = o.garble("fq_add", 3)
+    path = tmp_path / gsv.gc_file_name(7)
+    h = gsv.write_gc_file(str(path), g.ciphertexts)
+    assert path.name == "gc_7.bin" and path.stat().st_size == 16 * g.n_ciphertexts
+    assert h == g.ct_hash.tobytes()
+    cts, h2 = gsv.read_gc_file(str(path))
+    assert (cts == g.ciphertexts).all() and h2 == h
+    # the oracle evaluator (FileSource semantics) accepts the bytes as they are
+    bits = np.random.default_rng(0).integers(0, 2, g.n_in).astype(np.uint8)
+    act = np.where(bits[:, None] == 1, g.input_label0 ^ g.delta[None, :], g.input_label0)
+    e = o.evaluate("fq_add", (g.true_label0 ^ g.delta).tobytes(), g.false_label0.tobytes(), act, bits, cts)
+    assert e.ct_hash.tobytes() == h and e.n_consumed == g.n_ciphertexts
+    with open(path, "ab") as f:
+        f.write(b"\x00" * 5)
+    with pytest.raises(gsv.GsvError):
+        gsv.read_gc_file(str(path))
