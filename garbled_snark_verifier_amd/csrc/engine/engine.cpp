@@ -68,7 +68,8 @@ struct gsv_session {
   uint64_t replays = 1, ct_cap = 1;
   void *W = nullptr, *VB = nullptr, *CT = nullptr, *delta = nullptr, *out = nullptr, *out_bits = nullptr, *in_bits = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool ran = false, last_eval = false;
+  bool ran = false, last_eval = false, garbled = false;
+  std::vector<uint64_t> ct_uploaded;  // per instance: records supplied by gsv_session_upload_ciphertexts
   uint64_t ct_stride() const { return ct_cap * p->prog.n_ct; }
 };
 
@@ -252,6 +253,7 @@ int gsv_session_create(gsv_engine* e, const gsv_program* cp, size_t n_instances,
   HIPCHK(hipSetDevice(e->device));
   std::unique_ptr<gsv_session> s(new gsv_session());
   s->e = e; s->p = p; s->n_inst = n_instances; s->replays = replays; s->ct_cap = ct_capacity_replays;
+  s->ct_uploaded.assign(n_instances, 0);
   int rc = upload_program(e, p, &s->dp);
   if (rc) return rc;
   const Program& g = p->prog;
@@ -325,6 +327,7 @@ int gsv_session_upload_ciphertexts(gsv_session* s, size_t instance, const uint8_
   if (n_records > s->ct_stride()) return fail(GSV_ERR_INVALID, "more ciphertexts than the session's stream capacity");
   HIPCHK(hipSetDevice(s->e->device));
   if (n_records) HIPCHK(hipMemcpy(static_cast<uint8_t*>(s->CT) + instance * s->ct_stride() * 16, cts, n_records * 16, hipMemcpyHostToDevice));
+  s->ct_uploaded[instance] = n_records;
   return GSV_OK;
 }
 
@@ -359,8 +362,23 @@ static int launch(gsv_session* s, uint64_t gate_id_base, bool eval) {
   s->ran = true; s->last_eval = eval;
   return GSV_OK;
 }
-int gsv_session_garble(gsv_session* s, uint64_t gate_id_base) { return s ? launch(s, gate_id_base, false) : fail(GSV_ERR_INVALID, "null session"); }
-int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base) { return s ? launch(s, gate_id_base, true) : fail(GSV_ERR_INVALID, "null session"); }
+int gsv_session_garble(gsv_session* s, uint64_t gate_id_base) {
+  if (!s) return fail(GSV_ERR_INVALID, "null session");
+  int rc = launch(s, gate_id_base, false);
+  if (rc == GSV_OK) s->garbled = true;
+  return rc;
+}
+int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base) {
+  if (!s) return fail(GSV_ERR_INVALID, "null session");
+  // EvaluateMode panics with "Ciphertext source exhausted at gate .." when the source runs dry (evaluate_mode.rs:139-142).
+  const uint64_t need = s->p->prog.n_ct * s->replays;
+  if (s->ct_cap != s->replays) return fail(GSV_ERR_INVALID, "evaluate needs the whole ciphertext stream resident (ct_capacity_replays == replays)");
+  if (!s->garbled)
+    for (size_t i = 0; i < s->n_inst; ++i)
+      if (s->ct_uploaded[i] < need)
+        return fail(GSV_ERR_EXHAUSTED, "Ciphertext source exhausted: instance " + std::to_string(i) + " holds " + std::to_string(s->ct_uploaded[i]) + " of " + std::to_string(need) + " ciphertexts");
+  return launch(s, gate_id_base, true);
+}
 
 int gsv_session_sync(gsv_session* s) {
   if (!s) return fail(GSV_ERR_INVALID, "null session");

@@ -137,3 +137,25 @@ def test_properties_at_full_batch(engine):
     assert g.ciphertext_hash[0] == g.ciphertext_hash[15]
     assert len(set(g.ciphertext_hash[:15])) == 15
     _evaluate_and_check(gsv, engine, "fq_mul", g, prog, seeds)
+
+
+def test_evaluate_with_short_ciphertext_stream_fails_like_reference(engine):
+    """evaluate_mode.rs:139-142 panics "Ciphertext source exhausted at gate .."; the engine refuses the launch."""
+    import garbled_snark_verifier_amd as gsv
+    prog = gsv.Program.from_circuit("fq_add")
+    g = gsv.CircuitBuilder.streaming_garbling("fq_add", [1], engine=engine, program=prog)
+    bits = np.zeros((1, prog.info["n_inputs"]), np.uint8)
+    with pytest.raises(gsv.GsvError, match="exhausted"):
+        gsv.CircuitBuilder.streaming_evaluation("fq_add", g.true_label0 ^ g.delta, g.false_label0, g.input_label0, bits,
+                                                [g.ciphertexts[0][:-1]], engine=engine, program=prog)
+
+
+def test_empty_and_free_only_programs(engine):
+    """Edge cases: a circuit of free gates only emits no ciphertext; hash of the empty stream is S::ZERO bytes."""
+    import garbled_snark_verifier_amd as gsv
+    g, prog = _garble_and_check(gsv, engine, "gate:8", [9])
+    assert g.n_ciphertexts == 0 and g.ciphertext_hash[0] == bytes(16)
+    prog2 = gsv.Program.from_gates(2, [], [2, 3, 0, 1])  # outputs = inputs and constants, no gates at all
+    r = gsv.CircuitBuilder.streaming_garbling("", [4], engine=engine, program=prog2)
+    d, f, t, inp = gsv.labels_from_seed(4, 2)
+    assert (r.output_label0[0] == np.stack([inp[0], inp[1], f, t])).all()
