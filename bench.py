@@ -125,7 +125,7 @@ def main():
             "metric": "gates/sec (garble) on Groth16/BN254 verifier; ciphertext-hash match",
             "value": value, "unit": "gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u128 labels (u32 lanes)", "data": "synthetic",
+            "dtype": "u32", "data": "synthetic",
             "config": {"workload": "Groth16-shaped synthetic: chain of %d Fq12::mul_montgomery components = %d gates per instance "
                                    "(>= 11,174,708,821-gate verifier); %d cut-and-choose instances per GPU" % (replays, gates_per_replay * replays, B),
                        "instances_per_gpu": B, "replays": replays, "gates_per_instance": gates_per_replay * replays,
