@@ -227,9 +227,10 @@ static int upload_program(gsv_engine* e, gsv_program* p, DevProgram* out) {
   DevProgram d;
   const Program& g = p->prog;
   auto up = [&](void** dst, const void* src, size_t bytes) -> int {
-    if (bytes == 0) { *dst = nullptr; return GSV_OK; }
-    HIPCHK(hipMalloc(dst, bytes));
-    HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    // +16 bytes of zero padding: the kernel's record prefetch reads 16 bytes at the last 8-byte record
+    HIPCHK(hipMalloc(dst, bytes + 16));
+    HIPCHK(hipMemset(*dst, 0, bytes + 16));
+    if (bytes) HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
     d.bytes += bytes;
     return GSV_OK;
   };

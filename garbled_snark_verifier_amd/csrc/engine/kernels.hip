@@ -200,15 +200,23 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       if (!inst_active) { d.y = 0; d.w = 0; }
       return d;
     };
-    auto load_rec = [&](const u32x4& d) -> u32x4 {  // record of this lane's first (or only) gate of step d
-      u32x4 r = {0, 0, 0, 0};
+    // Record of this lane's first (or only) gate of step d.  ALWAYS exactly one 16-byte vector load per lane and
+    // per wave, whatever the lane has to do: the step barrier's counted vmcnt relies on it.  Free-gate records
+    // are 8 bytes, so their load also brings the following record (the array is padded by 16 bytes on upload);
+    // lanes without a gate read the step table's first entry (always present).
+    const glb_u8* const and_bytes = (const glb_u8*)ka.ands;
+    const glb_u8* const xor_bytes = (const glb_u8*)ka.xors;
+    auto load_rec = [&](const u32x4& d) -> u32x4 {
+      const glb_u8* p = (const glb_u8*)ka.steps;
       if (is_narrow(d)) {
         const uint32_t na = d.y * LPG;
-        if (tid < na) r = and_q[size_t(d.x + tid / LPG)];
-        else if (tid < na + d.w) { const u32x2 x = xor_q[size_t(d.z + (tid - na))]; r.x = x.x; r.y = x.y; }
-      } else if (d.y >= BT || d.y % BT > 2u * (BT / LPG)) { if (tid < d.y) r = and_q[size_t(d.x + tid)]; }  // wide: first one-per-lane pass
-      else if (tid / LPG < d.y) r = and_q[size_t(d.x + tid / LPG)];  // wide with only a small remainder: first multi-lane pass
-      return r;
+        if (tid < na) p = and_bytes + size_t(d.x + tid / LPG) * 16u;
+        else if (tid < na + d.w) p = xor_bytes + size_t(d.z + (tid - na)) * 8u;
+      } else if (d.y >= BT || d.y % BT > 2u * (BT / LPG)) { if (tid < d.y) p = and_bytes + size_t(d.x + tid) * 16u; }  // wide: first one-per-lane pass
+      else if (tid / LPG < d.y) p = and_bytes + size_t(d.x + tid / LPG) * 16u;  // wide with only a small remainder: first multi-lane pass
+      // records are 8-byte aligned: two dwordx2 would be two vmcnt events, so read 16 bytes with 8-byte alignment
+      typedef u32x4 __attribute__((aligned(8))) u32x4_a8;
+      return *(const u32x4_a8 GSV_GLB*)p;
     };
     u32x4 sd = load_desc(0), r0 = load_rec(sd);
     u32x4 nsd = load_desc(1), n0 = load_rec(nsd);
