@@ -159,3 +159,24 @@ def test_empty_and_free_only_programs(engine):
     r = gsv.CircuitBuilder.streaming_garbling("", [4], engine=engine, program=prog2)
     d, f, t, inp = gsv.labels_from_seed(4, 2)
     assert (r.output_label0[0] == np.stack([inp[0], inp[1], f, t])).all()
+
+
+def test_lockstep_determinism_stress(engine):
+    """Race detector for the hand-counted step barrier: 128 instances with the SAME seed must produce 128 identical
+    ciphertext hashes / output labels, equal to the oracle's, on every one of several launches (all CUs busy)."""
+    import garbled_snark_verifier_amd as gsv
+    prog = gsv.Program.from_circuit("fq12_mul", chain_feedback=True)
+    B, R, seed = 128, 2, 11
+    n_in = prog.info["n_inputs"]
+    d, f, t, inp = gsv.labels_from_seed(seed, n_in)
+    sess = gsv.Session(engine, prog, B, R, R)
+    ref = o.garble("fq12_mul_chain:2", seed, capture_ct=False)
+    for _ in range(3):
+        sess.set_garble_inputs(np.tile(d, (B, 1)), np.tile(np.stack([f, t]), (B, 1, 1)), np.tile(inp, (B, 1, 1)))
+        sess.garble(0)
+        sess.sync()
+        out = sess.read_outputs()
+        assert (out == ref.output_label0[None]).all(), "output labels differ between identical instances / from the oracle"
+        for i in (0, 1, 63, 64, 127):
+            assert sess.ciphertext_hash(i) == ref.ct_hash.tobytes()
+    sess.close()
