@@ -7,7 +7,9 @@
 //   fq_complex          tests/streaming_evaluate.rs:401-407  ((a^2)*b + a)
 //   gate:T              tests/streaming_evaluate.rs:136-213  (one gate of discriminant T at the root)
 //   driver_mix          credits / dead-gate / pass-through / constant edge cases (circuit/mod.rs:419-836 shapes)
+//   random_circuit:SEED pseudo-random DAG with nested components for differential tests
 #pragma once
+#include <algorithm>
 #include <string>
 
 #include "bn254.hpp"
@@ -50,6 +52,61 @@ inline Wires driver_mix(CircuitContext& c, const Wires& in) {
   Wires nocarry = add_without_carry(c, Wires{sum[0], sum[1]}, Wires{sum[2], sum[3]});  // top carry dead
   WireId sel = selector(c, nocarry[0], nocarry[1], ch[1]);
   return {sel, ch[1], in[5], sum[3]};
+}
+
+// Deterministic pseudo-random circuit for differential tests: every gate type, constants as operands, the same
+// wire on both inputs, wires that are never read (dead gates), nested components whose outputs mix inputs,
+// constants and internal wires.  splitmix64 keeps the structure identical for every mode that runs it.
+struct Mix64 {
+  uint64_t s;
+  uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+  uint32_t below(uint32_t n) { return uint32_t(next() % n); }
+};
+inline Wires random_block(CircuitContext& c, const Wires& in, uint64_t seed, uint32_t n_gates, int depth) {
+  Mix64 rng{seed};
+  Wires pool = in;
+  auto pick = [&]() -> WireId {
+    uint32_t r = rng.below(20);
+    if (r == 0) return FALSE_WIRE;
+    if (r == 1) return TRUE_WIRE;
+    // favour recent wires so that chains (depth) and early deaths both occur
+    uint32_t span = std::min<uint32_t>(uint32_t(pool.size()), 1u + rng.below(24));
+    return (rng.below(3) == 0) ? pool[rng.below(uint32_t(pool.size()))] : pool[pool.size() - 1 - rng.below(span)];
+  };
+  for (uint32_t g = 0; g < n_gates; ++g) {
+    if (depth > 0 && rng.below(40) == 0) {
+      Wires ci;
+      uint32_t k = 2 + rng.below(5);
+      for (uint32_t i = 0; i < k; ++i) ci.push_back(pick());
+      uint64_t child_seed = rng.next();
+      uint32_t child_gates = 5 + rng.below(30);
+      uint32_t arity = 1 + rng.below(4);
+      ComponentKey key = KeyBuilder("test::random_block").param_usize("seed", child_seed).param_usize("gates", child_gates).finish(arity, ci.size());
+      ChildFn fn = [child_seed, child_gates, arity, depth](CircuitContext& cc, const Wires& x) -> Wires {
+        Wires all = random_block(cc, x, child_seed, child_gates, depth - 1);
+        Mix64 r2{child_seed ^ 0xABCDEFull};
+        Wires out;
+        for (uint32_t i = 0; i < arity; ++i) {
+          uint32_t sel = r2.below(8);
+          if (sel == 0) out.push_back(TRUE_WIRE);
+          else if (sel == 1) out.push_back(x[r2.below(uint32_t(x.size()))]);  // input passed through as an output
+          else out.push_back(all[all.size() - 1 - r2.below(std::min<uint32_t>(uint32_t(all.size()), 6u))]);
+        }
+        return out;
+      };
+      Wires o = c.with_named_child(key, ci, fn, arity);
+      // (the metadata pass sees mock outputs where the execution pass may see constants or passed-through inputs:
+      //  the generator must draw the same random numbers in both passes, so it never looks at the wire ids)
+      for (WireId w : o) if (rng.below(4) != 0) pool.push_back(w);  // some child outputs are dropped
+      continue;
+    }
+    GateType t = GateType(rng.below(10));  // And..Xnor (the in-place Not is covered by gate:10)
+    WireId a = pick(), b = (rng.below(16) == 0) ? a : pick();
+    WireId o = c.issue_wire();
+    c.add_gate(Gate::make(t, a, b, o));
+    if (rng.below(10) != 0) pool.push_back(o);  // ~10 % of the gates are never read: dead unless chosen as output
+  }
+  return pool;
 }
 }  // namespace detail
 
@@ -133,6 +190,17 @@ inline NamedCircuit make_circuit(const std::string& spec) {
         return Wires{o};
       };
     }
+  } else if (name == "random_circuit") {
+    // random_circuit:SEED — 24 inputs, ~3000 gates, 16 outputs
+    const uint64_t seed = param;
+    nc.n_inputs = 24; nc.n_outputs = 16;
+    nc.fn = [seed](CircuitContext& c, const Wires& in) {
+      Wires pool = detail::random_block(c, in, seed * 7919 + 1, 3000, 2);
+      detail::Mix64 r{seed ^ 0x5151ull};
+      Wires out;
+      for (int i = 0; i < 16; ++i) out.push_back(i == 0 ? in[3] : pool[pool.size() - 1 - r.below(200)]);
+      return out;
+    };
   } else if (name == "driver_mix") {
     nc.n_inputs = 6; nc.n_outputs = 4;
     nc.fn = detail::driver_mix;

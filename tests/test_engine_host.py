@@ -143,3 +143,11 @@ def test_gc_file_format_roundtrip(tmp_path):
         f.write(b"\x00" * 5)
     with pytest.raises(gsv.GsvError):
         gsv.read_gc_file(str(path))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_compiled_schedule_random_circuits(seed):
+    """Differential test on pseudo-random DAGs: ~5000 gates of all ten binary types, ~30 % dead gates, constants,
+    repeated operands, ~100 nested component calls with pass-through / constant outputs."""
+    sp = _hostsim_check("random_circuit:%d" % seed, seed)
+    assert sp.info["n_dead"] > 500 and sp.info["component_calls"] > 50

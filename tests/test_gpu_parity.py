@@ -180,3 +180,15 @@ def test_lockstep_determinism_stress(engine):
         for i in (0, 1, 63, 64, 127):
             assert sess.ciphertext_hash(i) == ref.ct_hash.tobytes()
     sess.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_circuits_differential(engine, seed):
+    """Pseudo-random DAGs (all gate types, dead gates, constants, nested components) x 3 instances: garble and
+    evaluate on the GPU against the oracle."""
+    import garbled_snark_verifier_amd as gsv
+    spec = "random_circuit:%d" % seed
+    seeds = [seed, seed + 100, seed + 200]
+    g, prog = _garble_and_check(gsv, engine, spec, seeds)
+    assert prog.info["n_dead"] > 500
+    _evaluate_and_check(gsv, engine, spec, g, prog, seeds, bit_seed=seed)
