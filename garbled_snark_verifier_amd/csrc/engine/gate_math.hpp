@@ -82,12 +82,12 @@ template <class Tab>
 GSV_HD uint32_t aes_col(const Tab& T, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t k) {
   return xor3(xor3(T.template lk<0, 0>(x0), T.template lk<1, 1>(x1), T.template lk<2, 2>(x2)), T.template lk<3, 3>(x3), k);
 }
-// Final round column: SubBytes + ShiftRows + AddRoundKey; the plain S-box byte sits in Te2 byte0,
-// Te3 byte1, Te0 byte2, Te1 byte3.
+// Final round column: SubBytes + ShiftRows + AddRoundKey; the plain S-box byte sits in Te2 byte0 and byte3
+// and in Te0 byte1 and byte2 (only the two tables the device keeps un-rotated are used).
 template <class Tab>
 GSV_HD uint32_t aes_last_col(const Tab& T, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t k) {
-  return xor3(xor3(T.template lk<2, 0>(x0) & 0x000000ffu, T.template lk<3, 1>(x1) & 0x0000ff00u, T.template lk<0, 2>(x2) & 0x00ff0000u),
-              T.template lk<1, 3>(x3) & 0xff000000u, k);
+  return xor3(xor3(T.template lk<2, 0>(x0) & 0x000000ffu, T.template lk<0, 1>(x1) & 0x0000ff00u, T.template lk<0, 2>(x2) & 0x00ff0000u),
+              T.template lk<2, 3>(x3) & 0xff000000u, k);
 }
 
 // One full AES-128 encryption of `in` (FIPS-197; equals _mm_aesenc x9 + _mm_aesenclast, aes_ni.rs:39-54).

@@ -18,6 +18,7 @@
 
 #include "gate_math.hpp"
 #include "kernel_api.h"
+#include "limits.h"
 
 namespace gsv {
 namespace dev {
@@ -28,20 +29,19 @@ __constant__ uint32_t c_rk[44];
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-// LDS map of a workgroup (163,328 of the CU's 163,840 bytes):
-//   [0, 32 KiB)            AES table Te0, every entry replicated once per LDS bank: dword x*32 + (lane & 31).
-//                          A wave's ds_read_b32 is served in two 32-lane groups (MI355X_MICROARCH.md §LDS);
-//                          inside a group lane j only touches bank j, so 64 data-dependent lookups cost the
-//                          conflict-free 2 cycles (SQ_LDS_BANK_CONFLICT = 0 in profiles/).  Te1..Te3 are byte
-//                          rotations of Te0 (one v_alignbit each).
-//   [32 KiB, +120 KiB)     label window: GSV_LDS_SLOTS x 16 B, the short-lived wires chosen by the compiler
-//   [.., +7.5 KiB)         plaintext bits of window wires (evaluate mode)
+// LDS map of a workgroup (limits.h; 163,632 of the CU's 163,840 bytes):
+//   [0, 64 KiB)   AES tables.  Entry x occupies the 256-byte stride [x*256, x*256+256): dwords 0..31 hold Te0[x]
+//                 replicated once per LDS bank, dwords 32..63 hold Te2[x] = rotl16(Te0[x]) likewise.
+//                 * bank = (address/4) mod 32 = lane & 31 for both halves, and a wave's ds_read_b32 is served in
+//                   two 32-lane groups (MI355X_MICROARCH.md §LDS): 64 data-dependent lookups never conflict;
+//                 * the 256-byte stride puts the index byte on a byte boundary of the address, so the whole lookup
+//                   address {byte1 = state byte, byte0 = lane*4} is ONE v_perm_b32 (an address built as
+//                   bfe + lshl_or cost two VALU ops per lookup = 45 % of the AES instruction stream);
+//                 * Te1 = rotl8(Te0), Te3 = rotl8(Te2): one v_alignbit for half of the lookups, none in the last round.
+//   [64 KiB, +90 KiB)      label window: GSV_LDS_SLOTS x 16 B, the short-lived wires chosen by the compiler
+//   [.., +5.6 KiB)         plaintext bits of window wires (evaluate mode)
 //   [.., +176 B)           the 44 round-key words (read with a wave-uniform address = LDS broadcast; keeping them
 //                          in SGPRs instead spilled ~60 SGPRs and put v_readlane/v_writelane into every step)
-#define GSV_LDS_SLOTS 7680u
-#define GSV_LDS_TABLE_BYTES 32768u
-#define GSV_LDS_RK_BASE (GSV_LDS_TABLE_BYTES + GSV_LDS_SLOTS * 16u + GSV_LDS_SLOTS)  // 44 round-key words
-#define GSV_LDS_BYTES (GSV_LDS_RK_BASE + 176u)
 #define GSV_SLOT_LDS_FLAG (1u << 20)
 #define GSV_SLOT_INDEX_MASK (GSV_SLOT_LDS_FLAG - 1u)
 #define GSV_SLOT_MASK ((1u << 21) - 1u)
@@ -58,13 +58,13 @@ typedef u32x2 GSV_GLB glb_u64;
 typedef uint8_t GSV_GLB glb_u8;
 
 struct LdsBankedTable {
-  uint32_t lane4;  // (lane & 31) * 4; the table starts at LDS byte 0
+  uint32_t lane4;  // (lane & 31) * 4
   template <int K, int BYTE>
   __device__ __forceinline__ uint32_t lk(uint32_t s) const {
-    // byte BYTE of s, times 128 (32 banks x 4 B), as bits 7..14
-    const uint32_t x = BYTE == 0 ? (s << 7) : BYTE == 1 ? (s >> 1) : BYTE == 2 ? (s >> 9) : (s >> 17);
-    const uint32_t v = *reinterpret_cast<const lds_u32*>(uintptr_t((x & 0x7f80u) | lane4));
-    return K == 0 ? v : __builtin_amdgcn_alignbit(v, v, 32 - 8 * K);  // rotl(v, 8K): Te_K from Te0
+    // LDS address = {0, 0, byte BYTE of s, lane4}: v_perm_b32 over {s (bytes 4..7), lane4 (bytes 0..3)}; 0x0c = zero byte
+    const uint32_t addr = __builtin_amdgcn_perm(s, lane4, 0x0c0c0000u | (uint32_t(4 + BYTE) << 8));
+    const uint32_t v = *reinterpret_cast<const lds_u32*>(uintptr_t(addr + ((K & 2) ? 128u : 0u)));  // Te0 or Te2 half
+    return (K & 1) ? __builtin_amdgcn_alignbit(v, v, 24) : v;                                       // Te1 / Te3 = rotl8
   }
   __device__ __forceinline__ uint32_t rk(int i) const { return *reinterpret_cast<const lds_u32*>(uintptr_t(GSV_LDS_RK_BASE + 4u * uint32_t(i))); }
 };
@@ -127,8 +127,8 @@ __device__ __forceinline__ uint32_t aes128_quad(const LdsBankedTable& T, const u
     const uint32_t u0 = T.lk<0, 0>(s), u1 = T.lk<1, 1>(s), u2 = T.lk<2, 2>(s), u3 = T.lk<3, 3>(s);
     s = u0 ^ quad_from<GSV_QP_NEXT1>(u1) ^ quad_from<GSV_QP_NEXT2>(u2) ^ quad_from<GSV_QP_NEXT3>(u3) ^ rkc[r];
   }
-  const uint32_t m0 = T.lk<2, 0>(s) & 0x000000ffu, m1 = T.lk<3, 1>(s) & 0x0000ff00u;
-  const uint32_t m2 = T.lk<0, 2>(s) & 0x00ff0000u, m3 = T.lk<1, 3>(s) & 0xff000000u;
+  const uint32_t m0 = T.lk<2, 0>(s) & 0x000000ffu, m1 = T.lk<0, 1>(s) & 0x0000ff00u;  // S-box byte from the un-rotated tables
+  const uint32_t m2 = T.lk<0, 2>(s) & 0x00ff0000u, m3 = T.lk<2, 3>(s) & 0xff000000u;
   return m0 ^ quad_from<GSV_QP_NEXT1>(m1) ^ quad_from<GSV_QP_NEXT2>(m2) ^ quad_from<GSV_QP_NEXT3>(m3) ^ rkc[10];
 }
 __device__ __forceinline__ uint32_t tweak_word(uint64_t gate_id, uint32_t c) {  // column c of tweak_of(gate_id)
@@ -144,7 +144,8 @@ template <bool EVAL, int NI>
 __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelArgs ka) {
   extern __shared__ __attribute__((aligned(16))) char s_mem[];
   (void)s_mem;  // the dynamic LDS block starts at LDS address 0 (no static __shared__ in this kernel)
-  for (uint32_t i = threadIdx.x; i < GSV_LDS_TABLE_BYTES / 4; i += GSV_BLOCK_THREADS) *reinterpret_cast<lds_u32*>(uintptr_t(i * 4u)) = ka.te[i >> 5];
+  // dword i of the table region: entry x = i / 64; first 32 dwords Te0[x], next 32 dwords Te2[x] (ka.te = Te0..Te3, 256 words each)
+  for (uint32_t i = threadIdx.x; i < GSV_LDS_TABLE_BYTES / 4; i += GSV_BLOCK_THREADS) *reinterpret_cast<lds_u32*>(uintptr_t(i * 4u)) = ka.te[((i & 32u) ? 512u : 0u) + (i >> 6)];
   if (threadIdx.x < 44) *reinterpret_cast<lds_u32*>(uintptr_t(GSV_LDS_RK_BASE + 4u * threadIdx.x)) = c_rk[threadIdx.x];
   __syncthreads();
   constexpr uint32_t BT = GSV_BLOCK_THREADS / NI;  // threads per instance

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../circuit/circuit.hpp"
+#include "limits.h"
 
 namespace gsv {
 
@@ -95,7 +96,7 @@ constexpr uint32_t SLOT_LDS_FLAG = 1u << 20;
 constexpr uint32_t SLOT_INDEX_MASK = SLOT_LDS_FLAG - 1;
 constexpr uint32_t SLOT_MASK = (1u << SLOT_BITS) - 1;
 constexpr uint32_t SLOT_FALSE = 0, SLOT_TRUE = 1, SLOT_ZERO = 2, SLOT_FIRST_INPUT = 3;
-constexpr uint32_t LDS_WINDOW_SLOTS = 7680;  // 120 KiB of the CU's 160 KiB (32 KiB go to the banked AES table)
+constexpr uint32_t LDS_WINDOW_SLOTS = GSV_LDS_SLOTS;  // 90 KiB of the CU's 160 KiB (64 KiB go to the banked AES tables)
 
 // Free gate, 8 bytes:   bits 0..20 a | 21..41 b | 42..62 c | 63 xnor
 struct XorRec { uint64_t v; };
