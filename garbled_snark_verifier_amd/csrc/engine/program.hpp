@@ -159,6 +159,8 @@ class SlotPool {
   void release(uint32_t i) { used_[i] = 0; ++n_free_; }
   void reserve_low(uint32_t n) { if (used_.size() < n) used_.resize(n, 0); for (uint32_t i = high_; i < n; ++i) used_[i] = 1; high_ = std::max(high_, n); cursor_ = high_; }
   uint32_t high() const { return high_; }
+  // slots that alloc() can still hand out right now (fixed pools only)
+  uint32_t available() const { return n_free_ + (fixed_ ? uint32_t(used_.size()) - high_ : 0u); }
  private:
   std::vector<uint8_t> used_;
   uint32_t high_ = 0, cursor_ = 0, n_free_ = 0;
@@ -249,14 +251,34 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
   }
   uint32_t live = next_in, peak = next_in;
   p.steps.reserve(n_steps);
+  std::vector<uint64_t> cand;
+  std::vector<uint32_t> want_lds;
   for (uint32_t s = 0; s < n_steps; ++s) {
     StepDesc sd{uint32_t(p.ands.size()), cnt[2 * size_t(s) + 1] - cnt[2 * size_t(s)], uint32_t(p.xors.size()),
                 cnt[2 * size_t(s) + 2] - cnt[2 * size_t(s) + 1]};
+    // Which of this step's outputs get a window slot: the eligible ones (short-lived, not pinned) with the SHORTEST
+    // lifetimes first — they free their slot soonest, so the window serves the largest number of wires.
+    want_lds.clear();
+    if (opt.lds_slots) {
+      cand.clear();
+      for (uint32_t k = cnt[2 * size_t(s)]; k < cnt[2 * size_t(s) + 2]; ++k) {
+        uint32_t c = t.c[order[k]];
+        if (last_use[c] == NEVER) continue;
+        uint32_t life = dies_at(c, s) - s;
+        if (life <= opt.lds_max_lifetime) cand.push_back((uint64_t(life) << 32) | k);
+      }
+      uint32_t avail = lds.available();
+      if (cand.size() > avail) { std::nth_element(cand.begin(), cand.begin() + avail, cand.end()); cand.resize(avail); }
+      for (uint64_t v : cand) want_lds.push_back(uint32_t(v));
+      std::sort(want_lds.begin(), want_lds.end());
+    }
+    size_t wl = 0;
     for (uint32_t k = cnt[2 * size_t(s)]; k < cnt[2 * size_t(s) + 2]; ++k) {
       size_t i = order[k];
       uint32_t c = t.c[i];
       uint32_t sl = DEAD_WIRE;
-      if (opt.lds_slots && last_use[c] != NEVER && dies_at(c, s) - s <= opt.lds_max_lifetime) {
+      if (wl < want_lds.size() && want_lds[wl] == k) {
+        ++wl;
         uint32_t l = lds.alloc();
         if (l != DEAD_WIRE) sl = l | SLOT_LDS_FLAG;
       }
