@@ -113,7 +113,7 @@ def main():
     # passes of this same command and committed under profiles/ (a run cannot read its own counters); only reported
     # when the committed measurement was taken on the configuration being run.
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_v3_full", "traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01_final", "traffic.json")
     if os.path.exists(tpath) and B == 256 and replays == -(-VERIFIER_GATES // gates_per_replay) and world == 1:
         with open(tpath) as f:
             traffic = float(json.load(f)["hbm_bytes_raw"])

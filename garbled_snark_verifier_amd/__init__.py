@@ -45,7 +45,7 @@ EXPORTS = [
     "gsv_recorder_push_gates", "gsv_recorder_declare_outputs", "gsv_recorder_record_circuit", "gsv_recorder_counts", "gsv_program_compile", "gsv_program_destroy",
     "gsv_program_get_info", "gsv_engine_create", "gsv_engine_destroy", "gsv_labels_from_seed", "gsv_session_create", "gsv_session_destroy",
     "gsv_session_set_garble_inputs", "gsv_session_garble", "gsv_session_set_evaluate_inputs", "gsv_session_upload_ciphertexts",
-    "gsv_session_evaluate", "gsv_session_sync", "gsv_session_last_kernel_ms", "gsv_session_read_outputs", "gsv_session_read_ciphertexts",
+    "gsv_session_evaluate", "gsv_session_set_hasher", "gsv_session_sync", "gsv_session_last_kernel_ms", "gsv_session_read_outputs", "gsv_session_read_ciphertexts",
     "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_commit_labels",
 ]
 
@@ -83,6 +83,7 @@ def lib():
         L.gsv_session_set_evaluate_inputs.argtypes = [vp, u8p, u8p, u8p]
         L.gsv_session_upload_ciphertexts.argtypes = [vp, C.c_size_t, u8p, C.c_uint64]
         L.gsv_session_evaluate.argtypes = [vp, C.c_uint64]
+        L.gsv_session_set_hasher.argtypes = [vp, C.c_int]
         L.gsv_session_sync.argtypes = [vp]
         L.gsv_session_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_double)]
         L.gsv_session_read_outputs.argtypes = [vp, u8p, u8p]
@@ -246,6 +247,10 @@ class Session:
     def evaluate(self, gate_id_base=0):
         _chk(lib().gsv_session_evaluate(self.h, gate_id_base))
 
+    def set_hasher(self, kind):
+        """'aes' (AesNiHasher, default) or 'blake3' (Blake3Hasher)."""
+        _chk(lib().gsv_session_set_hasher(self.h, {"aes": 0, "blake3": 1}[kind]))
+
     def sync(self):
         _chk(lib().gsv_session_sync(self.h))
 
@@ -289,7 +294,7 @@ class CircuitBuilder:
     """Host-side mirror of the reference's CircuitBuilder entry points for the garble/evaluate path."""
 
     @staticmethod
-    def streaming_garbling(circuit, seeds, engine=None, program=None, replays=1, keep_ciphertexts=True):
+    def streaming_garbling(circuit, seeds, engine=None, program=None, replays=1, keep_ciphertexts=True, hasher="aes"):
         """Garble `circuit` once per seed (one instance per seed, all on `engine`'s GPU).
         Mirrors CircuitBuilder::streaming_garbling(inputs, cap, seed, AESAccumulatingHash, f) per instance
         (src/circuit/mod.rs:185-203): labels from the seed's ChaCha stream, ciphertext hash = CBC-MAC."""
@@ -304,6 +309,7 @@ class CircuitBuilder:
         for i, s in enumerate(seeds):
             delta[i], consts[i, 0], consts[i, 1], inputs[i] = labels_from_seed(s, n_in)
         sess = Session(engine, program, B, replays)
+        sess.set_hasher(hasher)
         sess.set_garble_inputs(delta, consts, inputs)
         sess.garble(0)
         sess.sync()
@@ -319,7 +325,8 @@ class CircuitBuilder:
         return r
 
     @staticmethod
-    def streaming_evaluation(circuit, true_active, false_active, input_active, input_bits, ciphertexts, engine=None, program=None, replays=1):
+    def streaming_evaluation(circuit, true_active, false_active, input_active, input_bits, ciphertexts, engine=None, program=None, replays=1,
+                             hasher="aes"):
         """Evaluate instances from their ciphertext streams (src/circuit/mod.rs:225-249).  Arrays carry a
         leading instance dimension; `ciphertexts` is a list of [n,16] uint8 arrays (gc_{i}.bin bytes)."""
         engine = engine or Engine(0)
@@ -328,6 +335,7 @@ class CircuitBuilder:
         B = ta.shape[0]
         consts = np.stack([fa, ta], axis=1)
         sess = Session(engine, program, B, replays)
+        sess.set_hasher(hasher)
         sess.set_evaluate_inputs(consts, input_active, input_bits)
         for i in range(B):
             sess.upload_ciphertexts(i, ciphertexts[i])

@@ -69,6 +69,7 @@ struct gsv_session {
   void *W = nullptr, *VB = nullptr, *CT = nullptr, *delta = nullptr, *out = nullptr, *out_bits = nullptr, *in_bits = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ran = false, last_eval = false, garbled = false;
+  int hasher = 0;  // 0 AesNiHasher, 1 Blake3Hasher
   std::vector<uint64_t> ct_uploaded;  // per instance: records supplied by gsv_session_upload_ciphertexts
   uint64_t ct_stride() const { return ct_cap * p->prog.n_ct; }
 };
@@ -344,6 +345,7 @@ static int launch(gsv_session* s, uint64_t gate_id_base, bool eval) {
   ka.n_steps = uint32_t(g.steps.size()); ka.n_slots = g.n_slots; ka.replays = uint32_t(s->replays); ka.ct_cap_replays = uint32_t(s->ct_cap);
   ka.n_fb = uint32_t(g.fb_src_slot.size()); ka.fb_stage_base = g.fb_stage_base;
   ka.n_instances = uint32_t(s->n_inst);
+  ka.hasher = uint32_t(s->hasher);
   {
     const char* e = getenv("GSV_INSTANCES_PER_WG");
     ka.instances_per_wg = (e && atoi(e) == 2 && g.lds_slots_limit <= LDS_WINDOW_SLOTS / 2 && s->n_inst >= 2) ? 2u : 1u;
@@ -379,6 +381,12 @@ int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base) {
       if (s->ct_uploaded[i] < need)
         return fail(GSV_ERR_EXHAUSTED, "Ciphertext source exhausted: instance " + std::to_string(i) + " holds " + std::to_string(s->ct_uploaded[i]) + " of " + std::to_string(need) + " ciphertexts");
   return launch(s, gate_id_base, true);
+}
+
+int gsv_session_set_hasher(gsv_session* s, int kind) {
+  if (!s || (kind != GSV_HASHER_AES && kind != GSV_HASHER_BLAKE3)) return fail(GSV_ERR_INVALID, "unknown hasher");
+  s->hasher = kind;
+  return GSV_OK;
 }
 
 int gsv_session_sync(gsv_session* s) {

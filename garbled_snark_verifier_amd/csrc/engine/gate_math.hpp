@@ -136,6 +136,48 @@ GSV_HD void aes128_encrypt2(const Tab& T, const Label& in0, const Label& in1, La
 template <class Tab>
 GSV_HD Label hash_with_gate(const Tab& T, const Label& x, uint64_t gate_id) { return aes128_encrypt(T, lxor(x, tweak_of(gate_id))); }
 
+// ---- Blake3Hasher (src/hashers/mod.rs:22-51): first 16 bytes of BLAKE3(label_bytes || LE64(gate_id)).
+// The 24-byte message is one block of one chunk: compress(IV, m, counter 0, block_len 24,
+// CHUNK_START | CHUNK_END | ROOT).  Message words 0..3 are the label's little-endian words, 4..5 the gate id.
+GSV_HD uint32_t b3_rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+#define GSV_B3_G(a, b, c, d, mx, my)                                             \
+  a = a + b + (mx); d = b3_rotr(d ^ a, 16); c = c + d; b = b3_rotr(b ^ c, 12);   \
+  a = a + b + (my); d = b3_rotr(d ^ a, 8);  c = c + d; b = b3_rotr(b ^ c, 7);
+GSV_HD Label blake3_hash_with_gate(const Label& x, uint64_t gate_id) {
+  uint32_t m[16] = {x.w[0], x.w[1], x.w[2], x.w[3], uint32_t(gate_id), uint32_t(gate_id >> 32), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t s0 = 0x6A09E667u, s1 = 0xBB67AE85u, s2 = 0x3C6EF372u, s3 = 0xA54FF53Au, s4 = 0x510E527Fu, s5 = 0x9B05688Cu, s6 = 0x1F83D9ABu,
+           s7 = 0x5BE0CD19u, s8 = 0x6A09E667u, s9 = 0xBB67AE85u, s10 = 0x3C6EF372u, s11 = 0xA54FF53Au, s12 = 0u, s13 = 0u, s14 = 24u,
+           s15 = 1u | 2u | 8u;
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    GSV_B3_G(s0, s4, s8, s12, m[0], m[1]) GSV_B3_G(s1, s5, s9, s13, m[2], m[3])
+    GSV_B3_G(s2, s6, s10, s14, m[4], m[5]) GSV_B3_G(s3, s7, s11, s15, m[6], m[7])
+    GSV_B3_G(s0, s5, s10, s15, m[8], m[9]) GSV_B3_G(s1, s6, s11, s12, m[10], m[11])
+    GSV_B3_G(s2, s7, s8, s13, m[12], m[13]) GSV_B3_G(s3, s4, s9, s14, m[14], m[15])
+    if (r < 6) {  // MSG_PERMUTATION = {2,6,3,10,7,0,4,13,1,11,12,5,9,14,15,8}
+      uint32_t p[16] = {m[2], m[6], m[3], m[10], m[7], m[0], m[4], m[13], m[1], m[11], m[12], m[5], m[9], m[14], m[15], m[8]};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m[i] = p[i];
+    }
+  }
+  return Label{{s0 ^ s8, s1 ^ s9, s2 ^ s10, s3 ^ s11}};
+}
+// Same half-gate algebra as below with the Blake3 PRF (no tweak: the gate id is part of the message).
+GSV_HD void garble_and_blake3(uint32_t t, const Label& a0, const Label& b0, const Label& delta, uint64_t gate_id, Label& c0, Label& ct) {
+  Label sel = lxor_if(a0, delta, alpha_a(t));
+  Label oth = lxor(sel, delta);
+  Label hs = blake3_hash_with_gate(sel, gate_id), ho = blake3_hash_with_gate(oth, gate_id);
+  Label bsel = lxor_if(b0, delta, alpha_b(t));
+  ct = lxor(lxor(hs, ho), bsel);
+  c0 = lxor_if(hs, delta, alpha_c(t));
+}
+GSV_HD Label degarble_and_blake3(uint32_t t, const Label& ct, const Label& a, uint32_t a_value, const Label& b, uint64_t gate_id) {
+  Label h = blake3_hash_with_gate(a, gate_id);
+  uint32_t use_ct = (a_value ^ alpha_a(t)) & 1u;
+  Label z{{0, 0, 0, 0}};
+  return lxor(h, lxor_if(z, lxor(ct, b), use_ct));
+}
+
 // garble_gate, AND-family arm (halfgates_garbling.rs:17-35).  t < 8.
 template <class Tab>
 GSV_HD void garble_and(const Tab& T, uint32_t t, const Label& a0, const Label& b0, const Label& delta, uint64_t gate_id,

@@ -33,6 +33,7 @@ struct KernelArgs {
   uint32_t fb_stage_base;
   uint32_t n_instances;
   uint32_t instances_per_wg;  // 1 or 2 (2 needs a program compiled for half the LDS window)
+  uint32_t hasher;            // 0 = AesNiHasher, 1 = Blake3Hasher
   uint32_t diag;  // timing experiments only (GSV_DIAG env): 1 = skip AES, 2 = no record prefetch, 4 = skip label loads, 8 = skip stores
 };
 

@@ -140,7 +140,9 @@ __device__ __forceinline__ uint32_t tweak_word(uint64_t gate_id, uint32_t c) {  
 // NI = instances per workgroup.  NI = 2 splits the 1024 threads into two halves that garble two instances of the
 // same program in lockstep (they share the step barrier and the AES table; each has half of the label window):
 // the many steps that are narrower than half a workgroup then cost their fixed latency once for two instances.
-template <bool EVAL, int NI>
+// HASH = 0: AesNiHasher (fixed-key AES, the hot path); HASH = 1: Blake3Hasher (src/hashers/mod.rs:22-51; the PRF most of
+// the reference's own tests use) — pure 32-bit add/xor/rotate, one gate per lane in every step (no multi-lane form).
+template <bool EVAL, int NI, int HASH>
 __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelArgs ka) {
   extern __shared__ __attribute__((aligned(16))) char s_mem[];
   (void)s_mem;  // the dynamic LDS block starts at LDS address 0 (no static __shared__ in this kernel)
@@ -195,7 +197,9 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     // ops retire in issue order and the N youngest ops of the wave are, by construction (compiler barriers pin
     // the order), the record prefetch load and, when the wave's last pass held AND gates, the ciphertext store.
     const uint32_t last_step = ka.n_steps - 1;
-    auto is_narrow = [&](const u32x4& d) -> bool { return !no_narrow && d.y != 0 && d.y * LPG + d.w <= BT; };
+    auto is_narrow = [&](const u32x4& d) -> bool { return HASH == 0 && !no_narrow && d.y != 0 && d.y * LPG + d.w <= BT; };
+    // wide steps: is the AND remainder small enough for the multi-lane form?
+    auto small_rem = [&](uint32_t n_and) -> bool { return HASH == 0 && (n_and % BT) <= 2u * (BT / LPG); };
     auto load_desc = [&](uint32_t s) -> u32x4 {
       u32x4 d = step_q[s < last_step ? s : last_step];  // wave-uniform address: a scalar (SMEM) load, two steps ahead of its use
       if (!inst_active) { d.y = 0; d.w = 0; }
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         const uint32_t na = d.y * LPG;
         if (tid < na) p = and_bytes + size_t(d.x + tid / LPG) * 16u;
         else if (tid < na + d.w) p = xor_bytes + size_t(d.z + (tid - na)) * 8u;
-      } else if (d.y >= BT || d.y % BT > 2u * (BT / LPG)) { if (tid < d.y) p = and_bytes + size_t(d.x + tid) * 16u; }  // wide: first one-per-lane pass
+      } else if (d.y >= BT || !small_rem(d.y)) { if (tid < d.y) p = and_bytes + size_t(d.x + tid) * 16u; }  // wide: first one-per-lane pass
       else if (tid / LPG < d.y) p = and_bytes + size_t(d.x + tid / LPG) * 16u;  // wide with only a small remainder: first multi-lane pass
       // records are 8-byte aligned: two dwordx2 would be two vmcnt events, so read 16 bytes with 8-byte alignment
       typedef u32x4 __attribute__((aligned(8))) u32x4_a8;
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         // cost the full ~5 us AES latency for a handful of waves, the multi-lane form ~1 us per BT/LPG gates.
         // (remainders larger than two multi-lane passes are cheaper as one partly filled one-per-lane pass)
         const uint32_t and_rem = and_cnt % BT;
-        const uint32_t and_full = (and_rem <= 2u * (BT / LPG)) ? and_cnt - and_rem : and_cnt;
+        const uint32_t and_full = small_rem(and_cnt) ? and_cnt - and_rem : and_cnt;
         u32x4 qnext = r0;
         for (uint32_t i = tid; i < and_full; i += BT) {
           const u32x4 q = qnext;
@@ -344,11 +348,13 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           uint32_t vc = 0;
           if (!EVAL) {
             if (no_aes) { c0 = lxor(a, b); ct = lxor(a, tweak_of(gid)); }
+            else if (HASH == 1) garble_and_blake3(t, a, b, delta, gid, c0, ct);
             else garble_and(aes, t, a, b, delta, gid, c0, ct);
           } else {
             const uint32_t va = wf.ld_bit(sa), vb = wf.ld_bit(sb);
             const u32x4 cv = CT[ct_base + cti];
-            c0 = degarble_and(aes, t, Label{{cv.x, cv.y, cv.z, cv.w}}, a, va, b, gid);
+            if (HASH == 1) c0 = degarble_and_blake3(t, Label{{cv.x, cv.y, cv.z, cv.w}}, a, va, b, gid);
+            else c0 = degarble_and(aes, t, Label{{cv.x, cv.y, cv.z, cv.w}}, a, va, b, gid);
             vc = gate_eval_bit(t, va, vb);
           }
           if (!no_store || c0.w[0] == 0x12345678u) {
@@ -431,8 +437,9 @@ int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, in
   if (!attr_done) {
     // the kernels address LDS from byte 0: there must be no static LDS in front of the dynamic block
     hipFuncAttributes fa;
-    const void* kernels[4] = {reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 1>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 1>),
-                              reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 2>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 2>)};
+    const void* kernels[6] = {reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 1, 0>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 1, 0>),
+                              reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 2, 0>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 2, 0>),
+                              reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 1, 1>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 1, 1>)};
     for (const void* k : kernels) {
       if (hipFuncGetAttributes(&fa, k) != hipSuccess || fa.sharedSizeBytes != 0) return int(hipErrorInvalidValue);
       hipError_t e0 = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
@@ -440,14 +447,18 @@ int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, in
     }
     attr_done = true;
   }
-  const uint32_t ni = ka->instances_per_wg == 2 ? 2u : 1u;
+  const bool blake3 = ka->hasher == 1;
+  const uint32_t ni = (ka->instances_per_wg == 2 && !blake3) ? 2u : 1u;
   const dim3 grid((n_instances + ni - 1) / ni);
-  if (ni == 2) {
-    if (evaluate) hipLaunchKernelGGL((gsv::dev::run_program_kernel<true, 2>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
-    else hipLaunchKernelGGL((gsv::dev::run_program_kernel<false, 2>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
+  if (blake3) {
+    if (evaluate) hipLaunchKernelGGL((gsv::dev::run_program_kernel<true, 1, 1>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
+    else hipLaunchKernelGGL((gsv::dev::run_program_kernel<false, 1, 1>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
+  } else if (ni == 2) {
+    if (evaluate) hipLaunchKernelGGL((gsv::dev::run_program_kernel<true, 2, 0>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
+    else hipLaunchKernelGGL((gsv::dev::run_program_kernel<false, 2, 0>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
   } else {
-    if (evaluate) hipLaunchKernelGGL((gsv::dev::run_program_kernel<true, 1>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
-    else hipLaunchKernelGGL((gsv::dev::run_program_kernel<false, 1>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
+    if (evaluate) hipLaunchKernelGGL((gsv::dev::run_program_kernel<true, 1, 0>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
+    else hipLaunchKernelGGL((gsv::dev::run_program_kernel<false, 1, 0>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
   }
   return int(hipGetLastError());
 }

@@ -123,6 +123,12 @@ int gsv_session_set_evaluate_inputs(gsv_session* s, const uint8_t* const_active,
 int gsv_session_upload_ciphertexts(gsv_session* s, size_t instance, const uint8_t* cts, uint64_t n_records);
 int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base);
 
+/* Gate PRF (`H: GateHasher`, src/hashers/mod.rs:15-20): GSV_HASHER_AES = AesNiHasher (default; the benchmarked
+ * path, hashers/mod.rs:54-96), GSV_HASHER_BLAKE3 = Blake3Hasher (hashers/mod.rs:22-51, the crate's DefaultHasher). */
+#define GSV_HASHER_AES 0
+#define GSV_HASHER_BLAKE3 1
+int gsv_session_set_hasher(gsv_session* s, int kind);
+
 int gsv_session_sync(gsv_session* s);
 /* seconds of device time of the last garble/evaluate launch (HIP events on the engine stream) */
 int gsv_session_last_kernel_ms(gsv_session* s, double* ms);

@@ -172,6 +172,49 @@ static inline void hash2_with_gate(const S& l0, const S& l1, uint64_t gate_id, S
   h1 = hash_with_gate(l1, gate_id);
 }
 
+// ---------------------------------------------------------------------------------------
+// Blake3Hasher (src/hashers/mod.rs:22-51): blake3(label_bytes || gate_id.to_le_bytes())[0..16].
+// blake3 1.8.2 is a Cargo.lock dependency, not vendored; this restates the published BLAKE3 compression function
+// for inputs of at most one 64-byte block (one chunk, flags CHUNK_START|CHUNK_END|ROOT).  Pinned by the
+// official test vectors for input lengths 0..8, 63, 64 (tests/test_oracle_kat.py).
+static void blake3_short(const uint8_t* data, size_t n, uint8_t out[32]) {
+  static const uint32_t IV[8] = {0x6A09E667, 0xBB67AE85, 0x3C6EF372, 0xA54FF53A, 0x510E527F, 0x9B05688C, 0x1F83D9AB, 0x5BE0CD19};
+  static const int PERM[16] = {2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8};
+  if (n > 64) gsv_panic("blake3_short: more than one block");
+  uint8_t block[64] = {0};
+  std::memcpy(block, data, n);
+  uint32_t m[16], v[16];
+  for (int i = 0; i < 16; ++i) m[i] = uint32_t(block[4 * i]) | uint32_t(block[4 * i + 1]) << 8 | uint32_t(block[4 * i + 2]) << 16 | uint32_t(block[4 * i + 3]) << 24;
+  for (int i = 0; i < 8; ++i) v[i] = IV[i];
+  for (int i = 0; i < 4; ++i) v[8 + i] = IV[i];
+  v[12] = 0; v[13] = 0; v[14] = uint32_t(n); v[15] = 1u | 2u | 8u;
+  auto rotr = [](uint32_t x, int k) { return (x >> k) | (x << (32 - k)); };
+  auto g = [&](int a, int b, int c, int d, uint32_t mx, uint32_t my) {
+    v[a] = v[a] + v[b] + mx; v[d] = rotr(v[d] ^ v[a], 16); v[c] = v[c] + v[d]; v[b] = rotr(v[b] ^ v[c], 12);
+    v[a] = v[a] + v[b] + my; v[d] = rotr(v[d] ^ v[a], 8);  v[c] = v[c] + v[d]; v[b] = rotr(v[b] ^ v[c], 7);
+  };
+  for (int r = 0; r < 7; ++r) {
+    g(0, 4, 8, 12, m[0], m[1]); g(1, 5, 9, 13, m[2], m[3]); g(2, 6, 10, 14, m[4], m[5]); g(3, 7, 11, 15, m[6], m[7]);
+    g(0, 5, 10, 15, m[8], m[9]); g(1, 6, 11, 12, m[10], m[11]); g(2, 7, 8, 13, m[12], m[13]); g(3, 4, 9, 14, m[14], m[15]);
+    uint32_t p[16];
+    for (int i = 0; i < 16; ++i) p[i] = m[PERM[i]];
+    std::memcpy(m, p, sizeof m);
+  }
+  for (int i = 0; i < 8; ++i) {
+    uint32_t w = v[i] ^ v[i + 8];
+    out[4 * i] = uint8_t(w); out[4 * i + 1] = uint8_t(w >> 8); out[4 * i + 2] = uint8_t(w >> 16); out[4 * i + 3] = uint8_t(w >> 24);
+  }
+}
+static int g_hasher = 0;  // 0 = AesNiHasher (the hot path), 1 = Blake3Hasher
+static inline S blake3_hash_with_gate(const S& label, uint64_t gate_id) {
+  uint8_t msg[24], out[32];
+  std::memcpy(msg, label.b, 16);
+  for (int i = 0; i < 8; ++i) msg[16 + i] = uint8_t(gate_id >> (8 * i));  // usize::to_le_bytes on a 64-bit target
+  blake3_short(msg, 24, out);
+  S r; std::memcpy(r.b, out, 16);
+  return r;
+}
+
 // src/core/gate_type.rs:20-37 alphas_const
 static inline void alphas(GateType t, bool& aa, bool& ab, bool& ac) {
   int v = int(t);
@@ -191,7 +234,8 @@ static inline bool garble_gate(GateType t, const S& a0, const S& b0, const S& de
       S selected = aa ? (a0 ^ delta) : a0;
       S other = aa ? a0 : (a0 ^ delta);
       S h0, h1;
-      hash2_with_gate(selected, other, gate_id, h0, h1);
+      if (g_hasher == 1) { h0 = blake3_hash_with_gate(selected, gate_id); h1 = blake3_hash_with_gate(other, gate_id); }
+      else hash2_with_gate(selected, other, gate_id, h0, h1);
       S b_sel = ab ? (b0 ^ delta) : b0;
       ct = h0 ^ h1 ^ b_sel;
       c0 = ac ? (h0 ^ delta) : h0;
@@ -209,7 +253,7 @@ static inline S degarble_gate(GateType t, NextCt&& next_ct, const S& a, bool a_v
     case GateType::Not: return a;
     default: {
       S ct = next_ct();
-      S h = hash_with_gate(a, gate_id);
+      S h = (g_hasher == 1) ? blake3_hash_with_gate(a, gate_id) : hash_with_gate(a, gate_id);
       bool aa, ab, ac;
       alphas(t, aa, ab, ac);
       if (a_value != aa) return ct ^ h ^ b;
@@ -500,6 +544,15 @@ extern "C" {
 const char* gsvo_last_error() { return g_err.c_str(); }
 int gsvo_have_aesni() { return GSVO_HAVE_AESNI; }
 void gsvo_set_use_aesni(int on) { g_use_aesni = GSVO_HAVE_AESNI && on; }
+void gsvo_set_hasher(int kind) { g_hasher = kind == 1 ? 1 : 0; }  // 0 AesNiHasher, 1 Blake3Hasher
+int gsvo_blake3_short(const uint8_t* data, uint64_t n, uint8_t out[32]) {
+  try { blake3_short(data, size_t(n), out); return 0; } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+void gsvo_blake3_hash_with_gate(const uint8_t label[16], uint64_t gate_id, uint8_t out[16]) {
+  S l; std::memcpy(l.b, label, 16);
+  S h = blake3_hash_with_gate(l, gate_id);
+  std::memcpy(out, h.b, 16);
+}
 
 int gsvo_circuit_info(const char* circuit, uint64_t* n_in, uint64_t* n_out) {
   try { NamedCircuit nc = make_circuit(circuit); *n_in = nc.n_inputs; *n_out = nc.n_outputs; return 0; }

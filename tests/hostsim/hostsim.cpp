@@ -19,6 +19,7 @@ using namespace gsv;
 using gsv::dev::Label;
 
 static thread_local std::string g_err;
+static int g_hasher = 0;  // 0 AES, 1 Blake3
 
 static Label load(const uint8_t* p) { Label l; std::memcpy(l.w, p, 16); return l; }
 static void store(uint8_t* p, const Label& l) { std::memcpy(p, l.w, 16); }
@@ -102,12 +103,13 @@ int hostsim_run(SimProgram* sp, int evaluate, uint32_t replays, uint64_t gid_bas
           Label a = load(lab(sa)), b = load(lab(sb));
           if (!evaluate) {
             Label c0, c;
-            dev::garble_and(aes, ty, a, b, d, gid, c0, c);
+            if (g_hasher == 1) dev::garble_and_blake3(ty, a, b, d, gid, c0, c);
+            else dev::garble_and(aes, ty, a, b, d, gid, c0, c);
             wr.push_back({sc, c0});
             store(ct + size_t(cti) * 16, c);
           } else {
             Label c = load(ct + size_t(cti) * 16);
-            wr.push_back({sc, dev::degarble_and(aes, ty, c, a, bit(sa), b, gid)});
+            wr.push_back({sc, g_hasher == 1 ? dev::degarble_and_blake3(ty, c, a, bit(sa), b, gid) : dev::degarble_and(aes, ty, c, a, bit(sa), b, gid)});
             wb.push_back({sc, uint8_t(dev::gate_eval_bit(ty, bit(sa), bit(sb)))});
           }
         }
@@ -147,6 +149,9 @@ int hostsim_trace(const char* spec, uint64_t cap, uint8_t* type, uint32_t* a, ui
     return 0;
   } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
+
+void hostsim_set_hasher(int k) { g_hasher = k == 1 ? 1 : 0; }
+void hostsim_blake3_hash(const uint8_t label[16], uint64_t gid, uint8_t out[16]) { store(out, dev::blake3_hash_with_gate(load(label), gid)); }
 
 // host crypto of the product, for known-answer tests
 void hostsim_labels_from_seed(uint64_t seed, uint64_t n, uint8_t* out) {

@@ -28,6 +28,8 @@ def lib():
         L.hostsim_aes_portable.argtypes = [u8p, u8p]
         L.hostsim_hash.argtypes = [u8p, C.c_uint64, u8p]
         L.hostsim_sbox.argtypes = [u8p]
+        L.hostsim_set_hasher.argtypes = [C.c_int]
+        L.hostsim_blake3_hash.argtypes = [u8p, C.c_uint64, u8p]
         _lib = L
     return _lib
 
@@ -113,3 +115,14 @@ def sbox():
     o = np.zeros(256, np.uint8)
     lib().hostsim_sbox(_p(o))
     return o
+
+
+def set_hasher(kind):
+    lib().hostsim_set_hasher({"aes": 0, "blake3": 1}[kind])
+
+
+def blake3_hash(label, gid):
+    i = np.frombuffer(bytes(label), np.uint8).copy()
+    o = np.zeros(16, np.uint8)
+    lib().hostsim_blake3_hash(_p(i), gid, _p(o))
+    return o.tobytes()

@@ -46,6 +46,9 @@ def lib():
         L.gsvo_evaluate.argtypes = [C.c_char_p, C.c_uint64, u8p, u8p, u8p, u8p, u8p, C.c_uint64, u8p, u8p, u8p, u64p]
         L.gsvo_bench_garble.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_double), u64p, u8p]
         L.gsvo_set_use_aesni.argtypes = [C.c_int]
+        L.gsvo_set_hasher.argtypes = [C.c_int]
+        L.gsvo_blake3_short.argtypes = [u8p, C.c_uint64, u8p]
+        L.gsvo_blake3_hash_with_gate.argtypes = [u8p, C.c_uint64, u8p]
         _lib = L
     return _lib
 
@@ -67,6 +70,24 @@ def _b16(x):
     a = np.frombuffer(bytes(x), dtype=np.uint8).copy()
     assert a.size == 16
     return a
+
+
+def set_hasher(kind):
+    """'aes' = AesNiHasher (default), 'blake3' = Blake3Hasher (src/hashers/mod.rs:22-51)."""
+    lib().gsvo_set_hasher({"aes": 0, "blake3": 1}[kind])
+
+
+def blake3_short(data):
+    a = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+    out = np.zeros(32, np.uint8)
+    _check(lib().gsvo_blake3_short(_p(a) if a.size else None, a.size, _p(out)))
+    return out.tobytes()
+
+
+def blake3_hash_with_gate(label, gate_id):
+    out = np.zeros(16, np.uint8)
+    lib().gsvo_blake3_hash_with_gate(_p(_b16(label)), gate_id, _p(out))
+    return out.tobytes()
 
 
 def circuit_info(circuit):
