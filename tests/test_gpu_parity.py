@@ -192,3 +192,26 @@ def test_random_circuits_differential(engine, seed):
     g, prog = _garble_and_check(gsv, engine, spec, seeds)
     assert prog.info["n_dead"] > 500
     _evaluate_and_check(gsv, engine, spec, g, prog, seeds, bit_seed=seed)
+
+
+def test_cut_and_choose_fanout_and_commit_records(engine):
+    """Garbler::create -> commit (cut_and_choose/garbler.rs:191-257) on the GPU: 16 instances of one compiled circuit in a
+    single launch, commit record per instance = ciphertext CBC-MAC + AES_K(label) of constants and outputs
+    (GarbledInstanceCommit, garbler.rs:63-99; AesLabelCommitHasher, cut_and_choose/mod.rs:41-48), compared with records built
+    from the oracle's garbling of the same seeds."""
+    import garbled_snark_verifier_amd as gsv
+    from garbled_snark_verifier_amd import sharding
+    total = 16
+    seeds = [int(x) for x in sharding.instance_seeds(1234, total)]
+    prog = gsv.Program.from_circuit("fq_mul")
+    g = gsv.CircuitBuilder.streaming_garbling("fq_mul", seeds, engine=engine, program=prog, keep_ciphertexts=False)
+    recs = np.stack([sharding.commit_record(i, g.ciphertext_hash[i], g.output_label0[i], g.delta[i], g.false_label0[i], g.true_label0[i]) for i in range(total)])
+    import torch
+    table = sharding.all_gather_records(torch.from_numpy(recs), total, 0, 1)
+    assert table.shape == (total, sharding.record_len(254))
+    for i in (0, 7, 15):
+        ref = o.garble("fq_mul", seeds[i], capture_ct=False)
+        exp = sharding.commit_record(i, ref.ct_hash.tobytes(), ref.output_label0, ref.delta, ref.false_label0, ref.true_label0)
+        assert (table[i].numpy() == exp).all()
+    # AES_K(label): one-block CBC-MAC from the zero state
+    assert bytes(table[0].numpy()[24:40]) == o.cbcmac(g.false_label0[0].tobytes())
