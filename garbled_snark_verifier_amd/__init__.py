@@ -47,6 +47,7 @@ EXPORTS = [
     "gsv_session_set_garble_inputs", "gsv_session_garble", "gsv_session_set_evaluate_inputs", "gsv_session_upload_ciphertexts",
     "gsv_session_evaluate", "gsv_session_set_hasher", "gsv_session_sync", "gsv_session_last_kernel_ms", "gsv_session_read_outputs", "gsv_session_read_ciphertexts",
     "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_commit_labels",
+    "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
 ]
 
 
@@ -91,6 +92,9 @@ def lib():
         L.gsv_session_ciphertext_hash.argtypes = [vp, C.c_size_t, u8p]
         L.gsv_cbcmac_update.argtypes = [u8p, u8p, C.c_uint64]
         L.gsv_commit_labels.argtypes = [u8p, C.c_uint64, u8p]
+        L.gsv_session_enable_step_clock.argtypes = [vp]
+        L.gsv_session_read_step_clock.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.gsv_program_step_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
         _lib = L
     return _lib
 
@@ -134,6 +138,12 @@ class Program:
         info = _ProgramInfo()
         _chk(lib().gsv_program_get_info(self.h, C.byref(info)))
         self.info = {n: (list(getattr(info, n)) if n == "gate_count" else int(getattr(info, n))) for n, _ in _ProgramInfo._fields_}
+
+    def step_stats(self):
+        """Diagnostics: per step [and_cnt, xor_cnt, lds_reads, hbm_reads, lds_writes, hbm_writes]."""
+        out = np.zeros((self.info["n_steps"], 6), np.uint32)
+        _chk(lib().gsv_program_step_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
 
     @classmethod
     def from_circuit(cls, spec, chain_feedback=False):
@@ -253,6 +263,15 @@ class Session:
 
     def sync(self):
         _chk(lib().gsv_session_sync(self.h))
+
+    def enable_step_clock(self):
+        """Diagnostics: instance 0 stamps a 100 MHz clock at every step of a launch's last replay."""
+        _chk(lib().gsv_session_enable_step_clock(self.h))
+
+    def read_step_clock(self):
+        out = np.zeros(self.program.info["n_steps"] + 1, np.uint64)
+        _chk(lib().gsv_session_read_step_clock(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
 
     def last_kernel_ms(self):
         ms = C.c_double()

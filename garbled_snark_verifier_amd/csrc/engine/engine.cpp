@@ -66,7 +66,7 @@ struct gsv_session {
   DevProgram dp;
   size_t n_inst = 0;
   uint64_t replays = 1, ct_cap = 1;
-  void *W = nullptr, *VB = nullptr, *CT = nullptr, *delta = nullptr, *out = nullptr, *out_bits = nullptr, *in_bits = nullptr;
+  void *W = nullptr, *VB = nullptr, *CT = nullptr, *delta = nullptr, *out = nullptr, *out_bits = nullptr, *in_bits = nullptr, *step_clock = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ran = false, last_eval = false, garbled = false;
   int hasher = 0;  // 0 AesNiHasher, 1 Blake3Hasher
@@ -152,6 +152,9 @@ int gsv_program_compile(gsv_recorder* r, const uint32_t* fb_out_idx, const uint3
   std::unique_ptr<gsv_program> p(new gsv_program());
   CompileOptions opt;
   if (const char* e = getenv("GSV_LDS_LIFETIME")) opt.lds_max_lifetime = uint32_t(atoi(e));  // tuning knobs (defaults are the measured best)
+  if (const char* e = getenv("GSV_SCHEDULE")) opt.schedule = uint32_t(atoi(e));
+  if (const char* e = getenv("GSV_ORDER_BY_READER")) opt.order_by_reader = atoi(e) != 0;
+  if (const char* e = getenv("GSV_HBM_ARENA")) opt.hbm_arena_factor = uint32_t(atoi(e));
   if (const char* e = getenv("GSV_LDS_SLOTS")) opt.lds_slots = std::min<uint32_t>(uint32_t(atoi(e)), LDS_WINDOW_SLOTS);
   // two instances per workgroup (set before compiling): each gets half of the LDS label window
   if (const char* e = getenv("GSV_INSTANCES_PER_WG")) if (atoi(e) == 2) opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / 2);
@@ -277,7 +280,7 @@ void gsv_session_destroy(gsv_session* s) {
   if (!s) return;
   (void)hipSetDevice(s->e->device);
   (void)hipStreamSynchronize(s->e->stream);
-  for (void* q : {s->W, s->VB, s->CT, s->delta, s->out, s->out_bits, s->in_bits}) if (q) (void)hipFree(q);
+  for (void* q : {s->W, s->VB, s->CT, s->delta, s->out, s->out_bits, s->in_bits, s->step_clock}) if (q) (void)hipFree(q);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -346,6 +349,7 @@ static int launch(gsv_session* s, uint64_t gate_id_base, bool eval) {
   ka.n_fb = uint32_t(g.fb_src_slot.size()); ka.fb_stage_base = g.fb_stage_base;
   ka.n_instances = uint32_t(s->n_inst);
   ka.hasher = uint32_t(s->hasher);
+  ka.step_clock = static_cast<unsigned long long*>(s->step_clock);
   {
     const char* e = getenv("GSV_INSTANCES_PER_WG");
     ka.instances_per_wg = (e && atoi(e) == 2 && g.lds_slots_limit <= LDS_WINDOW_SLOTS / 2 && s->n_inst >= 2) ? 2u : 1u;
@@ -393,6 +397,41 @@ int gsv_session_sync(gsv_session* s) {
   if (!s) return fail(GSV_ERR_INVALID, "null session");
   HIPCHK(hipSetDevice(s->e->device));
   HIPCHK(hipStreamSynchronize(s->e->stream));
+  return GSV_OK;
+}
+// Diagnostics: per-step wall-clock stamps (100 MHz) of instance 0's workgroup during the last replay of a launch.
+int gsv_session_enable_step_clock(gsv_session* s) {
+  if (!s) return fail(GSV_ERR_INVALID, "null session");
+  HIPCHK(hipSetDevice(s->e->device));
+  if (!s->step_clock) {
+    const size_t bytes = (s->p->prog.steps.size() + 1) * sizeof(uint64_t);
+    HIPCHK(hipMalloc(&s->step_clock, bytes));
+    HIPCHK(hipMemset(s->step_clock, 0, bytes));
+  }
+  return GSV_OK;
+}
+int gsv_session_read_step_clock(gsv_session* s, uint64_t* out) {
+  if (!s || !out || !s->step_clock || !s->ran) return fail(GSV_ERR_INVALID, "step clock not enabled / nothing ran");
+  HIPCHK(hipSetDevice(s->e->device));
+  HIPCHK(hipStreamSynchronize(s->e->stream));
+  HIPCHK(hipMemcpy(out, s->step_clock, (s->p->prog.steps.size() + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return GSV_OK;
+}
+// Diagnostics: per step {and_cnt, xor_cnt, lds_reads, hbm_reads, lds_writes, hbm_writes} decoded from the compiled records.
+int gsv_program_step_stats(const gsv_program* p, uint32_t* out6) {
+  if (!p || !out6) return fail(GSV_ERR_INVALID, "null argument");
+  const Program& g = p->prog;
+  for (size_t s = 0; s < g.steps.size(); ++s) {
+    const StepDesc& d = g.steps[s];
+    uint32_t* o = out6 + 6 * s;
+    o[0] = d.and_cnt; o[1] = d.xor_cnt; o[2] = o[3] = o[4] = o[5] = 0;
+    auto acc = [&](uint64_t lo) {
+      const uint32_t a = uint32_t(lo) & SLOT_MASK, b = uint32_t(lo >> 21) & SLOT_MASK, c = uint32_t(lo >> 42) & SLOT_MASK;
+      o[(a & SLOT_LDS_FLAG) ? 2 : 3]++; o[(b & SLOT_LDS_FLAG) ? 2 : 3]++; o[(c & SLOT_LDS_FLAG) ? 4 : 5]++;
+    };
+    for (uint32_t k = 0; k < d.and_cnt; ++k) acc(g.ands[d.and_off + k].lo);
+    for (uint32_t k = 0; k < d.xor_cnt; ++k) acc(g.xors[d.xor_off + k].v);
+  }
   return GSV_OK;
 }
 int gsv_session_last_kernel_ms(gsv_session* s, double* ms) {

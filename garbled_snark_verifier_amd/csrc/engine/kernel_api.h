@@ -12,8 +12,8 @@ namespace dev {
 
 struct KernelArgs {
   const void* steps;   // StepDesc[n_steps]   {and_off, and_cnt, xor_off, xor_cnt}
-  const void* ands;    // AndRec[]            32 B
-  const void* xors;    // XorRec[]            16 B
+  const void* ands;    // AndRec[]            16 B
+  const void* xors;    // XorRec[]            8 B
   uint4* W;            // [n_instances][n_slots] labels
   uint8_t* VB;         // [n_instances][n_slots] plaintext bits (evaluate only)
   uint4* CT;           // [n_instances][ct_stride] ciphertext streams
@@ -34,6 +34,7 @@ struct KernelArgs {
   uint32_t n_instances;
   uint32_t instances_per_wg;  // 1 or 2 (2 needs a program compiled for half the LDS window)
   uint32_t hasher;            // 0 = AesNiHasher, 1 = Blake3Hasher
+  unsigned long long* step_clock;  // diagnostics: workgroup 0 stamps the 100 MHz wall clock at the start of every step of the last replay (null = off)
   uint32_t diag;  // timing experiments only (GSV_DIAG env): 1 = skip AES, 2 = no record prefetch, 4 = skip label loads, 8 = skip stores
 };
 

@@ -262,6 +262,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       const uint32_t and_off = sd.x, and_cnt = sd.y, xor_off = sd.z, total = sd.y + sd.w;
       const u32x4 n2sd = load_desc(s + 2);  // lands during this step; its record load is issued at the end
       bool young_ct = false;                 // did this wave issue a ciphertext store AFTER its last label store?
+      if (ka.step_clock && blockIdx.x == 0 && threadIdx.x == 0 && rep + 1 == ka.replays) ka.step_clock[s] = wall_clock64();  // older than this step's stores
       if (is_narrow(sd)) {
         // ------------------------------------------------------------------ narrow step: one pass
         const uint32_t na = and_cnt * LPG;
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       nsd = n2sd; n0 = n2r;
     }
     __syncthreads();
+    if (ka.step_clock && blockIdx.x == 0 && threadIdx.x == 0 && rep + 1 == ka.replays) ka.step_clock[ka.n_steps] = wall_clock64();
     // replay epilogue: feedback copies through staging slots (sources may alias destinations; all in HBM)
     if (ka.n_fb) {
       const uint32_t nfb = inst_active ? ka.n_fb : 0u;

@@ -134,6 +134,9 @@ struct Program {
 struct CompileOptions {
   uint32_t lds_slots = LDS_WINDOW_SLOTS;  // 0 = keep every wire in HBM
   uint32_t lds_max_lifetime = 8;          // a wire goes to the LDS window only if it dies within this many steps
+  uint32_t schedule = 0;                  // 0 = ASAP levels, 1 = ALAP levels (experiment)
+  bool order_by_reader = true;            // order the gates of a step by the position of their output's first reader
+  uint32_t hbm_arena_factor = 4;          // HBM wire file = factor x peak live wires (next-fit then sweeps mostly free space)
 };
 
 // next-fit slot pool over a bitmap: consecutive allocations get ascending (mostly consecutive) slots, so the
@@ -158,6 +161,8 @@ class SlotPool {
   }
   void release(uint32_t i) { used_[i] = 0; ++n_free_; }
   void reserve_low(uint32_t n) { if (used_.size() < n) used_.resize(n, 0); for (uint32_t i = high_; i < n; ++i) used_[i] = 1; high_ = std::max(high_, n); cursor_ = high_; }
+  // growable pools: make [high, n) allocatable right away (a roomy arena keeps next-fit allocations contiguous)
+  void preextend(uint32_t n) { if (n > high_) { if (used_.size() < n) used_.resize(n, 0); n_free_ += n - high_; high_ = n; } }
   uint32_t high() const { return high_; }
   // slots that alloc() can still hand out right now (fixed pools only)
   uint32_t available() const { return n_free_ + (fixed_ ? uint32_t(used_.size()) - high_ : 0u); }
@@ -191,6 +196,19 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
     n_steps = std::max(n_steps, lev[c]);
     p.and_depth = std::max(p.and_depth, ad[c]);
   }
+  if (opt.schedule == 1) {
+    // ALAP: a gate runs one step before its earliest reader (circuit outputs: the last step); depth unchanged
+    std::vector<uint32_t> need(nw, n_steps + 1);
+    for (size_t i = n; i-- > 0;) {
+      uint32_t c = t.c[i];
+      if (c == DEAD_WIRE) continue;
+      uint32_t al = need[c] - 1;  // level in 1..n_steps
+      if (al < lev[c]) gsv_panic("internal: ALAP below ASAP");
+      lev[c] = al;
+      need[t.a[i]] = std::min(need[t.a[i]], al);
+      if (t.type[i] != uint8_t(GateType::Not)) need[t.b[i]] = std::min(need[t.b[i]], al);
+    }
+  }
   auto step_of = [&](size_t i) -> uint32_t { return lev[t.c[i]] - 1; };
   // 2. counting sort of live gates by (step, kind): AND-family first, then free gates
   std::vector<uint32_t> cnt(2 * size_t(n_steps) + 1, 0);
@@ -201,6 +219,28 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
   {
     std::vector<uint32_t> cursor(cnt.begin(), cnt.end() - 1);
     for (size_t i = 0; i < n; ++i) if (t.c[i] != DEAD_WIRE) order[cursor[2 * size_t(step_of(i)) + (t.type[i] < 8 ? 0 : 1)]++] = uint32_t(i);
+  }
+  // 2b. Order inside a step.  Lanes of a wave take consecutive records, and a step's outputs get consecutive slots
+  // in record order, so the order decides how many 128-byte lines one wave-wide label load or store touches.
+  // Stream order scatters them; ordering every step's gates by the position of their output's FIRST reader
+  // (steps processed last to first, so reader positions are final) makes producer order follow consumer order.
+  if (opt.order_by_reader) {
+    std::vector<uint32_t> minpos(nw, 0xFFFFFFFFu);
+    std::vector<std::pair<uint32_t, uint32_t>> keyed;
+    for (uint32_t s = n_steps; s-- > 0;) {
+      for (int kind = 1; kind >= 0; --kind) {
+        const uint32_t lo = cnt[2 * size_t(s) + kind], hi = cnt[2 * size_t(s) + kind + 1];
+        keyed.clear();
+        for (uint32_t k = lo; k < hi; ++k) keyed.push_back({minpos[t.c[order[k]]], order[k]});
+        std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, uint32_t>& x, const std::pair<uint32_t, uint32_t>& y) { return x.first < y.first; });
+        for (uint32_t k = lo; k < hi; ++k) order[k] = keyed[k - lo].second;
+      }
+      for (uint32_t k = cnt[2 * size_t(s)]; k < cnt[2 * size_t(s) + 2]; ++k) {
+        const size_t i = order[k];
+        minpos[t.a[i]] = std::min(minpos[t.a[i]], k);
+        if (t.type[i] != uint8_t(GateType::Not)) minpos[t.b[i]] = std::min(minpos[t.b[i]], k);
+      }
+    }
   }
   // 3. last reader step per wire (live gates only).  NEVER = pinned, UNUSED = no live reader.
   constexpr uint32_t NEVER = 0xFFFFFFFFu, UNUSED = 0xFFFFFFFEu;
@@ -248,6 +288,15 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
       if (t.c[i] != DEAD_WIRE && t.type[i] < 8) ++k;
     }
     p.n_ct = k;
+  }
+  if (opt.hbm_arena_factor > 1) {
+    uint32_t lv = next_in, pk = next_in;
+    for (uint32_t s = 0; s < n_steps; ++s) {
+      lv += cnt[2 * size_t(s) + 2] - cnt[2 * size_t(s)];
+      pk = std::max(pk, lv);
+      lv -= die_cnt[s + 1] - die_cnt[s];
+    }
+    hbm.preextend(uint32_t(std::min<uint64_t>(uint64_t(opt.hbm_arena_factor) * pk, SLOT_INDEX_MASK - feedback.size() - 1)));
   }
   uint32_t live = next_in, peak = next_in;
   p.steps.reserve(n_steps);

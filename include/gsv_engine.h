@@ -132,6 +132,12 @@ int gsv_session_set_hasher(gsv_session* s, int kind);
 int gsv_session_sync(gsv_session* s);
 /* seconds of device time of the last garble/evaluate launch (HIP events on the engine stream) */
 int gsv_session_last_kernel_ms(gsv_session* s, double* ms);
+/* Diagnostics (tools/step_profile.py; no reference counterpart).  step clock: 100 MHz wall-clock stamps taken by instance 0's
+ * workgroup at the start of every step of the LAST replay of a launch, n_steps+1 values.  step stats: per step
+ * {and_cnt, xor_cnt, lds_reads, hbm_reads, lds_writes, hbm_writes}. */
+int gsv_session_enable_step_clock(gsv_session* s);
+int gsv_session_read_step_clock(gsv_session* s, uint64_t* out /* n_steps+1 */);
+int gsv_program_step_stats(const gsv_program* p, uint32_t* out /* n_steps*6 */);
 
 /* Outputs after sync.  Garble: label0 per output wire (label1 = label0 ^ delta).  Evaluate: active
  * label + plaintext bit per output wire. */
