@@ -30,9 +30,9 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--instances", type=int, default=256, help="cut-and-choose instances per GPU per step (one workgroup = one CU each)")
+    ap.add_argument("--instances", type=int, default=512, help="cut-and-choose instances per GPU per step (more than the 256 CUs: two per workgroup)")
     ap.add_argument("--replays", type=int, default=0, help="Fq12-mul components per instance (0 = enough for 11.17 B gates)")
     ap.add_argument("--ct-ring", type=int, default=2, help="replays of ciphertexts kept per instance in HBM")
     ap.add_argument("--cpu-baseline-chain", type=int, default=8, help="Fq12 muls garbled by the CPU oracle for cpu_baseline (0 = skip)")
@@ -73,6 +73,7 @@ def main():
     for i, s in enumerate(seeds):
         delta[i], consts[i, 0], consts[i, 1], inputs[i] = gsv.labels_from_seed(s, n_in)
     sess = gsv.Session(engine, prog, B, replays, min(args.ct_ring, replays))
+    ni = sess.instances_per_workgroup
 
     def barrier():
         torch.cuda.synchronize()
@@ -114,7 +115,7 @@ def main():
     # when the committed measurement was taken on the configuration being run.
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_final", "traffic.json")
-    if os.path.exists(tpath) and B == 256 and replays == -(-VERIFIER_GATES // gates_per_replay) and world == 1:
+    if os.path.exists(tpath) and B == 512 and ni == 2 and replays == -(-VERIFIER_GATES // gates_per_replay) and world == 1:
         with open(tpath) as f:
             traffic = float(json.load(f)["hbm_bytes_raw"])
     result = None
@@ -128,7 +129,7 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "Groth16-shaped synthetic: chain of %d Fq12::mul_montgomery components = %d gates per instance "
                                    "(>= 11,174,708,821-gate verifier); %d cut-and-choose instances per GPU" % (replays, gates_per_replay * replays, B),
-                       "instances_per_gpu": B, "replays": replays, "gates_per_instance": gates_per_replay * replays,
+                       "instances_per_gpu": B, "instances_per_workgroup": ni, "replays": replays, "gates_per_instance": gates_per_replay * replays,
                        "nonfree_fraction": f_nf, "program_steps": info["n_steps"], "and_depth": info["and_depth"],
                        "wire_slots": info["n_slots"], "program_image_bytes": info["device_bytes"], "compile_s": compile_s},
             "per_instance_gates_per_s": gates_per_replay * replays / avg_kernel_s,
@@ -141,10 +142,13 @@ def main():
         if not args.no_check:
             import oracle_lib as o
             # bit-exactness of this very program against the CPU oracle on the chain's first two components
-            chk = gsv.CircuitBuilder.streaming_garbling("fq12_mul", [seeds[0]], engine=engine, program=prog, replays=2, keep_ciphertexts=False)
+            # (same program variant / kernel instantiation as the timed launches: three instances, the middle one checked)
+            os.environ["GSV_INSTANCES_PER_WG"] = str(ni)
+            chk = gsv.CircuitBuilder.streaming_garbling("fq12_mul", [seeds[1], seeds[0], seeds[2]], engine=engine, program=prog, replays=2, keep_ciphertexts=False)
+            del os.environ["GSV_INSTANCES_PER_WG"]
             ref = o.garble("fq12_mul_chain:2", seeds[0], capture_ct=False)
-            result["ciphertext_hash_match"] = bool(chk.ciphertext_hash[0] == ref.ct_hash.tobytes() and (chk.output_label0[0] == ref.output_label0).all())
-            result["hash_check"] = {"circuit": "fq12_mul_chain:2", "seed": seeds[0], "gpu": chk.ciphertext_hash[0].hex(), "oracle": ref.ct_hash.tobytes().hex()}
+            result["ciphertext_hash_match"] = bool(chk.ciphertext_hash[1] == ref.ct_hash.tobytes() and (chk.output_label0[1] == ref.output_label0).all())
+            result["hash_check"] = {"circuit": "fq12_mul_chain:2", "seed": seeds[0], "gpu": chk.ciphertext_hash[1].hex(), "oracle": ref.ct_hash.tobytes().hex()}
         if args.cpu_baseline_chain and world == 1:
             import oracle_lib as o
             spec = "fq12_mul_chain:%d" % args.cpu_baseline_chain

@@ -47,7 +47,7 @@ EXPORTS = [
     "gsv_session_set_garble_inputs", "gsv_session_garble", "gsv_session_set_evaluate_inputs", "gsv_session_upload_ciphertexts",
     "gsv_session_evaluate", "gsv_session_set_hasher", "gsv_session_sync", "gsv_session_last_kernel_ms", "gsv_session_read_outputs", "gsv_session_read_ciphertexts",
     "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_commit_labels",
-    "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
+    "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
 ]
 
 
@@ -92,6 +92,7 @@ def lib():
         L.gsv_session_ciphertext_hash.argtypes = [vp, C.c_size_t, u8p]
         L.gsv_cbcmac_update.argtypes = [u8p, u8p, C.c_uint64]
         L.gsv_commit_labels.argtypes = [u8p, C.c_uint64, u8p]
+        L.gsv_session_instances_per_workgroup.argtypes = [vp, C.POINTER(C.c_int)]
         L.gsv_session_enable_step_clock.argtypes = [vp]
         L.gsv_session_read_step_clock.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.gsv_program_step_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
@@ -263,6 +264,12 @@ class Session:
 
     def sync(self):
         _chk(lib().gsv_session_sync(self.h))
+
+    @property
+    def instances_per_workgroup(self):
+        n = C.c_int()
+        _chk(lib().gsv_session_instances_per_workgroup(self.h, C.byref(n)))
+        return n.value
 
     def enable_step_clock(self):
         """Diagnostics: instance 0 stamps a 100 MHz clock at every step of a launch's last replay."""

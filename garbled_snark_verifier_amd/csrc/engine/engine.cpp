@@ -44,10 +44,21 @@ struct DevProgram {
   size_t bytes = 0;
 };
 
+// What a program was compiled from: kept so that the half-window variant (two instances per workgroup) can be
+// compiled the first time a session needs it.
+struct ProgramSource {
+  Trace trace;
+  std::vector<uint32_t> inputs, outputs;
+  std::vector<std::pair<uint32_t, uint32_t>> feedback;
+  CompileOptions opt;
+};
+
 struct gsv_program {
-  Program prog;
+  Program prog;                    // full LDS window: one instance per workgroup
+  std::unique_ptr<Program> prog2;  // half window: two instances per workgroup (compiled on demand)
+  std::unique_ptr<ProgramSource> src;
   std::mutex mu;
-  std::map<int, DevProgram> dev;  // per device
+  std::map<std::pair<int, int>, DevProgram> dev;  // per (device, instances per workgroup)
   size_t image_bytes() const {
     return prog.steps.size() * sizeof(StepDesc) + prog.ands.size() * sizeof(AndRec) + prog.xors.size() * sizeof(XorRec) +
            (prog.fb_src_slot.size() * 2 + prog.output_slots.size()) * sizeof(uint32_t);
@@ -68,10 +79,12 @@ struct gsv_session {
   uint64_t replays = 1, ct_cap = 1;
   void *W = nullptr, *VB = nullptr, *CT = nullptr, *delta = nullptr, *out = nullptr, *out_bits = nullptr, *in_bits = nullptr, *step_clock = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  uint32_t ni = 1;  // instances per workgroup of this session's launches
+  const Program& prog() const { return ni == 2 ? *p->prog2 : p->prog; }
   bool ran = false, last_eval = false, garbled = false;
   int hasher = 0;  // 0 AesNiHasher, 1 Blake3Hasher
   std::vector<uint64_t> ct_uploaded;  // per instance: records supplied by gsv_session_upload_ciphertexts
-  uint64_t ct_stride() const { return ct_cap * p->prog.n_ct; }
+  uint64_t ct_stride() const { return ct_cap * p->prog.n_ct; }  // n_ct does not depend on the variant
 };
 
 extern "C" {
@@ -156,11 +169,10 @@ int gsv_program_compile(gsv_recorder* r, const uint32_t* fb_out_idx, const uint3
   if (const char* e = getenv("GSV_ORDER_BY_READER")) opt.order_by_reader = atoi(e) != 0;
   if (const char* e = getenv("GSV_HBM_ARENA")) opt.hbm_arena_factor = uint32_t(atoi(e));
   if (const char* e = getenv("GSV_LDS_SLOTS")) opt.lds_slots = std::min<uint32_t>(uint32_t(atoi(e)), LDS_WINDOW_SLOTS);
-  // two instances per workgroup (set before compiling): each gets half of the LDS label window
-  if (const char* e = getenv("GSV_INSTANCES_PER_WG")) if (atoi(e) == 2) opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / 2);
   p->prog = compile_program(r->mode.trace(), r->inputs, r->outputs, fb, opt);
   for (size_t i = 0; i < p->prog.input_slots.size(); ++i)
     if (p->prog.input_slots[i] != SLOT_FIRST_INPUT + i) return fail(GSV_ERR_CIRCUIT, "internal: inputs are not slot-contiguous");
+  p->src.reset(new ProgramSource{r->mode.trace(), r->inputs, r->outputs, fb, opt});
   *out = p.release();
   return GSV_OK;
   GSV_CATCH
@@ -168,7 +180,7 @@ int gsv_program_compile(gsv_recorder* r, const uint32_t* fb_out_idx, const uint3
 void gsv_program_destroy(gsv_program* p) {
   if (!p) return;
   for (auto& kv : p->dev) {
-    (void)hipSetDevice(kv.first);
+    (void)hipSetDevice(kv.first.first);
     for (void* q : {kv.second.steps, kv.second.ands, kv.second.xors, kv.second.fb_src, kv.second.fb_dst, kv.second.out_slots})
       if (q) (void)hipFree(q);
   }
@@ -224,12 +236,21 @@ int gsv_labels_from_seed(uint64_t seed, size_t n_inputs, uint8_t delta[16], uint
 }
 
 // ---------------------------------------------------------------- sessions
-static int upload_program(gsv_engine* e, gsv_program* p, DevProgram* out) {
+static int upload_program(gsv_engine* e, gsv_program* p, uint32_t ni, DevProgram* out) {
   std::lock_guard<std::mutex> lk(p->mu);
-  auto it = p->dev.find(e->device);
+  auto it = p->dev.find({e->device, int(ni)});
   if (it != p->dev.end()) { *out = it->second; return GSV_OK; }
+  if (ni == 2 && !p->prog2) {  // first session with two instances per workgroup: compile for half of the LDS window
+    GSV_TRY
+    CompileOptions opt = p->src->opt;
+    opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / 2);
+    p->prog2.reset(new Program(compile_program(p->src->trace, p->src->inputs, p->src->outputs, p->src->feedback, opt)));
+    for (size_t i = 0; i < p->prog2->input_slots.size(); ++i)
+      if (p->prog2->input_slots[i] != SLOT_FIRST_INPUT + i) return fail(GSV_ERR_CIRCUIT, "internal: inputs are not slot-contiguous");
+    GSV_CATCH
+  }
   DevProgram d;
-  const Program& g = p->prog;
+  const Program& g = ni == 2 ? *p->prog2 : p->prog;
   auto up = [&](void** dst, const void* src, size_t bytes) -> int {
     // +16 bytes of zero padding: the kernel's record prefetch reads 16 bytes at the last 8-byte record
     HIPCHK(hipMalloc(dst, bytes + 16));
@@ -245,7 +266,7 @@ static int upload_program(gsv_engine* e, gsv_program* p, DevProgram* out) {
   if ((rc = up(&d.fb_src, g.fb_src_slot.data(), g.fb_src_slot.size() * 4))) return rc;
   if ((rc = up(&d.fb_dst, g.fb_dst_slot.data(), g.fb_dst_slot.size() * 4))) return rc;
   if ((rc = up(&d.out_slots, g.output_slots.data(), g.output_slots.size() * 4))) return rc;
-  p->dev[e->device] = d;
+  p->dev[{e->device, int(ni)}] = d;
   *out = d;
   return GSV_OK;
 }
@@ -259,9 +280,17 @@ int gsv_session_create(gsv_engine* e, const gsv_program* cp, size_t n_instances,
   std::unique_ptr<gsv_session> s(new gsv_session());
   s->e = e; s->p = p; s->n_inst = n_instances; s->replays = replays; s->ct_cap = ct_capacity_replays;
   s->ct_uploaded.assign(n_instances, 0);
-  int rc = upload_program(e, p, &s->dp);
+  // Two instances per workgroup once there are more instances than CUs (each then works with half of the LDS label
+  // window, see kernels.hip); GSV_INSTANCES_PER_WG=1|2 overrides.
+  {
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, e->device));
+    s->ni = n_instances > size_t(prop.multiProcessorCount) ? 2u : 1u;
+    if (const char* ev = getenv("GSV_INSTANCES_PER_WG")) { int v = atoi(ev); if (v == 1 || (v == 2 && n_instances >= 2)) s->ni = uint32_t(v); }
+  }
+  int rc = upload_program(e, p, s->ni, &s->dp);
   if (rc) return rc;
-  const Program& g = p->prog;
+  const Program& g = s->prog();
   HIPCHK(hipMalloc(&s->W, n_instances * size_t(g.n_slots) * 16));
   HIPCHK(hipMalloc(&s->VB, n_instances * size_t(g.n_slots)));
   HIPCHK(hipMemset(s->VB, 0, n_instances * size_t(g.n_slots)));
@@ -288,7 +317,7 @@ void gsv_session_destroy(gsv_session* s) {
 
 static int stage_labels(gsv_session* s, const uint8_t* consts, const uint8_t* inputs) {
   // Per instance the wire file starts [FALSE, TRUE, ZERO, input0, input1, ...]: one strided copy.
-  const Program& g = s->p->prog;
+  const Program& g = s->prog();
   const size_t n_in = g.input_slots.size();
   const size_t row = (SLOT_FIRST_INPUT + n_in) * 16;
   std::vector<uint8_t> host(s->n_inst * row, 0);
@@ -301,17 +330,17 @@ static int stage_labels(gsv_session* s, const uint8_t* consts, const uint8_t* in
 }
 
 int gsv_session_set_garble_inputs(gsv_session* s, const uint8_t* delta, const uint8_t* const_label0, const uint8_t* input_label0) {
-  if (!s || !delta || !const_label0 || (!input_label0 && !s->p->prog.input_slots.empty())) return fail(GSV_ERR_INVALID, "null argument");
+  if (!s || !delta || !const_label0 || (!input_label0 && !s->prog().input_slots.empty())) return fail(GSV_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(s->e->device));
   HIPCHK(hipMemcpy(s->delta, delta, s->n_inst * 16, hipMemcpyHostToDevice));
   return stage_labels(s, const_label0, input_label0);
 }
 int gsv_session_set_evaluate_inputs(gsv_session* s, const uint8_t* const_active, const uint8_t* input_active, const uint8_t* input_bits) {
-  if (!s || !const_active || ((!input_active || !input_bits) && !s->p->prog.input_slots.empty())) return fail(GSV_ERR_INVALID, "null argument");
+  if (!s || !const_active || ((!input_active || !input_bits) && !s->prog().input_slots.empty())) return fail(GSV_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(s->e->device));
   int rc = stage_labels(s, const_active, input_active);
   if (rc) return rc;
-  const Program& g = s->p->prog;
+  const Program& g = s->prog();
   const size_t n_in = g.input_slots.size();
   // plaintext bits: constants FALSE=0 / TRUE=1 (evaluate_mode.rs:104-121), then the input bits
   HIPCHK(hipMemset(s->VB, 0, s->n_inst * size_t(g.n_slots)));
@@ -337,7 +366,7 @@ int gsv_session_upload_ciphertexts(gsv_session* s, size_t instance, const uint8_
 }
 
 static int launch(gsv_session* s, uint64_t gate_id_base, bool eval) {
-  const Program& g = s->p->prog;
+  const Program& g = s->prog();
   HIPCHK(hipSetDevice(s->e->device));
   dev::KernelArgs ka{};
   ka.steps = s->dp.steps; ka.ands = s->dp.ands; ka.xors = s->dp.xors;
@@ -350,10 +379,7 @@ static int launch(gsv_session* s, uint64_t gate_id_base, bool eval) {
   ka.n_instances = uint32_t(s->n_inst);
   ka.hasher = uint32_t(s->hasher);
   ka.step_clock = static_cast<unsigned long long*>(s->step_clock);
-  {
-    const char* e = getenv("GSV_INSTANCES_PER_WG");
-    ka.instances_per_wg = (e && atoi(e) == 2 && g.lds_slots_limit <= LDS_WINDOW_SLOTS / 2 && s->n_inst >= 2) ? 2u : 1u;
-  }
+  ka.instances_per_wg = s->ni;
   if (const char* dg = getenv("GSV_DIAG")) ka.diag = uint32_t(atoi(dg));  // timing experiments: outputs are wrong when set
   HIPCHK(hipEventRecord(s->ev0, s->e->stream));
   if (ka.n_steps) {
@@ -378,7 +404,7 @@ int gsv_session_garble(gsv_session* s, uint64_t gate_id_base) {
 int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base) {
   if (!s) return fail(GSV_ERR_INVALID, "null session");
   // EvaluateMode panics with "Ciphertext source exhausted at gate .." when the source runs dry (evaluate_mode.rs:139-142).
-  const uint64_t need = s->p->prog.n_ct * s->replays;
+  const uint64_t need = s->prog().n_ct * s->replays;
   if (s->ct_cap != s->replays) return fail(GSV_ERR_INVALID, "evaluate needs the whole ciphertext stream resident (ct_capacity_replays == replays)");
   if (!s->garbled)
     for (size_t i = 0; i < s->n_inst; ++i)
@@ -404,7 +430,7 @@ int gsv_session_enable_step_clock(gsv_session* s) {
   if (!s) return fail(GSV_ERR_INVALID, "null session");
   HIPCHK(hipSetDevice(s->e->device));
   if (!s->step_clock) {
-    const size_t bytes = (s->p->prog.steps.size() + 1) * sizeof(uint64_t);
+    const size_t bytes = (s->prog().steps.size() + 1) * sizeof(uint64_t);
     HIPCHK(hipMalloc(&s->step_clock, bytes));
     HIPCHK(hipMemset(s->step_clock, 0, bytes));
   }
@@ -414,7 +440,7 @@ int gsv_session_read_step_clock(gsv_session* s, uint64_t* out) {
   if (!s || !out || !s->step_clock || !s->ran) return fail(GSV_ERR_INVALID, "step clock not enabled / nothing ran");
   HIPCHK(hipSetDevice(s->e->device));
   HIPCHK(hipStreamSynchronize(s->e->stream));
-  HIPCHK(hipMemcpy(out, s->step_clock, (s->p->prog.steps.size() + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, s->step_clock, (s->prog().steps.size() + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return GSV_OK;
 }
 // Diagnostics: per step {and_cnt, xor_cnt, lds_reads, hbm_reads, lds_writes, hbm_writes} decoded from the compiled records.
@@ -434,6 +460,11 @@ int gsv_program_step_stats(const gsv_program* p, uint32_t* out6) {
   }
   return GSV_OK;
 }
+int gsv_session_instances_per_workgroup(const gsv_session* s, int* n) {
+  if (!s || !n) return fail(GSV_ERR_INVALID, "null argument");
+  *n = int(s->ni);
+  return GSV_OK;
+}
 int gsv_session_last_kernel_ms(gsv_session* s, double* ms) {
   if (!s || !ms || !s->ran) return fail(GSV_ERR_INVALID, "no launch recorded");
   HIPCHK(hipEventSynchronize(s->ev1));
@@ -446,7 +477,7 @@ int gsv_session_read_outputs(gsv_session* s, uint8_t* labels, uint8_t* bits) {
   if (!s || !labels || !s->ran) return fail(GSV_ERR_INVALID, "bad argument / nothing ran");
   HIPCHK(hipSetDevice(s->e->device));
   HIPCHK(hipStreamSynchronize(s->e->stream));
-  const size_t n = s->n_inst * s->p->prog.output_slots.size();
+  const size_t n = s->n_inst * s->prog().output_slots.size();
   if (n) HIPCHK(hipMemcpy(labels, s->out, n * 16, hipMemcpyDeviceToHost));
   if (bits) {
     if (!s->last_eval) return fail(GSV_ERR_INVALID, "plaintext bits exist only after evaluate");

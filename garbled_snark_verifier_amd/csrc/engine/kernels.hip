@@ -140,6 +140,10 @@ __device__ __forceinline__ uint32_t tweak_word(uint64_t gate_id, uint32_t c) {  
 // NI = instances per workgroup.  NI = 2 splits the 1024 threads into two halves that garble two instances of the
 // same program in lockstep (they share the step barrier and the AES table; each has half of the label window):
 // the many steps that are narrower than half a workgroup then cost their fixed latency once for two instances.
+// The host picks NI = 2 when a launch holds more instances than the GPU has CUs (+16 % at 512 instances; with
+// <= 256 instances NI = 1 keeps every CU busy instead).  Measured and rejected: per-instance software barriers
+// (LDS arrival counters) that let the two halves drift into different phases (no gain over lockstep: waves of the
+// two halves already overlap each other's latencies) and NI = 4 (quarter windows: -6 %).
 // HASH = 0: AesNiHasher (fixed-key AES, the hot path); HASH = 1: Blake3Hasher (src/hashers/mod.rs:22-51; the PRF most of
 // the reference's own tests use) — pure 32-bit add/xor/rotate, one gate per lane in every step (no multi-lane form).
 template <bool EVAL, int NI, int HASH>
@@ -297,35 +301,46 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           if (j < xor_cnt) r = xor_q[size_t(xor_off + j)];
           return r;
         };
+        // The free-gate phase is a software pipeline over batches of XB*BT gates: while batch k is XORed and stored,
+        // the operand loads of batch k+1 and the records of batch k+2 are in flight, so a batch exposes ONE memory
+        // latency (not record -> operands -> store back to back).  Batch 0's operands and batch 1's records are
+        // issued BEFORE the AES passes and land behind them.
         constexpr int XB = 2;
-        u32x2 xr[XB];
+        u32x2 xr[XB], xrn[XB];
         Label xa[XB], xb[XB];
-        auto issue_xor_batch = [&](uint32_t base) {
+        uint32_t xv[XB];  // evaluate: XOR of the operands' plaintext bits
+        auto load_xor_recs = [&](uint32_t base, u32x2 (&r)[XB]) {
 #pragma unroll
-          for (int j = 0; j < XB; ++j) xr[j] = load_xor_rec(base + uint32_t(j) * BT + tid);
+          for (int j = 0; j < XB; ++j) r[j] = load_xor_rec(base + uint32_t(j) * BT + tid);
+        };
+        auto issue_xor_operands = [&](uint32_t base) {
 #pragma unroll
           for (int j = 0; j < XB; ++j) {
             const uint32_t sa = xr[j].x & GSV_SLOT_MASK, sb = ((xr[j].x >> 21) | (xr[j].y << 11)) & GSV_SLOT_MASK;
-            xa[j] = delta; xb[j] = delta;
-            if (!no_load && base + uint32_t(j) * BT + tid < xor_cnt) { xa[j] = wf.ld(sa); xb[j] = wf.ld(sb); }
+            xa[j] = delta; xb[j] = delta; xv[j] = 0;
+            if (!no_load && base + uint32_t(j) * BT + tid < xor_cnt) {
+              xa[j] = wf.ld(sa); xb[j] = wf.ld(sb);
+              if (EVAL) xv[j] = wf.ld_bit(sa) ^ wf.ld_bit(sb);
+            }
           }
         };
         auto finish_xor_batch = [&](uint32_t base) {
 #pragma unroll
           for (int j = 0; j < XB; ++j) {
             if (base + uint32_t(j) * BT + tid < xor_cnt) {
-              const uint32_t sa = xr[j].x & GSV_SLOT_MASK, sb = ((xr[j].x >> 21) | (xr[j].y << 11)) & GSV_SLOT_MASK;
               const uint32_t sc = (xr[j].y >> 10) & GSV_SLOT_MASK, top = xr[j].y >> 31;
               Label c0 = lxor(xa[j], xb[j]);
               if (!EVAL) c0 = lxor_if(c0, delta, top);
               if (!no_store || c0.w[0] == 0x12345678u) {
                 wf.st(sc, c0);
-                if (EVAL) wf.st_bit(sc, (wf.ld_bit(sa) ^ wf.ld_bit(sb) ^ top) & 1u);
+                if (EVAL) wf.st_bit(sc, (xv[j] ^ top) & 1u);
               }
             }
           }
         };
-        issue_xor_batch(0);
+        load_xor_recs(0, xr);
+        issue_xor_operands(0);
+        load_xor_recs(uint32_t(XB) * BT, xrn);
         // ---- AND-family gates: whole passes of BT gates in the one-gate-per-lane form (two interleaved AES blocks
         // per lane), then the remainder in the LPG-lanes-per-gate form: a partly filled one-gate-per-lane pass would
         // cost the full ~5 us AES latency for a handful of waves, the multi-lane form ~1 us per BT/LPG gates.
@@ -371,8 +386,14 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         }
         // ---- free-gate batches (their label stores are the wave's youngest stores: no young ciphertext store)
         for (uint32_t base = 0; base < xor_cnt; base += XB * BT) {
-          if (base) issue_xor_batch(base);
           finish_xor_batch(base);
+          const uint32_t nb = base + XB * BT;
+#pragma unroll
+          for (int j = 0; j < XB; ++j) xr[j] = xrn[j];
+          if (nb < xor_cnt) {
+            issue_xor_operands(nb);
+            load_xor_recs(nb + XB * BT, xrn);
+          }
         }
         young_ct = !EVAL && !no_store && xor_cnt == 0 && and_full == and_cnt && wave_first < and_cnt &&
                    (wave_first + ((and_cnt - 1u - wave_first) / BT) * BT) < and_cnt;

@@ -130,6 +130,10 @@ int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base);
 int gsv_session_set_hasher(gsv_session* s, int kind);
 
 int gsv_session_sync(gsv_session* s);
+/* 1 or 2: how many instances share a workgroup (= a CU) in this session's launches.  Chosen at creation: 2 once the
+ * session holds more instances than the device has CUs (each instance then works with half of the LDS label window;
+ * the program variant for it is compiled on first use), else 1.  Results do not depend on it. */
+int gsv_session_instances_per_workgroup(const gsv_session* s, int* n);
 /* seconds of device time of the last garble/evaluate launch (HIP events on the engine stream) */
 int gsv_session_last_kernel_ms(gsv_session* s, double* ms);
 /* Diagnostics (tools/step_profile.py; no reference counterpart).  step clock: 100 MHz wall-clock stamps taken by instance 0's

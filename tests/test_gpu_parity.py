@@ -215,3 +215,27 @@ def test_cut_and_choose_fanout_and_commit_records(engine):
         assert (table[i].numpy() == exp).all()
     # AES_K(label): one-block CBC-MAC from the zero state
     assert bytes(table[0].numpy()[24:40]) == o.cbcmac(g.false_label0[0].tobytes())
+
+
+def test_two_instances_per_workgroup(engine, monkeypatch):
+    """More instances than CUs: sessions switch to two instances per workgroup (each with half of the LDS label window,
+    program variant compiled on demand).  Forced here on small batches, odd batch size included (idle second half),
+    garble and evaluate, against the oracle; then a >256-instance batch where the engine picks it by itself, checked
+    through lock-step determinism (identical seeds -> identical streams) and spot instances against the oracle."""
+    import garbled_snark_verifier_amd as gsv
+    monkeypatch.setenv("GSV_INSTANCES_PER_WG", "2")
+    for spec, seeds in (("fq_mul", [5, 6, 7]), ("driver_mix", [1, 2]), ("fq_complex", [9, 10, 11, 12, 13])):
+        g, prog = _garble_and_check(gsv, engine, spec, seeds)
+        _evaluate_and_check(gsv, engine, spec, g, prog, seeds)
+    g, prog = _garble_and_check(gsv, engine, "fq12_mul", [21, 22, 23], replays=2, oracle_spec="fq12_mul_chain:2")
+    _evaluate_and_check(gsv, engine, "fq12_mul", g, prog, [21, 22, 23], replays=2, oracle_spec="fq12_mul_chain:2")
+    monkeypatch.delenv("GSV_INSTANCES_PER_WG")
+    total = 300  # > 256 CUs
+    seeds = [1000 + (i % 50) for i in range(total)]
+    prog = gsv.Program.from_circuit("fq_mul")
+    r = gsv.CircuitBuilder.streaming_garbling("fq_mul", seeds, engine=engine, program=prog, keep_ciphertexts=False)
+    for i in range(50, total):
+        assert r.ciphertext_hash[i] == r.ciphertext_hash[i % 50] and (r.output_label0[i] == r.output_label0[i % 50]).all()
+    for i in (0, 49, 299):
+        ref = o.garble("fq_mul", seeds[i], capture_ct=False)
+        assert ref.ct_hash.tobytes() == r.ciphertext_hash[i] and (ref.output_label0 == r.output_label0[i]).all()
