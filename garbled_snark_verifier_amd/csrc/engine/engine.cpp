@@ -40,7 +40,7 @@ struct gsv_recorder {
 };
 
 struct DevProgram {
-  void *steps = nullptr, *ands = nullptr, *xors = nullptr, *fb_src = nullptr, *fb_dst = nullptr, *out_slots = nullptr;
+  void *steps = nullptr, *ands = nullptr, *xors = nullptr, *fb_src = nullptr, *fb_dst = nullptr, *out_slots = nullptr, *ct_pos = nullptr;
   size_t bytes = 0;
 };
 
@@ -77,7 +77,7 @@ struct gsv_session {
   DevProgram dp;
   size_t n_inst = 0;
   uint64_t replays = 1, ct_cap = 1;
-  void *W = nullptr, *VB = nullptr, *CT = nullptr, *delta = nullptr, *out = nullptr, *out_bits = nullptr, *in_bits = nullptr, *step_clock = nullptr;
+  void *W = nullptr, *VB = nullptr, *CT = nullptr, *delta = nullptr, *out = nullptr, *out_bits = nullptr, *in_bits = nullptr, *step_clock = nullptr, *ct_stage = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint32_t ni = 1;  // instances per workgroup of this session's launches
   const Program& prog() const { return ni == 2 ? *p->prog2 : p->prog; }
@@ -181,7 +181,7 @@ void gsv_program_destroy(gsv_program* p) {
   if (!p) return;
   for (auto& kv : p->dev) {
     (void)hipSetDevice(kv.first.first);
-    for (void* q : {kv.second.steps, kv.second.ands, kv.second.xors, kv.second.fb_src, kv.second.fb_dst, kv.second.out_slots})
+    for (void* q : {kv.second.steps, kv.second.ands, kv.second.xors, kv.second.fb_src, kv.second.fb_dst, kv.second.out_slots, kv.second.ct_pos})
       if (q) (void)hipFree(q);
   }
   delete p;
@@ -266,6 +266,7 @@ static int upload_program(gsv_engine* e, gsv_program* p, uint32_t ni, DevProgram
   if ((rc = up(&d.fb_src, g.fb_src_slot.data(), g.fb_src_slot.size() * 4))) return rc;
   if ((rc = up(&d.fb_dst, g.fb_dst_slot.data(), g.fb_dst_slot.size() * 4))) return rc;
   if ((rc = up(&d.out_slots, g.output_slots.data(), g.output_slots.size() * 4))) return rc;
+  if ((rc = up(&d.ct_pos, g.ct_pos.data(), g.ct_pos.size() * 4))) return rc;
   p->dev[{e->device, int(ni)}] = d;
   *out = d;
   return GSV_OK;
@@ -309,7 +310,7 @@ void gsv_session_destroy(gsv_session* s) {
   if (!s) return;
   (void)hipSetDevice(s->e->device);
   (void)hipStreamSynchronize(s->e->stream);
-  for (void* q : {s->W, s->VB, s->CT, s->delta, s->out, s->out_bits, s->in_bits, s->step_clock}) if (q) (void)hipFree(q);
+  for (void* q : {s->W, s->VB, s->CT, s->delta, s->out, s->out_bits, s->in_bits, s->step_clock, s->ct_stage}) if (q) (void)hipFree(q);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -356,11 +357,39 @@ int gsv_session_set_evaluate_inputs(gsv_session* s, const uint8_t* const_active,
   }
   return GSV_OK;
 }
+// The device stream of an instance holds each replay's ciphertexts in PROGRAM order (coalesced stores, program.hpp);
+// every host-facing call speaks GATE order (the reference's stream / gc_{i}.bin order) through a staging buffer
+// and a gather / scatter kernel.
+static const uint64_t CT_STAGE_RECORDS = 1ull << 20;  // 16 MiB
+static int ensure_ct_stage(gsv_session* s) {
+  if (!s->ct_stage) HIPCHK(hipMalloc(&s->ct_stage, CT_STAGE_RECORDS * 16));
+  return GSV_OK;
+}
+// copies stream records [first, first+n) of one instance, in gate order, to host memory
+static int fetch_ciphertexts(gsv_session* s, size_t instance, uint64_t first, uint64_t n, uint8_t* out) {
+  int rc = ensure_ct_stage(s);
+  if (rc) return rc;
+  if (gsvk_permute_ciphertexts(static_cast<uint8_t*>(s->CT) + instance * s->ct_stride() * 16, s->dp.ct_pos, s->prog().n_ct, first, n, s->ct_stage, 0, s->e->stream) != 0)
+    return fail(GSV_ERR_DEVICE, "ciphertext gather launch failed");
+  HIPCHK(hipMemcpyAsync(out, s->ct_stage, n * 16, hipMemcpyDeviceToHost, s->e->stream));
+  HIPCHK(hipStreamSynchronize(s->e->stream));
+  return GSV_OK;
+}
+
 int gsv_session_upload_ciphertexts(gsv_session* s, size_t instance, const uint8_t* cts, uint64_t n_records) {
   if (!s || instance >= s->n_inst || (!cts && n_records)) return fail(GSV_ERR_INVALID, "bad argument");
   if (n_records > s->ct_stride()) return fail(GSV_ERR_INVALID, "more ciphertexts than the session's stream capacity");
   HIPCHK(hipSetDevice(s->e->device));
-  if (n_records) HIPCHK(hipMemcpy(static_cast<uint8_t*>(s->CT) + instance * s->ct_stride() * 16, cts, n_records * 16, hipMemcpyHostToDevice));
+  // gate-order records from the host -> program-order positions of the device stream (staged in chunks)
+  int rc = ensure_ct_stage(s);
+  if (rc) return rc;
+  for (uint64_t off = 0; off < n_records; off += CT_STAGE_RECORDS) {
+    const uint64_t n = std::min<uint64_t>(CT_STAGE_RECORDS, n_records - off);
+    HIPCHK(hipMemcpyAsync(s->ct_stage, cts + off * 16, n * 16, hipMemcpyHostToDevice, s->e->stream));
+    if (gsvk_permute_ciphertexts(static_cast<uint8_t*>(s->CT) + instance * s->ct_stride() * 16, s->dp.ct_pos, s->prog().n_ct, off, n, s->ct_stage, 1, s->e->stream) != 0)
+      return fail(GSV_ERR_DEVICE, "ciphertext scatter launch failed");
+    HIPCHK(hipStreamSynchronize(s->e->stream));
+  }
   s->ct_uploaded[instance] = n_records;
   return GSV_OK;
 }
@@ -490,7 +519,11 @@ int gsv_session_read_ciphertexts(gsv_session* s, size_t instance, uint64_t first
   if (first + n_records > s->ct_stride()) return fail(GSV_ERR_INVALID, "range exceeds the retained ciphertext stream");
   HIPCHK(hipSetDevice(s->e->device));
   HIPCHK(hipStreamSynchronize(s->e->stream));
-  if (n_records) HIPCHK(hipMemcpy(out, static_cast<uint8_t*>(s->CT) + (instance * s->ct_stride() + first) * 16, n_records * 16, hipMemcpyDeviceToHost));
+  for (uint64_t off = 0; off < n_records; off += CT_STAGE_RECORDS) {
+    const uint64_t n = std::min<uint64_t>(CT_STAGE_RECORDS, n_records - off);
+    int rc = fetch_ciphertexts(s, instance, first + off, n, out + off * 16);
+    if (rc) return rc;
+  }
   return GSV_OK;
 }
 int gsv_session_ciphertext_hash(gsv_session* s, size_t instance, uint8_t hash[16]) {
@@ -499,12 +532,13 @@ int gsv_session_ciphertext_hash(gsv_session* s, size_t instance, uint8_t hash[16
   HIPCHK(hipSetDevice(s->e->device));
   HIPCHK(hipStreamSynchronize(s->e->stream));
   const uint64_t total = s->ct_stride();
-  const uint64_t chunk = 1ull << 20;  // 16 MiB of records per D2H
+  const uint64_t chunk = CT_STAGE_RECORDS;
   std::vector<uint8_t> buf(size_t(std::min<uint64_t>(chunk, total ? total : 1)) * 16);
   CbcMacHost mac;
   for (uint64_t off = 0; off < total; off += chunk) {
     uint64_t n = std::min(chunk, total - off);
-    HIPCHK(hipMemcpy(buf.data(), static_cast<uint8_t*>(s->CT) + (instance * total + off) * 16, n * 16, hipMemcpyDeviceToHost));
+    int rc = fetch_ciphertexts(s, instance, off, n, buf.data());
+    if (rc) return rc;
     mac.update(buf.data(), n);
   }
   mac.digest(hash);

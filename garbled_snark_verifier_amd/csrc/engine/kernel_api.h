@@ -46,5 +46,7 @@ int gsvk_upload_round_keys(const uint32_t rk[44]);
 int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, int evaluate, hipStream_t stream);
 int gsvk_gather_outputs(const void* W, const void* VB, uint32_t n_slots, const uint32_t* slots, uint32_t n_out, uint32_t n_instances,
                         void* out, void* out_bits, hipStream_t stream);
+// stage[i] <-> stream[(idx / n_ct) * n_ct + ct_pos[idx % n_ct]] for idx = first + i, i < n  (scatter != 0: stage -> stream)
+int gsvk_permute_ciphertexts(void* stream, const void* ct_pos, uint64_t n_ct, uint64_t first, uint64_t n, void* stage, int scatter, hipStream_t s);
 int gsvk_scatter_bits(void* VB, uint32_t n_slots, uint32_t first_slot, const void* bits, uint32_t n, uint32_t n_instances, hipStream_t stream);
 }

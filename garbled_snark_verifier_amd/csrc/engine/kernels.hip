@@ -446,6 +446,15 @@ __global__ void scatter_bits_kernel(uint8_t* VB, uint32_t n_slots, uint32_t firs
   VB[size_t(inst) * n_slots + first_slot + i] = bits[size_t(inst) * n + i];
 }
 
+// Gate order <-> program order of the ciphertext stream (see program.hpp, ct_pos): one record per thread.
+__global__ void permute_ciphertexts_kernel(uint4* stream, const uint32_t* ct_pos, uint64_t n_ct, uint64_t first, uint64_t n, uint4* stage, int scatter) {
+  const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t idx = first + i, rep = idx / n_ct, g = idx - rep * n_ct;
+  const uint64_t pos = rep * n_ct + ct_pos[g];
+  if (scatter) stream[pos] = stage[i]; else stage[i] = stream[pos];
+}
+
 }  // namespace dev
 }  // namespace gsv
 
@@ -490,6 +499,12 @@ int gsvk_gather_outputs(const void* W, const void* VB, uint32_t n_slots, const u
   dim3 grid((n_out + 255) / 256, n_instances);
   hipLaunchKernelGGL(gsv::dev::gather_outputs_kernel, grid, dim3(256), 0, stream, static_cast<const uint4*>(W), static_cast<const uint8_t*>(VB),
                      n_slots, slots, n_out, static_cast<uint4*>(out), static_cast<uint8_t*>(out_bits));
+  return int(hipGetLastError());
+}
+int gsvk_permute_ciphertexts(void* stream, const void* ct_pos, uint64_t n_ct, uint64_t first, uint64_t n, void* stage, int scatter, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gsv::dev::permute_ciphertexts_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, s, static_cast<uint4*>(stream),
+                     static_cast<const uint32_t*>(ct_pos), n_ct, first, n, static_cast<uint4*>(stage), scatter);
   return int(hipGetLastError());
 }
 int gsvk_scatter_bits(void* VB, uint32_t n_slots, uint32_t first_slot, const void* bits, uint32_t n, uint32_t n_instances, hipStream_t stream) {

@@ -104,7 +104,8 @@ inline XorRec pack_xor(uint32_t a, uint32_t b, uint32_t c, bool xnor) {
   return XorRec{uint64_t(a) | (uint64_t(b) << 21) | (uint64_t(c) << 42) | (uint64_t(xnor ? 1 : 0) << 63)};
 }
 // AND-family gate, 16 bytes: lo = a | b<<21 | c<<42 | (type&1)<<63 ; hi = type>>1 (2 bits) | gid<<2 (31 bits) | ct<<33 (31 bits)
-// gid / ct are relative to the replay's gate-id and ciphertext bases.
+// gid is relative to the replay's gate-id base; ct is the record's own index in the program (= where its ciphertext
+// sits inside the replay's block of the device stream).
 struct AndRec { uint64_t lo, hi; };
 inline AndRec pack_and(uint32_t a, uint32_t b, uint32_t c, uint32_t type, uint32_t gid, uint32_t ct) {
   return AndRec{uint64_t(a) | (uint64_t(b) << 21) | (uint64_t(c) << 42) | (uint64_t(type & 1u) << 63),
@@ -124,6 +125,7 @@ struct Program {
   std::vector<uint32_t> fb_src_slot, fb_dst_slot;  // replay epilogue: W[dst] <- W[src]
   uint64_t n_gates = 0;        // gates in stream order INCLUDING dead ones (= gate_ids consumed per replay)
   uint64_t n_ct = 0;           // ciphertexts per replay (AND-family, live)
+  std::vector<uint32_t> ct_pos;  // gate-order ciphertext index -> position inside a replay's block of the device stream
   uint64_t n_dead = 0;
   uint64_t gate_count[GATE_TYPE_COUNT] = {0};
   uint32_t and_depth = 0, n_and_steps = 0, max_step_width = 0;
@@ -288,6 +290,7 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
       if (t.c[i] != DEAD_WIRE && t.type[i] < 8) ++k;
     }
     p.n_ct = k;
+    p.ct_pos.assign(size_t(k), 0);
   }
   if (opt.hbm_arena_factor > 1) {
     uint32_t lv = next_in, pk = next_in;
@@ -344,7 +347,13 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
       ((sa & SLOT_LDS_FLAG) ? p.reads_lds : p.reads_hbm)++;
       ((sb & SLOT_LDS_FLAG) ? p.reads_lds : p.reads_hbm)++;
       ((sl & SLOT_LDS_FLAG) ? p.writes_lds : p.writes_hbm)++;
-      if (ty < 8) p.ands.push_back(pack_and(sa, sb, sl, ty, uint32_t(i), ct_index[i]));
+      if (ty < 8) {
+        // The ciphertext goes to the gate's PROGRAM-order position: the lanes of a wave then write one contiguous
+        // kilobyte.  At the gate-order index every store was its own 128-byte line (1.1 stores per line touched,
+        // -16 % throughput); readers of the stream get gate order back through ct_pos (engine.cpp).
+        p.ct_pos[ct_index[i]] = uint32_t(p.ands.size());
+        p.ands.push_back(pack_and(sa, sb, sl, ty, uint32_t(i), uint32_t(p.ands.size())));
+      }
       else p.xors.push_back(pack_xor(sa, sb, sl, ty != uint8_t(GateType::Xor)));
     }
     peak = std::max(peak, live);

@@ -78,6 +78,9 @@ int hostsim_run(SimProgram* sp, int evaluate, uint32_t replays, uint64_t gid_bas
       if (evaluate) VB[g.input_slots[i]] = input_bits[i] ? 1 : 0;
     }
     Label d = evaluate ? Label{{0, 0, 0, 0}} : load(delta);
+    // the records carry PROGRAM-order ciphertext positions; this interpreter's `cts` buffer is in gate order
+    std::vector<uint32_t> gate_of(g.ct_pos.size());
+    for (size_t k = 0; k < g.ct_pos.size(); ++k) gate_of[g.ct_pos[k]] = uint32_t(k);
     for (uint32_t rep = 0; rep < replays; ++rep) {
       const uint64_t gb = gid_base + uint64_t(rep) * g.n_gates;
       uint8_t* ct = cts + size_t(rep) * g.n_ct * 16;
@@ -99,7 +102,7 @@ int hostsim_run(SimProgram* sp, int evaluate, uint32_t replays, uint64_t gid_bas
           const uint32_t sa = uint32_t(r.lo) & SLOT_MASK, sb = uint32_t(r.lo >> 21) & SLOT_MASK, sc = uint32_t(r.lo >> 42) & SLOT_MASK;
           const uint32_t ty = uint32_t(r.lo >> 63) | (uint32_t(r.hi & 3u) << 1);
           const uint64_t gid = gb + ((r.hi >> 2) & 0x7FFFFFFFull);
-          const uint32_t cti = uint32_t(r.hi >> 33);
+          const uint32_t cti = gate_of[uint32_t(r.hi >> 33)];
           Label a = load(lab(sa)), b = load(lab(sb));
           if (!evaluate) {
             Label c0, c;

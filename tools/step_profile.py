@@ -16,10 +16,11 @@ prog = gsv.Program.from_circuit(spec, chain_feedback=True)
 st = prog.step_stats().astype(np.int64)
 n_in = prog.info["n_inputs"]
 and_cnt, xor_cnt, rl, rh, wl, wh = (st[:, i] for i in range(6))
-narrow = (and_cnt > 0) & (and_cnt * 8 + xor_cnt <= 1024)
-cls = np.where(narrow, 0, np.where(and_cnt + xor_cnt <= 1024, 1, np.where(and_cnt + xor_cnt <= 4096, 2, 3)))
 names = ["narrow (multi-lane AES)", "wide <=1024 gates", "wide <=4096 gates", "wide >4096 gates"]
 for B in batches:
+    BT = 1024 // (2 if B > 256 else 1)  # threads per instance (two instances per workgroup above 256 instances; HBM columns are the 1-per-WG variant's)
+    narrow = (and_cnt > 0) & (and_cnt * 8 + xor_cnt <= BT)
+    cls = np.where(narrow, 0, np.where(and_cnt + xor_cnt <= 1024, 1, np.where(and_cnt + xor_cnt <= 4096, 2, 3)))
     d, f, t, inp = gsv.labels_from_seed(1, n_in)
     sess = gsv.Session(eng, prog, B, 3, 1)
     sess.enable_step_clock()
