@@ -165,7 +165,8 @@ int gsv_program_compile(gsv_recorder* r, const uint32_t* fb_out_idx, const uint3
   std::unique_ptr<gsv_program> p(new gsv_program());
   CompileOptions opt;
   if (const char* e = getenv("GSV_LDS_LIFETIME")) opt.lds_max_lifetime = uint32_t(atoi(e));  // tuning knobs (defaults are the measured best)
-  if (const char* e = getenv("GSV_SCHEDULE")) opt.schedule = uint32_t(atoi(e));
+  if (const char* e = getenv("GSV_FUSE")) opt.fuse = atoi(e) != 0;
+  if (const char* e = getenv("GSV_FUSE_DUP")) opt.fuse_dup_fanout = uint32_t(atoi(e));
   if (const char* e = getenv("GSV_ORDER_BY_READER")) opt.order_by_reader = atoi(e) != 0;
   if (const char* e = getenv("GSV_HBM_ARENA")) opt.hbm_arena_factor = uint32_t(atoi(e));
   if (const char* e = getenv("GSV_LDS_SLOTS")) opt.lds_slots = std::min<uint32_t>(uint32_t(atoi(e)), LDS_WINDOW_SLOTS);
@@ -252,9 +253,9 @@ static int upload_program(gsv_engine* e, gsv_program* p, uint32_t ni, DevProgram
   DevProgram d;
   const Program& g = ni == 2 ? *p->prog2 : p->prog;
   auto up = [&](void** dst, const void* src, size_t bytes) -> int {
-    // +16 bytes of zero padding: the kernel's record prefetch reads 16 bytes at the last 8-byte record
-    HIPCHK(hipMalloc(dst, bytes + 16));
-    HIPCHK(hipMemset(*dst, 0, bytes + 16));
+    // +32 bytes of zero padding: the kernel's record prefetch reads 24 bytes wherever a lane's record starts
+    HIPCHK(hipMalloc(dst, bytes + 32));
+    HIPCHK(hipMemset(*dst, 0, bytes + 32));
     if (bytes) HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
     d.bytes += bytes;
     return GSV_OK;
@@ -480,12 +481,18 @@ int gsv_program_step_stats(const gsv_program* p, uint32_t* out6) {
     const StepDesc& d = g.steps[s];
     uint32_t* o = out6 + 6 * s;
     o[0] = d.and_cnt; o[1] = d.xor_cnt; o[2] = o[3] = o[4] = o[5] = 0;
-    auto acc = [&](uint64_t lo) {
-      const uint32_t a = uint32_t(lo) & SLOT_MASK, b = uint32_t(lo >> 21) & SLOT_MASK, c = uint32_t(lo >> 42) & SLOT_MASK;
-      o[(a & SLOT_LDS_FLAG) ? 2 : 3]++; o[(b & SLOT_LDS_FLAG) ? 2 : 3]++; o[(c & SLOT_LDS_FLAG) ? 4 : 5]++;
-    };
-    for (uint32_t k = 0; k < d.and_cnt; ++k) acc(g.ands[d.and_off + k].lo);
-    for (uint32_t k = 0; k < d.xor_cnt; ++k) acc(g.xors[d.xor_off + k].v);
+    auto rd = [&](uint32_t sl) { if (sl != SLOT_LDS_ZERO) o[(sl & SLOT_LDS_FLAG) ? 2 : 3]++; };
+    auto wr = [&](uint32_t sl) { o[(sl & SLOT_LDS_FLAG) ? 4 : 5]++; };
+    for (uint32_t k = 0; k < d.and_cnt; ++k) {
+      const AndRec& r = g.ands[d.and_off + k];
+      rd(uint32_t(r.w0) & SLOT_MASK); rd(uint32_t(r.w0 >> 21) & SLOT_MASK); rd(uint32_t(r.w0 >> 42) & SLOT_MASK);
+      rd(uint32_t(r.w1) & SLOT_MASK); rd(uint32_t(r.w1 >> 21) & SLOT_MASK); wr(uint32_t(r.w1 >> 42) & SLOT_MASK);
+    }
+    for (uint32_t k = 0; k < d.xor_cnt; ++k) {
+      const XorRec& r = g.xors[d.xor_off + k];
+      rd(uint32_t(r.w0) & SLOT_MASK); rd(uint32_t(r.w0 >> 21) & SLOT_MASK); rd(uint32_t(r.w0 >> 42) & SLOT_MASK);
+      rd(uint32_t(r.w1) & SLOT_MASK); wr(uint32_t(r.w1 >> 21) & SLOT_MASK);
+    }
   }
   return GSV_OK;
 }

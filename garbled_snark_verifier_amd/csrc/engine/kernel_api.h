@@ -12,8 +12,8 @@ namespace dev {
 
 struct KernelArgs {
   const void* steps;   // StepDesc[n_steps]   {and_off, and_cnt, xor_off, xor_cnt}
-  const void* ands;    // AndRec[]            16 B
-  const void* xors;    // XorRec[]            8 B
+  const void* ands;    // AndRec[]            32 B
+  const void* xors;    // XorRec[]            16 B
   uint4* W;            // [n_instances][n_slots] labels
   uint8_t* VB;         // [n_instances][n_slots] plaintext bits (evaluate only)
   uint4* CT;           // [n_instances][ct_stride] ciphertext streams

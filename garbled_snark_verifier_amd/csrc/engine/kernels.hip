@@ -153,10 +153,15 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   // dword i of the table region: entry x = i / 64; first 32 dwords Te0[x], next 32 dwords Te2[x] (ka.te = Te0..Te3, 256 words each)
   for (uint32_t i = threadIdx.x; i < GSV_LDS_TABLE_BYTES / 4; i += GSV_BLOCK_THREADS) *reinterpret_cast<lds_u32*>(uintptr_t(i * 4u)) = ka.te[((i & 32u) ? 512u : 0u) + (i >> 6)];
   if (threadIdx.x < 44) *reinterpret_cast<lds_u32*>(uintptr_t(GSV_LDS_RK_BASE + 4u * threadIdx.x)) = c_rk[threadIdx.x];
+  // window entry 0 of every instance: the all-zero label (and plaintext bit 0) that absent operands of fused gates name
+  if (threadIdx.x < 4u * NI) *reinterpret_cast<lds_u32*>(uintptr_t(GSV_LDS_TABLE_BYTES + (threadIdx.x / 4u) * (GSV_LDS_SLOTS / NI) * 16u + (threadIdx.x % 4u) * 4u)) = 0u;
+  if (threadIdx.x < uint32_t(NI)) *reinterpret_cast<lds_u8*>(uintptr_t(GSV_LDS_TABLE_BYTES + GSV_LDS_SLOTS * 16u + threadIdx.x * (GSV_LDS_SLOTS / NI))) = uint8_t(0);
   __syncthreads();
   constexpr uint32_t BT = GSV_BLOCK_THREADS / NI;  // threads per instance
-  const uint32_t sub = threadIdx.x / BT;            // which instance of this workgroup
-  const uint32_t tid = threadIdx.x % BT;            // lane index inside the instance's thread group
+  // which instance of this workgroup: wave-uniform (BT is a multiple of 64), so say so — every per-instance base
+  // address below then lives in SGPRs instead of costing a VGPR each
+  const uint32_t sub = NI == 1 ? 0u : uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / BT)));
+  const uint32_t tid = threadIdx.x - sub * BT;      // lane index inside the instance's thread group
   const LdsBankedTable aes{(tid & 31u) * 4u};
   // narrow-step mode: LPG lanes per AND gate (garble: two blocks x 4 columns; evaluate: one block x 4 columns)
   constexpr uint32_t LPG = EVAL ? 4u : 8u;
@@ -179,8 +184,6 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   if (!EVAL) { const u32x4 d = ((const glb_u128*)ka.delta)[inst]; delta = Label{{d.x, d.y, d.z, d.w}}; }
   // this lane's column of delta (selects, not a runtime-indexed array: that would be promoted to static LDS)
   const uint32_t dq = col == 0 ? delta.w[0] : col == 1 ? delta.w[1] : col == 2 ? delta.w[2] : delta.w[3];
-  const glb_u128* __restrict__ and_q = (const glb_u128*)ka.ands;  // 16 B records
-  const glb_u64* __restrict__ xor_q = (const glb_u64*)ka.xors;    // 8 B records
   const glb_u128* __restrict__ step_q = (const glb_u128*)ka.steps;
   const bool no_store = (ka.diag & 8u) != 0, no_load = (ka.diag & 4u) != 0, no_aes = (ka.diag & 1u) != 0, no_narrow = (ka.diag & 16u) != 0;
 
@@ -194,12 +197,18 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     //   narrow (and_cnt*LPG + xor_cnt <= 1024): LPG consecutive lanes share AND gate i/LPG, free gates follow.
     // Either way AND work and XOR work are contiguous lane ranges: only a boundary wave diverges on the gate kind.
     //
+    // Records (program.hpp): AND-family 32 bytes {a1,a2,b1 | b2,p,out | gate id, type}, free 16 bytes {x1,x2,x3 | x4,out}:
+    //   out = AND_t(a1 ^ a2, b1 ^ b2) ^ p      /      out = x1 ^ x2 ^ x3 ^ x4 (^ delta)
+    // Absent operands name window entry 0 (an all-zero label), so every lane runs the same instruction stream.
+    // The ciphertext of AND record k goes to position k of the replay's block of the stream.
+    //
     // Software pipeline, two steps deep: while step s computes, the descriptor (scalar load: the whole
     // step bookkeeping stays on the scalar unit, which matters because all 16 waves run it even when only one
-    // has gates) + this lane's first record of step s+2 are in flight (program records stream from HBM).  The step barrier must only wait for what other
-    // waves will read — this step's label stores — so it is a hand-counted `s_waitcnt vmcnt(N)`: vector-memory
-    // ops retire in issue order and the N youngest ops of the wave are, by construction (compiler barriers pin
-    // the order), the record prefetch load and, when the wave's last pass held AND gates, the ciphertext store.
+    // has gates) + this lane's first record of step s+2 are in flight (program records stream from HBM).  The step
+    // barrier must only wait for what other waves will read — this step's label stores — so it is a hand-counted
+    // `s_waitcnt vmcnt(N)`: vector-memory ops retire in issue order and the N youngest ops of the wave are, by
+    // construction (compiler barriers pin the order), the record prefetch load and, when the wave's last pass
+    // held AND gates, the ciphertext store.
     const uint32_t last_step = ka.n_steps - 1;
     auto is_narrow = [&](const u32x4& d) -> bool { return HASH == 0 && !no_narrow && d.y != 0 && d.y * LPG + d.w <= BT; };
     // wide steps: is the AND remainder small enough for the multi-lane form?
@@ -209,82 +218,108 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       if (!inst_active) { d.y = 0; d.w = 0; }
       return d;
     };
-    // Record of this lane's first (or only) gate of step d.  ALWAYS exactly one 16-byte vector load per lane and
-    // per wave, whatever the lane has to do: the step barrier's counted vmcnt relies on it.  Free-gate records
-    // are 8 bytes, so their load also brings the following record (the array is padded by 16 bytes on upload);
-    // lanes without a gate read the step table's first entry (always present).
+    // First 16 bytes (the operand / output slots) of this lane's first (or only) record of step d.  ALWAYS exactly one
+    // vector load per lane and per wave, whatever the lane has to do: the step barrier's counted vmcnt relies on it.
+    // Lanes without a gate read the step table's first entry (always present).  The second half of an AND record
+    // (gate id, third type bit) is only needed when the AES starts: it is loaded together with the operands.
     const glb_u8* const and_bytes = (const glb_u8*)ka.ands;
     const glb_u8* const xor_bytes = (const glb_u8*)ka.xors;
-    auto load_rec = [&](const u32x4& d) -> u32x4 {
+    typedef u32x4 Rec;
+    auto load_rec = [&](const u32x4& d) -> Rec {
       const glb_u8* p = (const glb_u8*)ka.steps;
       if (is_narrow(d)) {
         const uint32_t na = d.y * LPG;
-        if (tid < na) p = and_bytes + size_t(d.x + tid / LPG) * 16u;
-        else if (tid < na + d.w) p = xor_bytes + size_t(d.z + (tid - na)) * 8u;
-      } else if (d.y >= BT || !small_rem(d.y)) { if (tid < d.y) p = and_bytes + size_t(d.x + tid) * 16u; }  // wide: first one-per-lane pass
-      else if (tid / LPG < d.y) p = and_bytes + size_t(d.x + tid / LPG) * 16u;  // wide with only a small remainder: first multi-lane pass
-      // records are 8-byte aligned: two dwordx2 would be two vmcnt events, so read 16 bytes with 8-byte alignment
-      typedef u32x4 __attribute__((aligned(8))) u32x4_a8;
-      return *(const u32x4_a8 GSV_GLB*)p;
+        if (tid < na) p = and_bytes + size_t(d.x + tid / LPG) * 32u;
+        else if (tid < na + d.w) p = xor_bytes + size_t(d.z + (tid - na)) * 16u;
+      } else if (d.y >= BT || !small_rem(d.y)) { if (tid < d.y) p = and_bytes + size_t(d.x + tid) * 32u; }  // wide: first one-per-lane pass
+      else if (tid / LPG < d.y) p = and_bytes + size_t(d.x + tid / LPG) * 32u;  // wide with only a small remainder: first multi-lane pass
+      return *(const glb_u128*)p;
     };
-    u32x4 sd = load_desc(0), r0 = load_rec(sd);
-    u32x4 nsd = load_desc(1), n0 = load_rec(nsd);
+    auto load_and_rec = [&](uint32_t k) -> Rec { return *(const glb_u128*)(and_bytes + size_t(k) * 32u); };      // record k of the AND array, first half
+    auto load_and_hi = [&](uint32_t k) -> u32x2 { return *(const glb_u64*)(and_bytes + size_t(k) * 32u + 16u); };  // second half
+    Rec r0, n0;
+    u32x4 sd = load_desc(0);
+    r0 = load_rec(sd);
+    u32x4 nsd = load_desc(1);
+    n0 = load_rec(nsd);
     const uint32_t wave_first = __builtin_amdgcn_readfirstlane(tid);  // index of the wave's first lane inside its instance group
+    // decoded AND record
+    struct AndOp { uint32_t a1, a2, b1, b2, p, c, t; uint64_t gid; };
+    auto decode_and = [&](const Rec& q, const u32x2& hi) -> AndOp {
+      AndOp o;
+      o.a1 = q.x & GSV_SLOT_MASK;
+      o.a2 = ((q.x >> 21) | (q.y << 11)) & GSV_SLOT_MASK;
+      o.b1 = (q.y >> 10) & GSV_SLOT_MASK;
+      o.b2 = q.z & GSV_SLOT_MASK;
+      o.p = ((q.z >> 21) | (q.w << 11)) & GSV_SLOT_MASK;
+      o.c = (q.w >> 10) & GSV_SLOT_MASK;
+      o.t = (q.y >> 31) | ((q.w >> 31) << 1) | (((hi.y >> 8) & 1u) << 2);
+      o.gid = gid_base + (uint64_t(hi.x) | (uint64_t(hi.y & 0xFFu) << 32));
+      return o;
+    };
     // One AND-family gate spread over LPG lanes (garble: two AES blocks x 4 columns, evaluate: one block x 4 columns).
-    // Called with LPG-aligned groups of active lanes; `q` is the gate's 16-byte record (same in all lanes of the group).
-    auto and_multilane = [&](const u32x4& q) {
-      const uint32_t sa = q.x & GSV_SLOT_MASK;
-      const uint32_t sb = ((q.x >> 21) | (q.y << 11)) & GSV_SLOT_MASK;
-      const uint32_t sc = (q.y >> 10) & GSV_SLOT_MASK;
-      const uint32_t t = (q.y >> 31) | ((q.z & 3u) << 1);
-      const uint64_t hi = (uint64_t(q.w) << 32) | q.z;
-      const uint64_t gid = gid_base + ((hi >> 2) & 0x7FFFFFFFull);
-      const uint32_t cti = uint32_t(hi >> 33);
-      uint32_t a_c = dq, b_c = dq;
-      if (!no_load) { a_c = wf.ld_word(sa, col); b_c = wf.ld_word(sb, col); }
-      const uint32_t twc = tweak_word(gid, col);
+    // Called with LPG-aligned groups of active lanes; `q` is the gate's record (same in all lanes of the group), `cti`
+    // its index in the program's AND array.
+    auto and_multilane = [&](const Rec& q, uint32_t cti) {
+      const AndOp o = decode_and(q, load_and_hi(cti));
+      const uint32_t t = o.t;
+      uint32_t a_c = dq, b_c = dq, p_c = 0;
+      if (!no_load) {
+        a_c = wf.ld_word(o.a1, col) ^ wf.ld_word(o.a2, col);
+        b_c = wf.ld_word(o.b1, col) ^ wf.ld_word(o.b2, col);
+        p_c = wf.ld_word(o.p, col);
+      }
+      const uint32_t twc = tweak_word(o.gid, col);
       if (!EVAL) {
         uint32_t x = a_c ^ (alpha_a(t) ? dq : 0u);  // selected_a ; lanes of the second quad take other_a
         if (blk) x ^= dq;
         const uint32_t h = no_aes ? (x ^ twc) : aes128_quad(aes, rkc, x ^ twc);
-        const uint32_t o = uint32_t(__shfl_xor(int(h), 4));  // the other block's column c
-        const uint32_t c0_c = h ^ (alpha_c(t) ? dq : 0u);
-        const uint32_t ct_c = h ^ o ^ b_c ^ (alpha_b(t) ? dq : 0u);
-        if (!blk && !no_store) wf.st_word(sc, col, c0_c);
+        const uint32_t o2 = uint32_t(__shfl_xor(int(h), 4));  // the other block's column c
+        const uint32_t c0_c = h ^ (alpha_c(t) ? dq : 0u) ^ p_c;
+        const uint32_t ct_c = h ^ o2 ^ b_c ^ (alpha_b(t) ? dq : 0u);
+        if (!blk && !no_store) wf.st_word(o.c, col, c0_c);
         asm volatile("" ::: "memory");
         if (!blk && !no_store) CTw[(ct_base + cti) * 4u + col] = ct_c;
       } else {
-        const uint32_t va = wf.ld_bit(sa), vb = wf.ld_bit(sb);
+        const uint32_t va = (wf.ld_bit(o.a1) ^ wf.ld_bit(o.a2)) & 1u, vb = (wf.ld_bit(o.b1) ^ wf.ld_bit(o.b2)) & 1u, vp = wf.ld_bit(o.p) & 1u;
         const uint32_t ct_c = CTw[(ct_base + cti) * 4u + col];
         const uint32_t h = no_aes ? (a_c ^ twc) : aes128_quad(aes, rkc, a_c ^ twc);
         const uint32_t use_ct = (va ^ alpha_a(t)) & 1u;
-        wf.st_word(sc, col, h ^ (use_ct ? (ct_c ^ b_c) : 0u));
-        if (col == 0) wf.st_bit(sc, gate_eval_bit(t, va, vb));
+        wf.st_word(o.c, col, h ^ (use_ct ? (ct_c ^ b_c) : 0u) ^ p_c);
+        if (col == 0) wf.st_bit(o.c, (gate_eval_bit(t, va, vb) ^ vp) & 1u);
       }
+    };
+    // decoded free-gate record (u32x4 = w0 | w1)
+    struct XorOp { uint32_t x1, x2, x3, x4, c, par; };
+    auto decode_xor = [&](const u32x4& r) -> XorOp {
+      XorOp o;
+      o.x1 = r.x & GSV_SLOT_MASK;
+      o.x2 = ((r.x >> 21) | (r.y << 11)) & GSV_SLOT_MASK;
+      o.x3 = (r.y >> 10) & GSV_SLOT_MASK;
+      o.par = r.y >> 31;
+      o.x4 = r.z & GSV_SLOT_MASK;
+      o.c = ((r.z >> 21) | (r.w << 11)) & GSV_SLOT_MASK;
+      return o;
     };
     for (uint32_t s = 0; s < ka.n_steps; ++s) {
       const uint32_t and_off = sd.x, and_cnt = sd.y, xor_off = sd.z, total = sd.y + sd.w;
+      (void)total;
       const u32x4 n2sd = load_desc(s + 2);  // lands during this step; its record load is issued at the end
       bool young_ct = false;                 // did this wave issue a ciphertext store AFTER its last label store?
       if (ka.step_clock && blockIdx.x == 0 && threadIdx.x == 0 && rep + 1 == ka.replays) ka.step_clock[s] = wall_clock64();  // older than this step's stores
       if (is_narrow(sd)) {
         // ------------------------------------------------------------------ narrow step: one pass
         const uint32_t na = and_cnt * LPG;
-        const u32x4 q = r0;
-        const uint32_t sa = q.x & GSV_SLOT_MASK;
-        const uint32_t sb = ((q.x >> 21) | (q.y << 11)) & GSV_SLOT_MASK;
-        const uint32_t sc = (q.y >> 10) & GSV_SLOT_MASK;
-        const uint32_t top = q.y >> 31;
         if (tid < na) {
-          and_multilane(q);
+          and_multilane(r0, and_off + tid / LPG);
         } else if (tid < na + sd.w) {
-          Label a = delta, b = delta;
-          if (!no_load) { a = wf.ld(sa); b = wf.ld(sb); }
-          Label c0 = lxor(a, b);
-          if (!EVAL) c0 = lxor_if(c0, delta, top);
+          const XorOp o = decode_xor(r0);
+          Label c0 = delta;
+          if (!no_load) c0 = lxor(lxor(wf.ld(o.x1), wf.ld(o.x2)), lxor(wf.ld(o.x3), wf.ld(o.x4)));
+          if (!EVAL) c0 = lxor_if(c0, delta, o.par);
           if (!no_store || c0.w[0] == 0x12345678u) {
-            wf.st(sc, c0);
-            if (EVAL) wf.st_bit(sc, (wf.ld_bit(sa) ^ wf.ld_bit(sb) ^ top) & 1u);
+            wf.st(o.c, c0);
+            if (EVAL) wf.st_bit(o.c, (wf.ld_bit(o.x1) ^ wf.ld_bit(o.x2) ^ wf.ld_bit(o.x3) ^ wf.ld_bit(o.x4) ^ o.par) & 1u);
           }
         }
         // the AND lanes come first, so a wave holding any AND lane issued its ciphertext store last... unless it
@@ -293,34 +328,32 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       } else {
         // ------------------------------------------------------------------ wide step
         // AND-family gates: passes of 1024 gates, one per lane (two interleaved AES blocks each).
-        // Free gates: batches of 4 per lane with all eight operand loads of a batch issued together; the first
-        // batch's loads are issued BEFORE the AES passes so their HBM/LDS latency hides behind the AES work.
         const uint32_t xor_cnt = sd.w;
-        auto load_xor_rec = [&](uint32_t j) -> u32x2 {
-          u32x2 r = {0, 0};
-          if (j < xor_cnt) r = xor_q[size_t(xor_off + j)];
-          return r;
-        };
+        const glb_u128* const xq = (const glb_u128*)ka.xors + xor_off;
         // The free-gate phase is a software pipeline over batches of XB*BT gates: while batch k is XORed and stored,
         // the operand loads of batch k+1 and the records of batch k+2 are in flight, so a batch exposes ONE memory
-        // latency (not record -> operands -> store back to back).  Batch 0's operands and batch 1's records are
-        // issued BEFORE the AES passes and land behind them.
+        // latency (not record -> operands -> store back to back).  The records of batch 0 are issued BEFORE the AES
+        // passes and land behind them.
         constexpr int XB = 2;
-        u32x2 xr[XB], xrn[XB];
-        Label xa[XB], xb[XB];
+        u32x4 xr[XB], xrn[XB];
+        Label xa[XB];
         uint32_t xv[XB];  // evaluate: XOR of the operands' plaintext bits
-        auto load_xor_recs = [&](uint32_t base, u32x2 (&r)[XB]) {
+        auto load_xor_recs = [&](uint32_t base, u32x4 (&r)[XB]) {
 #pragma unroll
-          for (int j = 0; j < XB; ++j) r[j] = load_xor_rec(base + uint32_t(j) * BT + tid);
+          for (int j = 0; j < XB; ++j) {
+            const uint32_t g = base + uint32_t(j) * BT + tid;
+            r[j] = u32x4{0, 0, 0, 0};
+            if (g < xor_cnt) r[j] = xq[g];
+          }
         };
         auto issue_xor_operands = [&](uint32_t base) {
 #pragma unroll
           for (int j = 0; j < XB; ++j) {
-            const uint32_t sa = xr[j].x & GSV_SLOT_MASK, sb = ((xr[j].x >> 21) | (xr[j].y << 11)) & GSV_SLOT_MASK;
-            xa[j] = delta; xb[j] = delta; xv[j] = 0;
+            const XorOp o = decode_xor(xr[j]);
+            xa[j] = delta; xv[j] = 0;
             if (!no_load && base + uint32_t(j) * BT + tid < xor_cnt) {
-              xa[j] = wf.ld(sa); xb[j] = wf.ld(sb);
-              if (EVAL) xv[j] = wf.ld_bit(sa) ^ wf.ld_bit(sb);
+              xa[j] = lxor(lxor(wf.ld(o.x1), wf.ld(o.x2)), lxor(wf.ld(o.x3), wf.ld(o.x4)));
+              if (EVAL) xv[j] = wf.ld_bit(o.x1) ^ wf.ld_bit(o.x2) ^ wf.ld_bit(o.x3) ^ wf.ld_bit(o.x4);
             }
           }
         };
@@ -328,63 +361,63 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
 #pragma unroll
           for (int j = 0; j < XB; ++j) {
             if (base + uint32_t(j) * BT + tid < xor_cnt) {
-              const uint32_t sc = (xr[j].y >> 10) & GSV_SLOT_MASK, top = xr[j].y >> 31;
-              Label c0 = lxor(xa[j], xb[j]);
-              if (!EVAL) c0 = lxor_if(c0, delta, top);
+              const XorOp o = decode_xor(xr[j]);
+              Label c0 = xa[j];
+              if (!EVAL) c0 = lxor_if(c0, delta, o.par);
               if (!no_store || c0.w[0] == 0x12345678u) {
-                wf.st(sc, c0);
-                if (EVAL) wf.st_bit(sc, (xv[j] ^ top) & 1u);
+                wf.st(o.c, c0);
+                if (EVAL) wf.st_bit(o.c, (xv[j] ^ o.par) & 1u);
               }
             }
           }
         };
         load_xor_recs(0, xr);
-        issue_xor_operands(0);
-        load_xor_recs(uint32_t(XB) * BT, xrn);
         // ---- AND-family gates: whole passes of BT gates in the one-gate-per-lane form (two interleaved AES blocks
         // per lane), then the remainder in the LPG-lanes-per-gate form: a partly filled one-gate-per-lane pass would
         // cost the full ~5 us AES latency for a handful of waves, the multi-lane form ~1 us per BT/LPG gates.
         // (remainders larger than two multi-lane passes are cheaper as one partly filled one-per-lane pass)
         const uint32_t and_rem = and_cnt % BT;
         const uint32_t and_full = small_rem(and_cnt) ? and_cnt - and_rem : and_cnt;
-        u32x4 qnext = r0;
+        Rec qnext = r0;
         for (uint32_t i = tid; i < and_full; i += BT) {
-          const u32x4 q = qnext;
-          if (i + BT < and_full) qnext = and_q[size_t(and_off + i + BT)];
-          const uint32_t sa = q.x & GSV_SLOT_MASK;
-          const uint32_t sb = ((q.x >> 21) | (q.y << 11)) & GSV_SLOT_MASK;
-          const uint32_t sc = (q.y >> 10) & GSV_SLOT_MASK;
-          const uint32_t t = (q.y >> 31) | ((q.z & 3u) << 1);
-          const uint64_t hi = (uint64_t(q.w) << 32) | q.z;
-          const uint64_t gid = gid_base + ((hi >> 2) & 0x7FFFFFFFull);
-          const uint32_t cti = uint32_t(hi >> 33);
-          Label a = delta, b = delta;
-          if (!no_load) { a = wf.ld(sa); b = wf.ld(sb); }
+          const Rec q = qnext;
+          if (i + BT < and_full) qnext = load_and_rec(and_off + i + BT);
+          const uint32_t cti = and_off + i;
+          const AndOp o = decode_and(q, load_and_hi(cti));
+          const uint32_t t = o.t;
+          Label a = delta, b = delta, pl{{0, 0, 0, 0}};
+          if (!no_load) {
+            a = lxor(wf.ld(o.a1), wf.ld(o.a2));
+            b = lxor(wf.ld(o.b1), wf.ld(o.b2));
+            pl = wf.ld(o.p);
+          }
           Label c0, ct{{0, 0, 0, 0}};
           uint32_t vc = 0;
           if (!EVAL) {
-            if (no_aes) { c0 = lxor(a, b); ct = lxor(a, tweak_of(gid)); }
-            else if (HASH == 1) garble_and_blake3(t, a, b, delta, gid, c0, ct);
-            else garble_and(aes, t, a, b, delta, gid, c0, ct);
+            if (no_aes) { c0 = lxor(a, b); ct = lxor(a, tweak_of(o.gid)); }
+            else if (HASH == 1) garble_and_blake3(t, a, b, delta, o.gid, c0, ct);
+            else garble_and(aes, t, a, b, delta, o.gid, c0, ct);
           } else {
-            const uint32_t va = wf.ld_bit(sa), vb = wf.ld_bit(sb);
+            const uint32_t va = (wf.ld_bit(o.a1) ^ wf.ld_bit(o.a2)) & 1u, vb = (wf.ld_bit(o.b1) ^ wf.ld_bit(o.b2)) & 1u, vp = wf.ld_bit(o.p) & 1u;
             const u32x4 cv = CT[ct_base + cti];
-            if (HASH == 1) c0 = degarble_and_blake3(t, Label{{cv.x, cv.y, cv.z, cv.w}}, a, va, b, gid);
-            else c0 = degarble_and(aes, t, Label{{cv.x, cv.y, cv.z, cv.w}}, a, va, b, gid);
-            vc = gate_eval_bit(t, va, vb);
+            if (HASH == 1) c0 = degarble_and_blake3(t, Label{{cv.x, cv.y, cv.z, cv.w}}, a, va, b, o.gid);
+            else c0 = degarble_and(aes, t, Label{{cv.x, cv.y, cv.z, cv.w}}, a, va, b, o.gid);
+            vc = (gate_eval_bit(t, va, vb) ^ vp) & 1u;
           }
+          c0 = lxor(c0, pl);
           if (!no_store || c0.w[0] == 0x12345678u) {
-            wf.st(sc, c0);
-            if (EVAL) wf.st_bit(sc, vc);
+            wf.st(o.c, c0);
+            if (EVAL) wf.st_bit(o.c, vc);
           }
           if (!EVAL && !no_store) CT[ct_base + cti] = u32x4{ct.w[0], ct.w[1], ct.w[2], ct.w[3]};
         }
         for (uint32_t g = and_full + tid / LPG; g < and_cnt; g += BT / LPG) {
           // the first remainder record was prefetched two steps ago when the step has no whole pass
-          const u32x4 q = (and_full == 0 && g == tid / LPG) ? r0 : u32x4(and_q[size_t(and_off + g)]);
-          and_multilane(q);
+          const Rec q = (and_full == 0 && g == tid / LPG) ? r0 : load_and_rec(and_off + g);
+          and_multilane(q, and_off + g);
         }
         // ---- free-gate batches (their label stores are the wave's youngest stores: no young ciphertext store)
+        if (xor_cnt) { issue_xor_operands(0); load_xor_recs(uint32_t(XB) * BT, xrn); }
         for (uint32_t base = 0; base < xor_cnt; base += XB * BT) {
           finish_xor_batch(base);
           const uint32_t nb = base + XB * BT;
@@ -399,7 +432,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
                    (wave_first + ((and_cnt - 1u - wave_first) / BT) * BT) < and_cnt;
       }
       asm volatile("" ::: "memory");
-      const u32x4 n2r = load_rec(n2sd);  // the wave's youngest load: may stay in flight across the barrier
+      const Rec n2r = load_rec(n2sd);  // the wave's youngest load: may stay in flight across the barrier
       asm volatile("" ::: "memory");
       if (young_ct) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");

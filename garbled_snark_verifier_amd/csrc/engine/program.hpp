@@ -90,26 +90,34 @@ class RecordMode final : public CircuitMode {
 // ---- device-facing program format (little-endian; uploaded verbatim) -----------------------------
 // A wire location ("slot") is 21 bits: bit 20 set = entry of the workgroup's LDS label window,
 // clear = entry of the instance's wire file in HBM.  HBM slots 0/1/2 hold the FALSE constant, the TRUE
-// constant and the all-zero label (lets the in-place NOT gate be encoded as XNOR(a, ZERO)).
+// constant and the all-zero label; window entry 0 is an all-zero label too (never allocated): it stands
+// for the ABSENT operands of a fused gate, so that every record has the same shape.
 constexpr uint32_t SLOT_BITS = 21;
 constexpr uint32_t SLOT_LDS_FLAG = 1u << 20;
 constexpr uint32_t SLOT_INDEX_MASK = SLOT_LDS_FLAG - 1;
 constexpr uint32_t SLOT_MASK = (1u << SLOT_BITS) - 1;
 constexpr uint32_t SLOT_FALSE = 0, SLOT_TRUE = 1, SLOT_ZERO = 2, SLOT_FIRST_INPUT = 3;
+constexpr uint32_t SLOT_LDS_ZERO = SLOT_LDS_FLAG | 0u;
 constexpr uint32_t LDS_WINDOW_SLOTS = GSV_LDS_SLOTS;  // 90 KiB of the CU's 160 KiB (64 KiB go to the banked AES tables)
 
-// Free gate, 8 bytes:   bits 0..20 a | 21..41 b | 42..62 c | 63 xnor
-struct XorRec { uint64_t v; };
-inline XorRec pack_xor(uint32_t a, uint32_t b, uint32_t c, bool xnor) {
-  return XorRec{uint64_t(a) | (uint64_t(b) << 21) | (uint64_t(c) << 42) | (uint64_t(xnor ? 1 : 0) << 63)};
+// Fused gates (see fuse_trace).  Labels are XOR-linear, so a free gate whose output has one reader (or is cheap
+// to recompute) is folded into that reader, and the XOR that consumes a single-reader AND output is folded into the
+// AND.  A full adder (4 XOR + 1 AND, three dependent levels) becomes ONE fused AND (one level) and one 3-input XOR:
+//   AND-family : out = AND_t(a1 ^ a2, b1 ^ b2) ^ p     t = the 3 alpha bits with the folded inputs' NOT-parities XORed in
+//   free       : out = x1 ^ x2 ^ x3 ^ x4 (^ delta)
+// Free gate, 16 bytes:        w0 = x1 | x2<<21 | x3<<42 | parity<<63 ;  w1 = x4 | out<<21
+struct XorRec { uint64_t w0, w1; };
+inline XorRec pack_xor(const uint32_t x[4], uint32_t c, bool parity) {
+  return XorRec{uint64_t(x[0]) | (uint64_t(x[1]) << 21) | (uint64_t(x[2]) << 42) | (uint64_t(parity ? 1 : 0) << 63), uint64_t(x[3]) | (uint64_t(c) << 21)};
 }
-// AND-family gate, 16 bytes: lo = a | b<<21 | c<<42 | (type&1)<<63 ; hi = type>>1 (2 bits) | gid<<2 (31 bits) | ct<<33 (31 bits)
-// gid is relative to the replay's gate-id base; ct is the record's own index in the program (= where its ciphertext
-// sits inside the replay's block of the device stream).
-struct AndRec { uint64_t lo, hi; };
-inline AndRec pack_and(uint32_t a, uint32_t b, uint32_t c, uint32_t type, uint32_t gid, uint32_t ct) {
-  return AndRec{uint64_t(a) | (uint64_t(b) << 21) | (uint64_t(c) << 42) | (uint64_t(type & 1u) << 63),
-                uint64_t(type >> 1) | (uint64_t(gid) << 2) | (uint64_t(ct) << 33)};
+// AND-family gate, 32 bytes:  w0 = a1 | a2<<21 | b1<<42 | (t&1)<<63 ;  w1 = b2 | p<<21 | out<<42 | ((t>>1)&1)<<63 ;
+//                             w2 = gate id relative to the replay's base (40 bits) | (t>>2)<<40 ;  w3 = 0
+// The ciphertext of record k of the program goes to position k of the replay's block of the device stream.
+struct AndRec { uint64_t w0, w1, w2, w3; };
+inline AndRec pack_and(const uint32_t in[5], uint32_t c, uint32_t type, uint64_t gid) {
+  return AndRec{uint64_t(in[0]) | (uint64_t(in[1]) << 21) | (uint64_t(in[2]) << 42) | (uint64_t(type & 1u) << 63),
+                uint64_t(in[3]) | (uint64_t(in[4]) << 21) | (uint64_t(c) << 42) | (uint64_t((type >> 1) & 1u) << 63),
+                gid | (uint64_t((type >> 2) & 1u) << 40), 0};
 }
 struct StepDesc { uint32_t and_off, and_cnt, xor_off, xor_cnt; };  // one dependency level: AND-family + free gates
 
@@ -128,6 +136,7 @@ struct Program {
   std::vector<uint32_t> ct_pos;  // gate-order ciphertext index -> position inside a replay's block of the device stream
   uint64_t n_dead = 0;
   uint64_t gate_count[GATE_TYPE_COUNT] = {0};
+  uint64_t n_fused_free = 0;   // free gates left after fusion (the device executes n_ct + n_fused_free records per replay)
   uint32_t and_depth = 0, n_and_steps = 0, max_step_width = 0;
   uint32_t peak_live = 0;
   uint64_t reads_lds = 0, reads_hbm = 0, writes_lds = 0, writes_hbm = 0;  // label accesses per replay by location
@@ -136,9 +145,10 @@ struct Program {
 struct CompileOptions {
   uint32_t lds_slots = LDS_WINDOW_SLOTS;  // 0 = keep every wire in HBM
   uint32_t lds_max_lifetime = 8;          // a wire goes to the LDS window only if it dies within this many steps
-  uint32_t schedule = 0;                  // 0 = ASAP levels, 1 = ALAP levels (experiment)
   bool order_by_reader = true;            // order the gates of a step by the position of their output's first reader
   uint32_t hbm_arena_factor = 4;          // HBM wire file = factor x peak live wires (next-fit then sweeps mostly free space)
+  bool fuse = true;                       // fold free gates into their readers / into the AND that feeds them
+  uint32_t fuse_dup_fanout = 2;           // a free gate of <= 2 operands is also folded (recomputed) when it has up to this many readers
 };
 
 // next-fit slot pool over a bitmap: consecutive allocations get ascending (mostly consecutive) slots, so the
@@ -174,53 +184,164 @@ class SlotPool {
   bool fixed_;
 };
 
+// ---- gate fusion ---------------------------------------------------------------------------------
+constexpr uint32_t FUSED_AND = 0x80;
+struct FusedOps {
+  std::vector<uint8_t> kind;   // FUSED_AND | 3-bit type   or   parity bit of a free op
+  std::vector<uint32_t> in;    // 5 per op: AND a1,a2,b1,b2,p ; free x1..x4,- ; DEAD_WIRE = absent
+  std::vector<uint32_t> out;
+  std::vector<uint32_t> gid;   // stream index of the AND gate (its gate id inside a replay); unused for free ops
+  size_t size() const { return out.size(); }
+  void push(uint8_t k, const uint32_t i5[5], uint32_t o, uint32_t g) { kind.push_back(k); in.insert(in.end(), i5, i5 + 5); out.push_back(o); gid.push_back(g); }
+};
+
+inline FusedOps fuse_trace(const Trace& t, const std::vector<uint32_t>& inputs, const std::vector<uint32_t>& outputs, const CompileOptions& opt) {
+  const size_t n = t.size();
+  const uint32_t nw = t.n_wires;
+  constexpr uint8_t NOT = uint8_t(GateType::Not), XOR = uint8_t(GateType::Xor), XNOR = uint8_t(GateType::Xnor);
+  FusedOps f;
+  if (!opt.fuse) {
+    for (size_t i = 0; i < n; ++i) {
+      if (t.c[i] == DEAD_WIRE) continue;
+      const uint8_t ty = t.type[i];
+      if (ty < 8) { const uint32_t in[5] = {t.a[i], DEAD_WIRE, t.b[i], DEAD_WIRE, DEAD_WIRE}; f.push(uint8_t(FUSED_AND | ty), in, t.c[i], uint32_t(i)); }
+      else { const uint32_t in[5] = {t.a[i], ty == NOT ? DEAD_WIRE : t.b[i], DEAD_WIRE, DEAD_WIRE, DEAD_WIRE}; f.push(ty == XOR ? 0 : 1, in, t.c[i], 0); }
+    }
+    return f;
+  }
+  constexpr uint32_t KX = 4;
+  struct Expr { uint32_t w[KX]; uint8_t n, par; };  // sorted wire list (duplicates cancelled) and NOT-parity
+  std::vector<uint8_t> fan(nw, 0), pinned(nw, 0), isfree(nw, 0), need(nw, 0);
+  std::vector<uint32_t> cons(nw, DEAD_WIRE);  // a reader (THE reader when fan == 1)
+  auto use = [&](uint32_t w, size_t i) { if (fan[w] < 255) ++fan[w]; cons[w] = uint32_t(i); };
+  for (size_t i = 0; i < n; ++i) {
+    if (t.c[i] == DEAD_WIRE) continue;
+    use(t.a[i], i);
+    if (t.type[i] != NOT) use(t.b[i], i);
+    if (t.type[i] >= 8) isfree[t.c[i]] = 1;
+  }
+  pinned[0] = pinned[1] = 1;
+  for (uint32_t w : inputs) pinned[w] = 1;
+  for (uint32_t w : outputs) pinned[w] = 1;
+  std::vector<Expr> expr(nw);
+  std::vector<uint8_t> absorbed(n, 0);
+  struct AndDec { uint32_t in[5]; uint32_t out; uint8_t type; };
+  std::vector<AndDec> decs;
+  auto single = [](uint32_t x) { Expr e; e.n = 1; e.par = 0; e.w[0] = x; return e; };
+  // operand list of wire x for a reader that takes at most `cap` wires from it
+  auto resolve = [&](uint32_t x, uint32_t cap) -> Expr {
+    if (isfree[x] && !pinned[x]) {
+      const Expr& ex = expr[x];
+      if (ex.n <= cap && (fan[x] == 1 || (fan[x] <= opt.fuse_dup_fanout && ex.n <= 2))) return ex;
+    }
+    need[x] = 1;
+    return single(x);
+  };
+  struct Wide { uint32_t w[2 * KX]; uint32_t n; };
+  auto symdiff = [](const Expr& a, const Expr& b) {
+    Wide r; r.n = 0;
+    uint32_t i = 0, j = 0;
+    while (i < a.n || j < b.n) {
+      if (j == b.n || (i < a.n && a.w[i] < b.w[j])) r.w[r.n++] = a.w[i++];
+      else if (i == a.n || b.w[j] < a.w[i]) r.w[r.n++] = b.w[j++];
+      else { ++i; ++j; }
+    }
+    return r;
+  };
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t c = t.c[i];
+    if (c == DEAD_WIRE || absorbed[i]) continue;
+    const uint8_t ty = t.type[i];
+    const uint32_t a = t.a[i], b = t.b[i];
+    if (ty >= 8) {
+      Expr ea = resolve(a, KX), eb;
+      if (ty == NOT) { eb.n = 0; eb.par = 0; } else eb = resolve(b, KX);
+      Wide r = symdiff(ea, eb);
+      if (r.n > KX) {  // too long: read the longer folded side as a wire instead, then the other one
+        if (ea.n >= eb.n && ea.n > 1) { ea = single(a); need[a] = 1; } else { eb = single(b); need[b] = 1; }
+        r = symdiff(ea, eb);
+        if (r.n > KX) { ea = single(a); need[a] = 1; eb = single(b); need[b] = 1; r = symdiff(ea, eb); }
+      }
+      Expr e; e.n = uint8_t(r.n); e.par = uint8_t(ea.par ^ eb.par ^ (ty != XOR ? 1 : 0));
+      for (uint32_t k = 0; k < r.n; ++k) e.w[k] = r.w[k];
+      expr[c] = e;
+    } else {
+      const Expr ea = resolve(a, 2), eb = resolve(b, 2);
+      AndDec d;
+      d.in[0] = ea.n > 0 ? ea.w[0] : DEAD_WIRE; d.in[1] = ea.n > 1 ? ea.w[1] : DEAD_WIRE;
+      d.in[2] = eb.n > 0 ? eb.w[0] : DEAD_WIRE; d.in[3] = eb.n > 1 ? eb.w[1] : DEAD_WIRE;
+      d.in[4] = DEAD_WIRE;
+      d.type = uint8_t(ty ^ (ea.par << 2) ^ (eb.par << 1));
+      d.out = c;
+      // the single reader of this AND is a XOR/XNOR with an operand that already exists: fold it into the AND's output
+      if (fan[c] == 1 && !pinned[c]) {
+        const size_t j = cons[c];
+        const uint8_t tj = t.type[j];
+        if ((tj == XOR || tj == XNOR) && t.c[j] != DEAD_WIRE) {
+          const uint32_t y = t.a[j] == c ? t.b[j] : t.a[j];
+          if (y != c && y < c) {  // SSA ids grow in definition order: y is defined before this gate
+            const Expr ey = resolve(y, 1);
+            d.in[4] = ey.n ? ey.w[0] : DEAD_WIRE;
+            d.type ^= uint8_t(ey.par ^ (tj == XNOR ? 1 : 0));
+            d.out = t.c[j];
+            absorbed[j] = 1;
+            isfree[d.out] = 0;
+          }
+        }
+      }
+      decs.push_back(d);
+    }
+  }
+  size_t kd = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t c = t.c[i];
+    if (c == DEAD_WIRE || absorbed[i]) continue;
+    if (t.type[i] < 8) { const AndDec& d = decs[kd++]; f.push(uint8_t(FUSED_AND | d.type), d.in, d.out, uint32_t(i)); continue; }
+    if (!need[c] && !pinned[c]) continue;  // folded into every reader
+    const Expr& e = expr[c];
+    uint32_t in[5] = {DEAD_WIRE, DEAD_WIRE, DEAD_WIRE, DEAD_WIRE, DEAD_WIRE};
+    for (uint32_t k = 0; k < e.n; ++k) in[k] = e.w[k];
+    f.push(e.par, in, c, 0);
+  }
+  return f;
+}
+
 // inputs / outputs: SSA ids of the circuit's input and output wires.
 // feedback: pairs (output index -> input index) copied at the end of every replay (chained circuits).
 inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inputs, const std::vector<uint32_t>& outputs,
                                const std::vector<std::pair<uint32_t, uint32_t>>& feedback = {}, const CompileOptions& opt = CompileOptions()) {
-  const size_t n = t.size();
   const uint32_t nw = t.n_wires;
   Program p;
-  p.n_gates = n;
-  if (n >= 0x7FFFFFFFull) gsv_panic("program too large: gate index must fit 31 bits per replay");
+  p.n_gates = t.size();
+  if (t.size() >= 0x7FFFFFFFull) gsv_panic("program too large: gate index must fit 31 bits per replay");
   if (opt.lds_slots > SLOT_INDEX_MASK) gsv_panic("LDS window larger than the slot encoding");
+  for (size_t i = 0; i < t.size(); ++i) { p.gate_count[t.type[i]]++; if (t.c[i] == DEAD_WIRE) p.n_dead++; }
+  const FusedOps f = fuse_trace(t, inputs, outputs, opt);
+  const size_t n = f.size();
+  auto is_and = [&](size_t i) { return (f.kind[i] & FUSED_AND) != 0; };
+  auto ins = [&](size_t i) { return &f.in[5 * i]; };
 
   // 1. ASAP dependency level per wire (inputs / constants = 0) and AND-depth (statistic).
   std::vector<uint32_t> lev(nw, 0), ad(nw, 0);
   uint32_t n_steps = 0;
   for (size_t i = 0; i < n; ++i) {
-    p.gate_count[t.type[i]]++;
-    uint32_t c = t.c[i];
-    if (c == DEAD_WIRE) { p.n_dead++; continue; }
-    uint32_t a = t.a[i], b = t.b[i];
-    lev[c] = std::max(lev[a], lev[b]) + 1;
-    ad[c] = std::max(ad[a], ad[b]) + (t.type[i] < 8 ? 1 : 0);
+    uint32_t l = 0, d = 0;
+    for (int k = 0; k < 5; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE) { l = std::max(l, lev[w]); d = std::max(d, ad[w]); } }
+    const uint32_t c = f.out[i];
+    lev[c] = l + 1;
+    ad[c] = d + (is_and(i) ? 1 : 0);
     n_steps = std::max(n_steps, lev[c]);
     p.and_depth = std::max(p.and_depth, ad[c]);
   }
-  if (opt.schedule == 1) {
-    // ALAP: a gate runs one step before its earliest reader (circuit outputs: the last step); depth unchanged
-    std::vector<uint32_t> need(nw, n_steps + 1);
-    for (size_t i = n; i-- > 0;) {
-      uint32_t c = t.c[i];
-      if (c == DEAD_WIRE) continue;
-      uint32_t al = need[c] - 1;  // level in 1..n_steps
-      if (al < lev[c]) gsv_panic("internal: ALAP below ASAP");
-      lev[c] = al;
-      need[t.a[i]] = std::min(need[t.a[i]], al);
-      if (t.type[i] != uint8_t(GateType::Not)) need[t.b[i]] = std::min(need[t.b[i]], al);
-    }
-  }
-  auto step_of = [&](size_t i) -> uint32_t { return lev[t.c[i]] - 1; };
-  // 2. counting sort of live gates by (step, kind): AND-family first, then free gates
+  auto step_of = [&](size_t i) -> uint32_t { return lev[f.out[i]] - 1; };
+  // 2. counting sort of the ops by (step, kind): AND-family first, then free gates
   std::vector<uint32_t> cnt(2 * size_t(n_steps) + 1, 0);
-  for (size_t i = 0; i < n; ++i) if (t.c[i] != DEAD_WIRE) cnt[2 * size_t(step_of(i)) + (t.type[i] < 8 ? 0 : 1) + 1]++;
+  for (size_t i = 0; i < n; ++i) cnt[2 * size_t(step_of(i)) + (is_and(i) ? 0 : 1) + 1]++;
   for (size_t k = 0; k < 2 * size_t(n_steps); ++k) cnt[k + 1] += cnt[k];
-  const size_t n_live = cnt[2 * size_t(n_steps)];
-  std::vector<uint32_t> order(n_live);
+  std::vector<uint32_t> order(n);
   {
     std::vector<uint32_t> cursor(cnt.begin(), cnt.end() - 1);
-    for (size_t i = 0; i < n; ++i) if (t.c[i] != DEAD_WIRE) order[cursor[2 * size_t(step_of(i)) + (t.type[i] < 8 ? 0 : 1)]++] = uint32_t(i);
+    for (size_t i = 0; i < n; ++i) order[cursor[2 * size_t(step_of(i)) + (is_and(i) ? 0 : 1)]++] = uint32_t(i);
   }
   // 2b. Order inside a step.  Lanes of a wave take consecutive records, and a step's outputs get consecutive slots
   // in record order, so the order decides how many 128-byte lines one wave-wide label load or store touches.
@@ -233,24 +354,20 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
       for (int kind = 1; kind >= 0; --kind) {
         const uint32_t lo = cnt[2 * size_t(s) + kind], hi = cnt[2 * size_t(s) + kind + 1];
         keyed.clear();
-        for (uint32_t k = lo; k < hi; ++k) keyed.push_back({minpos[t.c[order[k]]], order[k]});
+        for (uint32_t k = lo; k < hi; ++k) keyed.push_back({minpos[f.out[order[k]]], order[k]});
         std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, uint32_t>& x, const std::pair<uint32_t, uint32_t>& y) { return x.first < y.first; });
         for (uint32_t k = lo; k < hi; ++k) order[k] = keyed[k - lo].second;
       }
-      for (uint32_t k = cnt[2 * size_t(s)]; k < cnt[2 * size_t(s) + 2]; ++k) {
-        const size_t i = order[k];
-        minpos[t.a[i]] = std::min(minpos[t.a[i]], k);
-        if (t.type[i] != uint8_t(GateType::Not)) minpos[t.b[i]] = std::min(minpos[t.b[i]], k);
-      }
+      for (uint32_t k = cnt[2 * size_t(s)]; k < cnt[2 * size_t(s) + 2]; ++k)
+        for (int q = 0; q < 5; ++q) { const uint32_t w = ins(order[k])[q]; if (w != DEAD_WIRE) minpos[w] = std::min(minpos[w], k); }
     }
   }
-  // 3. last reader step per wire (live gates only).  NEVER = pinned, UNUSED = no live reader.
+  // 3. last reader step per wire.  NEVER = pinned, UNUSED = no reader.
   constexpr uint32_t NEVER = 0xFFFFFFFFu, UNUSED = 0xFFFFFFFEu;
   std::vector<uint32_t> last_use(nw, UNUSED);
   for (size_t i = 0; i < n; ++i) {
-    if (t.c[i] == DEAD_WIRE) continue;
-    uint32_t s = step_of(i);
-    for (uint32_t w : {t.a[i], t.b[i]}) if (last_use[w] == UNUSED || last_use[w] < s) last_use[w] = s;
+    const uint32_t s = step_of(i);
+    for (int q = 0; q < 5; ++q) { const uint32_t w = ins(i)[q]; if (w != DEAD_WIRE && (last_use[w] == UNUSED || last_use[w] < s)) last_use[w] = s; }
   }
   last_use[0] = last_use[1] = NEVER;
   for (uint32_t w : inputs) last_use[w] = NEVER;
@@ -262,11 +379,13 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
   for (uint32_t w : inputs) { if (slot[w] == DEAD_WIRE) slot[w] = next_in++; }
   SlotPool hbm, lds(opt.lds_slots);
   hbm.reserve_low(next_in);
+  if (opt.lds_slots) lds.reserve_low(1);  // window entry 0 = the all-zero label of absent operands
+  const uint32_t absent = opt.lds_slots ? SLOT_LDS_ZERO : SLOT_ZERO;
   auto dies_at = [&](uint32_t w, uint32_t def_step) -> uint32_t { return last_use[w] == UNUSED ? def_step : last_use[w]; };
   std::vector<uint32_t> die_cnt(size_t(n_steps) + 1, 0);
-  for (size_t k = 0; k < n_live; ++k) {
-    size_t i = order[k];
-    uint32_t c = t.c[i];
+  for (size_t k = 0; k < n; ++k) {
+    const size_t i = order[k];
+    const uint32_t c = f.out[i];
     if (last_use[c] == NEVER) continue;
     die_cnt[dies_at(c, step_of(i)) + 1]++;
   }
@@ -274,23 +393,21 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
   std::vector<uint32_t> die_list(die_cnt[n_steps]);
   {
     std::vector<uint32_t> cur(die_cnt.begin(), die_cnt.end() - 1);
-    for (size_t k = 0; k < n_live; ++k) {
-      size_t i = order[k];
-      uint32_t c = t.c[i];
+    for (size_t k = 0; k < n; ++k) {
+      const size_t i = order[k];
+      const uint32_t c = f.out[i];
       if (last_use[c] == NEVER) continue;
       die_list[cur[dies_at(c, step_of(i))]++] = c;
     }
   }
-  // ciphertext index: prefix count of live AND-family gates in STREAM order
-  std::vector<uint32_t> ct_index(n);
+  // gate-order ciphertext index of an AND op = its rank among the AND ops (the fused list keeps stream order)
+  std::vector<uint32_t> ct_index(n, 0);
   {
     uint64_t k = 0;
-    for (size_t i = 0; i < n; ++i) {
-      ct_index[i] = uint32_t(k);
-      if (t.c[i] != DEAD_WIRE && t.type[i] < 8) ++k;
-    }
+    for (size_t i = 0; i < n; ++i) if (is_and(i)) ct_index[i] = uint32_t(k++);
     p.n_ct = k;
     p.ct_pos.assign(size_t(k), 0);
+    p.n_fused_free = n - k;
   }
   if (opt.hbm_arena_factor > 1) {
     uint32_t lv = next_in, pk = next_in;
@@ -314,24 +431,24 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
     if (opt.lds_slots) {
       cand.clear();
       for (uint32_t k = cnt[2 * size_t(s)]; k < cnt[2 * size_t(s) + 2]; ++k) {
-        uint32_t c = t.c[order[k]];
+        const uint32_t c = f.out[order[k]];
         if (last_use[c] == NEVER) continue;
-        uint32_t life = dies_at(c, s) - s;
+        const uint32_t life = dies_at(c, s) - s;
         if (life <= opt.lds_max_lifetime) cand.push_back((uint64_t(life) << 32) | k);
       }
-      uint32_t avail = lds.available();
+      const uint32_t avail = lds.available();
       if (cand.size() > avail) { std::nth_element(cand.begin(), cand.begin() + avail, cand.end()); cand.resize(avail); }
       for (uint64_t v : cand) want_lds.push_back(uint32_t(v));
       std::sort(want_lds.begin(), want_lds.end());
     }
     size_t wl = 0;
     for (uint32_t k = cnt[2 * size_t(s)]; k < cnt[2 * size_t(s) + 2]; ++k) {
-      size_t i = order[k];
-      uint32_t c = t.c[i];
+      const size_t i = order[k];
+      const uint32_t c = f.out[i];
       uint32_t sl = DEAD_WIRE;
       if (wl < want_lds.size() && want_lds[wl] == k) {
         ++wl;
-        uint32_t l = lds.alloc();
+        const uint32_t l = lds.alloc();
         if (l != DEAD_WIRE) sl = l | SLOT_LDS_FLAG;
       }
       if (sl == DEAD_WIRE) {
@@ -340,25 +457,28 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
       }
       slot[c] = sl;
       ++live;
-      uint32_t sa = slot[t.a[i]], sb = slot[t.b[i]];
-      if (sa == DEAD_WIRE || sb == DEAD_WIRE) gsv_panic("internal: operand without slot");
-      const uint8_t ty = t.type[i];
-      if (ty == uint8_t(GateType::Not)) sb = SLOT_ZERO;  // NOT(a) == XNOR(a, ZERO)
-      ((sa & SLOT_LDS_FLAG) ? p.reads_lds : p.reads_hbm)++;
-      ((sb & SLOT_LDS_FLAG) ? p.reads_lds : p.reads_hbm)++;
+      uint32_t si[5];
+      for (int q = 0; q < 5; ++q) {
+        const uint32_t w = ins(i)[q];
+        if (w == DEAD_WIRE) { si[q] = absent; continue; }
+        si[q] = slot[w];
+        if (si[q] == DEAD_WIRE) gsv_panic("internal: operand without slot");
+        ((si[q] & SLOT_LDS_FLAG) ? p.reads_lds : p.reads_hbm)++;
+      }
       ((sl & SLOT_LDS_FLAG) ? p.writes_lds : p.writes_hbm)++;
-      if (ty < 8) {
+      if (is_and(i)) {
         // The ciphertext goes to the gate's PROGRAM-order position: the lanes of a wave then write one contiguous
         // kilobyte.  At the gate-order index every store was its own 128-byte line (1.1 stores per line touched,
         // -16 % throughput); readers of the stream get gate order back through ct_pos (engine.cpp).
         p.ct_pos[ct_index[i]] = uint32_t(p.ands.size());
-        p.ands.push_back(pack_and(sa, sb, sl, ty, uint32_t(i), uint32_t(p.ands.size())));
+        p.ands.push_back(pack_and(si, sl, f.kind[i] & 7u, f.gid[i]));
+      } else {
+        p.xors.push_back(pack_xor(si, sl, (f.kind[i] & 1u) != 0));
       }
-      else p.xors.push_back(pack_xor(sa, sb, sl, ty != uint8_t(GateType::Xor)));
     }
     peak = std::max(peak, live);
     for (uint32_t k = die_cnt[s]; k < die_cnt[s + 1]; ++k) {
-      uint32_t sl = slot[die_list[k]];
+      const uint32_t sl = slot[die_list[k]];
       if (sl & SLOT_LDS_FLAG) lds.release(sl & SLOT_INDEX_MASK); else hbm.release(sl);
       --live;
     }

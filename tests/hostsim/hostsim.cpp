@@ -72,7 +72,8 @@ int hostsim_run(SimProgram* sp, int evaluate, uint32_t replays, uint64_t gid_bas
     auto bit = [&](uint32_t slot) -> uint8_t& { return (slot & SLOT_LDS_FLAG) ? LB[slot & SLOT_INDEX_MASK] : VB[slot]; };
     std::memcpy(&W[0], consts, 32);
     std::memset(&W[size_t(SLOT_ZERO) * 16], 0, 16);
-    VB[0] = 0; VB[1] = 1; VB[SLOT_ZERO] = 0;
+    std::memset(&LW[0], 0, 16);  // window entry 0: the all-zero label of absent operands
+    VB[0] = 0; VB[1] = 1; VB[SLOT_ZERO] = 0; LB[0] = 0;
     for (size_t i = 0; i < g.input_slots.size(); ++i) {
       std::memcpy(&W[size_t(g.input_slots[i]) * 16], inputs + 16 * i, 16);
       if (evaluate) VB[g.input_slots[i]] = input_bits[i] ? 1 : 0;
@@ -91,29 +92,35 @@ int hostsim_run(SimProgram* sp, int evaluate, uint32_t replays, uint64_t gid_bas
         std::vector<std::pair<uint32_t, uint8_t>> wb;
         wr.reserve(sd.and_cnt + sd.xor_cnt);
         for (uint32_t k = sd.xor_cnt; k-- > 0;) {
-          const uint64_t v = g.xors[sd.xor_off + k].v;
-          const uint32_t sa = uint32_t(v) & SLOT_MASK, sb = uint32_t(v >> 21) & SLOT_MASK, sc = uint32_t(v >> 42) & SLOT_MASK, xnor = uint32_t(v >> 63);
-          Label x = dev::lxor(load(lab(sa)), load(lab(sb)));
-          if (!evaluate) wr.push_back({sc, dev::lxor_if(x, d, xnor)});
-          else { wr.push_back({sc, x}); wb.push_back({sc, uint8_t((bit(sa) ^ bit(sb) ^ xnor) & 1u)}); }
+          const XorRec& r = g.xors[sd.xor_off + k];
+          const uint32_t sx[4] = {uint32_t(r.w0) & SLOT_MASK, uint32_t(r.w0 >> 21) & SLOT_MASK, uint32_t(r.w0 >> 42) & SLOT_MASK, uint32_t(r.w1) & SLOT_MASK};
+          const uint32_t sc = uint32_t(r.w1 >> 21) & SLOT_MASK, par = uint32_t(r.w0 >> 63);
+          Label x{{0, 0, 0, 0}};
+          uint32_t vb = par;
+          for (uint32_t q : sx) { x = dev::lxor(x, load(lab(q))); vb ^= bit(q); }
+          if (!evaluate) wr.push_back({sc, dev::lxor_if(x, d, par)});
+          else { wr.push_back({sc, x}); wb.push_back({sc, uint8_t(vb & 1u)}); }
         }
         for (uint32_t k = sd.and_cnt; k-- > 0;) {
           const AndRec& r = g.ands[sd.and_off + k];
-          const uint32_t sa = uint32_t(r.lo) & SLOT_MASK, sb = uint32_t(r.lo >> 21) & SLOT_MASK, sc = uint32_t(r.lo >> 42) & SLOT_MASK;
-          const uint32_t ty = uint32_t(r.lo >> 63) | (uint32_t(r.hi & 3u) << 1);
-          const uint64_t gid = gb + ((r.hi >> 2) & 0x7FFFFFFFull);
-          const uint32_t cti = gate_of[uint32_t(r.hi >> 33)];
-          Label a = load(lab(sa)), b = load(lab(sb));
+          const uint32_t a1 = uint32_t(r.w0) & SLOT_MASK, a2 = uint32_t(r.w0 >> 21) & SLOT_MASK, b1 = uint32_t(r.w0 >> 42) & SLOT_MASK;
+          const uint32_t b2 = uint32_t(r.w1) & SLOT_MASK, sp = uint32_t(r.w1 >> 21) & SLOT_MASK, sc = uint32_t(r.w1 >> 42) & SLOT_MASK;
+          const uint32_t ty = uint32_t(r.w0 >> 63) | (uint32_t(r.w1 >> 63) << 1) | (uint32_t((r.w2 >> 40) & 1u) << 2);
+          const uint64_t gid = gb + (r.w2 & 0xFFFFFFFFFFull);
+          const uint32_t cti = gate_of[sd.and_off + k];  // the ciphertext of record k sits at position k of the device stream
+          const Label a = dev::lxor(load(lab(a1)), load(lab(a2))), b = dev::lxor(load(lab(b1)), load(lab(b2))), pl = load(lab(sp));
+          const uint32_t va = (bit(a1) ^ bit(a2)) & 1u, vb = (bit(b1) ^ bit(b2)) & 1u, vp = bit(sp) & 1u;
           if (!evaluate) {
             Label c0, c;
             if (g_hasher == 1) dev::garble_and_blake3(ty, a, b, d, gid, c0, c);
             else dev::garble_and(aes, ty, a, b, d, gid, c0, c);
-            wr.push_back({sc, c0});
+            wr.push_back({sc, dev::lxor(c0, pl)});
             store(ct + size_t(cti) * 16, c);
           } else {
             Label c = load(ct + size_t(cti) * 16);
-            wr.push_back({sc, g_hasher == 1 ? dev::degarble_and_blake3(ty, c, a, bit(sa), b, gid) : dev::degarble_and(aes, ty, c, a, bit(sa), b, gid)});
-            wb.push_back({sc, uint8_t(dev::gate_eval_bit(ty, bit(sa), bit(sb)))});
+            const Label h = g_hasher == 1 ? dev::degarble_and_blake3(ty, c, a, va, b, gid) : dev::degarble_and(aes, ty, c, a, va, b, gid);
+            wr.push_back({sc, dev::lxor(h, pl)});
+            wb.push_back({sc, uint8_t((dev::gate_eval_bit(ty, va, vb) ^ vp) & 1u)});
           }
         }
         for (auto& x : wr) store(lab(x.first), x.second);
