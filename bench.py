@@ -114,7 +114,7 @@ def main():
     # passes of this same command and committed under profiles/ (a run cannot read its own counters); only reported
     # when the committed measurement was taken on the configuration being run.
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_final", "traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01_fused", "traffic.json")
     if os.path.exists(tpath) and B == 512 and ni == 2 and replays == -(-VERIFIER_GATES // gates_per_replay) and world == 1:
         with open(tpath) as f:
             traffic = float(json.load(f)["hbm_bytes_raw"])
@@ -134,8 +134,12 @@ def main():
                        "wire_slots": info["n_slots"], "program_image_bytes": info["device_bytes"], "compile_s": compile_s},
             "per_instance_gates_per_s": gates_per_replay * replays / avg_kernel_s,
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "run_program_kernel<false>", "kernel_ms_avg": avg_kernel_s * 1e3,
+                         "traffic": traffic, "kernel": "run_program_kernel<false, %d, 0>" % ni, "kernel_ms_avg": avg_kernel_s * 1e3,
                          "bytes_per_gate": bytes_per_gate, "algorithmic_bytes_per_launch": gates_per_step_rank * bytes_per_gate,
+                         # what actually binds (DESIGN.md "Roofline model"): T-table AES issue, 741 VALU + 364 LDS wave-instructions
+                         # per 64 garbled ANDs -> ~5 us per 1024 ANDs per CU -> 4.9e10 AND/s per GPU
+                         "aes_ceiling_gates_per_s": 4.9e10 / f_nf, "aes_ceiling_frac": (gates_per_step_rank / avg_kernel_s) / (4.9e10 / f_nf),
+                         "device_records_per_replay": info["n_ciphertexts"] + info.get("n_fused_free", 0),
                          "lds_label_reads_frac": info["reads_lds"] / max(1, info["reads_lds"] + info["reads_hbm"]),
                          "lds_label_writes_frac": info["writes_lds"] / max(1, info["writes_lds"] + info["writes_hbm"])},
         }

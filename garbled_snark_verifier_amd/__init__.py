@@ -33,7 +33,7 @@ class GsvError(RuntimeError):
 class _ProgramInfo(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_inputs", "n_outputs", "n_gates", "n_ciphertexts", "n_dead")] + [("gate_count", C.c_uint64 * 11)] + [
         (n, C.c_uint64) for n in ("n_steps", "and_depth", "n_and_steps", "max_step_width", "n_slots", "peak_live", "device_bytes", "n_lds_slots",
-                                 "reads_lds", "reads_hbm", "writes_lds", "writes_hbm")]
+                                 "reads_lds", "reads_hbm", "writes_lds", "writes_hbm", "n_fused_free")]
 
 
 class _Gate(C.Structure):

@@ -61,7 +61,7 @@ struct gsv_program {
   std::map<std::pair<int, int>, DevProgram> dev;  // per (device, instances per workgroup)
   size_t image_bytes() const {
     return prog.steps.size() * sizeof(StepDesc) + prog.ands.size() * sizeof(AndRec) + prog.xors.size() * sizeof(XorRec) +
-           (prog.fb_src_slot.size() * 2 + prog.output_slots.size()) * sizeof(uint32_t);
+           (prog.fb_src_slot.size() * 2 + prog.output_slots.size() + prog.ct_pos.size()) * sizeof(uint32_t);
   }
 };
 
@@ -197,6 +197,7 @@ int gsv_program_get_info(const gsv_program* p, gsv_program_info* info) {
   info->n_steps = g.steps.size(); info->and_depth = g.and_depth; info->n_and_steps = g.n_and_steps; info->max_step_width = g.max_step_width;
   info->n_slots = g.n_slots; info->peak_live = g.peak_live; info->device_bytes = p->image_bytes();
   info->n_lds_slots = g.n_lds_slots; info->reads_lds = g.reads_lds; info->reads_hbm = g.reads_hbm; info->writes_lds = g.writes_lds; info->writes_hbm = g.writes_hbm;
+  info->n_fused_free = g.n_fused_free;
   return GSV_OK;
 }
 
