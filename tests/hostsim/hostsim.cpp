@@ -7,6 +7,7 @@
 // REVERSE order so that any dependency between gates of one step (a scheduling bug) shows up as a
 // mismatch against the oracle.  This file is linked only into tests/hostsim/libgsv_hostsim.so; the
 // product library (libgsv_engine.so) has no CPU execution path.
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -32,7 +33,7 @@ extern "C" {
 
 const char* hostsim_last_error() { return g_err.c_str(); }
 
-int hostsim_compile(const char* spec, int chain_feedback, SimProgram** out, uint64_t* info /* 17 */) {
+int hostsim_compile(const char* spec, int chain_feedback, SimProgram** out, uint64_t* info /* 18 */) {
   try {
     NamedCircuit nc = make_circuit(spec);
     RecordMode mode;
@@ -43,13 +44,17 @@ int hostsim_compile(const char* spec, int chain_feedback, SimProgram** out, uint
     std::vector<std::pair<uint32_t, uint32_t>> fb;
     if (chain_feedback) for (uint32_t i = 0; i < out_ssa.size(); ++i) fb.push_back({i, i});  // output i -> input i
     auto sp = std::make_unique<SimProgram>();
-    sp->prog = compile_program(mode.trace(), in_ssa, out_ssa, fb);
+    CompileOptions opt;
+    if (const char* e = getenv("GSV_FUSE")) opt.fuse = atoi(e) != 0;  // same knob as the engine (engine.cpp)
+    if (const char* e = getenv("GSV_LDS_SLOTS")) opt.lds_slots = std::min<uint32_t>(uint32_t(atoi(e)), LDS_WINDOW_SLOTS);
+    sp->prog = compile_program(mode.trace(), in_ssa, out_ssa, fb, opt);
     const Program& g = sp->prog;
     if (info) {
       info[0] = g.input_slots.size(); info[1] = g.output_slots.size(); info[2] = g.n_gates; info[3] = g.n_ct; info[4] = g.n_dead;
       info[5] = g.steps.size(); info[6] = g.and_depth; info[7] = g.n_and_steps; info[8] = g.max_step_width; info[9] = g.n_slots;
       info[10] = g.peak_live; info[11] = run.ctx().component_calls;
       info[12] = g.n_lds_slots; info[13] = g.reads_lds; info[14] = g.reads_hbm; info[15] = g.writes_lds; info[16] = g.writes_hbm;
+      info[17] = g.n_fused_free;
     }
     *out = sp.release();
     return 0;

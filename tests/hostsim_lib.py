@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "hostsim", "libgsv_hostsim.so")
 _lib = None
 INFO_FIELDS = ["n_inputs", "n_outputs", "n_gates", "n_ct", "n_dead", "n_steps", "and_depth", "n_and_steps", "max_step_width", "n_slots",
-               "peak_live", "component_calls", "n_lds_slots", "reads_lds", "reads_hbm", "writes_lds", "writes_hbm"]
+               "peak_live", "component_calls", "n_lds_slots", "reads_lds", "reads_hbm", "writes_lds", "writes_hbm", "n_fused_free"]
 
 
 def lib():
@@ -41,7 +41,7 @@ def _p(a):
 class SimProgram:
     def __init__(self, spec, chain_feedback=False):
         h = C.c_void_p()
-        info = np.zeros(17, np.uint64)
+        info = np.zeros(len(INFO_FIELDS), np.uint64)
         if lib().hostsim_compile(spec.encode(), int(chain_feedback), C.byref(h), info.ctypes.data_as(C.POINTER(C.c_uint64))):
             raise RuntimeError(lib().hostsim_last_error().decode())
         self.h = h

@@ -151,3 +151,25 @@ def test_compiled_schedule_random_circuits(seed):
     repeated operands, ~100 nested component calls with pass-through / constant outputs."""
     sp = _hostsim_check("random_circuit:%d" % seed, seed)
     assert sp.info["n_dead"] > 500 and sp.info["component_calls"] > 50
+
+
+def test_gate_fusion_shapes_and_unfused_path(monkeypatch):
+    """Gate fusion (program.hpp fuse_trace): the reference's ripple-carry adder (gadgets/basic.rs:7-32: half adder + 253 full
+    adders = 254 AND + 1013 XOR on 760 dependent levels) must compile to 254 fused ANDs on 254 levels plus the 254 sum bits
+    as 3-input XORs; the unfused compilation of the same trace stays available (GSV_FUSE=0) and both interpret to the
+    oracle's ciphertexts, labels and bits."""
+    sp = _hostsim_check("u254_add", 7)
+    assert sp.info["n_ct"] == 254 and sp.info["n_steps"] == 254 and sp.info["n_fused_free"] == 254
+    fused = {spec: h.SimProgram(spec).info for spec in ("fq_mul", "driver_mix")}
+    monkeypatch.setenv("GSV_FUSE", "0")
+    sp0 = _hostsim_check("u254_add", 7)
+    assert sp0.info["n_steps"] > 700 and sp0.info["n_fused_free"] == 1013
+    for spec, seed in (("fq_mul", 1), ("driver_mix", 2), ("random_circuit:5", 3)):
+        sp0 = _hostsim_check(spec, seed)
+        if spec in fused:
+            assert sp0.info["n_ct"] == fused[spec]["n_ct"] and sp0.info["n_gates"] == fused[spec]["n_gates"]
+            assert sp0.info["n_steps"] >= fused[spec]["n_steps"] and sp0.info["n_fused_free"] >= fused[spec]["n_fused_free"]
+    # all-HBM compilation (no LDS window): absent operands then name the HBM zero slot
+    monkeypatch.setenv("GSV_LDS_SLOTS", "0")
+    monkeypatch.delenv("GSV_FUSE")
+    _hostsim_check("fq_add", 4)

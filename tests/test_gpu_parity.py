@@ -239,3 +239,14 @@ def test_two_instances_per_workgroup(engine, monkeypatch):
     for i in (0, 49, 299):
         ref = o.garble("fq_mul", seeds[i], capture_ct=False)
         assert ref.ct_hash.tobytes() == r.ciphertext_hash[i] and (ref.output_label0 == r.output_label0[i]).all()
+
+
+def test_unfused_compilation_on_gpu(engine, monkeypatch):
+    """The same kernels run a program compiled WITHOUT gate fusion (GSV_FUSE=0: every reference gate is its own record,
+    absent operand fields name the zero slot): results must not depend on the compiler's folding decisions."""
+    import garbled_snark_verifier_amd as gsv
+    monkeypatch.setenv("GSV_FUSE", "0")
+    for spec, seeds in (("fq_mul", [3, 4]), ("driver_mix", [8]), ("random_circuit:3", [5])):
+        g, prog = _garble_and_check(gsv, engine, spec, seeds)
+        assert prog.info["n_fused_free"] == sum(prog.info["gate_count"][8:]) - (prog.info["n_dead"] - (sum(prog.info["gate_count"][:8]) - prog.info["n_ciphertexts"]))
+        _evaluate_and_check(gsv, engine, spec, g, prog, seeds)
