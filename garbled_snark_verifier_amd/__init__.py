@@ -47,7 +47,7 @@ EXPORTS = [
     "gsv_session_set_garble_inputs", "gsv_session_garble", "gsv_session_set_evaluate_inputs", "gsv_session_upload_ciphertexts",
     "gsv_session_evaluate", "gsv_session_set_hasher", "gsv_session_sync", "gsv_session_last_kernel_ms", "gsv_session_read_outputs", "gsv_session_read_ciphertexts",
     "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_commit_labels",
-    "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
+    "gsv_session_garble_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
 ]
 
 
@@ -92,6 +92,7 @@ def lib():
         L.gsv_session_ciphertext_hash.argtypes = [vp, C.c_size_t, u8p]
         L.gsv_cbcmac_update.argtypes = [u8p, u8p, C.c_uint64]
         L.gsv_commit_labels.argtypes = [u8p, C.c_uint64, u8p]
+        L.gsv_session_garble_streaming.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_uint64, C.c_int, u8p]
         L.gsv_session_instances_per_workgroup.argtypes = [vp, C.POINTER(C.c_int)]
         L.gsv_session_enable_step_clock.argtypes = [vp]
         L.gsv_session_read_step_clock.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -244,6 +245,13 @@ class Session:
 
     def garble(self, gate_id_base=0):
         _chk(lib().gsv_session_garble(self.h, gate_id_base))
+
+    def garble_streaming(self, gate_id_base=0, directory=None, first_index=0, threads=0):
+        """Garble all replays while the host drains the stream segment by segment: returns the per-instance ciphertext
+        hashes (CBC-MAC, gate order) and, with `directory`, writes gc_<first_index+i>.bin files."""
+        out = np.zeros((self.n, 16), np.uint8)
+        _chk(lib().gsv_session_garble_streaming(self.h, gate_id_base, directory.encode() if directory else None, first_index, threads, _p(out)))
+        return [bytes(out[i]) for i in range(self.n)]
 
     def set_evaluate_inputs(self, const_active, input_active, input_bits):
         c = _u8(const_active, (self.n, 32))

@@ -3,11 +3,15 @@
 // garble/evaluate — without a HIP device gsv_engine_create fails with GSV_ERR_DEVICE.
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/gsv_engine.h"
@@ -77,7 +81,7 @@ struct gsv_session {
   DevProgram dp;
   size_t n_inst = 0;
   uint64_t replays = 1, ct_cap = 1;
-  void *W = nullptr, *VB = nullptr, *CT = nullptr, *delta = nullptr, *out = nullptr, *out_bits = nullptr, *in_bits = nullptr, *step_clock = nullptr, *ct_stage = nullptr;
+  void *W = nullptr, *VB = nullptr, *CT = nullptr, *delta = nullptr, *out = nullptr, *out_bits = nullptr, *in_bits = nullptr, *step_clock = nullptr, *ct_stage = nullptr, *ct_gate = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint32_t ni = 1;  // instances per workgroup of this session's launches
   const Program& prog() const { return ni == 2 ? *p->prog2 : p->prog; }
@@ -312,7 +316,7 @@ void gsv_session_destroy(gsv_session* s) {
   if (!s) return;
   (void)hipSetDevice(s->e->device);
   (void)hipStreamSynchronize(s->e->stream);
-  for (void* q : {s->W, s->VB, s->CT, s->delta, s->out, s->out_bits, s->in_bits, s->step_clock, s->ct_stage}) if (q) (void)hipFree(q);
+  for (void* q : {s->W, s->VB, s->CT, s->delta, s->out, s->out_bits, s->in_bits, s->step_clock, s->ct_stage, s->ct_gate}) if (q) (void)hipFree(q);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -396,7 +400,7 @@ int gsv_session_upload_ciphertexts(gsv_session* s, size_t instance, const uint8_
   return GSV_OK;
 }
 
-static int launch(gsv_session* s, uint64_t gate_id_base, bool eval) {
+static int launch(gsv_session* s, uint64_t gate_id_base, bool eval, uint64_t rep_base = 0, uint64_t n_replays = 0) {
   const Program& g = s->prog();
   HIPCHK(hipSetDevice(s->e->device));
   dev::KernelArgs ka{};
@@ -405,7 +409,7 @@ static int launch(gsv_session* s, uint64_t gate_id_base, bool eval) {
   ka.delta = static_cast<const uint4*>(s->delta); ka.te = static_cast<const uint32_t*>(s->e->te);
   ka.fb_src = static_cast<const uint32_t*>(s->dp.fb_src); ka.fb_dst = static_cast<const uint32_t*>(s->dp.fb_dst);
   ka.ct_stride = s->ct_stride(); ka.gid_base = gate_id_base; ka.n_gates = g.n_gates; ka.n_ct = g.n_ct;
-  ka.n_steps = uint32_t(g.steps.size()); ka.n_slots = g.n_slots; ka.replays = uint32_t(s->replays); ka.ct_cap_replays = uint32_t(s->ct_cap);
+  ka.n_steps = uint32_t(g.steps.size()); ka.n_slots = g.n_slots; ka.replays = uint32_t(n_replays ? n_replays : s->replays); ka.rep_base = uint32_t(rep_base); ka.ct_cap_replays = uint32_t(s->ct_cap);
   ka.n_fb = uint32_t(g.fb_src_slot.size()); ka.fb_stage_base = g.fb_stage_base;
   ka.n_instances = uint32_t(s->n_inst);
   ka.hasher = uint32_t(s->hasher);
@@ -431,6 +435,116 @@ int gsv_session_garble(gsv_session* s, uint64_t gate_id_base) {
   int rc = launch(s, gate_id_base, false);
   if (rc == GSV_OK) s->garbled = true;
   return rc;
+}
+// Garble + drain.  The launch is cut into segments of one device ring (ct_cap replays).  After a segment the ring
+// (program order) is gathered into a second device buffer in GATE order (a ~ms kernel between two garbling launches,
+// which own every CU while they run); while the next segment is garbled, host threads copy that buffer out with plain
+// sequential D2H copies (the copy engines work beside the kernel), fold each instance's bytes into its CBC-MAC (strictly
+// serial per instance, hence the host: ciphertext_hasher.rs:23-29) and optionally append them to gc_<index>.bin
+// (ciphertext_repository.rs:94-127).
+int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes) {
+  if (!s || !hashes) return fail(GSV_ERR_INVALID, "null argument");
+  const Program& g = s->prog();
+  const uint64_t n_ct = g.n_ct, total = s->replays, seg = s->ct_cap;
+  const size_t n_inst = s->n_inst;
+  size_t T = n_threads > 0 ? size_t(n_threads) : std::max<size_t>(1, std::min<size_t>(n_inst, std::thread::hardware_concurrency()));
+  T = std::min(T, n_inst);
+  HIPCHK(hipSetDevice(s->e->device));
+  const uint64_t seg_records = seg * n_ct;  // per instance
+  if (!s->ct_gate && seg_records) HIPCHK(hipMalloc(&s->ct_gate, n_inst * seg_records * 16));
+  std::vector<CbcMacHost> macs(n_inst);
+  std::vector<FILE*> files(n_inst, nullptr);
+  auto close_files = [&]() { for (FILE*& f : files) if (f) { std::fclose(f); f = nullptr; } };
+  if (dir)
+    for (size_t i = 0; i < n_inst; ++i) {
+      const std::string path = std::string(dir) + "/gc_" + std::to_string(first_index + i) + ".bin";
+      files[i] = std::fopen(path.c_str(), "wb");
+      if (!files[i]) { close_files(); return fail(GSV_ERR_INVALID, "cannot create " + path); }
+    }
+  std::atomic<int> err{0};
+  // Many host threads are wanted for the MACs (one serial chain per instance) but only a few D2H copies should be in
+  // flight at once: measured on the MI355X box, 128 concurrent copy streams move 9 GB/s where a handful move 22 GB/s.
+  // (and the number of STREAMS matters as much as the number of copies: the copies share a small pool of streams)
+  struct CopyGate {
+    std::mutex mu; std::condition_variable cv; std::vector<hipStream_t> idle;
+    hipStream_t acquire() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !idle.empty(); }); hipStream_t st = idle.back(); idle.pop_back(); return st; }
+    void release(hipStream_t st) { { std::lock_guard<std::mutex> lk(mu); idle.push_back(st); } cv.notify_one(); }
+  } copy_gate;
+  const int n_copy_streams = getenv("GSV_DRAIN_COPIES") ? std::max(1, atoi(getenv("GSV_DRAIN_COPIES"))) : 6;
+  std::vector<hipStream_t> copy_streams;
+  // per-worker copy stream + two pinned chunk buffers (copy chunk j+1 while chunk j is hashed), created once
+  const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(seg_records, 1), 256ull << 10);  // records (4 MiB: page-locking the buffers is part of every call)
+  struct Worker { void* pinned[2] = {nullptr, nullptr}; };
+  std::vector<Worker> workers(T);
+  auto release_workers = [&]() {
+    for (Worker& w : workers) for (void*& q : w.pinned) if (q) { (void)hipHostFree(q); q = nullptr; }
+    for (hipStream_t st : copy_streams) (void)hipStreamDestroy(st);
+    copy_streams.clear();
+  };
+  {
+    bool ok = true;
+    for (int k = 0; k < n_copy_streams && ok; ++k) {
+      hipStream_t st;
+      ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+      if (ok) { copy_streams.push_back(st); copy_gate.idle.push_back(st); }
+    }
+    for (Worker& w : workers) for (void*& q : w.pinned) ok = ok && hipHostMalloc(&q, chunk * 16, hipHostMallocDefault) == hipSuccess;
+    if (!ok) { release_workers(); close_files(); return fail(GSV_ERR_DEVICE, "cannot allocate the drain buffers"); }
+  }
+  // one drain = all instances x `n_rep` replays sitting in the gate-order buffer
+  auto drain = [&](uint64_t n_rep, std::vector<std::thread>& pool) {
+    for (size_t t = 0; t < T; ++t)
+      pool.emplace_back([&, t, n_rep]() {
+        if (hipSetDevice(s->e->device) != hipSuccess) { err = 1; return; }
+        Worker& w = workers[t];
+        const uint64_t n = n_rep * n_ct;
+        for (size_t i = t; i < n_inst && !err && n; i += T) {
+          const uint8_t* src = static_cast<const uint8_t*>(s->ct_gate) + i * seg_records * 16;
+          // a copy holds a slot of the gate from issue to completion
+          auto copy = [&](uint64_t off, int b) {
+            hipStream_t st = copy_gate.acquire();
+            const bool ok = hipMemcpyAsync(w.pinned[b], src + off * 16, std::min(chunk, n - off) * 16, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                            hipStreamSynchronize(st) == hipSuccess;
+            copy_gate.release(st);
+            return ok;
+          };
+          int b = 0;
+          if (!copy(0, 0)) { err = 1; break; }
+          for (uint64_t off = 0; off < n; off += chunk, b ^= 1) {
+            const uint64_t m = std::min(chunk, n - off);
+            macs[i].update(static_cast<const uint8_t*>(w.pinned[b]), m);
+            if (dir && std::fwrite(w.pinned[b], 16, m, files[i]) != m) { err = 2; break; }
+            if (off + chunk < n && !copy(off + chunk, b ^ 1)) { err = 1; break; }
+          }
+        }
+      });
+  };
+  // Pipeline: kernel k+1 runs beside drain k.  Drains are serialised (an instance's MAC must see its replays in order);
+  // the gather of segment k+1 needs the gate-order buffer back, i.e. drain k joined.
+  std::vector<std::thread> cur;
+  auto join = [](std::vector<std::thread>& p) { for (auto& th : p) th.join(); p.clear(); };
+  int rc = GSV_OK;
+  for (uint64_t r0 = 0; r0 < total && rc == GSV_OK; r0 += seg) {
+    const uint64_t r1 = std::min(total, r0 + seg);
+    // ring slots are (replay % ct_cap): a segment starts at a multiple of ct_cap, so its replays sit in slots 0..n_rep-1
+    rc = launch(s, gate_id_base, false, r0, r1 - r0);
+    if (rc != GSV_OK) break;
+    join(cur);
+    if (gsvk_gather_segment(s->CT, s->ct_stride(), s->dp.ct_pos, n_ct, uint32_t(r1 - r0), uint32_t(n_inst), s->ct_gate, seg_records, s->e->stream) != 0) {
+      rc = fail(GSV_ERR_DEVICE, "ciphertext gather launch failed");
+      break;
+    }
+    if (hipStreamSynchronize(s->e->stream) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "kernel failed"); break; }
+    drain(r1 - r0, cur);
+  }
+  join(cur);
+  release_workers();
+  close_files();
+  if (rc != GSV_OK) return rc;
+  if (err) return fail(err == 2 ? GSV_ERR_INVALID : GSV_ERR_DEVICE, err == 2 ? "short write to a gc file" : "device copy failed while draining ciphertexts");
+  for (size_t i = 0; i < n_inst; ++i) macs[i].digest(hashes + 16 * i);
+  s->garbled = true;
+  return GSV_OK;
 }
 int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base) {
   if (!s) return fail(GSV_ERR_INVALID, "null session");

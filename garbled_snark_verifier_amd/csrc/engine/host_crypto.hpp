@@ -100,6 +100,28 @@ class CbcMacHost {
     }
 #endif
   }
+  // the same chain over records picked through a permutation: block k is base[pos[k]] (device streams are kept in
+  // program order, the MAC runs in gate order)
+  void update_gather(const uint8_t* base, const uint32_t* pos, uint64_t n) {
+#if GSV_HOST_AESNI
+    const AesTables& t = AesTables::fixed_key();
+    __m128i rk[11];
+    for (int r = 0; r < 11; ++r) rk[r] = _mm_loadu_si128(reinterpret_cast<const __m128i*>(t.rk_bytes + 16 * r));
+    __m128i h = _mm_loadu_si128(reinterpret_cast<const __m128i*>(h_));
+    for (uint64_t i = 0; i < n; ++i) {
+      if (i + 24 < n) __builtin_prefetch(base + size_t(pos[i + 24]) * 16);
+      __m128i s = _mm_xor_si128(h, _mm_loadu_si128(reinterpret_cast<const __m128i*>(base + size_t(pos[i]) * 16)));
+      s = _mm_xor_si128(s, rk[0]);
+      s = _mm_aesenc_si128(s, rk[1]); s = _mm_aesenc_si128(s, rk[2]); s = _mm_aesenc_si128(s, rk[3]);
+      s = _mm_aesenc_si128(s, rk[4]); s = _mm_aesenc_si128(s, rk[5]); s = _mm_aesenc_si128(s, rk[6]);
+      s = _mm_aesenc_si128(s, rk[7]); s = _mm_aesenc_si128(s, rk[8]); s = _mm_aesenc_si128(s, rk[9]);
+      h = _mm_aesenclast_si128(s, rk[10]);
+    }
+    _mm_storeu_si128(reinterpret_cast<__m128i*>(h_), h);
+#else
+    for (uint64_t i = 0; i < n; ++i) update(base + size_t(pos[i]) * 16, 1);
+#endif
+  }
   void digest(uint8_t out[16]) const { std::memcpy(out, h_, 16); }
 
   static void encrypt_portable(const AesTables& t, const uint8_t in[16], uint8_t out[16]) {

@@ -188,8 +188,8 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   const bool no_store = (ka.diag & 8u) != 0, no_load = (ka.diag & 4u) != 0, no_aes = (ka.diag & 1u) != 0, no_narrow = (ka.diag & 16u) != 0;
 
   for (uint32_t rep = 0; rep < ka.replays; ++rep) {
-    const uint64_t gid_base = ka.gid_base + uint64_t(rep) * ka.n_gates;
-    const uint64_t ct_base = uint64_t(rep % ka.ct_cap_replays) * ka.n_ct;
+    const uint64_t gid_base = ka.gid_base + uint64_t(ka.rep_base + rep) * ka.n_gates;
+    const uint64_t ct_base = uint64_t((ka.rep_base + rep) % ka.ct_cap_replays) * ka.n_ct;
 
     // A step descriptor is {and_off, and_cnt, xor_off, xor_cnt}.  Lane -> gate mapping of a step:
     //   wide   (default)                : lane i takes AND gate i for i < and_cnt, else free gate i - and_cnt;
@@ -488,6 +488,17 @@ __global__ void permute_ciphertexts_kernel(uint4* stream, const uint32_t* ct_pos
   if (scatter) stream[pos] = stage[i]; else stage[i] = stream[pos];
 }
 
+// Whole-segment form for the streaming drain: for every instance, `n_rep` replays starting at ring slot 0 of the
+// program-order ring go to a gate-order buffer: out[inst][r * n_ct + g] = ring[inst][r * n_ct + ct_pos[g]].
+__global__ void gather_segment_kernel(const uint4* ring, uint64_t ring_stride, const uint32_t* ct_pos, uint64_t n_ct, uint32_t n_rep, uint4* out, uint64_t out_stride) {
+  const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= n_ct) return;
+  const uint32_t pos = ct_pos[g];
+  const uint4* src = ring + uint64_t(blockIdx.y) * ring_stride;
+  uint4* dst = out + uint64_t(blockIdx.y) * out_stride;
+  for (uint32_t r = 0; r < n_rep; ++r) dst[uint64_t(r) * n_ct + g] = src[uint64_t(r) * n_ct + pos];
+}
+
 }  // namespace dev
 }  // namespace gsv
 
@@ -538,6 +549,13 @@ int gsvk_permute_ciphertexts(void* stream, const void* ct_pos, uint64_t n_ct, ui
   if (n == 0) return 0;
   hipLaunchKernelGGL(gsv::dev::permute_ciphertexts_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, s, static_cast<uint4*>(stream),
                      static_cast<const uint32_t*>(ct_pos), n_ct, first, n, static_cast<uint4*>(stage), scatter);
+  return int(hipGetLastError());
+}
+int gsvk_gather_segment(const void* ring, uint64_t ring_stride, const void* ct_pos, uint64_t n_ct, uint32_t n_rep, uint32_t n_instances, void* out,
+                        uint64_t out_stride, hipStream_t s) {
+  if (n_ct == 0 || n_rep == 0) return 0;
+  hipLaunchKernelGGL(gsv::dev::gather_segment_kernel, dim3(uint32_t((n_ct + 255) / 256), n_instances), dim3(256), 0, s, static_cast<const uint4*>(ring), ring_stride,
+                     static_cast<const uint32_t*>(ct_pos), n_ct, n_rep, static_cast<uint4*>(out), out_stride);
   return int(hipGetLastError());
 }
 int gsvk_scatter_bits(void* VB, uint32_t n_slots, uint32_t first_slot, const void* bits, uint32_t n, uint32_t n_instances, hipStream_t stream) {

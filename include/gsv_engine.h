@@ -124,6 +124,16 @@ int gsv_session_set_evaluate_inputs(gsv_session* s, const uint8_t* const_active,
 int gsv_session_upload_ciphertexts(gsv_session* s, size_t instance, const uint8_t* cts, uint64_t n_records);
 int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base);
 
+/* Garble every replay AND consume the ciphertext stream while the GPU keeps garbling (CiphertextHandler at full size:
+ * circuit/mod.rs:140-178; AESAccumulatingHash, ciphertext_hasher.rs:23-29; the gc_{i}.bin writer,
+ * cut_and_choose/ciphertext_repository.rs:94-127).  The launch is cut into segments of one device ring
+ * (ct_capacity_replays replays); each finished segment is brought into gate order on the device (second buffer of the
+ * ring's size, allocated on first use), copied out while the next segment is garbled, folded into every instance's CBC-MAC
+ * by n_threads host threads (0 = one per instance up to the core count; the chain is serial per instance) and, if dir is
+ * not NULL, appended to <dir>/gc_<first_index + instance>.bin.  hashes receives n_instances x 16 bytes.  Output labels
+ * are read with gsv_session_read_outputs as after gsv_session_garble. */
+int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes);
+
 /* Gate PRF (`H: GateHasher`, src/hashers/mod.rs:15-20): GSV_HASHER_AES = AesNiHasher (default; the benchmarked
  * path, hashers/mod.rs:54-96), GSV_HASHER_BLAKE3 = Blake3Hasher (hashers/mod.rs:22-51, the crate's DefaultHasher). */
 #define GSV_HASHER_AES 0

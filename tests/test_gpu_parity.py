@@ -250,3 +250,34 @@ def test_unfused_compilation_on_gpu(engine, monkeypatch):
         g, prog = _garble_and_check(gsv, engine, spec, seeds)
         assert prog.info["n_fused_free"] == sum(prog.info["gate_count"][8:]) - (prog.info["n_dead"] - (sum(prog.info["gate_count"][:8]) - prog.info["n_ciphertexts"]))
         _evaluate_and_check(gsv, engine, spec, g, prog, seeds)
+
+
+def test_streaming_drain_hash_and_gc_files(engine, tmp_path):
+    """gsv_session_garble_streaming: a 6-link Fq2-mul chain garbled with a device ring of only 2 replays, drained segment by
+    segment into per-instance CBC-MACs and gc_<i>.bin files while the next segment is garbled.  The hashes and file bytes
+    must equal those of a session that retains the whole stream (same engine), the output labels must agree, and a
+    2-link Fq12 chain (ring 2 = two one-replay segments) must reproduce the oracle's hash."""
+    import garbled_snark_verifier_amd as gsv
+    prog = gsv.Program.from_circuit("fq2_mul", chain_feedback=True)
+    seeds, K = [11, 12, 13], 6
+    full = gsv.CircuitBuilder.streaming_garbling("fq2_mul", seeds, engine=engine, program=prog, replays=K)
+    n_in = prog.info["n_inputs"]
+    B = len(seeds)
+    sess = gsv.Session(engine, prog, B, K, 2)
+    sess.set_garble_inputs(full.delta, np.stack([full.false_label0, full.true_label0], 1), full.input_label0)
+    hashes = sess.garble_streaming(directory=str(tmp_path), first_index=40, threads=2)
+    assert hashes == list(full.ciphertext_hash)
+    assert (sess.read_outputs() == full.output_label0).all()
+    for i in range(B):
+        data, file_hash = gsv.read_gc_file(os.path.join(str(tmp_path), gsv.gc_file_name(40 + i)))
+        assert data.shape == (K * prog.info["n_ciphertexts"], 16) and (data == full.ciphertexts[i]).all() and file_hash == hashes[i]
+    sess.close()
+    # hash only, one thread per instance, against the oracle
+    prog12 = gsv.Program.from_circuit("fq12_mul", chain_feedback=True)
+    d, f, t, inp = gsv.labels_from_seed(77, prog12.info["n_inputs"])
+    s2 = gsv.Session(engine, prog12, 1, 2, 2)
+    s2.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
+    h2 = s2.garble_streaming()
+    ref = o.garble("fq12_mul_chain:2", 77, capture_ct=False)
+    assert h2[0] == ref.ct_hash.tobytes() and (s2.read_outputs()[0] == ref.output_label0).all()
+    s2.close()
