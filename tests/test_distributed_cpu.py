@@ -79,3 +79,27 @@ def test_shard_instances_partition():
             assert sorted(i for p in parts for i in p) == list(range(total))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
             assert all(i % world == r for r, p in enumerate(parts) for i in p)  # instance i -> GPU i mod n_gpu
+
+
+def test_regarbling_check_file_side_on_cpu(tmp_path):
+    """Evaluator::run_regarbling for instances KEPT for evaluation needs no GPU: gc_<i>.bin is streamed through the CBC-MAC
+    and compared with the committed ciphertext hash (evaluator.rs:105-138).  Files and commits come from the oracle here."""
+    import os
+    import garbled_snark_verifier_amd as gsv
+    from garbled_snark_verifier_amd import sharding
+    recs = []
+    for i, seed in enumerate([5, 6, 7]):
+        g = o.garble("u254_add", seed)
+        h = gsv.write_gc_file(os.path.join(str(tmp_path), gsv.gc_file_name(i)), g.ciphertexts)
+        assert h == g.ct_hash.tobytes()
+        recs.append(sharding.commit_record(i, h, g.output_label0, g.delta, g.false_label0, g.true_label0))
+    commits = np.stack(recs)
+    assert sharding.run_regarbling(commits, [0, 1, 2], {}, "u254_add", str(tmp_path)) == (True, {})
+    with open(os.path.join(str(tmp_path), gsv.gc_file_name(1)), "r+b") as f:
+        f.seek(100)
+        b = f.read(1)
+        f.seek(100)
+        f.write(bytes([b[0] ^ 0x80]))
+    os.remove(os.path.join(str(tmp_path), gsv.gc_file_name(2)))
+    ok, errors = sharding.run_regarbling(commits, [0, 1, 2], {}, "u254_add", str(tmp_path))
+    assert not ok and errors[1] == "ciphertext corrupted" and errors[2].startswith("failed to get ciphertext source") and 0 not in errors

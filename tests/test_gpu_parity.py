@@ -281,3 +281,34 @@ def test_streaming_drain_hash_and_gc_files(engine, tmp_path):
     ref = o.garble("fq12_mul_chain:2", 77, capture_ct=False)
     assert h2[0] == ref.ct_hash.tobytes() and (s2.read_outputs()[0] == ref.output_label0).all()
     s2.close()
+
+
+def test_cut_and_choose_regarbling_check(engine, tmp_path):
+    """The consumer side of cut-and-choose (cut_and_choose/evaluator.rs:83-181): 8 instances are garbled and committed with
+    their streams written to gc_<i>.bin; the evaluator keeps 3 for evaluation (file hash must match the commit) and regarbles
+    the 5 opened ones from their seeds in one launch (whole commit record must match).  Honest run passes; a flipped byte in
+    a kept file, a wrong seed and a missing seed are each caught with the reference's error."""
+    import garbled_snark_verifier_amd as gsv
+    from garbled_snark_verifier_amd import sharding
+    total = 8
+    seeds = [int(x) for x in sharding.instance_seeds(99, total)]
+    prog = gsv.Program.from_circuit("fq_mul")
+    commits = sharding.garble_and_commit("fq_mul", seeds, list(range(total)), engine=engine, program=prog, gc_dir=str(tmp_path))
+    # the commit records are the ones the oracle's garbling gives
+    for i in (0, 5):
+        ref = o.garble("fq_mul", seeds[i], capture_ct=False)
+        assert (commits[i] == sharding.commit_record(i, ref.ct_hash.tobytes(), ref.output_label0, ref.delta, ref.false_label0, ref.true_label0)).all()
+    keep = [1, 4, 6]
+    opened = {i: seeds[i] for i in range(total) if i not in keep}
+    ok, errors = sharding.run_regarbling(commits, keep, opened, "fq_mul", str(tmp_path), engine=engine, program=prog)
+    assert ok and not errors
+    # corrupted ciphertext file of a kept instance
+    path = os.path.join(str(tmp_path), gsv.gc_file_name(4))
+    raw = bytearray(open(path, "rb").read())
+    raw[12345] ^= 1
+    open(path, "wb").write(bytes(raw))
+    bad = dict(opened)
+    bad[2] = seeds[2] ^ 1   # garbler revealed a seed that does not reproduce its commit
+    del bad[7]              # and withheld another
+    ok, errors = sharding.run_regarbling(commits, keep, bad, "fq_mul", str(tmp_path), engine=engine, program=prog)
+    assert not ok and errors == {4: "ciphertext corrupted", 2: "regarbling failed", 7: "failed to find seed"}
