@@ -33,9 +33,11 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--instances", type=int, default=512, help="cut-and-choose instances per GPU per step (more than the 256 CUs: two per workgroup)")
-    ap.add_argument("--replays", type=int, default=0, help="Fq12-mul components per instance (0 = enough for 11.17 B gates)")
+    ap.add_argument("--replays", type=int, default=0, help="chain links per instance (0 = enough for 11.17 B gates)")
     ap.add_argument("--ct-ring", type=int, default=2, help="replays of ciphertexts kept per instance in HBM")
-    ap.add_argument("--cpu-baseline-chain", type=int, default=8, help="Fq12 muls garbled by the CPU oracle for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-baseline-chain", type=int, default=8, help="chain links garbled by the CPU oracle for cpu_baseline (0 = skip)")
+    ap.add_argument("--component", default="fq12_sqmul", choices=["fq12_sqmul", "fq12_mul"],
+                    help="link of the chain: fq12_sqmul = r <- Fq12::mul(Fq12::square(r), b) (33.9 M gates), fq12_mul = r <- Fq12::mul(r, b) (20.3 M)")
     ap.add_argument("--no-check", action="store_true")
     args = ap.parse_args()
 
@@ -56,7 +58,7 @@ def main():
 
     engine = gsv.Engine(local_rank)  # raises without a HIP device: no CPU fallback
     t0 = time.time()
-    prog = gsv.Program.from_circuit("fq12_mul", chain_feedback=True)
+    prog = gsv.Program.from_circuit(args.component, chain_feedback=True)
     compile_s = time.time() - t0
     info = prog.info
     gates_per_replay = info["n_gates"]
@@ -114,8 +116,8 @@ def main():
     # passes of this same command and committed under profiles/ (a run cannot read its own counters); only reported
     # when the committed measurement was taken on the configuration being run.
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_fused", "traffic.json")
-    if os.path.exists(tpath) and B == 512 and ni == 2 and replays == -(-VERIFIER_GATES // gates_per_replay) and world == 1:
+    tpath = os.path.join(ROOT, "profiles", "r01_sqmul", "traffic.json")
+    if os.path.exists(tpath) and args.component == "fq12_sqmul" and B == 512 and ni == 2 and replays == -(-VERIFIER_GATES // gates_per_replay) and world == 1:
         with open(tpath) as f:
             traffic = float(json.load(f)["hbm_bytes_raw"])
     result = None
@@ -127,8 +129,10 @@ def main():
             "value": value, "unit": "gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "Groth16-shaped synthetic: chain of %d Fq12::mul_montgomery components = %d gates per instance "
-                                   "(>= 11,174,708,821-gate verifier); %d cut-and-choose instances per GPU" % (replays, gates_per_replay * replays, B),
+            "config": {"workload": "Groth16-shaped synthetic: chain of %d %s links = %d gates per instance (the verifier has 11,174,708,821); "
+                                   "%d cut-and-choose instances per GPU" % (replays, {"fq12_sqmul": "Fq12 square-and-multiply (square_montgomery + mul_montgomery)",
+                                                                             "fq12_mul": "Fq12::mul_montgomery"}[args.component], gates_per_replay * replays, B),
+                       "component": args.component,
                        "instances_per_gpu": B, "instances_per_workgroup": ni, "replays": replays, "gates_per_instance": gates_per_replay * replays,
                        "nonfree_fraction": f_nf, "program_steps": info["n_steps"], "and_depth": info["and_depth"],
                        "wire_slots": info["n_slots"], "program_image_bytes": info["device_bytes"], "compile_s": compile_s},
@@ -148,14 +152,14 @@ def main():
             # bit-exactness of this very program against the CPU oracle on the chain's first two components
             # (same program variant / kernel instantiation as the timed launches: three instances, the middle one checked)
             os.environ["GSV_INSTANCES_PER_WG"] = str(ni)
-            chk = gsv.CircuitBuilder.streaming_garbling("fq12_mul", [seeds[1], seeds[0], seeds[2]], engine=engine, program=prog, replays=2, keep_ciphertexts=False)
+            chk = gsv.CircuitBuilder.streaming_garbling(args.component, [seeds[1], seeds[0], seeds[2]], engine=engine, program=prog, replays=2, keep_ciphertexts=False)
             del os.environ["GSV_INSTANCES_PER_WG"]
-            ref = o.garble("fq12_mul_chain:2", seeds[0], capture_ct=False)
+            ref = o.garble(args.component + "_chain:2", seeds[0], capture_ct=False)
             result["ciphertext_hash_match"] = bool(chk.ciphertext_hash[1] == ref.ct_hash.tobytes() and (chk.output_label0[1] == ref.output_label0).all())
-            result["hash_check"] = {"circuit": "fq12_mul_chain:2", "seed": seeds[0], "gpu": chk.ciphertext_hash[1].hex(), "oracle": ref.ct_hash.tobytes().hex()}
+            result["hash_check"] = {"circuit": args.component + "_chain:2", "seed": seeds[0], "gpu": chk.ciphertext_hash[1].hex(), "oracle": ref.ct_hash.tobytes().hex()}
         if args.cpu_baseline_chain and world == 1:
             import oracle_lib as o
-            spec = "fq12_mul_chain:%d" % args.cpu_baseline_chain
+            spec = "%s_chain:%d" % (args.component, args.cpu_baseline_chain)
             sec, gates, _ = o.bench_garble(spec, seed=0)
             result["cpu_baseline"] = {"value": gates / sec, "unit": "gates/s", "cores": 1, "kind": "port",
                                       "sample": "%s (%d gates) garbled once by the C++ oracle, AES-NI hash + inline CBC-MAC, 1 thread, %.1f s" % (spec, gates, sec)}

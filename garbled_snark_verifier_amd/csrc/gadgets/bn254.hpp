@@ -325,6 +325,52 @@ inline Fq12 mul_montgomery(CircuitContext& c, const Fq12& a, const Fq12& b) {  /
   });
   return Fq12::from_wires(out);
 }
+inline Fq12 square_montgomery(CircuitContext& c, const Fq12& a) {  // fq12.rs:311-324  (#[component])
+  Wires out = component(c, KeyBuilder("fq12::square_montgomery"), a.to_wires(), N, [](CircuitContext& cc, const Wires& in) {
+    Fq12 a = Fq12::from_wires(in);
+    Fq6 w1 = fq6::add(cc, a.c[0], a.c[1]);
+    Fq6 w2 = fq6::mul_by_nonresidue(cc, a.c[1]);
+    Fq6 w3 = fq6::add(cc, a.c[0], w2);
+    Fq6 w4 = fq6::mul_montgomery(cc, a.c[0], a.c[1]);
+    Fq6 w5 = fq6::mul_montgomery(cc, w1, w3);
+    Fq6 w6 = fq6::mul_by_nonresidue(cc, w4);
+    Fq6 w7 = fq6::add(cc, w4, w6);
+    Fq6 c0 = fq6::sub(cc, w5, w7);
+    Fq6 c1 = fq6::double_(cc, w4);
+    return Fq12{{c0, c1}}.to_wires();
+  });
+  return Fq12::from_wires(out);
+}
+// Granger-Scott squaring in the cyclotomic subgroup (fq12.rs:326-392; NOT a component: its gates belong to the caller)
+inline Fq12 cyclotomic_square_montgomery(CircuitContext& c, const Fq12& a) {
+  const Fq2 &c0 = a.c[0].c[0], &c1 = a.c[0].c[1], &c2 = a.c[0].c[2], &c3 = a.c[1].c[0], &c4 = a.c[1].c[1], &c5 = a.c[1].c[2];
+  // one "Fq4 squaring" of the pair (x, y); which operand is multiplied by the non-residue follows the reference line by line
+  auto fp4 = [&](const Fq2& x, const Fq2& y, const Fq2& beta_of, const Fq2& added_to, Fq2& t_even, Fq2& t_odd) {
+    Fq2 xy = fq2::mul_montgomery(c, x, y);
+    Fq2 x_plus_y = fq2::add(c, x, y);
+    Fq2 y_beta = fq2::mul_by_nonresidue(c, beta_of);
+    Fq2 x_plus_y_beta = fq2::add(c, added_to, y_beta);
+    Fq2 xy_beta = fq2::mul_by_nonresidue(c, xy);
+    Fq2 w1 = fq2::mul_montgomery(c, x_plus_y, x_plus_y_beta);
+    Fq2 w2 = fq2::add(c, xy, xy_beta);
+    t_even = fq2::sub(c, w1, w2);
+    t_odd = fq2::double_(c, xy);
+  };
+  Fq2 t0, t1, t2, t3, t4, t5;
+  fp4(c0, c4, c4, c0, t0, t1);  // fq12.rs:337-345
+  fp4(c2, c3, c2, c3, t2, t3);  // fq12.rs:347-355: y_beta = nonresidue * c2, x_plus_y_beta = c3 + y_beta
+  fp4(c1, c5, c5, c1, t4, t5);  // fq12.rs:357-365
+  auto three_minus = [&](const Fq2& t, const Fq2& cc) { Fq2 w1 = fq2::sub(c, t, cc); Fq2 w2 = fq2::double_(c, w1); return fq2::add(c, w2, t); };
+  auto three_plus = [&](const Fq2& t, const Fq2& cc) { Fq2 w1 = fq2::add(c, t, cc); Fq2 w2 = fq2::double_(c, w1); return fq2::add(c, w2, t); };
+  Fq2 z0 = three_minus(t0, c0);  // fq12.rs:367-369
+  Fq2 z4 = three_minus(t2, c1);  // :371-373
+  Fq2 z3 = three_minus(t4, c2);  // :375-377
+  Fq2 t5_beta = fq2::mul_by_nonresidue(c, t5);
+  Fq2 z2 = three_plus(t5_beta, c3);  // :379-382
+  Fq2 z1 = three_plus(t1, c4);       // :384-386
+  Fq2 z5 = three_plus(t3, c5);       // :388-390
+  return Fq12{{Fq6{{z0, z4, z3}}, Fq6{{z2, z1, z5}}}};
+}
 }  // namespace fq12
 
 }  // namespace gadgets

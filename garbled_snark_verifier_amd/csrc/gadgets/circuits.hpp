@@ -4,6 +4,8 @@
 //   fq_mul              BASELINE config 2   (src/gadgets/bn254/fp254impl.rs:219-230)
 //   fq12_mul            BASELINE config 3   (tests/fq12_mul_e2e.rs:166-173)
 //   fq12_mul_chain:K    Groth16-shaped SYNTHETIC for config 4: r <- Fq12::mul(r, b), K times
+//   fq12_square, fq12_cyclotomic_square   Fq12::square_montgomery (fq12.rs:311-324), cyclotomic_square_montgomery (fq12.rs:326-392)
+//   fq12_sqmul, fq12_sqmul_chain:K        square-and-multiply link r <- Fq12::mul(Fq12::square(r), b)
 //   fq_complex          tests/streaming_evaluate.rs:401-407  ((a^2)*b + a)
 //   gate:T              tests/streaming_evaluate.rs:136-213  (one gate of discriminant T at the root)
 //   driver_mix          credits / dead-gate / pass-through / constant edge cases (circuit/mod.rs:419-836 shapes)
@@ -174,6 +176,24 @@ inline NamedCircuit make_circuit(const std::string& spec) {
       Fq12 r = Fq12::from_wires(slice(in, 0, 3048));
       Fq12 b = Fq12::from_wires(slice(in, 3048, 6096));
       for (size_t i = 0; i < k; ++i) r = fq12::mul_montgomery(c, r, b);
+      return r.to_wires();
+    };
+  } else if (name == "fq12_square" || name == "fq12_cyclotomic_square") {
+    const bool cyc = name == "fq12_cyclotomic_square";
+    nc.n_inputs = 3048; nc.n_outputs = 3048;
+    nc.fn = [cyc](CircuitContext& c, const Wires& in) {
+      Fq12 a = Fq12::from_wires(in);
+      return (cyc ? fq12::cyclotomic_square_montgomery(c, a) : fq12::square_montgomery(c, a)).to_wires();
+    };
+  } else if (name == "fq12_sqmul" || name == "fq12_sqmul_chain") {
+    // square-and-multiply link (the shape of the Miller loop / final exponentiation): r <- Fq12::mul(Fq12::square(r), b), K times
+    size_t k = (name == "fq12_sqmul") ? 1 : size_t(param);
+    if (k == 0) gsv_panic("fq12_sqmul_chain: K must be >= 1");
+    nc.n_inputs = 6096; nc.n_outputs = 3048;
+    nc.fn = [k](CircuitContext& c, const Wires& in) {
+      Fq12 r = Fq12::from_wires(slice(in, 0, 3048));
+      Fq12 b = Fq12::from_wires(slice(in, 3048, 6096));
+      for (size_t i = 0; i < k; ++i) r = fq12::mul_montgomery(c, fq12::square_montgomery(c, r), b);
       return r.to_wires();
     };
   } else if (name == "gate") {

@@ -25,6 +25,9 @@ CASES = [
     ("fq_complex", "fq_complex", 1, 99),
     ("fq12_mul", "fq12_mul", 1, 0),
     ("fq12_mul_chain:3", "fq12_mul", 3, 1),
+    ("fq12_square", "fq12_square", 1, 2),
+    ("fq12_cyclotomic_square", "fq12_cyclotomic_square", 1, 3),
+    ("fq12_sqmul_chain:2", "fq12_sqmul", 2, 4),
 ]
 
 

@@ -94,6 +94,37 @@ def test_fq2_fq6_fq12_mul():
     assert int(gc.sum()) == 20_284_982 and peak <= 15_000  # capacity the reference's own test uses (tests/fq12_mul_e2e.rs:190)
 
 
+def test_fq12_square_and_cyclotomic_square():
+    """Fq12::square_montgomery (fq12.rs:311-324) on a random element and cyclotomic_square_montgomery (fq12.rs:326-392) on
+    an element of the cyclotomic subgroup f^((p^6-1)(p^2+1)), both against Python field arithmetic; the Granger-Scott formula
+    must NOT square a generic element (the test would be blind otherwise)."""
+    random.seed(5)
+    a = [random.randrange(P) for _ in range(12)]
+    ob, gc, _ = o.execute("fq12_square", bits_of(a), capacity=100_000)
+    A = T.f12_unflatten(a)
+    assert ints_of(ob) == [(x * T.RINV) % P for x in T.f12_flatten(T.f12_mul(A, A))]
+    assert int(gc.sum()) == 13_595_222 and int(gc[:8].sum()) == 3_664_258
+    one = T.f12_unflatten([1] + [0] * 11)
+
+    def f12_pow(x, e):
+        r = one
+        while e:
+            if e & 1:
+                r = T.f12_mul(r, x)
+            x = T.f12_mul(x, x)
+            e >>= 1
+        return r
+
+    f = T.f12_unflatten([random.randrange(P) for _ in range(12)])
+    c = f12_pow(f, (P ** 6 - 1) * (P ** 2 + 1))
+    R = o.FQ_R % P
+    ob, gc, _ = o.execute("fq12_cyclotomic_square", bits_of([(x * R) % P for x in T.f12_flatten(c)]), capacity=100_000)
+    assert ints_of(ob) == [(x * R) % P for x in T.f12_flatten(T.f12_mul(c, c))]
+    assert int(gc.sum()) == 8_032_850
+    ob, _, _ = o.execute("fq12_cyclotomic_square", bits_of(a), capacity=100_000)
+    assert ints_of(ob) != [(x * T.RINV) % P for x in T.f12_flatten(T.f12_mul(A, A))]
+
+
 def test_host_constants_match_python():
     """Off-circuit constants embedded in csrc/gadgets/bn254.hpp (fq.rs:56-76, fp254impl.rs:21-66)."""
     src = open(os.path.join(os.path.dirname(__file__), "..", "garbled_snark_verifier_amd", "csrc", "gadgets", "bn254.hpp")).read()

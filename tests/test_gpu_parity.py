@@ -111,6 +111,17 @@ def test_fq12_chain_replay_matches_streamed_chain(engine):
     _evaluate_and_check(gsv, engine, "fq12_mul", g, prog, [3], replays=2, oracle_spec="fq12_mul_chain:2")
 
 
+def test_fq12_square_and_square_multiply_chain(engine):
+    """Fq12::square_montgomery (13.6 M gates) and the cyclotomic squaring garbled + evaluated on the GPU against the oracle, and
+    the square-and-multiply link r <- mul(square(r), b) replayed twice with feedback == the streamed 2-link chain."""
+    import garbled_snark_verifier_amd as gsv
+    for spec, seeds in (("fq12_square", [2, 9]), ("fq12_cyclotomic_square", [3])):
+        g, prog = _garble_and_check(gsv, engine, spec, seeds)
+        _evaluate_and_check(gsv, engine, spec, g, prog, seeds)
+    g, prog = _garble_and_check(gsv, engine, "fq12_sqmul", [4], replays=2, oracle_spec="fq12_sqmul_chain:2")
+    _evaluate_and_check(gsv, engine, "fq12_sqmul", g, prog, [4], replays=2, oracle_spec="fq12_sqmul_chain:2")
+
+
 def test_golden_fixtures(engine):
     """Committed fixtures (tests/golden/make_golden.py): ciphertext hash + digest of output labels."""
     import hashlib
