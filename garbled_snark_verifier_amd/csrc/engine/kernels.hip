@@ -1,18 +1,20 @@
 // gfx950 (MI355X / CDNA4) kernels of the garbling engine.
 //
-// Execution model: one 1024-thread workgroup = one garbling instance on one CU.
-// The circuit is deep and narrow (Fq12 mul: ~20.3 M gates over ~10^4 dependent AND levels, mean
-// width a few hundred gates), so a step is latency-bound, not throughput-bound: the workgroup walks
-// the program's steps with `s_barrier` between them — no grid-wide synchronisation, no inter-CU
-// traffic — and independent cut-and-choose instances fill the other CUs.
-//   * two-level wire file: short-lived labels (most of them) in a 120 KiB LDS window chosen by the
-//     compiler's fan-out/lifetime pass, long-lived ones in W[instance][slot] in HBM (128-bit accesses,
-//     next-fit slot order so that a step's stores coalesce)
-//   * AES table Te0: 32 KiB in LDS, bank-replicated so lookups never conflict; round keys scalar
-//   * within a step the AND-family records and the free-gate records are two contiguous runs, so
-//     only one wave per step diverges on the gate kind (no per-lane ballot/compaction needed);
-//     records of the NEXT step are prefetched into registers before the barrier
-//   * ciphertexts are written straight to the instance's stream at their gate-order index
+// Execution model: one 1024-thread workgroup = one or two garbling instances on one CU.
+// The circuit is deep and narrow (Fq12 mul after gate fusion: 9.1 M device records over 8 197 dependent
+// steps, 6 665 of them forced by the AND depth), so a step is latency-bound as often as throughput-bound:
+// the workgroup walks the program's steps with `s_barrier` between them — no grid-wide synchronisation, no
+// inter-CU traffic — and independent cut-and-choose instances fill the other CUs.
+//   * two-level wire file: short-lived labels in a 90 KiB LDS window chosen by the compiler's
+//     fan-out/lifetime pass, long-lived ones in W[instance][slot] in HBM (128-bit accesses; the compiler
+//     orders every step's records so that a wave's label accesses fall into few 128-byte lines)
+//   * AES tables Te0/Te2: 64 KiB in LDS, bank-replicated so lookups never conflict, 256-byte entry stride so
+//     a lookup address is one v_perm_b32; round keys in LDS too
+//   * fused gates: out = AND_t(a1^a2, b1^b2) ^ p  and  out = x1^x2^x3^x4 (program.hpp); within a step the
+//     AND-family records and the free records are two contiguous runs, so only one wave per step diverges
+//     on the gate kind; records of step s+2 are prefetched into registers before the barrier of step s
+//   * ciphertexts are written at the AND record's own index (program order: coalesced), gate order is
+//     restored for the host by permute_ciphertexts_kernel / gather_segment_kernel
 // No MFMA: the work is byte-table lookups and 128-bit XORs.
 #include <hip/hip_runtime.h>
 
