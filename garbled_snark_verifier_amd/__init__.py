@@ -47,6 +47,7 @@ EXPORTS = [
     "gsv_session_set_garble_inputs", "gsv_session_garble", "gsv_session_set_evaluate_inputs", "gsv_session_upload_ciphertexts",
     "gsv_session_evaluate", "gsv_session_set_hasher", "gsv_session_sync", "gsv_session_last_kernel_ms", "gsv_session_read_outputs", "gsv_session_read_ciphertexts",
     "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_commit_labels",
+    "gsv_plan_create", "gsv_plan_destroy", "gsv_plan_add_call", "gsv_plan_finish", "gsv_plan_counts", "gsv_session_create_plan",
     "gsv_session_garble_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
 ]
 
@@ -92,6 +93,13 @@ def lib():
         L.gsv_session_ciphertext_hash.argtypes = [vp, C.c_size_t, u8p]
         L.gsv_cbcmac_update.argtypes = [u8p, u8p, C.c_uint64]
         L.gsv_commit_labels.argtypes = [u8p, C.c_uint64, u8p]
+        L.gsv_plan_create.argtypes = [C.POINTER(vp)]
+        L.gsv_plan_destroy.argtypes = [vp]
+        L.gsv_plan_destroy.restype = None
+        L.gsv_plan_add_call.argtypes = [vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.gsv_plan_finish.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32), C.c_size_t]
+        L.gsv_plan_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.gsv_session_create_plan.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
         L.gsv_session_garble_streaming.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_uint64, C.c_int, u8p]
         L.gsv_session_instances_per_workgroup.argtypes = [vp, C.POINTER(C.c_int)]
         L.gsv_session_enable_step_clock.argtypes = [vp]
@@ -226,15 +234,55 @@ class Engine:
             self.h = None
 
 
+class Plan:
+    """A sequence of calls to compiled programs over one wire file (gsv_plan): component-level programs."""
+
+    def __init__(self):
+        self.h = C.c_void_p()
+        _chk(lib().gsv_plan_create(C.byref(self.h)))
+        self.programs = []  # keep the programs alive
+        self.n_inputs = self.n_outputs = 0
+
+    def add_call(self, program, in_globals, out_globals):
+        a = np.ascontiguousarray(in_globals, np.uint32)
+        b = np.ascontiguousarray(out_globals, np.uint32)
+        assert a.size == program.info["n_inputs"] and b.size == program.info["n_outputs"]
+        _chk(lib().gsv_plan_add_call(self.h, program.h, a.ctypes.data_as(C.POINTER(C.c_uint32)), b.ctypes.data_as(C.POINTER(C.c_uint32))))
+        self.programs.append(program)
+
+    def finish(self, n_inputs, output_globals):
+        o = np.ascontiguousarray(output_globals, np.uint32)
+        _chk(lib().gsv_plan_finish(self.h, n_inputs, o.ctypes.data_as(C.POINTER(C.c_uint32)), o.size))
+        self.n_inputs, self.n_outputs = n_inputs, int(o.size)
+        g, c, k = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _chk(lib().gsv_plan_counts(self.h, C.byref(g), C.byref(c), C.byref(k)))
+        self.info = {"n_inputs": n_inputs, "n_outputs": int(o.size), "n_gates": g.value, "n_ciphertexts": c.value, "n_calls": k.value, "n_steps": 0}
+
+    def close(self):
+        if self.h:
+            lib().gsv_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Session:
-    """A batch of instances on one program (gsv_session)."""
+    """A batch of instances on one program (gsv_session) or, with a Plan, on a sequence of component programs."""
 
     def __init__(self, engine, program, n_instances=1, replays=1, ct_capacity_replays=None):
         self.engine, self.program = engine, program
         self.n, self.replays = n_instances, replays
         self.ct_cap = replays if ct_capacity_replays is None else ct_capacity_replays
         self.h = C.c_void_p()
-        _chk(lib().gsv_session_create(engine.h, program.h, n_instances, replays, self.ct_cap, C.byref(self.h)))
+        if isinstance(program, Plan):
+            assert replays == 1
+            _chk(lib().gsv_session_create_plan(engine.h, program.h, n_instances, C.byref(self.h)))
+        else:
+            _chk(lib().gsv_session_create(engine.h, program.h, n_instances, replays, self.ct_cap, C.byref(self.h)))
         self.n_in, self.n_out = program.info["n_inputs"], program.info["n_outputs"]
 
     def set_garble_inputs(self, delta, const_label0, input_label0):

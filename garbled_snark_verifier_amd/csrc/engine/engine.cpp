@@ -69,6 +69,22 @@ struct gsv_program {
   }
 };
 
+// A plan = a sequence of calls to compiled programs over ONE wire file per instance (component-level programs: the
+// reference instantiates the same component shapes thousands of times, streaming_mode.rs:150-247).  Wires that cross
+// calls live in a "global" region behind the programs' own slots; a call copies its inputs in, runs, copies its outputs out.
+struct PlanCall {
+  gsv_program* prog;
+  std::vector<uint32_t> in_globals, out_globals;
+  uint64_t gid_off = 0, ct_off = 0;  // gate ids / ciphertext records consumed by the calls before this one
+};
+struct gsv_plan {
+  std::vector<PlanCall> calls;
+  uint32_t n_globals = 0, n_inputs = 0;
+  std::vector<uint32_t> outputs;
+  uint64_t n_gates = 0, n_ct = 0;
+  bool finished = false;
+};
+
 struct gsv_engine {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -84,11 +100,20 @@ struct gsv_session {
   void *W = nullptr, *VB = nullptr, *CT = nullptr, *delta = nullptr, *out = nullptr, *out_bits = nullptr, *in_bits = nullptr, *step_clock = nullptr, *ct_stage = nullptr, *ct_gate = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint32_t ni = 1;  // instances per workgroup of this session's launches
-  const Program& prog() const { return ni == 2 ? *p->prog2 : p->prog; }
+  // plan sessions: `facade` stands in for the program (slots = wire-file stride, inputs / outputs in the global region)
+  const gsv_plan* plan = nullptr;
+  Program facade;
+  uint32_t global_base = 0;  // first slot of the plan's global region
+  struct CallDev { DevProgram dp; void *pre_src = nullptr, *pre_dst = nullptr, *post_src = nullptr, *post_dst = nullptr; };
+  std::vector<CallDev> call_dev;
+  void* plan_out_slots = nullptr;
+  const Program& prog() const { return plan ? facade : (ni == 2 ? *p->prog2 : p->prog); }
+  const Program& call_prog(size_t k) const { const gsv_program* q = plan->calls[k].prog; return ni == 2 ? *q->prog2 : q->prog; }
+  uint32_t first_input_slot() const { return plan ? global_base : SLOT_FIRST_INPUT; }
   bool ran = false, last_eval = false, garbled = false;
   int hasher = 0;  // 0 AesNiHasher, 1 Blake3Hasher
   std::vector<uint64_t> ct_uploaded;  // per instance: records supplied by gsv_session_upload_ciphertexts
-  uint64_t ct_stride() const { return ct_cap * p->prog.n_ct; }  // n_ct does not depend on the variant
+  uint64_t ct_stride() const { return plan ? plan->n_ct : ct_cap * p->prog.n_ct; }  // n_ct does not depend on the variant
 };
 
 extern "C" {
@@ -317,15 +342,129 @@ void gsv_session_destroy(gsv_session* s) {
   (void)hipSetDevice(s->e->device);
   (void)hipStreamSynchronize(s->e->stream);
   for (void* q : {s->W, s->VB, s->CT, s->delta, s->out, s->out_bits, s->in_bits, s->step_clock, s->ct_stage, s->ct_gate}) if (q) (void)hipFree(q);
+  for (auto& cd : s->call_dev) for (void* q : {cd.pre_src, cd.pre_dst, cd.post_src, cd.post_dst}) if (q) (void)hipFree(q);
+  if (s->plan_out_slots) (void)hipFree(s->plan_out_slots);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
+}
+
+// ---------------------------------------------------------------- plans
+int gsv_plan_create(gsv_plan** out) {
+  if (!out) return fail(GSV_ERR_INVALID, "null out");
+  *out = new gsv_plan();
+  return GSV_OK;
+}
+void gsv_plan_destroy(gsv_plan* p) { delete p; }
+int gsv_plan_add_call(gsv_plan* p, const gsv_program* prog, const uint32_t* in_globals, const uint32_t* out_globals) {
+  if (!p || !prog || p->finished) return fail(GSV_ERR_INVALID, "bad argument / plan already finished");
+  const Program& g = prog->prog;
+  if ((!in_globals && !g.input_slots.empty()) || (!out_globals && !g.output_slots.empty())) return fail(GSV_ERR_INVALID, "null wire list");
+  if (!g.fb_src_slot.empty()) return fail(GSV_ERR_INVALID, "a program compiled with feedback cannot be a plan call");
+  PlanCall c;
+  c.prog = const_cast<gsv_program*>(prog);
+  c.in_globals.assign(in_globals, in_globals + g.input_slots.size());
+  c.out_globals.assign(out_globals, out_globals + g.output_slots.size());
+  c.gid_off = p->n_gates; c.ct_off = p->n_ct;
+  p->n_gates += g.n_gates; p->n_ct += g.n_ct;
+  for (uint32_t w : c.in_globals) p->n_globals = std::max(p->n_globals, w + 1);
+  for (uint32_t w : c.out_globals) p->n_globals = std::max(p->n_globals, w + 1);
+  p->calls.push_back(std::move(c));
+  return GSV_OK;
+}
+int gsv_plan_finish(gsv_plan* p, uint32_t n_inputs, const uint32_t* output_globals, size_t n_outputs) {
+  if (!p || p->finished || (!output_globals && n_outputs)) return fail(GSV_ERR_INVALID, "bad argument");
+  // global wires 0..n_inputs-1 are the plan's inputs; every other global must be written by a call before it is read
+  std::vector<uint8_t> defined(std::max<uint32_t>(p->n_globals, n_inputs), 0);
+  for (uint32_t i = 0; i < n_inputs; ++i) defined[i] = 1;
+  for (const PlanCall& c : p->calls) {
+    for (uint32_t w : c.in_globals) if (!defined[w]) return fail(GSV_ERR_CIRCUIT, "plan call reads global wire " + std::to_string(w) + " before any call wrote it");
+    for (uint32_t w : c.out_globals) defined[w] = 1;
+  }
+  for (size_t i = 0; i < n_outputs; ++i)
+    if (output_globals[i] >= defined.size() || !defined[output_globals[i]]) return fail(GSV_ERR_CIRCUIT, "plan output is never written");
+  p->n_globals = uint32_t(defined.size());
+  p->n_inputs = n_inputs;
+  p->outputs.assign(output_globals, output_globals + n_outputs);
+  p->finished = true;
+  return GSV_OK;
+}
+int gsv_plan_counts(const gsv_plan* p, uint64_t* n_gates, uint64_t* n_ciphertexts, uint64_t* n_calls) {
+  if (!p) return fail(GSV_ERR_INVALID, "null plan");
+  if (n_gates) *n_gates = p->n_gates;
+  if (n_ciphertexts) *n_ciphertexts = p->n_ct;
+  if (n_calls) *n_calls = p->calls.size();
+  return GSV_OK;
+}
+int gsv_session_create_plan(gsv_engine* e, const gsv_plan* plan, size_t n_instances, gsv_session** out) {
+  if (!e || !plan || !out || n_instances == 0 || !plan->finished || plan->calls.empty()) return fail(GSV_ERR_INVALID, "bad argument / plan not finished");
+  HIPCHK(hipSetDevice(e->device));
+  std::unique_ptr<gsv_session> s(new gsv_session());
+  s->e = e; s->p = plan->calls[0].prog; s->plan = plan; s->n_inst = n_instances; s->replays = 1; s->ct_cap = 1;
+  s->ct_uploaded.assign(n_instances, 0);
+  {
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, e->device));
+    s->ni = n_instances > size_t(prop.multiProcessorCount) ? 2u : 1u;
+    if (const char* ev = getenv("GSV_INSTANCES_PER_WG")) { int v = atoi(ev); if (v == 1 || (v == 2 && n_instances >= 2)) s->ni = uint32_t(v); }
+  }
+  s->call_dev.resize(plan->calls.size());
+  uint32_t scratch = SLOT_FIRST_INPUT;
+  for (size_t k = 0; k < plan->calls.size(); ++k) {
+    int rc = upload_program(e, plan->calls[k].prog, s->ni, &s->call_dev[k].dp);
+    if (rc) return rc;
+    scratch = std::max(scratch, s->call_prog(k).n_slots);
+  }
+  s->global_base = scratch;
+  if (uint64_t(scratch) + plan->n_globals > 0xFFFFFFF0ull) return fail(GSV_ERR_CIRCUIT, "plan wire file too large");
+  Program& f = s->facade;
+  f.n_slots = scratch + plan->n_globals;
+  f.n_gates = plan->n_gates; f.n_ct = plan->n_ct;
+  for (uint32_t i = 0; i < plan->n_inputs; ++i) f.input_slots.push_back(scratch + i);
+  for (uint32_t w : plan->outputs) f.output_slots.push_back(scratch + w);
+  auto up32 = [&](void** dst, const std::vector<uint32_t>& v) -> int {
+    HIPCHK(hipMalloc(dst, v.size() * 4 + 16));
+    if (!v.empty()) HIPCHK(hipMemcpy(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    return GSV_OK;
+  };
+  for (size_t k = 0; k < plan->calls.size(); ++k) {
+    const PlanCall& c = plan->calls[k];
+    const Program& g = s->call_prog(k);
+    std::vector<uint32_t> src, dst;
+    for (size_t i = 0; i < c.in_globals.size(); ++i) { src.push_back(scratch + c.in_globals[i]); dst.push_back(g.input_slots[i]); }
+    int rc;
+    if ((rc = up32(&s->call_dev[k].pre_src, src)) || (rc = up32(&s->call_dev[k].pre_dst, dst))) return rc;
+    src.clear(); dst.clear();
+    for (size_t i = 0; i < c.out_globals.size(); ++i) { src.push_back(g.output_slots[i]); dst.push_back(scratch + c.out_globals[i]); }
+    if ((rc = up32(&s->call_dev[k].post_src, src)) || (rc = up32(&s->call_dev[k].post_dst, dst))) return rc;
+  }
+  { int rc = up32(&s->plan_out_slots, f.output_slots); if (rc) return rc; }
+  HIPCHK(hipMalloc(&s->W, n_instances * size_t(f.n_slots) * 16));
+  HIPCHK(hipMalloc(&s->VB, n_instances * size_t(f.n_slots)));
+  HIPCHK(hipMemset(s->VB, 0, n_instances * size_t(f.n_slots)));
+  const size_t ct_bytes = n_instances * size_t(plan->n_ct) * 16;
+  HIPCHK(hipMalloc(&s->CT, ct_bytes ? ct_bytes : 16));
+  HIPCHK(hipMalloc(&s->delta, n_instances * 16));
+  HIPCHK(hipMalloc(&s->out, n_instances * f.output_slots.size() * 16 + 16));
+  HIPCHK(hipMalloc(&s->out_bits, n_instances * f.output_slots.size() + 16));
+  HIPCHK(hipMalloc(&s->in_bits, n_instances * f.input_slots.size() + 16));
+  HIPCHK(hipEventCreate(&s->ev0));
+  HIPCHK(hipEventCreate(&s->ev1));
+  *out = s.release();
+  return GSV_OK;
 }
 
 static int stage_labels(gsv_session* s, const uint8_t* consts, const uint8_t* inputs) {
   // Per instance the wire file starts [FALSE, TRUE, ZERO, input0, input1, ...]: one strided copy.
   const Program& g = s->prog();
   const size_t n_in = g.input_slots.size();
+  if (s->plan) {  // constants at slots 0..2, inputs at the head of the global region: two strided copies
+    std::vector<uint8_t> host(s->n_inst * 48, 0);
+    for (size_t i = 0; i < s->n_inst; ++i) std::memcpy(&host[i * 48], consts + 32 * i, 32);
+    HIPCHK(hipMemcpy2D(s->W, size_t(g.n_slots) * 16, host.data(), 48, 48, s->n_inst, hipMemcpyHostToDevice));
+    if (n_in) HIPCHK(hipMemcpy2D(static_cast<uint8_t*>(s->W) + size_t(s->global_base) * 16, size_t(g.n_slots) * 16, inputs, n_in * 16, n_in * 16, s->n_inst, hipMemcpyHostToDevice));
+    return GSV_OK;
+  }
   const size_t row = (SLOT_FIRST_INPUT + n_in) * 16;
   std::vector<uint8_t> host(s->n_inst * row, 0);
   for (size_t i = 0; i < s->n_inst; ++i) {
@@ -358,7 +497,7 @@ int gsv_session_set_evaluate_inputs(gsv_session* s, const uint8_t* const_active,
     std::vector<uint8_t> nb(s->n_inst * n_in);
     for (size_t i = 0; i < nb.size(); ++i) nb[i] = input_bits[i] ? 1 : 0;
     HIPCHK(hipMemcpy(s->in_bits, nb.data(), nb.size(), hipMemcpyHostToDevice));
-    if (gsvk_scatter_bits(s->VB, g.n_slots, SLOT_FIRST_INPUT, s->in_bits, uint32_t(n_in), uint32_t(s->n_inst), nullptr) != 0) return fail(GSV_ERR_DEVICE, "scatter_bits launch failed");
+    if (gsvk_scatter_bits(s->VB, g.n_slots, s->first_input_slot(), s->in_bits, uint32_t(n_in), uint32_t(s->n_inst), nullptr) != 0) return fail(GSV_ERR_DEVICE, "scatter_bits launch failed");
     HIPCHK(hipDeviceSynchronize());
   }
   return GSV_OK;
@@ -371,12 +510,25 @@ static int ensure_ct_stage(gsv_session* s) {
   if (!s->ct_stage) HIPCHK(hipMalloc(&s->ct_stage, CT_STAGE_RECORDS * 16));
   return GSV_OK;
 }
+// stage[0..n) <-> gate-order records [first, first+n) of one instance's stream.  Program sessions: one permutation per replay
+// block; plan sessions: one per call block.
+static int permute_range(gsv_session* s, size_t instance, uint64_t first, uint64_t n, int scatter) {
+  uint8_t* stream = static_cast<uint8_t*>(s->CT) + instance * s->ct_stride() * 16;
+  if (!s->plan) return gsvk_permute_ciphertexts(stream, s->dp.ct_pos, s->prog().n_ct, first, n, s->ct_stage, scatter, s->e->stream);
+  for (size_t k = 0; k < s->plan->calls.size(); ++k) {
+    const uint64_t b0 = s->plan->calls[k].ct_off, b1 = b0 + s->call_prog(k).n_ct;
+    const uint64_t lo = std::max(first, b0), hi = std::min(first + n, b1);
+    if (lo >= hi) continue;
+    int rc = gsvk_permute_ciphertexts(stream + b0 * 16, s->call_dev[k].dp.ct_pos, b1 - b0, lo - b0, hi - lo, static_cast<uint8_t*>(s->ct_stage) + (lo - first) * 16, scatter, s->e->stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
 // copies stream records [first, first+n) of one instance, in gate order, to host memory
 static int fetch_ciphertexts(gsv_session* s, size_t instance, uint64_t first, uint64_t n, uint8_t* out) {
   int rc = ensure_ct_stage(s);
   if (rc) return rc;
-  if (gsvk_permute_ciphertexts(static_cast<uint8_t*>(s->CT) + instance * s->ct_stride() * 16, s->dp.ct_pos, s->prog().n_ct, first, n, s->ct_stage, 0, s->e->stream) != 0)
-    return fail(GSV_ERR_DEVICE, "ciphertext gather launch failed");
+  if (permute_range(s, instance, first, n, 0) != 0) return fail(GSV_ERR_DEVICE, "ciphertext gather launch failed");
   HIPCHK(hipMemcpyAsync(out, s->ct_stage, n * 16, hipMemcpyDeviceToHost, s->e->stream));
   HIPCHK(hipStreamSynchronize(s->e->stream));
   return GSV_OK;
@@ -392,15 +544,16 @@ int gsv_session_upload_ciphertexts(gsv_session* s, size_t instance, const uint8_
   for (uint64_t off = 0; off < n_records; off += CT_STAGE_RECORDS) {
     const uint64_t n = std::min<uint64_t>(CT_STAGE_RECORDS, n_records - off);
     HIPCHK(hipMemcpyAsync(s->ct_stage, cts + off * 16, n * 16, hipMemcpyHostToDevice, s->e->stream));
-    if (gsvk_permute_ciphertexts(static_cast<uint8_t*>(s->CT) + instance * s->ct_stride() * 16, s->dp.ct_pos, s->prog().n_ct, off, n, s->ct_stage, 1, s->e->stream) != 0)
-      return fail(GSV_ERR_DEVICE, "ciphertext scatter launch failed");
+    if (permute_range(s, instance, off, n, 1) != 0) return fail(GSV_ERR_DEVICE, "ciphertext scatter launch failed");
     HIPCHK(hipStreamSynchronize(s->e->stream));
   }
   s->ct_uploaded[instance] = n_records;
   return GSV_OK;
 }
 
+static int launch_plan(gsv_session* s, uint64_t gate_id_base, bool eval);
 static int launch(gsv_session* s, uint64_t gate_id_base, bool eval, uint64_t rep_base = 0, uint64_t n_replays = 0) {
+  if (s->plan) return launch_plan(s, gate_id_base, eval);
   const Program& g = s->prog();
   HIPCHK(hipSetDevice(s->e->device));
   dev::KernelArgs ka{};
@@ -430,6 +583,40 @@ static int launch(gsv_session* s, uint64_t gate_id_base, bool eval, uint64_t rep
   s->ran = true; s->last_eval = eval;
   return GSV_OK;
 }
+// One kernel launch per call (a component runs for >100 ms, a launch costs ~10 us), wire hand-over by two small copy kernels.
+static int launch_plan(gsv_session* s, uint64_t gate_id_base, bool eval) {
+  const Program& f = s->facade;
+  HIPCHK(hipSetDevice(s->e->device));
+  HIPCHK(hipEventRecord(s->ev0, s->e->stream));
+  for (size_t k = 0; k < s->plan->calls.size(); ++k) {
+    const PlanCall& c = s->plan->calls[k];
+    const Program& g = s->call_prog(k);
+    const gsv_session::CallDev& cd = s->call_dev[k];
+    if (gsvk_copy_slots(s->W, eval ? s->VB : nullptr, f.n_slots, static_cast<const uint32_t*>(cd.pre_src), static_cast<const uint32_t*>(cd.pre_dst), uint32_t(c.in_globals.size()),
+                        uint32_t(s->n_inst), s->e->stream) != 0) return fail(GSV_ERR_DEVICE, "copy launch failed");
+    dev::KernelArgs ka{};
+    ka.steps = cd.dp.steps; ka.ands = cd.dp.ands; ka.xors = cd.dp.xors;
+    ka.W = static_cast<uint4*>(s->W); ka.VB = static_cast<uint8_t*>(s->VB); ka.CT = static_cast<uint4*>(s->CT);
+    ka.delta = static_cast<const uint4*>(s->delta); ka.te = static_cast<const uint32_t*>(s->e->te);
+    ka.ct_stride = s->ct_stride(); ka.ct_offset = c.ct_off; ka.gid_base = gate_id_base + c.gid_off; ka.n_gates = g.n_gates; ka.n_ct = g.n_ct;
+    ka.n_steps = uint32_t(g.steps.size()); ka.n_slots = f.n_slots; ka.replays = 1; ka.rep_base = 0; ka.ct_cap_replays = 1;
+    ka.n_instances = uint32_t(s->n_inst); ka.hasher = uint32_t(s->hasher); ka.instances_per_wg = s->ni;
+    if (ka.n_steps) {
+      int lrc = gsvk_launch_program(&ka, uint32_t(s->n_inst), eval ? 1 : 0, s->e->stream);
+      if (lrc != 0) return fail(GSV_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipError_t(lrc)));
+    }
+    if (gsvk_copy_slots(s->W, eval ? s->VB : nullptr, f.n_slots, static_cast<const uint32_t*>(cd.post_src), static_cast<const uint32_t*>(cd.post_dst), uint32_t(c.out_globals.size()),
+                        uint32_t(s->n_inst), s->e->stream) != 0) return fail(GSV_ERR_DEVICE, "copy launch failed");
+  }
+  HIPCHK(hipEventRecord(s->ev1, s->e->stream));
+  if (!f.output_slots.empty()) {
+    if (gsvk_gather_outputs(s->W, s->VB, f.n_slots, static_cast<const uint32_t*>(s->plan_out_slots), uint32_t(f.output_slots.size()), uint32_t(s->n_inst), s->out,
+                            eval ? s->out_bits : nullptr, s->e->stream) != 0) return fail(GSV_ERR_DEVICE, "gather launch failed");
+  }
+  s->ran = true; s->last_eval = eval;
+  return GSV_OK;
+}
+
 int gsv_session_garble(gsv_session* s, uint64_t gate_id_base) {
   if (!s) return fail(GSV_ERR_INVALID, "null session");
   int rc = launch(s, gate_id_base, false);
@@ -444,6 +631,7 @@ int gsv_session_garble(gsv_session* s, uint64_t gate_id_base) {
 // (ciphertext_repository.rs:94-127).
 int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes) {
   if (!s || !hashes) return fail(GSV_ERR_INVALID, "null argument");
+  if (s->plan) return fail(GSV_ERR_INVALID, "streaming drain of plan sessions is not implemented (use gsv_session_ciphertext_hash)");
   const Program& g = s->prog();
   const uint64_t n_ct = g.n_ct, total = s->replays, seg = s->ct_cap;
   const size_t n_inst = s->n_inst;

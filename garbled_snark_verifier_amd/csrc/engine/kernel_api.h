@@ -25,6 +25,7 @@ struct KernelArgs {
   uint64_t gid_base;   // gate_id of the first gate of replay 0
   uint64_t n_gates;    // gate_ids consumed per replay
   uint64_t n_ct;       // ciphertexts per replay
+  uint64_t ct_offset;  // first record of this launch inside every instance's stream (plans: the call's block)
   uint32_t n_steps;
   uint32_t n_slots;
   uint32_t replays;
@@ -52,5 +53,7 @@ int gsvk_permute_ciphertexts(void* stream, const void* ct_pos, uint64_t n_ct, ui
 // out[inst][r*n_ct + g] = ring[inst][r*n_ct + ct_pos[g]] for r < n_rep, every instance (strides in 16-byte records)
 int gsvk_gather_segment(const void* ring, uint64_t ring_stride, const void* ct_pos, uint64_t n_ct, uint32_t n_rep, uint32_t n_instances, void* out,
                         uint64_t out_stride, hipStream_t s);
+// W[inst][dst[i]] = W[inst][src[i]] (and the plaintext bits when VB != null) for every instance: wire hand-over between the calls of a plan
+int gsvk_copy_slots(void* W, void* VB, uint32_t n_slots, const uint32_t* src, const uint32_t* dst, uint32_t n, uint32_t n_instances, hipStream_t s);
 int gsvk_scatter_bits(void* VB, uint32_t n_slots, uint32_t first_slot, const void* bits, uint32_t n, uint32_t n_instances, hipStream_t stream);
 }

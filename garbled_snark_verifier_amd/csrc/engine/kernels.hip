@@ -180,7 +180,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   wf.bit_base = GSV_LDS_TABLE_BYTES + GSV_LDS_SLOTS * 16u + sub * (GSV_LDS_SLOTS / NI);
   wf.hbm = (glb_u128*)(ka.W + size_t(inst) * ka.n_slots);      // C-style cast: generic -> global address space
   wf.hbm_bits = (glb_u8*)(ka.VB + size_t(inst) * ka.n_slots);
-  glb_u128* __restrict__ CT = (glb_u128*)(ka.CT + size_t(inst) * ka.ct_stride);
+  glb_u128* __restrict__ CT = (glb_u128*)(ka.CT + size_t(inst) * ka.ct_stride + ka.ct_offset);
   glb_u32* __restrict__ CTw = (glb_u32*)CT;
   Label delta{{0, 0, 0, 0}};
   if (!EVAL) { const u32x4 d = ((const glb_u128*)ka.delta)[inst]; delta = Label{{d.x, d.y, d.z, d.w}}; }
@@ -481,6 +481,14 @@ __global__ void scatter_bits_kernel(uint8_t* VB, uint32_t n_slots, uint32_t firs
   VB[size_t(inst) * n_slots + first_slot + i] = bits[size_t(inst) * n + i];
 }
 
+__global__ void copy_slots_kernel(uint4* W, uint8_t* VB, uint32_t n_slots, const uint32_t* src, const uint32_t* dst, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t base = size_t(blockIdx.y) * n_slots;
+  W[base + dst[i]] = W[base + src[i]];
+  if (VB) VB[base + dst[i]] = VB[base + src[i]];
+}
+
 // Gate order <-> program order of the ciphertext stream (see program.hpp, ct_pos): one record per thread.
 __global__ void permute_ciphertexts_kernel(uint4* stream, const uint32_t* ct_pos, uint64_t n_ct, uint64_t first, uint64_t n, uint4* stage, int scatter) {
   const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -558,6 +566,11 @@ int gsvk_gather_segment(const void* ring, uint64_t ring_stride, const void* ct_p
   if (n_ct == 0 || n_rep == 0) return 0;
   hipLaunchKernelGGL(gsv::dev::gather_segment_kernel, dim3(uint32_t((n_ct + 255) / 256), n_instances), dim3(256), 0, s, static_cast<const uint4*>(ring), ring_stride,
                      static_cast<const uint32_t*>(ct_pos), n_ct, n_rep, static_cast<uint4*>(out), out_stride);
+  return int(hipGetLastError());
+}
+int gsvk_copy_slots(void* W, void* VB, uint32_t n_slots, const uint32_t* src, const uint32_t* dst, uint32_t n, uint32_t n_instances, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gsv::dev::copy_slots_kernel, dim3((n + 255) / 256, n_instances), dim3(256), 0, s, static_cast<uint4*>(W), static_cast<uint8_t*>(VB), n_slots, src, dst, n);
   return int(hipGetLastError());
 }
 int gsvk_scatter_bits(void* VB, uint32_t n_slots, uint32_t first_slot, const void* bits, uint32_t n, uint32_t n_instances, hipStream_t stream) {

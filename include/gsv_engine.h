@@ -97,6 +97,20 @@ typedef struct gsv_program_info {
 } gsv_program_info;
 int gsv_program_get_info(const gsv_program* p, gsv_program_info* info);
 
+/* ---- plans: component-level programs ----------------------------------------------------------------
+ * The reference instantiates a few component shapes thousands of times (with_named_child, streaming_mode.rs:150-247); the
+ * 11 B-gate verifier cannot be recorded as one flat program.  A plan is a sequence of CALLS to compiled programs over one
+ * wire file per instance: wires that cross calls are "global" wires (dense ids chosen by the caller; ids 0..n_inputs-1 are
+ * the plan's inputs); a call copies its inputs in, runs (one kernel launch), copies its outputs out.  Gate ids and the
+ * ciphertext stream continue from call to call, so a plan produces exactly the stream of the flat circuit
+ * call_1 ; call_2 ; ...  Programs used as calls are compiled without feedback. */
+typedef struct gsv_plan gsv_plan;
+int gsv_plan_create(gsv_plan** out);
+void gsv_plan_destroy(gsv_plan* p);
+int gsv_plan_add_call(gsv_plan* p, const gsv_program* prog, const uint32_t* in_globals /* n_inputs of prog */, const uint32_t* out_globals /* n_outputs of prog */);
+int gsv_plan_finish(gsv_plan* p, uint32_t n_inputs, const uint32_t* output_globals, size_t n_outputs);
+int gsv_plan_counts(const gsv_plan* p, uint64_t* n_gates, uint64_t* n_ciphertexts, uint64_t* n_calls);
+
 /* ---- engine --------------------------------------------------------------------------------- */
 int gsv_engine_create(int device, gsv_engine** out); /* fails with GSV_ERR_DEVICE if no HIP device */
 void gsv_engine_destroy(gsv_engine* e);
@@ -111,6 +125,9 @@ int gsv_labels_from_seed(uint64_t seed, size_t n_inputs, uint8_t delta[16], uint
  * (a ring indexed by replay); pass `replays` to keep the whole stream. */
 int gsv_session_create(gsv_engine* e, const gsv_program* p, size_t n_instances, uint64_t replays, uint64_t ct_capacity_replays, gsv_session** out);
 void gsv_session_destroy(gsv_session* s);
+/* A session over a plan: same calls as a program session (set_*_inputs, garble, evaluate, read_outputs, read / upload
+ * ciphertexts, ciphertext_hash; one pass, whole stream retained).  The plan and its programs must outlive the session. */
+int gsv_session_create_plan(gsv_engine* e, const gsv_plan* plan, size_t n_instances, gsv_session** out);
 
 /* Garble (GarbleMode): per instance i: delta[16i..], const_label0 = {false.label0, true.label0}
  * (32 B per instance), input_label0 (n_inputs*16 B per instance).  Asynchronous on the engine stream. */

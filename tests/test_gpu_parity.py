@@ -323,3 +323,46 @@ def test_cut_and_choose_regarbling_check(engine, tmp_path):
     del bad[7]              # and withheld another
     ok, errors = sharding.run_regarbling(commits, keep, bad, "fq_mul", str(tmp_path), engine=engine, program=prog)
     assert not ok and errors == {4: "ciphertext corrupted", 2: "regarbling failed", 7: "failed to find seed"}
+
+
+def test_plan_of_component_programs(engine):
+    """Component-level programs: the plan [Fq12::square(r) -> t ; Fq12::mul(t, b) -> r'] — two separately compiled programs over
+    one wire file, one kernel launch per call — must produce exactly the stream of the flat circuit mul(square(r), b):
+    ciphertexts (gate order, read across the call boundary), CBC-MAC, output labels; evaluation of the same plan must
+    decode to the oracle's bits."""
+    import garbled_snark_verifier_amd as gsv
+    # ---- Fq12 square then mul == fq12_sqmul
+    sq, mul = gsv.Program.from_circuit("fq12_square"), gsv.Program.from_circuit("fq12_mul")
+    N = 3048
+    r_, b_, t_, o_ = np.arange(0, N), np.arange(N, 2 * N), np.arange(2 * N, 3 * N), np.arange(3 * N, 4 * N)
+    plan = gsv.Plan()
+    plan.add_call(sq, r_, t_)
+    plan.add_call(mul, np.concatenate([t_, b_]), o_)
+    plan.finish(2 * N, o_)
+    assert plan.info["n_gates"] == sq.info["n_gates"] + mul.info["n_gates"] == 33_880_204
+    seeds = [31, 32]
+    B = len(seeds)
+    labs = [gsv.labels_from_seed(s, 2 * N) for s in seeds]
+    delta = np.stack([x[0] for x in labs]); consts = np.stack([np.stack([x[1], x[2]]) for x in labs]); inputs = np.stack([x[3] for x in labs])
+    sess = gsv.Session(engine, plan, B)
+    sess.set_garble_inputs(delta, consts, inputs)
+    sess.garble(0)
+    out = sess.read_outputs()
+    rng = np.random.default_rng(8)
+    bits = rng.integers(0, 2, size=(B, 2 * N)).astype(np.uint8)
+    for i, seed in enumerate(seeds):
+        ref = o.garble("fq12_sqmul", seed)
+        assert ref.n_ciphertexts == plan.info["n_ciphertexts"]
+        assert sess.ciphertext_hash(i) == ref.ct_hash.tobytes()
+        assert (out[i] == ref.output_label0).all()
+        lo = sq.info["n_ciphertexts"] - 1000  # a range that straddles the call boundary
+        assert (sess.read_ciphertexts(i, lo, 2000) == ref.ciphertexts[lo:lo + 2000]).all()
+    active = np.where(bits[:, :, None] == 1, inputs ^ delta[:, None, :], inputs)
+    ca = np.stack([consts[:, 0], consts[:, 1] ^ delta], axis=1)
+    sess.set_evaluate_inputs(ca, active, bits)
+    sess.evaluate(0)
+    oa, ob = sess.read_outputs(with_bits=True)
+    for i in range(B):
+        eb, _, _ = o.execute("fq12_sqmul", bits[i])
+        assert (ob[i] == eb).all() and (oa[i] == np.where(ob[i][:, None] == 1, out[i] ^ delta[i][None, :], out[i])).all()
+    sess.close()
