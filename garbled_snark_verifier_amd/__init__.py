@@ -47,7 +47,7 @@ EXPORTS = [
     "gsv_session_set_garble_inputs", "gsv_session_garble", "gsv_session_set_evaluate_inputs", "gsv_session_upload_ciphertexts",
     "gsv_session_evaluate", "gsv_session_set_hasher", "gsv_session_sync", "gsv_session_last_kernel_ms", "gsv_session_read_outputs", "gsv_session_read_ciphertexts",
     "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_commit_labels",
-    "gsv_plan_create", "gsv_plan_destroy", "gsv_plan_add_call", "gsv_plan_finish", "gsv_plan_counts", "gsv_session_create_plan",
+    "gsv_plan_from_circuit", "gsv_plan_io", "gsv_plan_create", "gsv_plan_destroy", "gsv_plan_add_call", "gsv_plan_finish", "gsv_plan_counts", "gsv_session_create_plan",
     "gsv_session_garble_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
 ]
 
@@ -93,6 +93,8 @@ def lib():
         L.gsv_session_ciphertext_hash.argtypes = [vp, C.c_size_t, u8p]
         L.gsv_cbcmac_update.argtypes = [u8p, u8p, C.c_uint64]
         L.gsv_commit_labels.argtypes = [u8p, C.c_uint64, u8p]
+        L.gsv_plan_from_circuit.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
+        L.gsv_plan_io.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.gsv_plan_create.argtypes = [C.POINTER(vp)]
         L.gsv_plan_destroy.argtypes = [vp]
         L.gsv_plan_destroy.restype = None
@@ -242,6 +244,21 @@ class Plan:
         _chk(lib().gsv_plan_create(C.byref(self.h)))
         self.programs = []  # keep the programs alive
         self.n_inputs = self.n_outputs = 0
+
+    @classmethod
+    def from_circuit(cls, spec, units):
+        """Record a built-in circuit with the named components (list of names such as "fq12::mul_montgomery") as calls."""
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        self.programs = []
+        _chk(lib().gsv_plan_from_circuit(spec.encode(), ",".join(units).encode(), C.byref(self.h)))
+        g, c, k = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _chk(lib().gsv_plan_counts(self.h, C.byref(g), C.byref(c), C.byref(k)))
+        n_in, n_out = C.c_uint64(), C.c_uint64()
+        _chk(lib().gsv_plan_io(self.h, C.byref(n_in), C.byref(n_out)))
+        self.n_inputs, self.n_outputs = n_in.value, n_out.value
+        self.info = {"n_inputs": n_in.value, "n_outputs": n_out.value, "n_gates": g.value, "n_ciphertexts": c.value, "n_calls": k.value, "n_steps": 0}
+        return self
 
     def add_call(self, program, in_globals, out_globals):
         a = np.ascontiguousarray(in_globals, np.uint32)

@@ -102,11 +102,23 @@ struct CircuitMode {
   // (reference: `lookup_wire(..) -> None`, which callers `.unwrap()`).
   virtual bool consume_wire(WireId w) = 0;
   virtual void add_credits(const WireId* wires, size_t n, Credits credits) = 0;
+  // Engine extension (no reference counterpart): a mode may take over a whole component call instead of letting the
+  // driver run its body — the plan recorder turns chosen components into calls of separately compiled programs.
+  // Returns null when the component is to be executed normally.
+  virtual struct UnitHook* unit_hook() { return nullptr; }
 };
 
 struct CircuitContext;
 using ChildFn = std::function<Wires(CircuitContext&, const Wires&)>;
 using ComponentKey = std::string;  // reference: 8-byte SipHash of the same fields (component_key.rs:16-39)
+struct ComponentMetaTemplate;
+struct UnitHook {
+  virtual ~UnitHook() = default;
+  // Called by with_named_child after the template lookup and the input bookkeeping, before the body would run.
+  // Return true after producing `out` (the component's output wires in the parent's id space); false = run the body.
+  virtual bool call_unit(const ComponentKey& key, const Wires& inputs, const std::vector<Credits>& out_credits, const ComponentMetaTemplate& tpl,
+                         const ChildFn& body, size_t arity, Wires& out) = 0;
+};
 
 struct CircuitContext {
   virtual ~CircuitContext() = default;
@@ -270,8 +282,15 @@ class StreamingContext final : public CircuitContext {
       if (w == UNREACHABLE || w == TRUE_WIRE || w == FALSE_WIRE) continue;
       if (!mode_.consume_wire(w)) gsv_panic("with_named_child: input wire missing from storage");
     }
-    stack_.push_back(std::move(inst));
     ++component_calls;
+    if (UnitHook* h = mode_.unit_hook()) {
+      Wires taken;
+      if (h->call_unit(key, inputs, out_credits, tpl, f, arity, taken)) {
+        if (taken.size() != arity) gsv_panic("unit hook returned wrong arity");
+        return taken;
+      }
+    }
+    stack_.push_back(std::move(inst));
     Wires out = f(*this, inputs);
     if (!stack_.back().empty()) gsv_panic("component left unused credits (template/structure mismatch)");
     stack_.pop_back();
@@ -303,6 +322,9 @@ using CircuitFn = std::function<Wires(CircuitContext&, const Wires&)>;
 class StreamingRunner {
  public:
   StreamingRunner(CircuitMode& mode, size_t n_inputs, CircuitFn f) : ctx_(mode), n_inputs_(n_inputs), f_(std::move(f)) {}
+  // Engine extension: run a component body as a root whose output i is read by nobody when live[i] == 0 (a component
+  // recorded on its own must make the same dead-gate decisions as inside its parent, where some outputs had no credits).
+  void set_output_liveness(std::vector<uint8_t> live) { out_live_ = std::move(live); }
 
   const Wires& prepare() {
     ComponentMetaBuilder meta(0);
@@ -311,7 +333,12 @@ class StreamingRunner {
     Wires meta_out = f_(meta, mock_in);
     ComponentMetaTemplate tpl = meta.build(meta_out);  // streaming_mode.rs:86
     std::vector<Credits> input_credits(n_inputs_, 1);  // :89 seed with 1
-    std::vector<Credits> inst = tpl.to_instance(std::vector<Credits>(meta_out.size(), 1), [&](size_t idx, Credits c) {
+    std::vector<Credits> root_out(meta_out.size(), 1);
+    if (!out_live_.empty()) {
+      if (out_live_.size() != meta_out.size()) gsv_panic("output liveness mask has the wrong length");
+      for (size_t i = 0; i < root_out.size(); ++i) root_out[i] = out_live_[i] ? 1 : 0;
+    }
+    std::vector<Credits> inst = tpl.to_instance(root_out, [&](size_t idx, Credits c) {
       size_t rev = n_inputs_ - 1 - idx;  // :93
       uint32_t v = uint32_t(input_credits[rev]) + c;
       if (v > 0xFFFF) gsv_panic("root input credits overflow");
@@ -336,6 +363,7 @@ class StreamingRunner {
   size_t n_inputs_;
   CircuitFn f_;
   Wires inputs_, outputs_;
+  std::vector<uint8_t> out_live_;
 };
 
 }  // namespace gsv

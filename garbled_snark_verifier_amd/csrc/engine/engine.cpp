@@ -18,6 +18,7 @@
 #include "../gadgets/circuits.hpp"
 #include "host_crypto.hpp"
 #include "kernel_api.h"
+#include "plan_builder.hpp"
 #include "program.hpp"
 
 using namespace gsv;
@@ -78,6 +79,7 @@ struct PlanCall {
   uint64_t gid_off = 0, ct_off = 0;  // gate ids / ciphertext records consumed by the calls before this one
 };
 struct gsv_plan {
+  std::vector<gsv_program*> owned;  // programs created by gsv_plan_from_circuit (destroyed with the plan)
   std::vector<PlanCall> calls;
   uint32_t n_globals = 0, n_inputs = 0;
   std::vector<uint32_t> outputs;
@@ -355,7 +357,11 @@ int gsv_plan_create(gsv_plan** out) {
   *out = new gsv_plan();
   return GSV_OK;
 }
-void gsv_plan_destroy(gsv_plan* p) { delete p; }
+void gsv_plan_destroy(gsv_plan* p) {
+  if (!p) return;
+  for (gsv_program* q : p->owned) gsv_program_destroy(q);
+  delete p;
+}
 int gsv_plan_add_call(gsv_plan* p, const gsv_program* prog, const uint32_t* in_globals, const uint32_t* out_globals) {
   if (!p || !prog || p->finished) return fail(GSV_ERR_INVALID, "bad argument / plan already finished");
   const Program& g = prog->prog;
@@ -367,8 +373,11 @@ int gsv_plan_add_call(gsv_plan* p, const gsv_program* prog, const uint32_t* in_g
   c.out_globals.assign(out_globals, out_globals + g.output_slots.size());
   c.gid_off = p->n_gates; c.ct_off = p->n_ct;
   p->n_gates += g.n_gates; p->n_ct += g.n_ct;
-  for (uint32_t w : c.in_globals) p->n_globals = std::max(p->n_globals, w + 1);
-  for (uint32_t w : c.out_globals) p->n_globals = std::max(p->n_globals, w + 1);
+  for (uint32_t w : c.in_globals) if (w < PLAN_WIRE_FALSE) p->n_globals = std::max(p->n_globals, w + 1);
+  for (uint32_t w : c.out_globals) {
+    if (w >= PLAN_WIRE_FALSE) return fail(GSV_ERR_INVALID, "a call cannot write a constant");
+    p->n_globals = std::max(p->n_globals, w + 1);
+  }
   p->calls.push_back(std::move(c));
   return GSV_OK;
 }
@@ -378,15 +387,64 @@ int gsv_plan_finish(gsv_plan* p, uint32_t n_inputs, const uint32_t* output_globa
   std::vector<uint8_t> defined(std::max<uint32_t>(p->n_globals, n_inputs), 0);
   for (uint32_t i = 0; i < n_inputs; ++i) defined[i] = 1;
   for (const PlanCall& c : p->calls) {
-    for (uint32_t w : c.in_globals) if (!defined[w]) return fail(GSV_ERR_CIRCUIT, "plan call reads global wire " + std::to_string(w) + " before any call wrote it");
+    for (uint32_t w : c.in_globals) if (w < PLAN_WIRE_FALSE && !defined[w]) return fail(GSV_ERR_CIRCUIT, "plan call reads global wire " + std::to_string(w) + " before any call wrote it");
     for (uint32_t w : c.out_globals) defined[w] = 1;
   }
   for (size_t i = 0; i < n_outputs; ++i)
-    if (output_globals[i] >= defined.size() || !defined[output_globals[i]]) return fail(GSV_ERR_CIRCUIT, "plan output is never written");
+    if (output_globals[i] < PLAN_WIRE_FALSE && (output_globals[i] >= defined.size() || !defined[output_globals[i]])) return fail(GSV_ERR_CIRCUIT, "plan output is never written");
   p->n_globals = uint32_t(defined.size());
   p->n_inputs = n_inputs;
   p->outputs.assign(output_globals, output_globals + n_outputs);
   p->finished = true;
+  return GSV_OK;
+}
+// Record one of the built-in restated circuits under the two-pass driver with the named components (comma separated,
+// e.g. "fq12::mul_montgomery,fq12::square_montgomery") turned into calls of separately compiled programs; everything
+// between them is compiled as glue programs (plan_builder.hpp).
+int gsv_plan_from_circuit(const char* spec, const char* units_csv, gsv_plan** out) {
+  if (!spec || !units_csv || !out) return fail(GSV_ERR_INVALID, "null argument");
+  GSV_TRY
+  std::vector<std::string> names;
+  {
+    std::string cur;
+    for (const char* q = units_csv;; ++q) {
+      if (*q == ',' || *q == 0) { if (!cur.empty()) names.push_back(cur); cur.clear(); if (!*q) break; }
+      else cur.push_back(*q);
+    }
+  }
+  NamedCircuit nc = make_circuit(spec);
+  PlanRecordMode mode(names);
+  StreamingRunner run(mode, nc.n_inputs, nc.fn);
+  std::vector<uint32_t> in_ssa, out_ssa;
+  for (WireId w : run.prepare()) in_ssa.push_back(mode.define_input(w));
+  for (WireId w : run.execute()) out_ssa.push_back(mode.current(w));
+  CompileOptions opt;
+  if (const char* e = getenv("GSV_FUSE")) opt.fuse = atoi(e) != 0;
+  BuiltPlan bp = finish_plan(mode, in_ssa, out_ssa, opt);
+  std::unique_ptr<gsv_plan> plan(new gsv_plan());
+  for (size_t k = 0; k < bp.programs.size(); ++k) {
+    gsv_program* q = new gsv_program();
+    plan->owned.push_back(q);
+    q->prog = std::move(bp.programs[k]);
+    q->src.reset(new ProgramSource{std::move(bp.traces[k]), bp.prog_inputs[k], bp.prog_outputs[k], {}, opt});
+    for (size_t i = 0; i < q->prog.input_slots.size(); ++i)
+      if (q->prog.input_slots[i] != SLOT_FIRST_INPUT + i) { gsv_plan_destroy(plan.release()); return fail(GSV_ERR_CIRCUIT, "internal: inputs are not slot-contiguous"); }
+  }
+  for (const BuiltPlan::Call& c : bp.calls) {
+    int rc = gsv_plan_add_call(plan.get(), plan->owned[size_t(c.program)], c.in_globals.data(), c.out_globals.data());
+    if (rc) { gsv_plan_destroy(plan.release()); return rc; }
+  }
+  int rc = gsv_plan_finish(plan.get(), bp.n_inputs, bp.outputs.data(), bp.outputs.size());
+  if (rc) { gsv_plan_destroy(plan.release()); return rc; }
+  if (plan->n_gates != mode.n_gates()) { gsv_plan_destroy(plan.release()); return fail(GSV_ERR_CIRCUIT, "internal: plan gate count differs from the recorded stream"); }
+  *out = plan.release();
+  return GSV_OK;
+  GSV_CATCH
+}
+int gsv_plan_io(const gsv_plan* p, uint64_t* n_inputs, uint64_t* n_outputs) {
+  if (!p || !p->finished) return fail(GSV_ERR_INVALID, "plan not finished");
+  if (n_inputs) *n_inputs = p->n_inputs;
+  if (n_outputs) *n_outputs = p->outputs.size();
   return GSV_OK;
 }
 int gsv_plan_counts(const gsv_plan* p, uint64_t* n_gates, uint64_t* n_ciphertexts, uint64_t* n_calls) {
@@ -421,7 +479,8 @@ int gsv_session_create_plan(gsv_engine* e, const gsv_plan* plan, size_t n_instan
   f.n_slots = scratch + plan->n_globals;
   f.n_gates = plan->n_gates; f.n_ct = plan->n_ct;
   for (uint32_t i = 0; i < plan->n_inputs; ++i) f.input_slots.push_back(scratch + i);
-  for (uint32_t w : plan->outputs) f.output_slots.push_back(scratch + w);
+  auto global_slot = [&](uint32_t w) -> uint32_t { return w == PLAN_WIRE_FALSE ? SLOT_FALSE : w == PLAN_WIRE_TRUE ? SLOT_TRUE : scratch + w; };
+  for (uint32_t w : plan->outputs) f.output_slots.push_back(global_slot(w));
   auto up32 = [&](void** dst, const std::vector<uint32_t>& v) -> int {
     HIPCHK(hipMalloc(dst, v.size() * 4 + 16));
     if (!v.empty()) HIPCHK(hipMemcpy(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice));
@@ -431,7 +490,7 @@ int gsv_session_create_plan(gsv_engine* e, const gsv_plan* plan, size_t n_instan
     const PlanCall& c = plan->calls[k];
     const Program& g = s->call_prog(k);
     std::vector<uint32_t> src, dst;
-    for (size_t i = 0; i < c.in_globals.size(); ++i) { src.push_back(scratch + c.in_globals[i]); dst.push_back(g.input_slots[i]); }
+    for (size_t i = 0; i < c.in_globals.size(); ++i) { src.push_back(global_slot(c.in_globals[i])); dst.push_back(g.input_slots[i]); }
     int rc;
     if ((rc = up32(&s->call_dev[k].pre_src, src)) || (rc = up32(&s->call_dev[k].pre_dst, dst))) return rc;
     src.clear(); dst.clear();

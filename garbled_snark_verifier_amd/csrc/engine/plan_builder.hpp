@@ -1,0 +1,283 @@
+// Plan builder: records a circuit under the unchanged two-pass driver, but turns chosen components ("units") into
+// CALLS of separately compiled programs instead of flattening them into the root trace.
+//
+// Why: the reference instantiates a few component shapes thousands of times (with_named_child,
+// src/circuit/streaming_mode.rs:150-247; the verifier is ~330 Fq12-sized multiplications/squarings plus glue).  A flat
+// recording costs 13 bytes of trace per gate — out of reach at 11 B gates — while a unit is recorded and compiled once
+// per (component key, liveness pattern of its outputs) and then only referenced.
+//
+// What is kept exact: the gate stream is the reference's — every gate of a unit consumes its gate id at its position
+// in the stream (the plan gives each call its gate-id and ciphertext offsets), and a unit recorded on its own makes the
+// same dead-gate decisions as inside its parent: an output wire without credits in the parent (zero fan-out there and
+// inside the component) is dead in the stand-alone recording too (StreamingRunner::set_output_liveness).
+//
+// The gates between units ("glue") are collected into segments; when the circuit is complete every wire that crosses a
+// segment boundary becomes a global wire of the plan and each glue segment is compiled as a program of its own.
+#pragma once
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <unordered_map>
+
+#include "program.hpp"
+
+namespace gsv {
+
+constexpr uint32_t PLAN_WIRE_FALSE = 0xFFFFFFFEu, PLAN_WIRE_TRUE = 0xFFFFFFFFu;  // call operands that are the constants
+
+struct PlanUnit {  // one compiled (component key, output liveness) pair
+  Trace trace;
+  std::vector<uint32_t> inputs, outputs;  // SSA ids inside the unit's own trace (outputs: only the produced ones)
+  std::vector<int32_t> out_index;         // per component output: index into `outputs`, -1 = dead, -2 = FALSE, -3 = TRUE, -(4+k) = input k passed through
+  uint64_t n_gates = 0;
+};
+
+struct PlanSegment {
+  int unit = -1;                      // >= 0: call of units[unit]; -1: glue
+  std::vector<uint32_t> in_ssa;       // unit: global SSA id (or PLAN_WIRE_*) per unit input
+  std::vector<uint32_t> out_ssa;      // unit: global SSA id per produced output
+  Trace glue;                         // glue: gates with GLOBAL SSA ids (a, b, c); n_wires unused
+};
+
+class PlanRecordMode final : public CircuitMode, public UnitHook {
+ public:
+  explicit PlanRecordMode(std::vector<std::string> unit_names) : unit_names_(std::move(unit_names)) { ver_.assign(2, 0); ver_[1] = 1; written_.assign(2, 1); }
+
+  // ---- CircuitMode (same rules as RecordMode, program.hpp)
+  WireId allocate_wire(Credits credits) override {
+    if (credits == 0) return UNREACHABLE;
+    WireId id = ver_.size();
+    ver_.push_back(0);
+    written_.push_back(0);
+    return id;
+  }
+  void evaluate_gate(const Gate& g) override {
+    uint32_t ra = read(g.a), rb = read(g.b);
+    Trace& t = glue();
+    t.type.push_back(uint8_t(g.t));
+    t.a.push_back(ra);
+    t.b.push_back(rb);
+    ++n_gates_;
+    if (g.c == UNREACHABLE) { t.c.push_back(DEAD_WIRE); return; }
+    if (g.c == FALSE_WIRE || g.c == TRUE_WIRE) gsv_panic("gate output is a constant wire");
+    t.c.push_back(define(g.c));
+  }
+  bool consume_wire(WireId w) override { return w < ver_.size() && (w < 2 || written_[size_t(w)]); }
+  void add_credits(const WireId*, size_t, Credits) override {}
+  UnitHook* unit_hook() override { return this; }
+
+  uint32_t define_input(WireId w) {
+    if (w == UNREACHABLE) gsv_panic("input wire has zero fan-out and no root credit");
+    return define(w);
+  }
+  uint32_t current(WireId w) { return read(w); }
+
+  // ---- UnitHook
+  bool call_unit(const ComponentKey& key, const Wires& inputs, const std::vector<Credits>& out_credits, const ComponentMetaTemplate& tpl, const ChildFn& body,
+                 size_t arity, Wires& out) override {
+    if (!is_unit(key)) return false;
+    using Out = ComponentMetaTemplate::Out;
+    // liveness of every output wire: credits inside the component + credits in the parent
+    std::vector<uint8_t> live(arity, 0);
+    std::string cache_key = key;
+    cache_key.push_back('!');
+    for (size_t i = 0; i < arity; ++i) {
+      live[i] = out_credits[i] != 0;
+      cache_key.push_back(live[i] ? '1' : '0');
+    }
+    auto it = unit_index_.find(cache_key);
+    if (it == unit_index_.end()) {
+      // record the component on its own (nested components are flattened into it)
+      RecordMode rec;
+      StreamingRunner run(rec, inputs.size(), body);
+      run.set_output_liveness(live);
+      auto u = std::make_unique<PlanUnit>();
+      const Wires& in = run.prepare();
+      for (WireId w : in) u->inputs.push_back(rec.define_input(w));
+      const Wires& o = run.execute();
+      if (o.size() != arity) gsv_panic("unit returned wrong arity");
+      for (size_t i = 0; i < arity; ++i) {
+        const WireId w = o[i];
+        if (w == UNREACHABLE) { u->out_index.push_back(-1); continue; }
+        if (w == FALSE_WIRE) { u->out_index.push_back(-2); continue; }
+        if (w == TRUE_WIRE) { u->out_index.push_back(-3); continue; }
+        bool passed = false;
+        for (size_t k = 0; k < in.size(); ++k) if (in[k] == w) { u->out_index.push_back(-int32_t(4 + k)); passed = true; break; }
+        if (passed) continue;
+        u->out_index.push_back(int32_t(u->outputs.size()));
+        u->outputs.push_back(rec.current(w));
+      }
+      u->trace = std::move(rec.trace());
+      u->n_gates = u->trace.size();
+      it = unit_index_.emplace(cache_key, int(units.size())).first;
+      units.push_back(std::move(u));
+    }
+    const PlanUnit& u = *units[size_t(it->second)];
+    (void)tpl; (void)Out::Internal;
+    PlanSegment seg;
+    seg.unit = it->second;
+    for (WireId w : inputs) seg.in_ssa.push_back(w == FALSE_WIRE ? PLAN_WIRE_FALSE : w == TRUE_WIRE ? PLAN_WIRE_TRUE : read(w));
+    seg.out_ssa.assign(u.outputs.size(), DEAD_WIRE);
+    out.assign(arity, UNREACHABLE);
+    for (size_t i = 0; i < arity; ++i) {
+      const int32_t oi = u.out_index[i];
+      if (oi == -1) continue;
+      if (oi == -2) { out[i] = FALSE_WIRE; continue; }
+      if (oi == -3) { out[i] = TRUE_WIRE; continue; }
+      if (oi <= -4) { out[i] = inputs[size_t(-oi - 4)]; continue; }
+      const WireId w = allocate_wire(1);  // the unit produced it: it exists in the parent whatever its remaining credits
+      seg.out_ssa[size_t(oi)] = define(w);
+      out[i] = w;
+    }
+    n_gates_ += u.n_gates;
+    segments.push_back(std::move(seg));
+    return true;
+  }
+
+  uint64_t n_gates() const { return n_gates_; }
+  uint32_t n_ssa() const { return next_ssa_; }
+  std::vector<std::unique_ptr<PlanUnit>> units;
+  std::vector<PlanSegment> segments;
+
+ private:
+  bool is_unit(const ComponentKey& key) const {
+    for (const std::string& n : unit_names_)
+      if (key.size() > n.size() && key.compare(0, n.size(), n) == 0 && (key[n.size()] == '#' || key[n.size()] == '|')) return true;
+    return false;
+  }
+  Trace& glue() {
+    if (segments.empty() || segments.back().unit >= 0) segments.emplace_back();
+    return segments.back().glue;
+  }
+  uint32_t read(WireId w) {
+    if (w == FALSE_WIRE) return 0;
+    if (w == TRUE_WIRE) return 1;
+    if (w >= ver_.size()) gsv_panic("PlanRecordMode: read of unknown wire");
+    if (!written_[size_t(w)]) gsv_panic("PlanRecordMode: wire read before it was written");
+    return ver_[size_t(w)];
+  }
+  uint32_t define(WireId w) {
+    if (w >= ver_.size() || w < 2) gsv_panic("PlanRecordMode: write to unknown wire");
+    if (next_ssa_ >= 0xFFFFFFF0u) gsv_panic("PlanRecordMode: SSA id overflow");
+    const uint32_t id = next_ssa_++;
+    ver_[size_t(w)] = id;
+    written_[size_t(w)] = 1;
+    return id;
+  }
+  std::vector<std::string> unit_names_;
+  std::unordered_map<std::string, int> unit_index_;
+  std::vector<uint32_t> ver_;
+  std::vector<uint8_t> written_;
+  uint32_t next_ssa_ = 2;  // 0 / 1 are the constants
+  uint64_t n_gates_ = 0;
+};
+
+// The finished plan in host form: programs (units first, then one per glue segment) and calls over global wire ids.
+struct BuiltPlan {
+  struct Call { int program; std::vector<uint32_t> in_globals, out_globals; };
+  std::vector<Program> programs;
+  std::vector<Trace> traces;  // kept per program so that the half-window variants can be compiled later
+  std::vector<std::vector<uint32_t>> prog_inputs, prog_outputs;
+  std::vector<Call> calls;
+  uint32_t n_inputs = 0;
+  std::vector<uint32_t> outputs;  // global ids (or PLAN_WIRE_*)
+  uint64_t n_gates = 0;
+};
+
+// inputs / outputs: global SSA ids of the circuit's inputs / outputs as PlanRecordMode handed them out.
+inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inputs, const std::vector<uint32_t>& outputs, const CompileOptions& opt = CompileOptions()) {
+  BuiltPlan bp;
+  const uint32_t nw = m.n_ssa();
+  constexpr int32_t SEG_INPUT = -1, SEG_NONE = -2;
+  std::vector<int32_t> def_seg(nw, SEG_NONE);
+  def_seg[0] = def_seg[1] = SEG_INPUT;
+  for (uint32_t w : inputs) def_seg[w] = SEG_INPUT;
+  for (size_t si = 0; si < m.segments.size(); ++si) {
+    const PlanSegment& s = m.segments[si];
+    if (s.unit >= 0) { for (uint32_t w : s.out_ssa) if (w != DEAD_WIRE) def_seg[w] = int32_t(si); }
+    else for (uint32_t c : s.glue.c) if (c != DEAD_WIRE) def_seg[c] = int32_t(si);
+  }
+  // wires read outside the segment that defines them (or circuit inputs / outputs) become globals
+  std::vector<uint8_t> crossing(nw, 0);
+  for (uint32_t w : inputs) crossing[w] = 1;
+  for (uint32_t w : outputs) if (w > 1) crossing[w] = 1;
+  for (size_t si = 0; si < m.segments.size(); ++si) {
+    const PlanSegment& s = m.segments[si];
+    if (s.unit >= 0) { for (uint32_t w : s.in_ssa) if (w < PLAN_WIRE_FALSE && w > 1) crossing[w] = 1; continue; }
+    for (size_t i = 0; i < s.glue.size(); ++i) {
+      if (s.glue.c[i] == DEAD_WIRE) continue;
+      for (uint32_t w : {s.glue.a[i], s.glue.b[i]}) if (w > 1 && def_seg[w] != int32_t(si)) crossing[w] = 1;
+    }
+  }
+  std::vector<uint32_t> global_of(nw, DEAD_WIRE);
+  uint32_t next_global = 0;
+  for (uint32_t w : inputs) global_of[w] = next_global++;
+  bp.n_inputs = next_global;
+  for (uint32_t w = 2; w < nw; ++w) if (crossing[w] && global_of[w] == DEAD_WIRE) global_of[w] = next_global++;
+  uint32_t trash = next_global;  // unit outputs nobody reads still have to land somewhere
+  uint32_t trash_len = 0;
+  auto add_program = [&](Trace&& t, std::vector<uint32_t> in, std::vector<uint32_t> out) -> int {
+    bp.programs.push_back(compile_program(t, in, out, {}, opt));
+    bp.traces.push_back(std::move(t));
+    bp.prog_inputs.push_back(std::move(in));
+    bp.prog_outputs.push_back(std::move(out));
+    return int(bp.programs.size()) - 1;
+  };
+  std::vector<int> unit_program(m.units.size(), -1);
+  for (size_t si = 0; si < m.segments.size(); ++si) {
+    PlanSegment& s = m.segments[si];
+    BuiltPlan::Call call;
+    if (s.unit >= 0) {
+      PlanUnit& u = *m.units[size_t(s.unit)];
+      if (unit_program[size_t(s.unit)] < 0) {
+        Trace copy = u.trace;  // the unit may be called again; keep its trace
+        unit_program[size_t(s.unit)] = add_program(std::move(copy), u.inputs, u.outputs);
+      }
+      call.program = unit_program[size_t(s.unit)];
+      for (uint32_t w : s.in_ssa) call.in_globals.push_back(w == PLAN_WIRE_FALSE || w == 0 ? PLAN_WIRE_FALSE : w == PLAN_WIRE_TRUE || w == 1 ? PLAN_WIRE_TRUE : global_of[w]);
+      uint32_t t_used = 0;
+      for (uint32_t w : s.out_ssa) {
+        if (w != DEAD_WIRE && global_of[w] != DEAD_WIRE) call.out_globals.push_back(global_of[w]);
+        else call.out_globals.push_back(trash + t_used++);
+      }
+      trash_len = std::max(trash_len, t_used);
+      bp.n_gates += u.n_gates;
+    } else {
+      // glue: renumber to a dense local trace: 0/1 constants, inputs = crossing wires defined elsewhere (first-use order)
+      Trace lt;
+      std::unordered_map<uint32_t, uint32_t> local;
+      std::vector<uint32_t> in_local, out_local;
+      auto loc = [&](uint32_t w) -> uint32_t {
+        if (w <= 1) return w;
+        auto f = local.find(w);
+        if (f != local.end()) return f->second;
+        const uint32_t id = lt.n_wires++;  // not defined in this segment so far: an input of the glue program
+        local.emplace(w, id);
+        in_local.push_back(id);
+        call.in_globals.push_back(global_of[w]);
+        return id;
+      };
+      // inputs must get the lowest ids (compile_program numbers input slots in list order; any ids work), gates follow
+      for (size_t i = 0; i < s.glue.size(); ++i) {
+        const uint32_t a = loc(s.glue.a[i]), b = loc(s.glue.b[i]);
+        lt.type.push_back(s.glue.type[i]); lt.a.push_back(a); lt.b.push_back(b);
+        if (s.glue.c[i] == DEAD_WIRE) { lt.c.push_back(DEAD_WIRE); continue; }
+        const uint32_t id = lt.n_wires++;
+        local[s.glue.c[i]] = id;
+        lt.c.push_back(id);
+        if (crossing[s.glue.c[i]]) { out_local.push_back(id); call.out_globals.push_back(global_of[s.glue.c[i]]); }
+      }
+      bp.n_gates += s.glue.size();
+      call.program = add_program(std::move(lt), in_local, out_local);
+      s.glue = Trace();  // free
+    }
+    bp.calls.push_back(std::move(call));
+  }
+  // trash globals sit behind the real ones
+  (void)trash_len;
+  for (uint32_t w : outputs) bp.outputs.push_back(w == 0 ? PLAN_WIRE_FALSE : w == 1 ? PLAN_WIRE_TRUE : global_of[w]);
+  return bp;
+}
+
+}  // namespace gsv

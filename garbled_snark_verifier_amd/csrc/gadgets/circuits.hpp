@@ -196,6 +196,19 @@ inline NamedCircuit make_circuit(const std::string& spec) {
       for (size_t i = 0; i < k; ++i) r = fq12::mul_montgomery(c, fq12::square_montgomery(c, r), b);
       return r.to_wires();
     };
+  } else if (name == "fq12_mix") {
+    // plan test shape: units (Fq12 square / mul) with glue between them, a unit output reused much later, and a final unit
+    // whose upper half is never read (its gates are dead: a second liveness pattern of the same component)
+    nc.n_inputs = 6096; nc.n_outputs = 1524;
+    nc.fn = [](CircuitContext& c, const Wires& in) {
+      Fq12 r = Fq12::from_wires(slice(in, 0, 3048));
+      Fq12 b = Fq12::from_wires(slice(in, 3048, 6096));
+      Fq12 t = fq12::square_montgomery(c, r);
+      Fq12 u{{fq6::add(c, t.c[0], b.c[0]), fq6::sub(c, t.c[1], b.c[1])}};
+      Fq12 v = fq12::mul_montgomery(c, u, b);
+      Fq12 w = fq12::mul_montgomery(c, v, t);
+      return w.c[0].to_wires();
+    };
   } else if (name == "gate") {
     if (!has_param || param > 10) gsv_panic("gate:T needs T in 0..10");
     GateType t = static_cast<GateType>(param);

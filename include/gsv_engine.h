@@ -110,6 +110,15 @@ void gsv_plan_destroy(gsv_plan* p);
 int gsv_plan_add_call(gsv_plan* p, const gsv_program* prog, const uint32_t* in_globals /* n_inputs of prog */, const uint32_t* out_globals /* n_outputs of prog */);
 int gsv_plan_finish(gsv_plan* p, uint32_t n_inputs, const uint32_t* output_globals, size_t n_outputs);
 int gsv_plan_counts(const gsv_plan* p, uint64_t* n_gates, uint64_t* n_ciphertexts, uint64_t* n_calls);
+int gsv_plan_io(const gsv_plan* p, uint64_t* n_inputs, uint64_t* n_outputs);
+/* Call operands naming the constant wires instead of a global wire. */
+#define GSV_PLAN_WIRE_FALSE 0xFFFFFFFEu
+#define GSV_PLAN_WIRE_TRUE 0xFFFFFFFFu
+/* Stand-alone harness: record one of the built-in restated circuits under the two-pass driver with the named components
+ * (comma separated, e.g. "fq12::mul_montgomery,fq12::square_montgomery") turned into calls; each distinct (component key,
+ * output liveness) pair is recorded and compiled once, the gates between units become glue programs.  The plan owns its
+ * programs.  (A Rust host reaches the same through a with_named_child hook; see INTEGRATION.md.) */
+int gsv_plan_from_circuit(const char* spec, const char* units_csv, gsv_plan** out);
 
 /* ---- engine --------------------------------------------------------------------------------- */
 int gsv_engine_create(int device, gsv_engine** out); /* fails with GSV_ERR_DEVICE if no HIP device */

@@ -13,6 +13,7 @@
 
 #include "../../garbled_snark_verifier_amd/csrc/engine/gate_math.hpp"
 #include "../../garbled_snark_verifier_amd/csrc/engine/host_crypto.hpp"
+#include "../../garbled_snark_verifier_amd/csrc/engine/plan_builder.hpp"
 #include "../../garbled_snark_verifier_amd/csrc/engine/program.hpp"
 #include "../../garbled_snark_verifier_amd/csrc/gadgets/circuits.hpp"
 
@@ -62,84 +63,176 @@ int hostsim_compile(const char* spec, int chain_feedback, SimProgram** out, uint
 }
 void hostsim_free(SimProgram* p) { delete p; }
 
+// One pass of one compiled program over a wire file (W labels / VB plaintext bits, at least g.n_slots entries; slots 0/1/2
+// = FALSE / TRUE / ZERO already set, inputs already in g.input_slots).  `ct` is this pass's ciphertext block in GATE order.
+static void interpret(const Program& g, bool evaluate, uint64_t gb, const Label& d, std::vector<uint8_t>& W, std::vector<uint8_t>& VB, uint8_t* ct) {
+  const AesTables& T = AesTables::fixed_key();
+  dev::PlainTables aes{{T.te[0], T.te[1], T.te[2], T.te[3]}, T.rk};
+  std::vector<uint8_t> LW(size_t(LDS_WINDOW_SLOTS) * 16, 0x5A), LB(LDS_WINDOW_SLOTS, 0);  // LDS window image
+  std::memset(&LW[0], 0, 16);  // window entry 0: the all-zero label of absent operands
+  LB[0] = 0;
+  auto lab = [&](uint32_t slot) -> uint8_t* { return (slot & SLOT_LDS_FLAG) ? &LW[size_t(slot & SLOT_INDEX_MASK) * 16] : &W[size_t(slot) * 16]; };
+  auto bit = [&](uint32_t slot) -> uint8_t& { return (slot & SLOT_LDS_FLAG) ? LB[slot & SLOT_INDEX_MASK] : VB[slot]; };
+  // the records carry PROGRAM-order ciphertext positions; `ct` is in gate order
+  std::vector<uint32_t> gate_of(g.ct_pos.size());
+  for (size_t k = 0; k < g.ct_pos.size(); ++k) gate_of[g.ct_pos[k]] = uint32_t(k);
+  for (const StepDesc& sd : g.steps) {
+    // snapshot semantics: all reads of a step see the state before the step (as on the GPU,
+    // where every lane loads its operands before anyone's store is guaranteed visible)
+    std::vector<std::pair<uint32_t, Label>> wr;
+    std::vector<std::pair<uint32_t, uint8_t>> wb;
+    wr.reserve(sd.and_cnt + sd.xor_cnt);
+    for (uint32_t k = sd.xor_cnt; k-- > 0;) {
+      const XorRec& r = g.xors[sd.xor_off + k];
+      const uint32_t sx[4] = {uint32_t(r.w0) & SLOT_MASK, uint32_t(r.w0 >> 21) & SLOT_MASK, uint32_t(r.w0 >> 42) & SLOT_MASK, uint32_t(r.w1) & SLOT_MASK};
+      const uint32_t sc = uint32_t(r.w1 >> 21) & SLOT_MASK, par = uint32_t(r.w0 >> 63);
+      Label x{{0, 0, 0, 0}};
+      uint32_t vb = par;
+      for (uint32_t q : sx) { x = dev::lxor(x, load(lab(q))); vb ^= bit(q); }
+      if (!evaluate) wr.push_back({sc, dev::lxor_if(x, d, par)});
+      else { wr.push_back({sc, x}); wb.push_back({sc, uint8_t(vb & 1u)}); }
+    }
+    for (uint32_t k = sd.and_cnt; k-- > 0;) {
+      const AndRec& r = g.ands[sd.and_off + k];
+      const uint32_t a1 = uint32_t(r.w0) & SLOT_MASK, a2 = uint32_t(r.w0 >> 21) & SLOT_MASK, b1 = uint32_t(r.w0 >> 42) & SLOT_MASK;
+      const uint32_t b2 = uint32_t(r.w1) & SLOT_MASK, sp = uint32_t(r.w1 >> 21) & SLOT_MASK, sc = uint32_t(r.w1 >> 42) & SLOT_MASK;
+      const uint32_t ty = uint32_t(r.w0 >> 63) | (uint32_t(r.w1 >> 63) << 1) | (uint32_t((r.w2 >> 40) & 1u) << 2);
+      const uint64_t gid = gb + (r.w2 & 0xFFFFFFFFFFull);
+      const uint32_t cti = gate_of[sd.and_off + k];  // the ciphertext of record k sits at position k of the device stream
+      const Label a = dev::lxor(load(lab(a1)), load(lab(a2))), b = dev::lxor(load(lab(b1)), load(lab(b2))), pl = load(lab(sp));
+      const uint32_t va = (bit(a1) ^ bit(a2)) & 1u, vb = (bit(b1) ^ bit(b2)) & 1u, vp = bit(sp) & 1u;
+      if (!evaluate) {
+        Label c0, c;
+        if (g_hasher == 1) dev::garble_and_blake3(ty, a, b, d, gid, c0, c);
+        else dev::garble_and(aes, ty, a, b, d, gid, c0, c);
+        wr.push_back({sc, dev::lxor(c0, pl)});
+        store(ct + size_t(cti) * 16, c);
+      } else {
+        Label c = load(ct + size_t(cti) * 16);
+        const Label h = g_hasher == 1 ? dev::degarble_and_blake3(ty, c, a, va, b, gid) : dev::degarble_and(aes, ty, c, a, va, b, gid);
+        wr.push_back({sc, dev::lxor(h, pl)});
+        wb.push_back({sc, uint8_t((dev::gate_eval_bit(ty, va, vb) ^ vp) & 1u)});
+      }
+    }
+    for (auto& x : wr) store(lab(x.first), x.second);
+    for (auto& x : wb) bit(x.first) = x.second;
+  }
+}
+
 // mode 0 = garble, 1 = evaluate.  Buffers as in include/gsv_engine.h (16-byte records).
 int hostsim_run(SimProgram* sp, int evaluate, uint32_t replays, uint64_t gid_base, const uint8_t delta[16], const uint8_t consts[32],
                 const uint8_t* inputs, const uint8_t* input_bits, uint8_t* cts /* in (evaluate) / out (garble): replays*n_ct*16 */,
                 uint8_t* out_labels, uint8_t* out_bits) {
   try {
     const Program& g = sp->prog;
-    const AesTables& T = AesTables::fixed_key();
-    dev::PlainTables aes{{T.te[0], T.te[1], T.te[2], T.te[3]}, T.rk};
     std::vector<uint8_t> W(size_t(g.n_slots) * 16, 0xA5);  // poison: reading a never-written slot is visible
     std::vector<uint8_t> VB(g.n_slots, 0);
-    std::vector<uint8_t> LW(size_t(LDS_WINDOW_SLOTS) * 16, 0x5A), LB(LDS_WINDOW_SLOTS, 0);  // LDS window image
-    auto lab = [&](uint32_t slot) -> uint8_t* { return (slot & SLOT_LDS_FLAG) ? &LW[size_t(slot & SLOT_INDEX_MASK) * 16] : &W[size_t(slot) * 16]; };
-    auto bit = [&](uint32_t slot) -> uint8_t& { return (slot & SLOT_LDS_FLAG) ? LB[slot & SLOT_INDEX_MASK] : VB[slot]; };
+    auto lab = [&](uint32_t slot) -> uint8_t* { if (slot & SLOT_LDS_FLAG) gsv_panic("pinned wire in the LDS window"); return &W[size_t(slot) * 16]; };
     std::memcpy(&W[0], consts, 32);
     std::memset(&W[size_t(SLOT_ZERO) * 16], 0, 16);
-    std::memset(&LW[0], 0, 16);  // window entry 0: the all-zero label of absent operands
-    VB[0] = 0; VB[1] = 1; VB[SLOT_ZERO] = 0; LB[0] = 0;
+    VB[0] = 0; VB[1] = 1; VB[SLOT_ZERO] = 0;
     for (size_t i = 0; i < g.input_slots.size(); ++i) {
       std::memcpy(&W[size_t(g.input_slots[i]) * 16], inputs + 16 * i, 16);
       if (evaluate) VB[g.input_slots[i]] = input_bits[i] ? 1 : 0;
     }
     Label d = evaluate ? Label{{0, 0, 0, 0}} : load(delta);
-    // the records carry PROGRAM-order ciphertext positions; this interpreter's `cts` buffer is in gate order
-    std::vector<uint32_t> gate_of(g.ct_pos.size());
-    for (size_t k = 0; k < g.ct_pos.size(); ++k) gate_of[g.ct_pos[k]] = uint32_t(k);
     for (uint32_t rep = 0; rep < replays; ++rep) {
-      const uint64_t gb = gid_base + uint64_t(rep) * g.n_gates;
-      uint8_t* ct = cts + size_t(rep) * g.n_ct * 16;
-      for (const StepDesc& sd : g.steps) {
-        // snapshot semantics: all reads of a step see the state before the step (as on the GPU,
-        // where every lane loads its operands before anyone's store is guaranteed visible)
-        std::vector<std::pair<uint32_t, Label>> wr;
-        std::vector<std::pair<uint32_t, uint8_t>> wb;
-        wr.reserve(sd.and_cnt + sd.xor_cnt);
-        for (uint32_t k = sd.xor_cnt; k-- > 0;) {
-          const XorRec& r = g.xors[sd.xor_off + k];
-          const uint32_t sx[4] = {uint32_t(r.w0) & SLOT_MASK, uint32_t(r.w0 >> 21) & SLOT_MASK, uint32_t(r.w0 >> 42) & SLOT_MASK, uint32_t(r.w1) & SLOT_MASK};
-          const uint32_t sc = uint32_t(r.w1 >> 21) & SLOT_MASK, par = uint32_t(r.w0 >> 63);
-          Label x{{0, 0, 0, 0}};
-          uint32_t vb = par;
-          for (uint32_t q : sx) { x = dev::lxor(x, load(lab(q))); vb ^= bit(q); }
-          if (!evaluate) wr.push_back({sc, dev::lxor_if(x, d, par)});
-          else { wr.push_back({sc, x}); wb.push_back({sc, uint8_t(vb & 1u)}); }
-        }
-        for (uint32_t k = sd.and_cnt; k-- > 0;) {
-          const AndRec& r = g.ands[sd.and_off + k];
-          const uint32_t a1 = uint32_t(r.w0) & SLOT_MASK, a2 = uint32_t(r.w0 >> 21) & SLOT_MASK, b1 = uint32_t(r.w0 >> 42) & SLOT_MASK;
-          const uint32_t b2 = uint32_t(r.w1) & SLOT_MASK, sp = uint32_t(r.w1 >> 21) & SLOT_MASK, sc = uint32_t(r.w1 >> 42) & SLOT_MASK;
-          const uint32_t ty = uint32_t(r.w0 >> 63) | (uint32_t(r.w1 >> 63) << 1) | (uint32_t((r.w2 >> 40) & 1u) << 2);
-          const uint64_t gid = gb + (r.w2 & 0xFFFFFFFFFFull);
-          const uint32_t cti = gate_of[sd.and_off + k];  // the ciphertext of record k sits at position k of the device stream
-          const Label a = dev::lxor(load(lab(a1)), load(lab(a2))), b = dev::lxor(load(lab(b1)), load(lab(b2))), pl = load(lab(sp));
-          const uint32_t va = (bit(a1) ^ bit(a2)) & 1u, vb = (bit(b1) ^ bit(b2)) & 1u, vp = bit(sp) & 1u;
-          if (!evaluate) {
-            Label c0, c;
-            if (g_hasher == 1) dev::garble_and_blake3(ty, a, b, d, gid, c0, c);
-            else dev::garble_and(aes, ty, a, b, d, gid, c0, c);
-            wr.push_back({sc, dev::lxor(c0, pl)});
-            store(ct + size_t(cti) * 16, c);
-          } else {
-            Label c = load(ct + size_t(cti) * 16);
-            const Label h = g_hasher == 1 ? dev::degarble_and_blake3(ty, c, a, va, b, gid) : dev::degarble_and(aes, ty, c, a, va, b, gid);
-            wr.push_back({sc, dev::lxor(h, pl)});
-            wb.push_back({sc, uint8_t((dev::gate_eval_bit(ty, va, vb) ^ vp) & 1u)});
-          }
-        }
-        for (auto& x : wr) store(lab(x.first), x.second);
-        for (auto& x : wb) bit(x.first) = x.second;
-      }
+      interpret(g, evaluate != 0, gid_base + uint64_t(rep) * g.n_gates, d, W, VB, cts + size_t(rep) * g.n_ct * 16);
       if (!g.fb_src_slot.empty()) {
         std::vector<uint8_t> tmp(g.fb_src_slot.size() * 16), tb(g.fb_src_slot.size());
-        for (size_t i = 0; i < g.fb_src_slot.size(); ++i) { std::memcpy(&tmp[16 * i], lab(g.fb_src_slot[i]), 16); tb[i] = bit(g.fb_src_slot[i]); }
-        for (size_t i = 0; i < g.fb_dst_slot.size(); ++i) { std::memcpy(lab(g.fb_dst_slot[i]), &tmp[16 * i], 16); bit(g.fb_dst_slot[i]) = tb[i]; }
+        for (size_t i = 0; i < g.fb_src_slot.size(); ++i) { std::memcpy(&tmp[16 * i], lab(g.fb_src_slot[i]), 16); tb[i] = VB[g.fb_src_slot[i]]; }
+        for (size_t i = 0; i < g.fb_dst_slot.size(); ++i) { std::memcpy(lab(g.fb_dst_slot[i]), &tmp[16 * i], 16); VB[g.fb_dst_slot[i]] = tb[i]; }
       }
     }
     for (size_t i = 0; i < g.output_slots.size(); ++i) {
       std::memcpy(out_labels + 16 * i, lab(g.output_slots[i]), 16);
-      if (out_bits) out_bits[i] = bit(g.output_slots[i]);
+      if (out_bits) out_bits[i] = VB[g.output_slots[i]];
+    }
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// ---- plans (plan_builder.hpp): a circuit recorded with some components as calls of separately compiled programs,
+// interpreted call by call over a global wire array — the host-side twin of engine.cpp's launch_plan.
+struct SimPlan {
+  BuiltPlan bp;
+  uint64_t n_ct = 0;
+};
+int hostsim_plan_build(const char* spec, const char* units_csv, SimPlan** out, uint64_t* info /* 8: n_inputs n_outputs n_gates n_ct n_calls n_programs n_globals n_unit_programs */) {
+  try {
+    std::vector<std::string> names;
+    std::string cur;
+    for (const char* q = units_csv;; ++q) {
+      if (*q == ',' || *q == 0) { if (!cur.empty()) names.push_back(cur); cur.clear(); if (!*q) break; }
+      else cur.push_back(*q);
+    }
+    NamedCircuit nc = make_circuit(spec);
+    PlanRecordMode mode(names);
+    StreamingRunner run(mode, nc.n_inputs, nc.fn);
+    std::vector<uint32_t> in_ssa, out_ssa;
+    for (WireId w : run.prepare()) in_ssa.push_back(mode.define_input(w));
+    for (WireId w : run.execute()) out_ssa.push_back(mode.current(w));
+    CompileOptions opt;
+    if (const char* e = getenv("GSV_FUSE")) opt.fuse = atoi(e) != 0;
+    auto sp = std::make_unique<SimPlan>();
+    const size_t n_units = mode.units.size();
+    sp->bp = finish_plan(mode, in_ssa, out_ssa, opt);
+    if (sp->bp.n_gates != mode.n_gates()) gsv_panic("plan gate count differs from the recorded stream");
+    uint32_t n_globals = sp->bp.n_inputs;
+    for (auto& c : sp->bp.calls) {
+      sp->n_ct += sp->bp.programs[size_t(c.program)].n_ct;
+      for (uint32_t w : c.in_globals) if (w < PLAN_WIRE_FALSE) n_globals = std::max(n_globals, w + 1);
+      for (uint32_t w : c.out_globals) n_globals = std::max(n_globals, w + 1);
+    }
+    if (info) {
+      info[0] = sp->bp.n_inputs; info[1] = sp->bp.outputs.size(); info[2] = sp->bp.n_gates; info[3] = sp->n_ct; info[4] = sp->bp.calls.size();
+      info[5] = sp->bp.programs.size(); info[6] = n_globals; info[7] = n_units;
+    }
+    *out = sp.release();
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+void hostsim_plan_free(SimPlan* p) { delete p; }
+int hostsim_plan_run(SimPlan* sp, int evaluate, uint64_t gid_base, const uint8_t delta[16], const uint8_t consts[32], const uint8_t* inputs,
+                     const uint8_t* input_bits, uint8_t* cts, uint8_t* out_labels, uint8_t* out_bits) {
+  try {
+    const BuiltPlan& bp = sp->bp;
+    uint32_t n_globals = bp.n_inputs;
+    for (auto& c : bp.calls) {
+      for (uint32_t w : c.in_globals) if (w < PLAN_WIRE_FALSE) n_globals = std::max(n_globals, w + 1);
+      for (uint32_t w : c.out_globals) n_globals = std::max(n_globals, w + 1);
+    }
+    std::vector<uint8_t> G(size_t(n_globals) * 16, 0xC3), GB(n_globals, 0);
+    for (uint32_t i = 0; i < bp.n_inputs; ++i) { std::memcpy(&G[size_t(i) * 16], inputs + 16 * i, 16); if (evaluate) GB[i] = input_bits[i] ? 1 : 0; }
+    const Label d = evaluate ? Label{{0, 0, 0, 0}} : load(delta);
+    uint64_t gid = gid_base, ct_off = 0;
+    for (const BuiltPlan::Call& c : bp.calls) {
+      const Program& g = bp.programs[size_t(c.program)];
+      std::vector<uint8_t> W(size_t(g.n_slots) * 16, 0xA5), VB(g.n_slots, 0);
+      std::memcpy(&W[0], consts, 32);
+      std::memset(&W[size_t(SLOT_ZERO) * 16], 0, 16);
+      VB[0] = 0; VB[1] = 1; VB[SLOT_ZERO] = 0;
+      for (size_t i = 0; i < c.in_globals.size(); ++i) {
+        const uint32_t w = c.in_globals[i], dst = g.input_slots[i];
+        if (w == PLAN_WIRE_FALSE) { std::memcpy(&W[size_t(dst) * 16], &W[0], 16); VB[dst] = 0; }
+        else if (w == PLAN_WIRE_TRUE) { std::memcpy(&W[size_t(dst) * 16], &W[16], 16); VB[dst] = 1; }
+        else { std::memcpy(&W[size_t(dst) * 16], &G[size_t(w) * 16], 16); VB[dst] = GB[w]; }
+      }
+      interpret(g, evaluate != 0, gid, d, W, VB, cts + ct_off * 16);
+      for (size_t i = 0; i < c.out_globals.size(); ++i) {
+        const uint32_t src = g.output_slots[i];
+        if (src & SLOT_LDS_FLAG) gsv_panic("program output in the LDS window");
+        std::memcpy(&G[size_t(c.out_globals[i]) * 16], &W[size_t(src) * 16], 16);
+        GB[c.out_globals[i]] = VB[src];
+      }
+      gid += g.n_gates;
+      ct_off += g.n_ct;
+    }
+    for (size_t i = 0; i < bp.outputs.size(); ++i) {
+      const uint32_t w = bp.outputs[i];
+      if (w == PLAN_WIRE_FALSE) { std::memcpy(out_labels + 16 * i, consts, 16); if (out_bits) out_bits[i] = 0; }
+      else if (w == PLAN_WIRE_TRUE) { std::memcpy(out_labels + 16 * i, consts + 16, 16); if (out_bits) out_bits[i] = 1; }
+      else { std::memcpy(out_labels + 16 * i, &G[size_t(w) * 16], 16); if (out_bits) out_bits[i] = GB[w]; }
     }
     return 0;
   } catch (const std::exception& e) { g_err = e.what(); return 1; }

@@ -22,6 +22,9 @@ def lib():
         L.hostsim_compile.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.hostsim_free.argtypes = [C.c_void_p]
         L.hostsim_run.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
+        L.hostsim_plan_build.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.hostsim_plan_free.argtypes = [C.c_void_p]
+        L.hostsim_plan_run.argtypes = [C.c_void_p, C.c_int, C.c_uint64, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
         L.hostsim_labels_from_seed.argtypes = [C.c_uint64, C.c_uint64, u8p]
         L.hostsim_cbcmac.argtypes = [u8p, C.c_uint64, u8p]
         L.hostsim_aes_ttable.argtypes = [u8p, u8p]
@@ -126,3 +129,41 @@ def blake3_hash(label, gid):
     o = np.zeros(16, np.uint8)
     lib().hostsim_blake3_hash(_p(i), gid, _p(o))
     return o.tobytes()
+
+
+PLAN_FIELDS = ["n_inputs", "n_outputs", "n_gates", "n_ct", "n_calls", "n_programs", "n_globals", "n_unit_programs"]
+
+
+class SimPlan:
+    """A circuit recorded with some components as calls of separately compiled programs (plan_builder.hpp), interpreted
+    call by call on the host."""
+
+    def __init__(self, spec, units):
+        h = C.c_void_p()
+        info = np.zeros(len(PLAN_FIELDS), np.uint64)
+        if lib().hostsim_plan_build(spec.encode(), ",".join(units).encode(), C.byref(h), info.ctypes.data_as(C.POINTER(C.c_uint64))):
+            raise RuntimeError(lib().hostsim_last_error().decode())
+        self.h = h
+        self.info = dict(zip(PLAN_FIELDS, (int(x) for x in info)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().hostsim_plan_free(self.h)
+
+    def garble(self, delta, consts, inputs, gid_base=0):
+        cts = np.zeros((self.info["n_ct"], 16), np.uint8)
+        out = np.zeros((self.info["n_outputs"], 16), np.uint8)
+        if lib().hostsim_plan_run(self.h, 0, gid_base, _p(np.ascontiguousarray(delta, np.uint8)), _p(np.ascontiguousarray(consts, np.uint8)),
+                                  _p(np.ascontiguousarray(inputs, np.uint8)), None, _p(cts), _p(out), None):
+            raise RuntimeError(lib().hostsim_last_error().decode())
+        return out, cts
+
+    def evaluate(self, consts_active, inputs_active, input_bits, cts, gid_base=0):
+        out = np.zeros((self.info["n_outputs"], 16), np.uint8)
+        bits = np.zeros(self.info["n_outputs"], np.uint8)
+        cts = np.ascontiguousarray(cts, np.uint8).copy()
+        z = np.zeros(16, np.uint8)
+        if lib().hostsim_plan_run(self.h, 1, gid_base, _p(z), _p(np.ascontiguousarray(consts_active, np.uint8)), _p(np.ascontiguousarray(inputs_active, np.uint8)),
+                                  _p(np.ascontiguousarray(input_bits, np.uint8)), _p(cts), _p(out), _p(bits)):
+            raise RuntimeError(lib().hostsim_last_error().decode())
+        return out, bits

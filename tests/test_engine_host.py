@@ -173,3 +173,31 @@ def test_gate_fusion_shapes_and_unfused_path(monkeypatch):
     monkeypatch.setenv("GSV_LDS_SLOTS", "0")
     monkeypatch.delenv("GSV_FUSE")
     _hostsim_check("fq_add", 4)
+
+
+@pytest.mark.parametrize("spec,units,seed", [
+    ("driver_mix", ["test::mixed_outputs"], 5),           # unit with pass-through / constant / internal outputs, nested child flattened
+    ("driver_mix", ["test::inner"], 5),                   # unit nested inside a flattened component; one of its outputs is dead
+    ("driver_mix", ["test::inner", "bigint::add"], 6),    # the same component with two output-liveness patterns (add / add_without_carry)
+    ("random_circuit:3", ["test::random_block"], 1),      # 145 calls, 72 distinct unit programs, glue in between
+    ("random_circuit:8", ["test::random_block"], 2),
+    ("fq_complex", ["fp254::montgomery_reduce", "bigint::mul_karatsuba"], 2),  # two units reused (3 programs for 5 calls)
+])
+def test_plan_builder_matches_flat_stream(spec, units, seed):
+    """plan_builder.hpp: the circuit recorded with some components as CALLS of separately compiled programs must give the
+    reference's stream exactly — ciphertexts in gate order across call boundaries, CBC-MAC, output labels, and on evaluation the
+    oracle's plaintext bits — including components whose outputs are dead / constants / passed-through inputs in the parent."""
+    sp = h.SimPlan(spec, units)
+    ref = o.garble(spec, seed)
+    n_in = ref.n_in
+    labs = h.labels_from_seed(seed, 3 + n_in)
+    delta, consts, inputs = labs[0], labs[1:3], labs[3:]
+    out, cts = sp.garble(delta, consts, inputs)
+    assert sp.info["n_gates"] == int(ref.gate_counts.sum()) and sp.info["n_calls"] >= 3
+    assert ref.n_ciphertexts == cts.shape[0] and (ref.ciphertexts == cts).all() and (ref.output_label0 == out).all()
+    assert h.cbcmac(cts) == ref.ct_hash.tobytes()
+    bits = np.random.default_rng(seed).integers(0, 2, n_in).astype(np.uint8)
+    act = np.where(bits[:, None] == 1, inputs ^ delta[None, :], inputs)
+    oa, ob = sp.evaluate(np.stack([consts[0], consts[1] ^ delta]), act, bits, cts)
+    eo, _, _ = o.execute(spec, bits)
+    assert (ob == eo).all() and (oa == np.where(ob[:, None] == 1, out ^ delta[None, :], out)).all()

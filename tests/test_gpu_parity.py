@@ -366,3 +366,47 @@ def test_plan_of_component_programs(engine):
         eb, _, _ = o.execute("fq12_sqmul", bits[i])
         assert (ob[i] == eb).all() and (oa[i] == np.where(ob[i][:, None] == 1, out[i] ^ delta[i][None, :], out[i])).all()
     sess.close()
+
+
+def test_plan_built_from_circuit_with_units(engine):
+    """Plan.from_circuit: the two-pass driver records `fq12_mix` (square; Fq6 add/sub glue; mul; mul with the square's output
+    reused; only c0 of the last product is returned, so that call runs a second variant of Fq12::mul with half of its outputs
+    dead) with the Fq12 components as calls.  Three unit programs + one glue program serve five calls; the stream, hash,
+    output labels and evaluated bits must be those of the flat circuit (oracle)."""
+    import garbled_snark_verifier_amd as gsv
+    plan = gsv.Plan.from_circuit("fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"])
+    assert plan.info["n_calls"] == 4 and plan.info["n_inputs"] == 6096 and plan.info["n_outputs"] == 1524
+    seeds = [41, 42, 43]
+    B = len(seeds)
+    n_in = plan.info["n_inputs"]
+    labs = [gsv.labels_from_seed(s, n_in) for s in seeds]
+    delta = np.stack([x[0] for x in labs]); consts = np.stack([np.stack([x[1], x[2]]) for x in labs]); inputs = np.stack([x[3] for x in labs])
+    sess = gsv.Session(engine, plan, B)
+    sess.set_garble_inputs(delta, consts, inputs)
+    sess.garble(0)
+    out = sess.read_outputs()
+    for i, seed in enumerate(seeds):
+        ref = o.garble("fq12_mix", seed, capture_ct=False)
+        assert plan.info["n_gates"] == int(ref.gate_counts.sum()) and plan.info["n_ciphertexts"] == ref.n_ciphertexts
+        assert sess.ciphertext_hash(i) == ref.ct_hash.tobytes()
+        assert (out[i] == ref.output_label0).all()
+    bits = np.random.default_rng(3).integers(0, 2, size=(B, n_in)).astype(np.uint8)
+    active = np.where(bits[:, :, None] == 1, inputs ^ delta[:, None, :], inputs)
+    sess.set_evaluate_inputs(np.stack([consts[:, 0], consts[:, 1] ^ delta], axis=1), active, bits)
+    sess.evaluate(0)
+    oa, ob = sess.read_outputs(with_bits=True)
+    for i in range(B):
+        eb, _, _ = o.execute("fq12_mix", bits[i])
+        assert (ob[i] == eb).all() and (oa[i] == np.where(ob[i][:, None] == 1, out[i] ^ delta[i][None, :], out[i])).all()
+    sess.close()
+    # small circuits with many calls, dead / constant / pass-through unit outputs (same cases as the host-interpreter test)
+    for spec, units, seed in (("driver_mix", ["test::inner", "bigint::add"], 6), ("random_circuit:3", ["test::random_block"], 1)):
+        p2 = gsv.Plan.from_circuit(spec, units)
+        ref = o.garble(spec, seed)
+        d, f, t, inp = gsv.labels_from_seed(seed, ref.n_in)
+        s2 = gsv.Session(engine, p2, 1)
+        s2.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
+        s2.garble(0)
+        assert s2.ciphertext_hash(0) == ref.ct_hash.tobytes() and (s2.read_outputs()[0] == ref.output_label0).all()
+        assert (s2.read_ciphertexts(0, 0, ref.n_ciphertexts) == ref.ciphertexts).all()
+        s2.close()
