@@ -47,7 +47,7 @@ EXPORTS = [
     "gsv_session_set_garble_inputs", "gsv_session_garble", "gsv_session_set_evaluate_inputs", "gsv_session_upload_ciphertexts",
     "gsv_session_evaluate", "gsv_session_set_hasher", "gsv_session_sync", "gsv_session_last_kernel_ms", "gsv_session_read_outputs", "gsv_session_read_ciphertexts",
     "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_commit_labels",
-    "gsv_plan_from_circuit", "gsv_plan_io", "gsv_plan_create", "gsv_plan_destroy", "gsv_plan_add_call", "gsv_plan_finish", "gsv_plan_counts", "gsv_session_create_plan",
+    "gsv_plan_from_circuit", "gsv_plan_io", "gsv_plan_create", "gsv_plan_destroy", "gsv_plan_add_call", "gsv_plan_finish", "gsv_plan_counts", "gsv_session_create_plan", "gsv_session_create_plan_ex",
     "gsv_session_garble_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
 ]
 
@@ -102,6 +102,7 @@ def lib():
         L.gsv_plan_finish.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32), C.c_size_t]
         L.gsv_plan_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.gsv_session_create_plan.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
+        L.gsv_session_create_plan_ex.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(vp)]
         L.gsv_session_garble_streaming.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_uint64, C.c_int, u8p]
         L.gsv_session_instances_per_workgroup.argtypes = [vp, C.POINTER(C.c_int)]
         L.gsv_session_enable_step_clock.argtypes = [vp]
@@ -290,14 +291,14 @@ class Plan:
 class Session:
     """A batch of instances on one program (gsv_session) or, with a Plan, on a sequence of component programs."""
 
-    def __init__(self, engine, program, n_instances=1, replays=1, ct_capacity_replays=None):
+    def __init__(self, engine, program, n_instances=1, replays=1, ct_capacity_replays=None, retain_stream=True):
         self.engine, self.program = engine, program
         self.n, self.replays = n_instances, replays
         self.ct_cap = replays if ct_capacity_replays is None else ct_capacity_replays
         self.h = C.c_void_p()
         if isinstance(program, Plan):
             assert replays == 1
-            _chk(lib().gsv_session_create_plan(engine.h, program.h, n_instances, C.byref(self.h)))
+            _chk(lib().gsv_session_create_plan_ex(engine.h, program.h, n_instances, int(bool(retain_stream)), C.byref(self.h)))
         else:
             _chk(lib().gsv_session_create(engine.h, program.h, n_instances, replays, self.ct_cap, C.byref(self.h)))
         self.n_in, self.n_out = program.info["n_inputs"], program.info["n_outputs"]

@@ -106,6 +106,8 @@ struct gsv_session {
   const gsv_plan* plan = nullptr;
   Program facade;
   uint32_t global_base = 0;  // first slot of the plan's global region
+  bool plan_retain = true;   // plan sessions: whole ciphertext stream kept on the device (else one call block: streaming only)
+  uint64_t plan_max_block = 0;
   struct CallDev { DevProgram dp; void *pre_src = nullptr, *pre_dst = nullptr, *post_src = nullptr, *post_dst = nullptr; };
   std::vector<CallDev> call_dev;
   void* plan_out_slots = nullptr;
@@ -115,7 +117,7 @@ struct gsv_session {
   bool ran = false, last_eval = false, garbled = false;
   int hasher = 0;  // 0 AesNiHasher, 1 Blake3Hasher
   std::vector<uint64_t> ct_uploaded;  // per instance: records supplied by gsv_session_upload_ciphertexts
-  uint64_t ct_stride() const { return plan ? plan->n_ct : ct_cap * p->prog.n_ct; }  // n_ct does not depend on the variant
+  uint64_t ct_stride() const { return plan ? (plan_retain ? plan->n_ct : plan_max_block) : ct_cap * p->prog.n_ct; }  // n_ct does not depend on the variant
 };
 
 extern "C" {
@@ -454,7 +456,8 @@ int gsv_plan_counts(const gsv_plan* p, uint64_t* n_gates, uint64_t* n_ciphertext
   if (n_calls) *n_calls = p->calls.size();
   return GSV_OK;
 }
-int gsv_session_create_plan(gsv_engine* e, const gsv_plan* plan, size_t n_instances, gsv_session** out) {
+int gsv_session_create_plan(gsv_engine* e, const gsv_plan* plan, size_t n_instances, gsv_session** out) { return gsv_session_create_plan_ex(e, plan, n_instances, 1, out); }
+int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_instances, int retain_stream, gsv_session** out) {
   if (!e || !plan || !out || n_instances == 0 || !plan->finished || plan->calls.empty()) return fail(GSV_ERR_INVALID, "bad argument / plan not finished");
   HIPCHK(hipSetDevice(e->device));
   std::unique_ptr<gsv_session> s(new gsv_session());
@@ -474,6 +477,8 @@ int gsv_session_create_plan(gsv_engine* e, const gsv_plan* plan, size_t n_instan
     scratch = std::max(scratch, s->call_prog(k).n_slots);
   }
   s->global_base = scratch;
+  s->plan_retain = retain_stream != 0;
+  for (size_t k = 0; k < plan->calls.size(); ++k) s->plan_max_block = std::max<uint64_t>(s->plan_max_block, s->call_prog(k).n_ct);
   if (uint64_t(scratch) + plan->n_globals > 0xFFFFFFF0ull) return fail(GSV_ERR_CIRCUIT, "plan wire file too large");
   Program& f = s->facade;
   f.n_slots = scratch + plan->n_globals;
@@ -501,7 +506,7 @@ int gsv_session_create_plan(gsv_engine* e, const gsv_plan* plan, size_t n_instan
   HIPCHK(hipMalloc(&s->W, n_instances * size_t(f.n_slots) * 16));
   HIPCHK(hipMalloc(&s->VB, n_instances * size_t(f.n_slots)));
   HIPCHK(hipMemset(s->VB, 0, n_instances * size_t(f.n_slots)));
-  const size_t ct_bytes = n_instances * size_t(plan->n_ct) * 16;
+  const size_t ct_bytes = n_instances * size_t(s->ct_stride()) * 16;
   HIPCHK(hipMalloc(&s->CT, ct_bytes ? ct_bytes : 16));
   HIPCHK(hipMalloc(&s->delta, n_instances * 16));
   HIPCHK(hipMalloc(&s->out, n_instances * f.output_slots.size() * 16 + 16));
@@ -643,37 +648,48 @@ static int launch(gsv_session* s, uint64_t gate_id_base, bool eval, uint64_t rep
   return GSV_OK;
 }
 // One kernel launch per call (a component runs for >100 ms, a launch costs ~10 us), wire hand-over by two small copy kernels.
-static int launch_plan(gsv_session* s, uint64_t gate_id_base, bool eval) {
+static int launch_plan_call(gsv_session* s, size_t k, uint64_t gate_id_base, bool eval) {
   const Program& f = s->facade;
-  HIPCHK(hipSetDevice(s->e->device));
-  HIPCHK(hipEventRecord(s->ev0, s->e->stream));
-  for (size_t k = 0; k < s->plan->calls.size(); ++k) {
-    const PlanCall& c = s->plan->calls[k];
-    const Program& g = s->call_prog(k);
-    const gsv_session::CallDev& cd = s->call_dev[k];
-    if (gsvk_copy_slots(s->W, eval ? s->VB : nullptr, f.n_slots, static_cast<const uint32_t*>(cd.pre_src), static_cast<const uint32_t*>(cd.pre_dst), uint32_t(c.in_globals.size()),
-                        uint32_t(s->n_inst), s->e->stream) != 0) return fail(GSV_ERR_DEVICE, "copy launch failed");
-    dev::KernelArgs ka{};
-    ka.steps = cd.dp.steps; ka.ands = cd.dp.ands; ka.xors = cd.dp.xors;
-    ka.W = static_cast<uint4*>(s->W); ka.VB = static_cast<uint8_t*>(s->VB); ka.CT = static_cast<uint4*>(s->CT);
-    ka.delta = static_cast<const uint4*>(s->delta); ka.te = static_cast<const uint32_t*>(s->e->te);
-    ka.ct_stride = s->ct_stride(); ka.ct_offset = c.ct_off; ka.gid_base = gate_id_base + c.gid_off; ka.n_gates = g.n_gates; ka.n_ct = g.n_ct;
-    ka.n_steps = uint32_t(g.steps.size()); ka.n_slots = f.n_slots; ka.replays = 1; ka.rep_base = 0; ka.ct_cap_replays = 1;
-    ka.n_instances = uint32_t(s->n_inst); ka.hasher = uint32_t(s->hasher); ka.instances_per_wg = s->ni;
-    if (ka.n_steps) {
-      int lrc = gsvk_launch_program(&ka, uint32_t(s->n_inst), eval ? 1 : 0, s->e->stream);
-      if (lrc != 0) return fail(GSV_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipError_t(lrc)));
-    }
-    if (gsvk_copy_slots(s->W, eval ? s->VB : nullptr, f.n_slots, static_cast<const uint32_t*>(cd.post_src), static_cast<const uint32_t*>(cd.post_dst), uint32_t(c.out_globals.size()),
-                        uint32_t(s->n_inst), s->e->stream) != 0) return fail(GSV_ERR_DEVICE, "copy launch failed");
+  const PlanCall& c = s->plan->calls[k];
+  const Program& g = s->call_prog(k);
+  const gsv_session::CallDev& cd = s->call_dev[k];
+  if (gsvk_copy_slots(s->W, eval ? s->VB : nullptr, f.n_slots, static_cast<const uint32_t*>(cd.pre_src), static_cast<const uint32_t*>(cd.pre_dst), uint32_t(c.in_globals.size()),
+                      uint32_t(s->n_inst), s->e->stream) != 0) return fail(GSV_ERR_DEVICE, "copy launch failed");
+  dev::KernelArgs ka{};
+  ka.steps = cd.dp.steps; ka.ands = cd.dp.ands; ka.xors = cd.dp.xors;
+  ka.W = static_cast<uint4*>(s->W); ka.VB = static_cast<uint8_t*>(s->VB); ka.CT = static_cast<uint4*>(s->CT);
+  ka.delta = static_cast<const uint4*>(s->delta); ka.te = static_cast<const uint32_t*>(s->e->te);
+  ka.ct_stride = s->ct_stride(); ka.ct_offset = s->plan_retain ? c.ct_off : 0; ka.gid_base = gate_id_base + c.gid_off; ka.n_gates = g.n_gates; ka.n_ct = g.n_ct;
+  ka.n_steps = uint32_t(g.steps.size()); ka.n_slots = f.n_slots; ka.replays = 1; ka.rep_base = 0; ka.ct_cap_replays = 1;
+  ka.n_instances = uint32_t(s->n_inst); ka.hasher = uint32_t(s->hasher); ka.instances_per_wg = s->ni;
+  if (ka.n_steps) {
+    int lrc = gsvk_launch_program(&ka, uint32_t(s->n_inst), eval ? 1 : 0, s->e->stream);
+    if (lrc != 0) return fail(GSV_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipError_t(lrc)));
   }
-  HIPCHK(hipEventRecord(s->ev1, s->e->stream));
+  if (gsvk_copy_slots(s->W, eval ? s->VB : nullptr, f.n_slots, static_cast<const uint32_t*>(cd.post_src), static_cast<const uint32_t*>(cd.post_dst), uint32_t(c.out_globals.size()),
+                      uint32_t(s->n_inst), s->e->stream) != 0) return fail(GSV_ERR_DEVICE, "copy launch failed");
+  return GSV_OK;
+}
+static int gather_plan_outputs(gsv_session* s, bool eval) {
+  const Program& f = s->facade;
   if (!f.output_slots.empty()) {
     if (gsvk_gather_outputs(s->W, s->VB, f.n_slots, static_cast<const uint32_t*>(s->plan_out_slots), uint32_t(f.output_slots.size()), uint32_t(s->n_inst), s->out,
                             eval ? s->out_bits : nullptr, s->e->stream) != 0) return fail(GSV_ERR_DEVICE, "gather launch failed");
   }
   s->ran = true; s->last_eval = eval;
   return GSV_OK;
+}
+// One kernel launch per call (a component runs for >100 ms, a launch costs ~10 us), wire hand-over by two small copy kernels.
+static int launch_plan(gsv_session* s, uint64_t gate_id_base, bool eval) {
+  if (!s->plan_retain) return fail(GSV_ERR_INVALID, "this plan session keeps one call block of ciphertexts only: use gsv_session_garble_streaming");
+  HIPCHK(hipSetDevice(s->e->device));
+  HIPCHK(hipEventRecord(s->ev0, s->e->stream));
+  for (size_t k = 0; k < s->plan->calls.size(); ++k) {
+    int rc = launch_plan_call(s, k, gate_id_base, eval);
+    if (rc) return rc;
+  }
+  HIPCHK(hipEventRecord(s->ev1, s->e->stream));
+  return gather_plan_outputs(s, eval);
 }
 
 int gsv_session_garble(gsv_session* s, uint64_t gate_id_base) {
@@ -690,9 +706,9 @@ int gsv_session_garble(gsv_session* s, uint64_t gate_id_base) {
 // (ciphertext_repository.rs:94-127).
 int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes) {
   if (!s || !hashes) return fail(GSV_ERR_INVALID, "null argument");
-  if (s->plan) return fail(GSV_ERR_INVALID, "streaming drain of plan sessions is not implemented (use gsv_session_ciphertext_hash)");
   const Program& g = s->prog();
-  const uint64_t n_ct = g.n_ct, total = s->replays, seg = s->ct_cap;
+  // program sessions: segments of one ring (ct_cap replays of n_ct records); plan sessions: one call per segment
+  const uint64_t n_ct = s->plan ? s->plan_max_block : g.n_ct, total = s->plan ? s->plan->calls.size() : s->replays, seg = s->plan ? 1 : s->ct_cap;
   const size_t n_inst = s->n_inst;
   size_t T = n_threads > 0 ? size_t(n_threads) : std::max<size_t>(1, std::min<size_t>(n_inst, std::thread::hardware_concurrency()));
   T = std::min(T, n_inst);
@@ -738,13 +754,12 @@ int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const ch
     for (Worker& w : workers) for (void*& q : w.pinned) ok = ok && hipHostMalloc(&q, chunk * 16, hipHostMallocDefault) == hipSuccess;
     if (!ok) { release_workers(); close_files(); return fail(GSV_ERR_DEVICE, "cannot allocate the drain buffers"); }
   }
-  // one drain = all instances x `n_rep` replays sitting in the gate-order buffer
-  auto drain = [&](uint64_t n_rep, std::vector<std::thread>& pool) {
+  // one drain = all instances x the `n` records per instance sitting in the gate-order buffer
+  auto drain = [&](uint64_t n, std::vector<std::thread>& pool) {
     for (size_t t = 0; t < T; ++t)
-      pool.emplace_back([&, t, n_rep]() {
+      pool.emplace_back([&, t, n]() {
         if (hipSetDevice(s->e->device) != hipSuccess) { err = 1; return; }
         Worker& w = workers[t];
-        const uint64_t n = n_rep * n_ct;
         for (size_t i = t; i < n_inst && !err && n; i += T) {
           const uint8_t* src = static_cast<const uint8_t*>(s->ct_gate) + i * seg_records * 16;
           // a copy holds a slot of the gate from issue to completion
@@ -773,18 +788,35 @@ int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const ch
   int rc = GSV_OK;
   for (uint64_t r0 = 0; r0 < total && rc == GSV_OK; r0 += seg) {
     const uint64_t r1 = std::min(total, r0 + seg);
-    // ring slots are (replay % ct_cap): a segment starts at a multiple of ct_cap, so its replays sit in slots 0..n_rep-1
-    rc = launch(s, gate_id_base, false, r0, r1 - r0);
-    if (rc != GSV_OK) break;
-    join(cur);
-    if (gsvk_gather_segment(s->CT, s->ct_stride(), s->dp.ct_pos, n_ct, uint32_t(r1 - r0), uint32_t(n_inst), s->ct_gate, seg_records, s->e->stream) != 0) {
-      rc = fail(GSV_ERR_DEVICE, "ciphertext gather launch failed");
-      break;
+    uint64_t n_records;  // per instance, in this segment
+    if (s->plan) {
+      const size_t k = size_t(r0);
+      rc = launch_plan_call(s, k, gate_id_base, false);
+      if (rc != GSV_OK) break;
+      join(cur);
+      const Program& cp = s->call_prog(k);
+      n_records = cp.n_ct;
+      const uint8_t* block = static_cast<const uint8_t*>(s->CT) + (s->plan_retain ? s->plan->calls[k].ct_off : 0) * 16;
+      if (gsvk_gather_segment(block, s->ct_stride(), s->call_dev[k].dp.ct_pos, cp.n_ct, 1, uint32_t(n_inst), s->ct_gate, seg_records, s->e->stream) != 0) {
+        rc = fail(GSV_ERR_DEVICE, "ciphertext gather launch failed");
+        break;
+      }
+    } else {
+      // ring slots are (replay % ct_cap): a segment starts at a multiple of ct_cap, so its replays sit in slots 0..n_rep-1
+      rc = launch(s, gate_id_base, false, r0, r1 - r0);
+      if (rc != GSV_OK) break;
+      join(cur);
+      n_records = (r1 - r0) * n_ct;
+      if (gsvk_gather_segment(s->CT, s->ct_stride(), s->dp.ct_pos, n_ct, uint32_t(r1 - r0), uint32_t(n_inst), s->ct_gate, seg_records, s->e->stream) != 0) {
+        rc = fail(GSV_ERR_DEVICE, "ciphertext gather launch failed");
+        break;
+      }
     }
     if (hipStreamSynchronize(s->e->stream) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "kernel failed"); break; }
-    drain(r1 - r0, cur);
+    drain(n_records, cur);
   }
   join(cur);
+  if (rc == GSV_OK && s->plan) rc = gather_plan_outputs(s, false);
   release_workers();
   close_files();
   if (rc != GSV_OK) return rc;
@@ -797,7 +829,7 @@ int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base) {
   if (!s) return fail(GSV_ERR_INVALID, "null session");
   // EvaluateMode panics with "Ciphertext source exhausted at gate .." when the source runs dry (evaluate_mode.rs:139-142).
   const uint64_t need = s->prog().n_ct * s->replays;
-  if (s->ct_cap != s->replays) return fail(GSV_ERR_INVALID, "evaluate needs the whole ciphertext stream resident (ct_capacity_replays == replays)");
+  if (s->ct_cap != s->replays || (s->plan && !s->plan_retain)) return fail(GSV_ERR_INVALID, "evaluate needs the whole ciphertext stream resident (ct_capacity_replays == replays)");
   if (!s->garbled)
     for (size_t i = 0; i < s->n_inst; ++i)
       if (s->ct_uploaded[i] < need)
@@ -885,6 +917,7 @@ int gsv_session_read_outputs(gsv_session* s, uint8_t* labels, uint8_t* bits) {
 }
 int gsv_session_read_ciphertexts(gsv_session* s, size_t instance, uint64_t first, uint64_t n_records, uint8_t* out) {
   if (!s || instance >= s->n_inst || (!out && n_records)) return fail(GSV_ERR_INVALID, "bad argument");
+  if (s->plan && !s->plan_retain) return fail(GSV_ERR_INVALID, "this plan session does not retain the ciphertext stream");
   if (first + n_records > s->ct_stride()) return fail(GSV_ERR_INVALID, "range exceeds the retained ciphertext stream");
   HIPCHK(hipSetDevice(s->e->device));
   HIPCHK(hipStreamSynchronize(s->e->stream));
@@ -897,7 +930,7 @@ int gsv_session_read_ciphertexts(gsv_session* s, size_t instance, uint64_t first
 }
 int gsv_session_ciphertext_hash(gsv_session* s, size_t instance, uint8_t hash[16]) {
   if (!s || instance >= s->n_inst || !hash) return fail(GSV_ERR_INVALID, "bad argument");
-  if (s->ct_cap != s->replays) return fail(GSV_ERR_INVALID, "the session retains only part of the stream (ct_capacity_replays < replays)");
+  if (s->ct_cap != s->replays || (s->plan && !s->plan_retain)) return fail(GSV_ERR_INVALID, "the session retains only part of the stream (ct_capacity_replays < replays)");
   HIPCHK(hipSetDevice(s->e->device));
   HIPCHK(hipStreamSynchronize(s->e->stream));
   const uint64_t total = s->ct_stride();

@@ -137,6 +137,9 @@ void gsv_session_destroy(gsv_session* s);
 /* A session over a plan: same calls as a program session (set_*_inputs, garble, evaluate, read_outputs, read / upload
  * ciphertexts, ciphertext_hash; one pass, whole stream retained).  The plan and its programs must outlive the session. */
 int gsv_session_create_plan(gsv_engine* e, const gsv_plan* plan, size_t n_instances, gsv_session** out);
+/* retain_stream = 0: the device keeps ONE call block of ciphertexts (plans of any length); such a session is driven by
+ * gsv_session_garble_streaming only (each call's block is drained while the next call runs). */
+int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_instances, int retain_stream, gsv_session** out);
 
 /* Garble (GarbleMode): per instance i: delta[16i..], const_label0 = {false.label0, true.label0}
  * (32 B per instance), input_label0 (n_inputs*16 B per instance).  Asynchronous on the engine stream. */

@@ -399,6 +399,16 @@ def test_plan_built_from_circuit_with_units(engine):
         eb, _, _ = o.execute("fq12_mix", bits[i])
         assert (ob[i] == eb).all() and (oa[i] == np.where(ob[i][:, None] == 1, out[i] ^ delta[i][None, :], out[i])).all()
     sess.close()
+    # the same plan without retaining the stream: one call block on the device, drained call by call while the next call runs
+    st = gsv.Session(engine, plan, B, retain_stream=False)
+    st.set_garble_inputs(delta, consts, inputs)
+    hashes = st.garble_streaming(threads=2)
+    assert (st.read_outputs() == out).all()
+    for i, seed in enumerate(seeds):
+        assert hashes[i] == o.garble("fq12_mix", seed, capture_ct=False).ct_hash.tobytes()
+    with pytest.raises(gsv.GsvError):
+        st.garble(0)  # a streaming-only session cannot keep the whole stream
+    st.close()
     # small circuits with many calls, dead / constant / pass-through unit outputs (same cases as the host-interpreter test)
     for spec, units, seed in (("driver_mix", ["test::inner", "bigint::add"], 6), ("random_circuit:3", ["test::random_block"], 1)):
         p2 = gsv.Plan.from_circuit(spec, units)
