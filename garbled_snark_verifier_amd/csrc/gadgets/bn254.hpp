@@ -341,8 +341,12 @@ inline Fq12 square_montgomery(CircuitContext& c, const Fq12& a) {  // fq12.rs:31
   });
   return Fq12::from_wires(out);
 }
-// Granger-Scott squaring in the cyclotomic subgroup (fq12.rs:326-392; NOT a component: its gates belong to the caller)
-inline Fq12 cyclotomic_square_montgomery(CircuitContext& c, const Fq12& a) {
+// Granger-Scott squaring in the cyclotomic subgroup (fq12.rs:326-392).  The reference does not make this a component; a
+// component boundary changes nothing in the gate stream (a wire is dead iff nothing reads it, wherever the boundary is),
+// and having one lets a plan record the 186 cyclotomic squarings of the final exponentiation once instead of 186 times.
+inline Fq12 cyclotomic_square_montgomery(CircuitContext& c0_, const Fq12& a_) {
+  Wires out = component(c0_, KeyBuilder("fq12::cyclotomic_square_montgomery"), a_.to_wires(), N, [](CircuitContext& c, const Wires& in) {
+  const Fq12 a = Fq12::from_wires(in);
   const Fq2 &c0 = a.c[0].c[0], &c1 = a.c[0].c[1], &c2 = a.c[0].c[2], &c3 = a.c[1].c[0], &c4 = a.c[1].c[1], &c5 = a.c[1].c[2];
   // one "Fq4 squaring" of the pair (x, y); which operand is multiplied by the non-residue follows the reference line by line
   auto fp4 = [&](const Fq2& x, const Fq2& y, const Fq2& beta_of, const Fq2& added_to, Fq2& t_even, Fq2& t_odd) {
@@ -369,7 +373,9 @@ inline Fq12 cyclotomic_square_montgomery(CircuitContext& c, const Fq12& a) {
   Fq2 z2 = three_plus(t5_beta, c3);  // :379-382
   Fq2 z1 = three_plus(t1, c4);       // :384-386
   Fq2 z5 = three_plus(t3, c5);       // :388-390
-  return Fq12{{Fq6{{z0, z4, z3}}, Fq6{{z2, z1, z5}}}};
+  return Fq12{{Fq6{{z0, z4, z3}}, Fq6{{z2, z1, z5}}}}.to_wires();
+  });
+  return Fq12::from_wires(out);
 }
 }  // namespace fq12
 

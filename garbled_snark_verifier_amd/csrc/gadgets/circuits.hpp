@@ -6,6 +6,7 @@
 //   fq12_mul_chain:K    Groth16-shaped SYNTHETIC for config 4: r <- Fq12::mul(r, b), K times
 //   fq12_square, fq12_cyclotomic_square   Fq12::square_montgomery (fq12.rs:311-324), cyclotomic_square_montgomery (fq12.rs:326-392)
 //   fq12_sqmul, fq12_sqmul_chain:K        square-and-multiply link r <- Fq12::mul(Fq12::square(r), b)
+//   fq_inverse, fq2_inverse, fq12_inverse, fq12_frobenius:I, fq12_conjugate, final_exp   (bn254_ext.hpp)
 //   fq_complex          tests/streaming_evaluate.rs:401-407  ((a^2)*b + a)
 //   gate:T              tests/streaming_evaluate.rs:136-213  (one gate of discriminant T at the root)
 //   driver_mix          credits / dead-gate / pass-through / constant edge cases (circuit/mod.rs:419-836 shapes)
@@ -14,7 +15,7 @@
 #include <algorithm>
 #include <string>
 
-#include "bn254.hpp"
+#include "bn254_ext.hpp"
 
 namespace gsv {
 
@@ -196,6 +197,26 @@ inline NamedCircuit make_circuit(const std::string& spec) {
       for (size_t i = 0; i < k; ++i) r = fq12::mul_montgomery(c, fq12::square_montgomery(c, r), b);
       return r.to_wires();
     };
+  } else if (name == "fq_inverse") {  // Fq::inverse_montgomery (fp254impl.rs:333-678)
+    nc.n_inputs = 254; nc.n_outputs = 254;
+    nc.fn = [](CircuitContext& c, const Wires& in) { return fq::inverse_montgomery(c, in); };
+  } else if (name == "fq2_inverse") {
+    nc.n_inputs = 508; nc.n_outputs = 508;
+    nc.fn = [](CircuitContext& c, const Wires& in) { return fq2::inverse_montgomery(c, Fq2::from_wires(in)).to_wires(); };
+  } else if (name == "fq12_inverse") {
+    nc.n_inputs = 3048; nc.n_outputs = 3048;
+    nc.fn = [](CircuitContext& c, const Wires& in) { return fq12::inverse_montgomery(c, Fq12::from_wires(in)).to_wires(); };
+  } else if (name == "fq12_frobenius") {  // fq12_frobenius:I, I in 1..3
+    if (!has_param || param < 1 || param > 3) gsv_panic("fq12_frobenius:I needs I in 1..3");
+    const size_t i = size_t(param);
+    nc.n_inputs = 3048; nc.n_outputs = 3048;
+    nc.fn = [i](CircuitContext& c, const Wires& in) { return fq12::frobenius_montgomery(c, Fq12::from_wires(in), i).to_wires(); };
+  } else if (name == "fq12_conjugate") {
+    nc.n_inputs = 3048; nc.n_outputs = 3048;
+    nc.fn = [](CircuitContext& c, const Wires& in) { return fq12::conjugate(c, Fq12::from_wires(in)).to_wires(); };
+  } else if (name == "final_exp") {  // final_exponentiation_montgomery (final_exponentiation.rs:99-135), ~2.9 B gates
+    nc.n_inputs = 3048; nc.n_outputs = 3048;
+    nc.fn = [](CircuitContext& c, const Wires& in) { return fq12::final_exponentiation_montgomery(c, Fq12::from_wires(in)).to_wires(); };
   } else if (name == "fq12_mix") {
     // plan test shape: units (Fq12 square / mul) with glue between them, a unit output reused much later, and a final unit
     // whose upper half is never read (its gates are dead: a second liveness pattern of the same component)

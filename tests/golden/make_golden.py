@@ -28,6 +28,10 @@ CASES = [
     ("fq12_square", "fq12_square", 1, 2),
     ("fq12_cyclotomic_square", "fq12_cyclotomic_square", 1, 3),
     ("fq12_sqmul_chain:2", "fq12_sqmul", 2, 4),
+    ("fq_inverse", "fq_inverse", 1, 5),
+    ("fq12_inverse", "fq12_inverse", 1, 6),
+    ("fq12_frobenius:1", "fq12_frobenius:1", 1, 7),
+    ("final_exp", "final_exp", 1, 8),  # 3,519,328,217 gates: the oracle needs ~2.5 minutes for this one
 ]
 
 

@@ -125,6 +125,80 @@ def test_fq12_square_and_cyclotomic_square():
     assert ints_of(ob) != [(x * T.RINV) % P for x in T.f12_flatten(T.f12_mul(A, A))]
 
 
+def _to_m(v):
+    return [(x * (o.FQ_R % P)) % P for x in v]
+
+
+def _from_m(v):
+    return [(x * T.RINV) % P for x in v]
+
+
+_ONE12 = T.f12_unflatten([1] + [0] * 11)
+
+
+def _f12_pow(x, e):
+    r = _ONE12
+    while e:
+        if e & 1:
+            r = T.f12_mul(r, x)
+        x = T.f12_mul(x, x)
+        e >>= 1
+    return r
+
+
+def test_inverses_frobenius_conjugate():
+    """bn254_ext.hpp against Python field arithmetic: Fq::inverse_montgomery (binary extended Euclid, fp254impl.rs:333-678;
+    edge values 1, 2, p-1, a multiple of 2^40), Fq2 / Fq12 inverses (a * a^-1 == 1), Frobenius maps x -> x^(p^i) for i = 1..3
+    (which also pins the tabulated ark_bn254 coefficients), conjugation = x^(p^6)."""
+    random.seed(1)
+    for a in [random.randrange(1, P), 1, 2, P - 1, 12 * (1 << 40)]:
+        ob, gc, _ = o.execute("fq_inverse", bits_of(_to_m([a])), capacity=200_000)
+        assert ints_of(ob) == _to_m([pow(a, -1, P)])
+    assert int(gc.sum()) == 23_200_543
+    a = [random.randrange(P) for _ in range(2)]
+    ob, _, _ = o.execute("fq2_inverse", bits_of(_to_m(a)), capacity=200_000)
+    assert T.f2_mul(tuple(a), tuple(_from_m(ints_of(ob)))) == (1, 0)
+    a = [random.randrange(P) for _ in range(12)]
+    A = T.f12_unflatten(a)
+    ob, gc, _ = o.execute("fq12_inverse", bits_of(_to_m(a)), capacity=200_000)
+    assert T.f12_flatten(T.f12_mul(A, T.f12_unflatten(_from_m(ints_of(ob))))) == T.f12_flatten(_ONE12)
+    assert int(gc.sum()) == 61_993_136
+    for i in (1, 2, 3):
+        ob, _, _ = o.execute("fq12_frobenius:%d" % i, bits_of(_to_m(a)), capacity=200_000)
+        assert _from_m(ints_of(ob)) == T.f12_flatten(_f12_pow(A, P ** i))
+    ob, _, _ = o.execute("fq12_conjugate", bits_of(_to_m(a)), capacity=200_000)
+    assert _from_m(ints_of(ob)) == T.f12_flatten(_f12_pow(A, P ** 6))
+
+
+@pytest.mark.skipif(not os.environ.get("GSV_SLOW"), reason="3.5 B gates through the CPU oracle take ~95 s; set GSV_SLOW=1")
+def test_final_exponentiation_matches_native_formula():
+    """final_exponentiation_montgomery (final_exponentiation.rs:99-135) in Execute mode == the reference's own native formula
+    (final_exponentiation.rs:37-63) evaluated with Python field arithmetic, and the result is an r-th root of unity."""
+    X = 4965661367192848881
+    conj = lambda x: _f12_pow(x, P ** 6)
+    inv = lambda x: _f12_pow(x, P ** 12 - 2)
+    frob = lambda x, i: _f12_pow(x, P ** i)
+    nx = lambda f: conj(_f12_pow(f, X))
+    m = T.f12_mul
+
+    def native(f):
+        u = m(inv(f), conj(f)); r = m(frob(u, 2), u)
+        y0 = nx(r); y1 = m(y0, y0); y2 = m(y1, y1); y3 = m(y2, y1)
+        y4 = nx(y3); y5 = m(y4, y4); y6 = nx(y5); y7 = conj(y3); y8 = conj(y6)
+        y9 = m(y8, y4); y10 = m(y9, y7); y11 = m(y10, y1); y12 = m(y10, y4); y13 = m(y12, r)
+        y14 = frob(y11, 1); y15 = m(y14, y13); y16 = frob(y10, 2); y17 = m(y16, y15); y18 = m(conj(r), y11)
+        return m(frob(y18, 3), y17)
+
+    random.seed(3)
+    a = [random.randrange(P) for _ in range(12)]
+    ob, gc, peak = o.execute("final_exp", bits_of(_to_m(a)), capacity=400_000)
+    got = _from_m(ints_of(ob))
+    assert got == T.f12_flatten(native(T.f12_unflatten(a)))
+    assert int(gc.sum()) == 3_519_328_217 and int(gc[:8].sum()) == 955_048_646 and peak < 30_000
+    r_order = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    assert T.f12_flatten(_f12_pow(T.f12_unflatten(got), r_order)) == T.f12_flatten(_ONE12)
+
+
 def test_host_constants_match_python():
     """Off-circuit constants embedded in csrc/gadgets/bn254.hpp (fq.rs:56-76, fp254impl.rs:21-66)."""
     src = open(os.path.join(os.path.dirname(__file__), "..", "garbled_snark_verifier_amd", "csrc", "gadgets", "bn254.hpp")).read()
