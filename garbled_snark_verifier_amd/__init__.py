@@ -312,9 +312,13 @@ class Session:
     def garble(self, gate_id_base=0):
         _chk(lib().gsv_session_garble(self.h, gate_id_base))
 
-    def garble_streaming(self, gate_id_base=0, directory=None, first_index=0, threads=0):
+    def garble_streaming(self, gate_id_base=0, directory=None, first_index=0, threads=0, discard=False):
         """Garble all replays while the host drains the stream segment by segment: returns the per-instance ciphertext
-        hashes (CBC-MAC, gate order) and, with `directory`, writes gc_<first_index+i>.bin files."""
+        hashes (CBC-MAC, gate order) and, with `directory`, writes gc_<first_index+i>.bin files.  discard=True: garble
+        only, the ciphertexts are dropped."""
+        if discard:
+            _chk(lib().gsv_session_garble_streaming(self.h, gate_id_base, None, 0, 0, None))
+            return None
         out = np.zeros((self.n, 16), np.uint8)
         _chk(lib().gsv_session_garble_streaming(self.h, gate_id_base, directory.encode() if directory else None, first_index, threads, _p(out)))
         return [bytes(out[i]) for i in range(self.n)]

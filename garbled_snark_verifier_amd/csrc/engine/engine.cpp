@@ -705,7 +705,21 @@ int gsv_session_garble(gsv_session* s, uint64_t gate_id_base) {
 // serial per instance, hence the host: ciphertext_hasher.rs:23-29) and optionally append them to gc_<index>.bin
 // (ciphertext_repository.rs:94-127).
 int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes) {
-  if (!s || !hashes) return fail(GSV_ERR_INVALID, "null argument");
+  if (!s) return fail(GSV_ERR_INVALID, "null argument");
+  if (!hashes && !dir) {  // discard the stream: garble only (output labels, device-rate measurements of long plans / chains)
+    HIPCHK(hipSetDevice(s->e->device));
+    HIPCHK(hipEventRecord(s->ev0, s->e->stream));
+    int rc = GSV_OK;
+    if (s->plan) {
+      for (size_t k = 0; k < s->plan->calls.size() && rc == GSV_OK; ++k) rc = launch_plan_call(s, k, gate_id_base, false);
+      if (rc == GSV_OK) { HIPCHK(hipEventRecord(s->ev1, s->e->stream)); rc = gather_plan_outputs(s, false); }
+    } else {
+      rc = launch(s, gate_id_base, false);
+    }
+    if (rc == GSV_OK) { HIPCHK(hipStreamSynchronize(s->e->stream)); s->garbled = !s->plan || s->plan_retain; }
+    return rc;
+  }
+  if (!hashes) return fail(GSV_ERR_INVALID, "null hash buffer");
   const Program& g = s->prog();
   // program sessions: segments of one ring (ct_cap replays of n_ct records); plan sessions: one call per segment
   const uint64_t n_ct = s->plan ? s->plan_max_block : g.n_ct, total = s->plan ? s->plan->calls.size() : s->replays, seg = s->plan ? 1 : s->ct_cap;

@@ -160,7 +160,8 @@ int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base);
  * ring's size, allocated on first use), copied out while the next segment is garbled, folded into every instance's CBC-MAC
  * by n_threads host threads (0 = one per instance up to the core count; the chain is serial per instance) and, if dir is
  * not NULL, appended to <dir>/gc_<first_index + instance>.bin.  hashes receives n_instances x 16 bytes.  Output labels
- * are read with gsv_session_read_outputs as after gsv_session_garble. */
+ * are read with gsv_session_read_outputs as after gsv_session_garble.  With hashes == NULL and dir == NULL the stream is
+ * discarded (garbling only: output labels, device-rate measurements). */
 int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes);
 
 /* Gate PRF (`H: GateHasher`, src/hashers/mod.rs:15-20): GSV_HASHER_AES = AesNiHasher (default; the benchmarked
