@@ -33,11 +33,26 @@ struct PlanUnit {  // one compiled (component key, output liveness) pair
   uint64_t n_gates = 0;
 };
 
+// A glue segment in canonical form: operands are either a wire defined earlier in the same segment (its definition index:
+// the SSA ids defined inside a segment are consecutive) or the k-th distinct outside wire in first-use order.  Segments
+// with the same canonical form (a gadget that is not a component, repeated) share one compiled program.
+struct GlueClass {
+  std::vector<uint8_t> type;
+  std::vector<uint32_t> a, b;     // bit 31 set: outside wire (low bits = ordinal, 0x7FFFFFFE / 0x7FFFFFFF = FALSE / TRUE); else definition index
+  std::vector<uint8_t> live;      // 1 = the gate defines a wire (definition index = number of live gates before it)
+  uint32_t n_inputs = 0, n_defs = 0;
+  std::vector<uint8_t> out_mark;  // per definition index: read outside its segment by SOME instance
+  uint64_t hash = 0;
+  bool same(const GlueClass& o) const { return n_inputs == o.n_inputs && type == o.type && a == o.a && b == o.b && live == o.live; }
+};
 struct PlanSegment {
   int unit = -1;                      // >= 0: call of units[unit]; -1: glue
-  std::vector<uint32_t> in_ssa;       // unit: global SSA id (or PLAN_WIRE_*) per unit input
+  std::vector<uint32_t> in_ssa;       // global SSA id (or PLAN_WIRE_*) per unit input / per outside wire of a glue segment
   std::vector<uint32_t> out_ssa;      // unit: global SSA id per produced output
-  Trace glue;                         // glue: gates with GLOBAL SSA ids (a, b, c); n_wires unused
+  Trace glue;                         // glue being recorded: gates with GLOBAL SSA ids; emptied when the segment is closed
+  int glue_class = -1;                // glue: index into PlanRecordMode::glue_classes
+  uint32_t base_ssa = 0;              // glue: SSA id of its first definition
+  uint64_t n_gates = 0;
 };
 
 class PlanRecordMode final : public CircuitMode, public UnitHook {
@@ -131,14 +146,61 @@ class PlanRecordMode final : public CircuitMode, public UnitHook {
       out[i] = w;
     }
     n_gates_ += u.n_gates;
+    close_glue();
     segments.push_back(std::move(seg));
     return true;
+  }
+  // Canonicalise the glue segment under construction (if any) and file it under its class.
+  void close_glue() {
+    if (segments.empty() || segments.back().unit >= 0 || segments.back().glue_class >= 0) return;
+    PlanSegment& s = segments.back();
+    const Trace& t = s.glue;
+    GlueClass g;
+    const size_t n = t.size();
+    g.type = t.type; g.a.resize(n); g.b.resize(n); g.live.resize(n);
+    uint32_t base = 0;
+    bool have_base = false;
+    for (size_t i = 0; i < n; ++i) if (t.c[i] != DEAD_WIRE) { base = t.c[i]; have_base = true; break; }
+    std::unordered_map<uint32_t, uint32_t> ordinal;
+    uint32_t defs = 0;
+    uint64_t h = 1469598103934665603ull;
+    auto mixh = [&](uint64_t v) { h ^= v; h *= 1099511628211ull; };
+    auto enc = [&](uint32_t w) -> uint32_t {
+      if (w == 0) return 0xFFFFFFFEu;
+      if (w == 1) return 0xFFFFFFFFu;
+      if (have_base && w >= base && w < base + defs) return w - base;  // defined earlier in this segment
+      auto f = ordinal.find(w);
+      if (f != ordinal.end()) return 0x80000000u | f->second;
+      const uint32_t k = uint32_t(s.in_ssa.size());
+      ordinal.emplace(w, k);
+      s.in_ssa.push_back(w);
+      return 0x80000000u | k;
+    };
+    for (size_t i = 0; i < n; ++i) {
+      g.a[i] = enc(t.a[i]); g.b[i] = enc(t.b[i]);
+      g.live[i] = t.c[i] != DEAD_WIRE;
+      if (g.live[i]) { if (t.c[i] != base + defs) gsv_panic("internal: glue definitions are not consecutive"); ++defs; }
+      mixh(g.type[i]); mixh(g.a[i]); mixh(g.b[i]); mixh(g.live[i]);
+    }
+    g.n_inputs = uint32_t(s.in_ssa.size()); g.n_defs = defs; g.hash = h;
+    g.out_mark.assign(defs, 0);
+    s.base_ssa = base; s.n_gates = n;
+    auto range = class_index_.equal_range(h);
+    for (auto it = range.first; it != range.second; ++it)
+      if (glue_classes[size_t(it->second)]->same(g)) { s.glue_class = it->second; break; }
+    if (s.glue_class < 0) {
+      s.glue_class = int(glue_classes.size());
+      class_index_.emplace(h, s.glue_class);
+      glue_classes.push_back(std::make_unique<GlueClass>(std::move(g)));
+    }
+    s.glue = Trace();  // the canonical form (kept once per class) is all that is needed from here on
   }
 
   uint64_t n_gates() const { return n_gates_; }
   uint32_t n_ssa() const { return next_ssa_; }
   std::vector<std::unique_ptr<PlanUnit>> units;
   std::vector<PlanSegment> segments;
+  std::vector<std::unique_ptr<GlueClass>> glue_classes;
 
  private:
   bool is_unit(const ComponentKey& key) const {
@@ -147,7 +209,7 @@ class PlanRecordMode final : public CircuitMode, public UnitHook {
     return false;
   }
   Trace& glue() {
-    if (segments.empty() || segments.back().unit >= 0) segments.emplace_back();
+    if (segments.empty() || segments.back().unit >= 0 || segments.back().glue_class >= 0) segments.emplace_back();
     return segments.back().glue;
   }
   uint32_t read(WireId w) {
@@ -167,6 +229,7 @@ class PlanRecordMode final : public CircuitMode, public UnitHook {
   }
   std::vector<std::string> unit_names_;
   std::unordered_map<std::string, int> unit_index_;
+  std::unordered_multimap<uint64_t, int> class_index_;
   std::vector<uint32_t> ver_;
   std::vector<uint8_t> written_;
   uint32_t next_ssa_ = 2;  // 0 / 1 are the constants
@@ -187,6 +250,7 @@ struct BuiltPlan {
 
 // inputs / outputs: global SSA ids of the circuit's inputs / outputs as PlanRecordMode handed them out.
 inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inputs, const std::vector<uint32_t>& outputs, const CompileOptions& opt = CompileOptions()) {
+  m.close_glue();
   BuiltPlan bp;
   const uint32_t nw = m.n_ssa();
   constexpr int32_t SEG_INPUT = -1, SEG_NONE = -2;
@@ -196,27 +260,26 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
   for (size_t si = 0; si < m.segments.size(); ++si) {
     const PlanSegment& s = m.segments[si];
     if (s.unit >= 0) { for (uint32_t w : s.out_ssa) if (w != DEAD_WIRE) def_seg[w] = int32_t(si); }
-    else for (uint32_t c : s.glue.c) if (c != DEAD_WIRE) def_seg[c] = int32_t(si);
+    else { const uint32_t nd = m.glue_classes[size_t(s.glue_class)]->n_defs; for (uint32_t d = 0; d < nd; ++d) def_seg[s.base_ssa + d] = int32_t(si); }
   }
-  // wires read outside the segment that defines them (or circuit inputs / outputs) become globals
+  // wires read outside the segment that defines them (or circuit inputs / outputs) become globals; a glue segment's
+  // outside wires are exactly its in_ssa list
   std::vector<uint8_t> crossing(nw, 0);
   for (uint32_t w : inputs) crossing[w] = 1;
   for (uint32_t w : outputs) if (w > 1) crossing[w] = 1;
-  for (size_t si = 0; si < m.segments.size(); ++si) {
-    const PlanSegment& s = m.segments[si];
-    if (s.unit >= 0) { for (uint32_t w : s.in_ssa) if (w < PLAN_WIRE_FALSE && w > 1) crossing[w] = 1; continue; }
-    for (size_t i = 0; i < s.glue.size(); ++i) {
-      if (s.glue.c[i] == DEAD_WIRE) continue;
-      for (uint32_t w : {s.glue.a[i], s.glue.b[i]}) if (w > 1 && def_seg[w] != int32_t(si)) crossing[w] = 1;
-    }
+  for (const PlanSegment& s : m.segments) for (uint32_t w : s.in_ssa) if (w < PLAN_WIRE_FALSE && w > 1) crossing[w] = 1;
+  // a glue class exports a definition if ANY of its instances has that wire read elsewhere
+  for (const PlanSegment& s : m.segments) {
+    if (s.unit >= 0) continue;
+    GlueClass& g = *m.glue_classes[size_t(s.glue_class)];
+    for (uint32_t d = 0; d < g.n_defs; ++d) if (crossing[s.base_ssa + d]) g.out_mark[d] = 1;
   }
   std::vector<uint32_t> global_of(nw, DEAD_WIRE);
   uint32_t next_global = 0;
   for (uint32_t w : inputs) global_of[w] = next_global++;
   bp.n_inputs = next_global;
   for (uint32_t w = 2; w < nw; ++w) if (crossing[w] && global_of[w] == DEAD_WIRE) global_of[w] = next_global++;
-  uint32_t trash = next_global;  // unit outputs nobody reads still have to land somewhere
-  uint32_t trash_len = 0;
+  const uint32_t trash = next_global;  // outputs nobody reads in this instance still have to land somewhere
   auto add_program = [&](Trace&& t, std::vector<uint32_t> in, std::vector<uint32_t> out) -> int {
     bp.programs.push_back(compile_program(t, in, out, {}, opt));
     bp.traces.push_back(std::move(t));
@@ -224,9 +287,9 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
     bp.prog_outputs.push_back(std::move(out));
     return int(bp.programs.size()) - 1;
   };
-  std::vector<int> unit_program(m.units.size(), -1);
-  for (size_t si = 0; si < m.segments.size(); ++si) {
-    PlanSegment& s = m.segments[si];
+  std::vector<int> unit_program(m.units.size(), -1), class_program(m.glue_classes.size(), -1);
+  std::vector<std::vector<uint32_t>> class_outputs(m.glue_classes.size());  // exported definition indices
+  for (const PlanSegment& s : m.segments) {
     BuiltPlan::Call call;
     if (s.unit >= 0) {
       PlanUnit& u = *m.units[size_t(s.unit)];
@@ -241,41 +304,40 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
         if (w != DEAD_WIRE && global_of[w] != DEAD_WIRE) call.out_globals.push_back(global_of[w]);
         else call.out_globals.push_back(trash + t_used++);
       }
-      trash_len = std::max(trash_len, t_used);
       bp.n_gates += u.n_gates;
     } else {
-      // glue: renumber to a dense local trace: 0/1 constants, inputs = crossing wires defined elsewhere (first-use order)
-      Trace lt;
-      std::unordered_map<uint32_t, uint32_t> local;
-      std::vector<uint32_t> in_local, out_local;
-      auto loc = [&](uint32_t w) -> uint32_t {
-        if (w <= 1) return w;
-        auto f = local.find(w);
-        if (f != local.end()) return f->second;
-        const uint32_t id = lt.n_wires++;  // not defined in this segment so far: an input of the glue program
-        local.emplace(w, id);
-        in_local.push_back(id);
-        call.in_globals.push_back(global_of[w]);
-        return id;
-      };
-      // inputs must get the lowest ids (compile_program numbers input slots in list order; any ids work), gates follow
-      for (size_t i = 0; i < s.glue.size(); ++i) {
-        const uint32_t a = loc(s.glue.a[i]), b = loc(s.glue.b[i]);
-        lt.type.push_back(s.glue.type[i]); lt.a.push_back(a); lt.b.push_back(b);
-        if (s.glue.c[i] == DEAD_WIRE) { lt.c.push_back(DEAD_WIRE); continue; }
-        const uint32_t id = lt.n_wires++;
-        local[s.glue.c[i]] = id;
-        lt.c.push_back(id);
-        if (crossing[s.glue.c[i]]) { out_local.push_back(id); call.out_globals.push_back(global_of[s.glue.c[i]]); }
+      const size_t ci = size_t(s.glue_class);
+      const GlueClass& g = *m.glue_classes[ci];
+      if (class_program[ci] < 0) {
+        // dense local trace: 0 / 1 constants, inputs 2 .. 2+n_inputs-1 (first-use order), definitions behind them
+        Trace lt;
+        lt.n_wires = 2 + g.n_inputs + g.n_defs;
+        auto dec = [&](uint32_t e) -> uint32_t {
+          if (e == 0xFFFFFFFEu) return 0;
+          if (e == 0xFFFFFFFFu) return 1;
+          return (e & 0x80000000u) ? 2 + (e & 0x7FFFFFFFu) : 2 + g.n_inputs + e;
+        };
+        uint32_t d = 0;
+        for (size_t i = 0; i < g.type.size(); ++i) {
+          lt.type.push_back(g.type[i]); lt.a.push_back(dec(g.a[i])); lt.b.push_back(dec(g.b[i]));
+          lt.c.push_back(g.live[i] ? 2 + g.n_inputs + d++ : DEAD_WIRE);
+        }
+        std::vector<uint32_t> in_local, out_local;
+        for (uint32_t k = 0; k < g.n_inputs; ++k) in_local.push_back(2 + k);
+        for (uint32_t k = 0; k < g.n_defs; ++k) if (g.out_mark[k]) { out_local.push_back(2 + g.n_inputs + k); class_outputs[ci].push_back(k); }
+        class_program[ci] = add_program(std::move(lt), in_local, out_local);
       }
-      bp.n_gates += s.glue.size();
-      call.program = add_program(std::move(lt), in_local, out_local);
-      s.glue = Trace();  // free
+      call.program = class_program[ci];
+      for (uint32_t w : s.in_ssa) call.in_globals.push_back(global_of[w]);
+      uint32_t t_used = 0;
+      for (uint32_t k : class_outputs[ci]) {
+        const uint32_t w = s.base_ssa + k;
+        call.out_globals.push_back(crossing[w] ? global_of[w] : trash + t_used++);
+      }
+      bp.n_gates += s.n_gates;
     }
     bp.calls.push_back(std::move(call));
   }
-  // trash globals sit behind the real ones
-  (void)trash_len;
   for (uint32_t w : outputs) bp.outputs.push_back(w == 0 ? PLAN_WIRE_FALSE : w == 1 ? PLAN_WIRE_TRUE : global_of[w]);
   return bp;
 }
