@@ -48,7 +48,7 @@ EXPORTS = [
     "gsv_session_evaluate", "gsv_session_set_hasher", "gsv_session_sync", "gsv_session_last_kernel_ms", "gsv_session_read_outputs", "gsv_session_read_ciphertexts",
     "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_commit_labels",
     "gsv_plan_from_circuit", "gsv_plan_io", "gsv_plan_create", "gsv_plan_destroy", "gsv_plan_add_call", "gsv_plan_finish", "gsv_plan_counts", "gsv_session_create_plan", "gsv_session_create_plan_ex",
-    "gsv_session_garble_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
+    "gsv_session_garble_streaming", "gsv_session_evaluate_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
 ]
 
 
@@ -103,6 +103,7 @@ def lib():
         L.gsv_plan_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.gsv_session_create_plan.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
         L.gsv_session_create_plan_ex.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(vp)]
+        L.gsv_session_evaluate_streaming.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_uint64, u8p]
         L.gsv_session_garble_streaming.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_uint64, C.c_int, u8p]
         L.gsv_session_instances_per_workgroup.argtypes = [vp, C.POINTER(C.c_int)]
         L.gsv_session_enable_step_clock.argtypes = [vp]
@@ -321,6 +322,12 @@ class Session:
             return None
         out = np.zeros((self.n, 16), np.uint8)
         _chk(lib().gsv_session_garble_streaming(self.h, gate_id_base, directory.encode() if directory else None, first_index, threads, _p(out)))
+        return [bytes(out[i]) for i in range(self.n)]
+
+    def evaluate_streaming(self, directory, first_index=0, gate_id_base=0):
+        """Evaluate with the ciphertexts read from gc_<first_index+i>.bin segment by segment; returns the files' CBC-MACs."""
+        out = np.zeros((self.n, 16), np.uint8)
+        _chk(lib().gsv_session_evaluate_streaming(self.h, gate_id_base, directory.encode(), first_index, _p(out)))
         return [bytes(out[i]) for i in range(self.n)]
 
     def set_evaluate_inputs(self, const_active, input_active, input_bits):

@@ -810,8 +810,8 @@ int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const ch
       join(cur);
       const Program& cp = s->call_prog(k);
       n_records = cp.n_ct;
-      const uint8_t* block = static_cast<const uint8_t*>(s->CT) + (s->plan_retain ? s->plan->calls[k].ct_off : 0) * 16;
-      if (gsvk_gather_segment(block, s->ct_stride(), s->call_dev[k].dp.ct_pos, cp.n_ct, 1, uint32_t(n_inst), s->ct_gate, seg_records, s->e->stream) != 0) {
+      uint8_t* block = static_cast<uint8_t*>(s->CT) + (s->plan_retain ? s->plan->calls[k].ct_off : 0) * 16;
+      if (gsvk_gather_segment(block, s->ct_stride(), s->call_dev[k].dp.ct_pos, cp.n_ct, 1, uint32_t(n_inst), s->ct_gate, seg_records, 0, s->e->stream) != 0) {
         rc = fail(GSV_ERR_DEVICE, "ciphertext gather launch failed");
         break;
       }
@@ -821,7 +821,7 @@ int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const ch
       if (rc != GSV_OK) break;
       join(cur);
       n_records = (r1 - r0) * n_ct;
-      if (gsvk_gather_segment(s->CT, s->ct_stride(), s->dp.ct_pos, n_ct, uint32_t(r1 - r0), uint32_t(n_inst), s->ct_gate, seg_records, s->e->stream) != 0) {
+      if (gsvk_gather_segment(s->CT, s->ct_stride(), s->dp.ct_pos, n_ct, uint32_t(r1 - r0), uint32_t(n_inst), s->ct_gate, seg_records, 0, s->e->stream) != 0) {
         rc = fail(GSV_ERR_DEVICE, "ciphertext gather launch failed");
         break;
       }
@@ -849,6 +849,63 @@ int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base) {
       if (s->ct_uploaded[i] < need)
         return fail(GSV_ERR_EXHAUSTED, "Ciphertext source exhausted: instance " + std::to_string(i) + " holds " + std::to_string(s->ct_uploaded[i]) + " of " + std::to_string(need) + " ciphertexts");
   return launch(s, gate_id_base, true);
+}
+
+// Evaluate with the ciphertexts coming from gc_<index>.bin files (EvaluateMode over a FileSource: evaluate_mode.rs:59-196,
+// ciphertext_source.rs:36-107), segment by segment: program sessions one ring at a time, plan sessions one call at a time.  The
+// records are read in gate order, uploaded, scattered to the program-order positions the kernel reads, and — as FileSource
+// does while reading — folded into the per-instance CBC-MAC, returned in `hashes` when it is not NULL.
+int gsv_session_evaluate_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, uint8_t* hashes) {
+  if (!s || !dir) return fail(GSV_ERR_INVALID, "null argument");
+  const Program& g = s->prog();
+  const uint64_t n_ct = s->plan ? s->plan_max_block : g.n_ct, total = s->plan ? s->plan->calls.size() : s->replays, seg = s->plan ? 1 : s->ct_cap;
+  const size_t n_inst = s->n_inst;
+  HIPCHK(hipSetDevice(s->e->device));
+  const uint64_t seg_records = seg * n_ct;
+  if (!s->ct_gate && seg_records) HIPCHK(hipMalloc(&s->ct_gate, n_inst * seg_records * 16));
+  std::vector<FILE*> files(n_inst, nullptr);
+  auto close_files = [&]() { for (FILE*& f : files) if (f) { std::fclose(f); f = nullptr; } };
+  for (size_t i = 0; i < n_inst; ++i) {
+    const std::string path = std::string(dir) + "/gc_" + std::to_string(first_index + i) + ".bin";
+    files[i] = std::fopen(path.c_str(), "rb");
+    if (!files[i]) { close_files(); return fail(GSV_ERR_INVALID, "cannot open " + path); }
+  }
+  std::vector<CbcMacHost> macs(n_inst);
+  std::vector<uint8_t> host;
+  int rc = GSV_OK;
+  HIPCHK(hipEventRecord(s->ev0, s->e->stream));
+  for (uint64_t r0 = 0; r0 < total && rc == GSV_OK; r0 += seg) {
+    const uint64_t r1 = std::min(total, r0 + seg);
+    const uint64_t n_records = s->plan ? s->call_prog(size_t(r0)).n_ct : (r1 - r0) * n_ct;  // per instance
+    host.resize(size_t(n_records) * 16);
+    for (size_t i = 0; i < n_inst && rc == GSV_OK; ++i) {
+      if (n_records && std::fread(host.data(), 16, n_records, files[i]) != n_records) {
+        // EvaluateMode panics with "Ciphertext source exhausted" when the source runs dry (evaluate_mode.rs:139-142)
+        rc = fail(GSV_ERR_EXHAUSTED, "Ciphertext source exhausted: gc file of instance " + std::to_string(i) + " is too short");
+        break;
+      }
+      macs[i].update(host.data(), n_records);
+      if (n_records && hipMemcpy(static_cast<uint8_t*>(s->ct_gate) + i * seg_records * 16, host.data(), n_records * 16, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(GSV_ERR_DEVICE, "ciphertext upload failed");
+    }
+    if (rc != GSV_OK) break;
+    if (s->plan) {
+      const size_t k = size_t(r0);
+      const Program& cp = s->call_prog(k);
+      uint8_t* block = static_cast<uint8_t*>(s->CT) + (s->plan_retain ? s->plan->calls[k].ct_off : 0) * 16;
+      if (gsvk_gather_segment(block, s->ct_stride(), s->call_dev[k].dp.ct_pos, cp.n_ct, 1, uint32_t(n_inst), s->ct_gate, seg_records, 1, s->e->stream) != 0) { rc = fail(GSV_ERR_DEVICE, "ciphertext scatter launch failed"); break; }
+      rc = launch_plan_call(s, k, gate_id_base, true);
+    } else {
+      if (gsvk_gather_segment(s->CT, s->ct_stride(), s->dp.ct_pos, n_ct, uint32_t(r1 - r0), uint32_t(n_inst), s->ct_gate, seg_records, 1, s->e->stream) != 0) { rc = fail(GSV_ERR_DEVICE, "ciphertext scatter launch failed"); break; }
+      rc = launch(s, gate_id_base, true, r0, r1 - r0);
+    }
+    if (rc == GSV_OK && hipStreamSynchronize(s->e->stream) != hipSuccess) rc = fail(GSV_ERR_DEVICE, "kernel failed");
+  }
+  close_files();
+  if (rc != GSV_OK) return rc;
+  if (s->plan) { HIPCHK(hipEventRecord(s->ev1, s->e->stream)); rc = gather_plan_outputs(s, true); if (rc) return rc; HIPCHK(hipStreamSynchronize(s->e->stream)); }
+  if (hashes) for (size_t i = 0; i < n_inst; ++i) macs[i].digest(hashes + 16 * i);
+  return GSV_OK;
 }
 
 int gsv_session_set_hasher(gsv_session* s, int kind) {

@@ -50,9 +50,9 @@ int gsvk_gather_outputs(const void* W, const void* VB, uint32_t n_slots, const u
                         void* out, void* out_bits, hipStream_t stream);
 // stage[i] <-> stream[(idx / n_ct) * n_ct + ct_pos[idx % n_ct]] for idx = first + i, i < n  (scatter != 0: stage -> stream)
 int gsvk_permute_ciphertexts(void* stream, const void* ct_pos, uint64_t n_ct, uint64_t first, uint64_t n, void* stage, int scatter, hipStream_t s);
-// out[inst][r*n_ct + g] = ring[inst][r*n_ct + ct_pos[g]] for r < n_rep, every instance (strides in 16-byte records)
-int gsvk_gather_segment(const void* ring, uint64_t ring_stride, const void* ct_pos, uint64_t n_ct, uint32_t n_rep, uint32_t n_instances, void* out,
-                        uint64_t out_stride, hipStream_t s);
+// out[inst][r*n_ct + g] = ring[inst][r*n_ct + ct_pos[g]] for r < n_rep, every instance (strides in 16-byte records); scatter != 0: the other way
+int gsvk_gather_segment(void* ring, uint64_t ring_stride, const void* ct_pos, uint64_t n_ct, uint32_t n_rep, uint32_t n_instances, void* out,
+                        uint64_t out_stride, int scatter, hipStream_t s);
 // W[inst][dst[i]] = W[inst][src[i]] (and the plaintext bits when VB != null) for every instance: wire hand-over between the calls of a plan
 int gsvk_copy_slots(void* W, void* VB, uint32_t n_slots, const uint32_t* src, const uint32_t* dst, uint32_t n, uint32_t n_instances, hipStream_t s);
 int gsvk_scatter_bits(void* VB, uint32_t n_slots, uint32_t first_slot, const void* bits, uint32_t n, uint32_t n_instances, hipStream_t stream);

@@ -500,13 +500,17 @@ __global__ void permute_ciphertexts_kernel(uint4* stream, const uint32_t* ct_pos
 
 // Whole-segment form for the streaming drain: for every instance, `n_rep` replays starting at ring slot 0 of the
 // program-order ring go to a gate-order buffer: out[inst][r * n_ct + g] = ring[inst][r * n_ct + ct_pos[g]].
-__global__ void gather_segment_kernel(const uint4* ring, uint64_t ring_stride, const uint32_t* ct_pos, uint64_t n_ct, uint32_t n_rep, uint4* out, uint64_t out_stride) {
+// scatter != 0 is the evaluator's direction: gate-order records (read from gc_<i>.bin) go to their program-order positions.
+__global__ void gather_segment_kernel(uint4* ring, uint64_t ring_stride, const uint32_t* ct_pos, uint64_t n_ct, uint32_t n_rep, uint4* out, uint64_t out_stride, int scatter) {
   const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (g >= n_ct) return;
   const uint32_t pos = ct_pos[g];
-  const uint4* src = ring + uint64_t(blockIdx.y) * ring_stride;
+  uint4* src = ring + uint64_t(blockIdx.y) * ring_stride;
   uint4* dst = out + uint64_t(blockIdx.y) * out_stride;
-  for (uint32_t r = 0; r < n_rep; ++r) dst[uint64_t(r) * n_ct + g] = src[uint64_t(r) * n_ct + pos];
+  for (uint32_t r = 0; r < n_rep; ++r) {
+    if (scatter) src[uint64_t(r) * n_ct + pos] = dst[uint64_t(r) * n_ct + g];
+    else dst[uint64_t(r) * n_ct + g] = src[uint64_t(r) * n_ct + pos];
+  }
 }
 
 }  // namespace dev
@@ -561,11 +565,11 @@ int gsvk_permute_ciphertexts(void* stream, const void* ct_pos, uint64_t n_ct, ui
                      static_cast<const uint32_t*>(ct_pos), n_ct, first, n, static_cast<uint4*>(stage), scatter);
   return int(hipGetLastError());
 }
-int gsvk_gather_segment(const void* ring, uint64_t ring_stride, const void* ct_pos, uint64_t n_ct, uint32_t n_rep, uint32_t n_instances, void* out,
-                        uint64_t out_stride, hipStream_t s) {
+int gsvk_gather_segment(void* ring, uint64_t ring_stride, const void* ct_pos, uint64_t n_ct, uint32_t n_rep, uint32_t n_instances, void* out,
+                        uint64_t out_stride, int scatter, hipStream_t s) {
   if (n_ct == 0 || n_rep == 0) return 0;
-  hipLaunchKernelGGL(gsv::dev::gather_segment_kernel, dim3(uint32_t((n_ct + 255) / 256), n_instances), dim3(256), 0, s, static_cast<const uint4*>(ring), ring_stride,
-                     static_cast<const uint32_t*>(ct_pos), n_ct, n_rep, static_cast<uint4*>(out), out_stride);
+  hipLaunchKernelGGL(gsv::dev::gather_segment_kernel, dim3(uint32_t((n_ct + 255) / 256), n_instances), dim3(256), 0, s, static_cast<uint4*>(ring), ring_stride,
+                     static_cast<const uint32_t*>(ct_pos), n_ct, n_rep, static_cast<uint4*>(out), out_stride, scatter);
   return int(hipGetLastError());
 }
 int gsvk_copy_slots(void* W, void* VB, uint32_t n_slots, const uint32_t* src, const uint32_t* dst, uint32_t n, uint32_t n_instances, hipStream_t s) {

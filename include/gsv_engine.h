@@ -164,6 +164,12 @@ int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base);
  * discarded (garbling only: output labels, device-rate measurements). */
 int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes);
 
+/* Evaluate with the ciphertexts streamed from <dir>/gc_<first_index + instance>.bin (EvaluateMode over a FileSource:
+ * evaluate_mode.rs:59-196, ciphertext_source.rs:36-107), one ring / one plan call at a time, for streams of any length.  Like
+ * FileSource the call hashes what it reads: `hashes` (optional, n_instances x 16) receives each file's CBC-MAC so that the caller
+ * can compare it with the garbler's commitment.  A file that is too short fails with GSV_ERR_EXHAUSTED. */
+int gsv_session_evaluate_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, uint8_t* hashes);
+
 /* Gate PRF (`H: GateHasher`, src/hashers/mod.rs:15-20): GSV_HASHER_AES = AesNiHasher (default; the benchmarked
  * path, hashers/mod.rs:54-96), GSV_HASHER_BLAKE3 = Blake3Hasher (hashers/mod.rs:22-51, the crate's DefaultHasher). */
 #define GSV_HASHER_AES 0
