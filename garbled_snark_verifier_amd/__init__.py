@@ -47,7 +47,8 @@ EXPORTS = [
     "gsv_session_set_garble_inputs", "gsv_session_garble", "gsv_session_set_evaluate_inputs", "gsv_session_upload_ciphertexts",
     "gsv_session_evaluate", "gsv_session_set_hasher", "gsv_session_sync", "gsv_session_last_kernel_ms", "gsv_session_read_outputs", "gsv_session_read_ciphertexts",
     "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_commit_labels",
-    "gsv_plan_from_circuit", "gsv_plan_io", "gsv_plan_create", "gsv_plan_destroy", "gsv_plan_add_call", "gsv_plan_finish", "gsv_plan_counts", "gsv_session_create_plan", "gsv_session_create_plan_ex",
+    "gsv_plan_from_circuit", "gsv_plan_io", "gsv_plan_recorder_create", "gsv_plan_recorder_destroy", "gsv_plan_recorder_allocate_wire",
+    "gsv_plan_recorder_declare_input", "gsv_plan_recorder_push_gates", "gsv_plan_recorder_call", "gsv_plan_recorder_finish", "gsv_plan_create", "gsv_plan_destroy", "gsv_plan_add_call", "gsv_plan_finish", "gsv_plan_counts", "gsv_session_create_plan", "gsv_session_create_plan_ex",
     "gsv_session_garble_streaming", "gsv_session_evaluate_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
 ]
 
@@ -95,6 +96,14 @@ def lib():
         L.gsv_commit_labels.argtypes = [u8p, C.c_uint64, u8p]
         L.gsv_plan_from_circuit.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
         L.gsv_plan_io.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.gsv_plan_recorder_create.argtypes = [C.POINTER(vp)]
+        L.gsv_plan_recorder_destroy.argtypes = [vp]
+        L.gsv_plan_recorder_destroy.restype = None
+        L.gsv_plan_recorder_allocate_wire.argtypes = [vp, C.c_uint16, C.POINTER(C.c_uint64)]
+        L.gsv_plan_recorder_declare_input.argtypes = [vp, C.c_uint64]
+        L.gsv_plan_recorder_push_gates.argtypes = [vp, C.POINTER(_Gate), C.c_size_t]
+        L.gsv_plan_recorder_call.argtypes = [vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.gsv_plan_recorder_finish.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(vp)]
         L.gsv_plan_create.argtypes = [C.POINTER(vp)]
         L.gsv_plan_destroy.argtypes = [vp]
         L.gsv_plan_destroy.restype = None
@@ -280,6 +289,68 @@ class Plan:
     def close(self):
         if self.h:
             lib().gsv_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PlanRecorder:
+    """The plan builder driven gate by gate through the C ABI (gsv_plan_recorder_*): what a host with its own two-pass
+    driver uses.  Wires: 0 / 1 constants, further ids handed out by allocate_wire."""
+
+    def __init__(self):
+        self.h = C.c_void_p()
+        _chk(lib().gsv_plan_recorder_create(C.byref(self.h)))
+        self.programs = []
+        self.n_inputs = 0
+
+    def allocate_wire(self, credits=1):
+        w = C.c_uint64()
+        _chk(lib().gsv_plan_recorder_allocate_wire(self.h, credits, C.byref(w)))
+        return w.value
+
+    def input_wire(self):
+        w = self.allocate_wire(1)
+        _chk(lib().gsv_plan_recorder_declare_input(self.h, w))
+        self.n_inputs += 1
+        return w
+
+    def push_gates(self, gates):
+        """gates: list of (gate_type, a, b, c); c == None marks a dead gate."""
+        arr = (_Gate * max(1, len(gates)))()
+        for i, (t, a, b, c) in enumerate(gates):
+            arr[i].wire_a, arr[i].wire_b, arr[i].gate_type = a, b, t
+            arr[i].wire_c = 0xFFFFFFFFFFFFFFFF if c is None else c
+        _chk(lib().gsv_plan_recorder_push_gates(self.h, arr, len(gates)))
+
+    def call(self, program, in_wires):
+        self.programs.append(program)
+        a = (C.c_uint64 * max(1, len(in_wires)))(*in_wires)
+        n_out = program.info["n_outputs"]
+        o = (C.c_uint64 * max(1, n_out))()
+        assert len(in_wires) == program.info["n_inputs"]
+        _chk(lib().gsv_plan_recorder_call(self.h, program.h, a, o))
+        return list(o[:n_out])
+
+    def finish(self, output_wires):
+        plan = Plan.__new__(Plan)
+        plan.h = C.c_void_p()
+        plan.programs = list(self.programs)
+        o = (C.c_uint64 * max(1, len(output_wires)))(*output_wires)
+        _chk(lib().gsv_plan_recorder_finish(self.h, o, len(output_wires), C.byref(plan.h)))
+        g, c, k = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _chk(lib().gsv_plan_counts(plan.h, C.byref(g), C.byref(c), C.byref(k)))
+        plan.n_inputs, plan.n_outputs = self.n_inputs, len(output_wires)
+        plan.info = {"n_inputs": self.n_inputs, "n_outputs": len(output_wires), "n_gates": g.value, "n_ciphertexts": c.value, "n_calls": k.value, "n_steps": 0}
+        return plan
+
+    def close(self):
+        if self.h:
+            lib().gsv_plan_recorder_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -443,6 +443,87 @@ int gsv_plan_from_circuit(const char* spec, const char* units_csv, gsv_plan** ou
   return GSV_OK;
   GSV_CATCH
 }
+// ---- plan recorder: the plan builder behind the C ABI, for a host that runs its own two-pass driver
+struct gsv_plan_recorder {
+  PlanRecordMode mode{std::vector<std::string>()};
+  std::vector<uint32_t> inputs;
+  std::vector<const gsv_program*> externals;
+  std::map<const gsv_program*, int> unit_of;
+};
+int gsv_plan_recorder_create(gsv_plan_recorder** out) {
+  if (!out) return fail(GSV_ERR_INVALID, "null out");
+  *out = new gsv_plan_recorder();
+  return GSV_OK;
+}
+void gsv_plan_recorder_destroy(gsv_plan_recorder* r) { delete r; }
+int gsv_plan_recorder_allocate_wire(gsv_plan_recorder* r, uint16_t credits, uint64_t* wire_out) {
+  if (!r || !wire_out) return fail(GSV_ERR_INVALID, "null argument");
+  GSV_TRY
+  *wire_out = r->mode.allocate_wire(credits);
+  return GSV_OK;
+  GSV_CATCH
+}
+int gsv_plan_recorder_declare_input(gsv_plan_recorder* r, uint64_t wire) {
+  if (!r) return fail(GSV_ERR_INVALID, "null recorder");
+  GSV_TRY
+  r->inputs.push_back(r->mode.define_input(wire));
+  return GSV_OK;
+  GSV_CATCH
+}
+int gsv_plan_recorder_push_gates(gsv_plan_recorder* r, const gsv_gate* gates, size_t n) {
+  if (!r || (!gates && n)) return fail(GSV_ERR_INVALID, "null argument");
+  GSV_TRY
+  for (size_t i = 0; i < n; ++i) {
+    if (gates[i].gate_type >= GATE_TYPE_COUNT) return fail(GSV_ERR_INVALID, "unknown gate type");
+    r->mode.evaluate_gate(Gate{gates[i].wire_a, gates[i].wire_b, gates[i].wire_c, static_cast<GateType>(gates[i].gate_type)});
+  }
+  return GSV_OK;
+  GSV_CATCH
+}
+int gsv_plan_recorder_call(gsv_plan_recorder* r, const gsv_program* program, const uint64_t* in_wires, uint64_t* out_wires) {
+  if (!r || !program) return fail(GSV_ERR_INVALID, "null argument");
+  const Program& g = program->prog;
+  if ((!in_wires && !g.input_slots.empty()) || (!out_wires && !g.output_slots.empty())) return fail(GSV_ERR_INVALID, "null wire list");
+  if (!g.fb_src_slot.empty()) return fail(GSV_ERR_INVALID, "a program compiled with feedback cannot be a plan call");
+  GSV_TRY
+  auto it = r->unit_of.find(program);
+  if (it == r->unit_of.end()) {
+    r->externals.push_back(program);
+    it = r->unit_of.emplace(program, r->mode.add_external_unit(int(r->externals.size()) - 1, g.n_gates, g.output_slots.size())).first;
+  }
+  Wires in(in_wires, in_wires + g.input_slots.size()), out;
+  r->mode.call_external(it->second, in, out);
+  for (size_t i = 0; i < out.size(); ++i) out_wires[i] = out[i];
+  return GSV_OK;
+  GSV_CATCH
+}
+int gsv_plan_recorder_finish(gsv_plan_recorder* r, const uint64_t* output_wires, size_t n_outputs, gsv_plan** out) {
+  if (!r || !out || (!output_wires && n_outputs)) return fail(GSV_ERR_INVALID, "null argument");
+  GSV_TRY
+  std::vector<uint32_t> out_ssa;
+  for (size_t i = 0; i < n_outputs; ++i) out_ssa.push_back(r->mode.current(output_wires[i]));
+  CompileOptions opt;
+  if (const char* e = getenv("GSV_FUSE")) opt.fuse = atoi(e) != 0;
+  BuiltPlan bp = finish_plan(r->mode, r->inputs, out_ssa, opt);
+  std::unique_ptr<gsv_plan> plan(new gsv_plan());
+  for (size_t k = 0; k < bp.programs.size(); ++k) {
+    gsv_program* q = new gsv_program();
+    plan->owned.push_back(q);
+    q->prog = std::move(bp.programs[k]);
+    q->src.reset(new ProgramSource{std::move(bp.traces[k]), bp.prog_inputs[k], bp.prog_outputs[k], {}, opt});
+  }
+  for (const BuiltPlan::Call& c : bp.calls) {
+    const gsv_program* q = c.program >= 0 ? plan->owned[size_t(c.program)] : r->externals[size_t(-1 - c.program)];
+    int rc = gsv_plan_add_call(plan.get(), q, c.in_globals.data(), c.out_globals.data());
+    if (rc) { gsv_plan_destroy(plan.release()); return rc; }
+  }
+  int rc = gsv_plan_finish(plan.get(), bp.n_inputs, bp.outputs.data(), bp.outputs.size());
+  if (rc) { gsv_plan_destroy(plan.release()); return rc; }
+  *out = plan.release();
+  return GSV_OK;
+  GSV_CATCH
+}
+
 int gsv_plan_io(const gsv_plan* p, uint64_t* n_inputs, uint64_t* n_outputs) {
   if (!p || !p->finished) return fail(GSV_ERR_INVALID, "plan not finished");
   if (n_inputs) *n_inputs = p->n_inputs;

@@ -31,6 +31,8 @@ struct PlanUnit {  // one compiled (component key, output liveness) pair
   std::vector<uint32_t> inputs, outputs;  // SSA ids inside the unit's own trace (outputs: only the produced ones)
   std::vector<int32_t> out_index;         // per component output: index into `outputs`, -1 = dead, -2 = FALSE, -3 = TRUE, -(4+k) = input k passed through
   uint64_t n_gates = 0;
+  int external = -1;  // >= 0: the program was compiled by the caller (C ABI plan recorder); trace / inputs / outputs are empty
+  size_t n_ext_outputs = 0;
 };
 
 // A glue segment in canonical form: operands are either a wire defined earlier in the same segment (its definition index:
@@ -196,6 +198,30 @@ class PlanRecordMode final : public CircuitMode, public UnitHook {
     s.glue = Trace();  // the canonical form (kept once per class) is all that is needed from here on
   }
 
+  // C ABI route (gsv_plan_recorder_*): the host recorded and compiled the unit itself; a call hands over parent wires
+  // and receives one fresh parent wire per program output.
+  int add_external_unit(int external_index, uint64_t n_gates, size_t n_outputs) {
+    auto u = std::make_unique<PlanUnit>();
+    u->external = external_index; u->n_gates = n_gates; u->n_ext_outputs = n_outputs;
+    units.push_back(std::move(u));
+    return int(units.size()) - 1;
+  }
+  void call_external(int unit, const Wires& inputs, Wires& out) {
+    const PlanUnit& u = *units[size_t(unit)];
+    PlanSegment seg;
+    seg.unit = unit;
+    for (WireId w : inputs) seg.in_ssa.push_back(w == FALSE_WIRE ? PLAN_WIRE_FALSE : w == TRUE_WIRE ? PLAN_WIRE_TRUE : read(w));
+    out.clear();
+    for (size_t i = 0; i < u.n_ext_outputs; ++i) {
+      const WireId w = allocate_wire(1);
+      seg.out_ssa.push_back(define(w));
+      out.push_back(w);
+    }
+    n_gates_ += u.n_gates;
+    close_glue();
+    segments.push_back(std::move(seg));
+  }
+
   uint64_t n_gates() const { return n_gates_; }
   uint32_t n_ssa() const { return next_ssa_; }
   std::vector<std::unique_ptr<PlanUnit>> units;
@@ -238,7 +264,7 @@ class PlanRecordMode final : public CircuitMode, public UnitHook {
 
 // The finished plan in host form: programs (units first, then one per glue segment) and calls over global wire ids.
 struct BuiltPlan {
-  struct Call { int program; std::vector<uint32_t> in_globals, out_globals; };
+  struct Call { int program; std::vector<uint32_t> in_globals, out_globals; };  // program < 0: external program -1 - program
   std::vector<Program> programs;
   std::vector<Trace> traces;  // kept per program so that the half-window variants can be compiled later
   std::vector<std::vector<uint32_t>> prog_inputs, prog_outputs;
@@ -293,11 +319,15 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
     BuiltPlan::Call call;
     if (s.unit >= 0) {
       PlanUnit& u = *m.units[size_t(s.unit)];
-      if (unit_program[size_t(s.unit)] < 0) {
-        Trace copy = u.trace;  // the unit may be called again; keep its trace
-        unit_program[size_t(s.unit)] = add_program(std::move(copy), u.inputs, u.outputs);
+      if (u.external >= 0) {
+        call.program = -1 - u.external;  // the caller's own program
+      } else {
+        if (unit_program[size_t(s.unit)] < 0) {
+          Trace copy = u.trace;  // the unit may be called again; keep its trace
+          unit_program[size_t(s.unit)] = add_program(std::move(copy), u.inputs, u.outputs);
+        }
+        call.program = unit_program[size_t(s.unit)];
       }
-      call.program = unit_program[size_t(s.unit)];
       for (uint32_t w : s.in_ssa) call.in_globals.push_back(w == PLAN_WIRE_FALSE || w == 0 ? PLAN_WIRE_FALSE : w == PLAN_WIRE_TRUE || w == 1 ? PLAN_WIRE_TRUE : global_of[w]);
       uint32_t t_used = 0;
       for (uint32_t w : s.out_ssa) {

@@ -217,6 +217,9 @@ inline NamedCircuit make_circuit(const std::string& spec) {
   } else if (name == "final_exp") {  // final_exponentiation_montgomery (final_exponentiation.rs:99-135), ~2.9 B gates
     nc.n_inputs = 3048; nc.n_outputs = 3048;
     nc.fn = [](CircuitContext& c, const Wires& in) { return fq12::final_exponentiation_montgomery(c, Fq12::from_wires(in)).to_wires(); };
+  } else if (name == "fq_addmul") {  // (a + b) * b: glue followed by a component, for the C-ABI plan recorder test
+    nc.n_inputs = 508; nc.n_outputs = 254;
+    nc.fn = [](CircuitContext& c, const Wires& in) { return fq::mul_montgomery(c, fq::add(c, slice(in, 0, 254), slice(in, 254, 508)), slice(in, 254, 508)); };
   } else if (name == "fq12_mix") {
     // plan test shape: units (Fq12 square / mul) with glue between them, a unit output reused much later, and a final unit
     // whose upper half is never read (its gates are dead: a second liveness pattern of the same component)

@@ -111,6 +111,21 @@ int gsv_plan_add_call(gsv_plan* p, const gsv_program* prog, const uint32_t* in_g
 int gsv_plan_finish(gsv_plan* p, uint32_t n_inputs, const uint32_t* output_globals, size_t n_outputs);
 int gsv_plan_counts(const gsv_plan* p, uint64_t* n_gates, uint64_t* n_ciphertexts, uint64_t* n_calls);
 int gsv_plan_io(const gsv_plan* p, uint64_t* n_inputs, uint64_t* n_outputs);
+/* Plan recorder: the same builder for a host that runs its OWN two-pass driver (a `GpuPlanMode: CircuitMode` on the Rust side,
+ * INTEGRATION.md §5).  Gates outside unit components are pushed as they come (they are cut into de-duplicated glue programs);
+ * a unit component is one gsv_plan_recorder_call with a program the host recorded and compiled from the component's body
+ * (gsv_recorder_* + gsv_program_compile, outputs = the wires the body PRODUCES): in_wires name the parent's wires, out_wires
+ * receive one fresh parent wire per program output.  finish computes the global wires and returns the plan (which owns the
+ * glue programs; the unit programs stay the caller's and must outlive the plan). */
+typedef struct gsv_plan_recorder gsv_plan_recorder;
+int gsv_plan_recorder_create(gsv_plan_recorder** out);
+void gsv_plan_recorder_destroy(gsv_plan_recorder* r);
+int gsv_plan_recorder_allocate_wire(gsv_plan_recorder* r, uint16_t credits, uint64_t* wire_out);
+int gsv_plan_recorder_declare_input(gsv_plan_recorder* r, uint64_t wire);
+int gsv_plan_recorder_push_gates(gsv_plan_recorder* r, const gsv_gate* gates, size_t n);
+int gsv_plan_recorder_call(gsv_plan_recorder* r, const gsv_program* program, const uint64_t* in_wires, uint64_t* out_wires);
+int gsv_plan_recorder_finish(gsv_plan_recorder* r, const uint64_t* output_wires, size_t n_outputs, gsv_plan** out);
+
 /* Call operands naming the constant wires instead of a global wire. */
 #define GSV_PLAN_WIRE_FALSE 0xFFFFFFFEu
 #define GSV_PLAN_WIRE_TRUE 0xFFFFFFFFu

@@ -513,3 +513,62 @@ def test_evaluate_streaming_from_gc_files(engine, tmp_path):
         assert (ob[i] == eb).all() and (oa[i] == np.where(ob[i][:, None] == 1, out0[i] ^ delta[i][None, :], out0[i])).all()
         assert commits[i] == o.garble("fq12_mix", seed, capture_ct=False).ct_hash.tobytes()
     es.close()
+
+
+def test_plan_recorder_through_the_c_abi(engine):
+    """gsv_plan_recorder_*: the plan builder driven the way a host with its own two-pass driver would.
+    The gates of Fq::add are pushed one by one as glue (taken from a recording of the component), Fq::mul_montgomery is a
+    call of a program the 'host' compiled itself, and the finished plan must garble to the stream of the flat circuit
+    (a + b) * b.  Then the Fq12 pair square -> mul without any glue."""
+    import ctypes as C
+    import garbled_snark_verifier_amd as gsv
+    import hostsim_lib as h
+    L = h.lib()
+    L.hostsim_trace.argtypes = [C.c_char_p, C.c_uint64] + [C.c_void_p] * 4 + [C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
+    cap = 10_000
+    ty = np.zeros(cap, np.uint8); ta = np.zeros(cap, np.uint32); tb = np.zeros(cap, np.uint32); tc = np.zeros(cap, np.uint32)
+    n, nw = C.c_uint64(), C.c_uint32()
+    in_ssa, out_ssa = np.zeros(508, np.uint32), np.zeros(254, np.uint32)
+    assert L.hostsim_trace(b"fq_add", cap, ty.ctypes.data, ta.ctypes.data, tb.ctypes.data, tc.ctypes.data, C.byref(n), C.byref(nw), in_ssa.ctypes.data, out_ssa.ctypes.data) == 0
+    rec = gsv.PlanRecorder()
+    a_w = [rec.input_wire() for _ in range(254)]
+    b_w = [rec.input_wire() for _ in range(254)]
+    wire = {0: 0, 1: 1}
+    for i, s in enumerate(in_ssa):
+        wire[int(s)] = (a_w + b_w)[i]
+    gates = []
+    for i in range(n.value):
+        c = None
+        if tc[i] != 0xFFFFFFFF:
+            c = rec.allocate_wire(1)
+        gates.append((int(ty[i]), wire[int(ta[i])], wire[int(tb[i])], c))
+        if c is not None:
+            wire[int(tc[i])] = c
+    rec.push_gates(gates)
+    mul = gsv.Program.from_circuit("fq_mul")
+    m_w = rec.call(mul, [wire[int(s)] for s in out_ssa] + b_w)
+    plan = rec.finish(m_w)
+    assert plan.info["n_calls"] == 2
+    seed = 17
+    ref = o.garble("fq_addmul", seed)
+    assert plan.info["n_gates"] == int(ref.gate_counts.sum())
+    d, f, t, inp = gsv.labels_from_seed(seed, 508)
+    s = gsv.Session(engine, plan, 1)
+    s.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
+    s.garble(0)
+    assert s.ciphertext_hash(0) == ref.ct_hash.tobytes() and (s.read_outputs()[0] == ref.output_label0).all()
+    assert (s.read_ciphertexts(0, 0, ref.n_ciphertexts) == ref.ciphertexts).all()
+    s.close()
+    # two external units, no glue
+    sq, mul12 = gsv.Program.from_circuit("fq12_square"), gsv.Program.from_circuit("fq12_mul")
+    rec = gsv.PlanRecorder()
+    r_w = [rec.input_wire() for _ in range(3048)]
+    b_w = [rec.input_wire() for _ in range(3048)]
+    plan = rec.finish(rec.call(mul12, rec.call(sq, r_w) + b_w))
+    ref = o.garble("fq12_sqmul", 18, capture_ct=False)
+    d, f, t, inp = gsv.labels_from_seed(18, 6096)
+    s = gsv.Session(engine, plan, 1)
+    s.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
+    s.garble(0)
+    assert s.ciphertext_hash(0) == ref.ct_hash.tobytes() and (s.read_outputs()[0] == ref.output_label0).all()
+    s.close()
