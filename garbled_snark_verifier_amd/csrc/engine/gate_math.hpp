@@ -86,8 +86,14 @@ GSV_HD uint32_t aes_col(const Tab& T, uint32_t x0, uint32_t x1, uint32_t x2, uin
 // and in Te0 byte1 and byte2 (only the two tables the device keeps un-rotated are used).
 template <class Tab>
 GSV_HD uint32_t aes_last_col(const Tab& T, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t k) {
-  return xor3(xor3(T.template lk<2, 0>(x0) & 0x000000ffu, T.template lk<0, 1>(x1) & 0x0000ff00u, T.template lk<0, 2>(x2) & 0x00ff0000u),
-              T.template lk<2, 3>(x3) & 0xff000000u, k);
+  const uint32_t m0 = T.template lk<2, 0>(x0), m1 = T.template lk<0, 1>(x1), m2 = T.template lk<0, 2>(x2), m3 = T.template lk<2, 3>(x3);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // byte assembly with two v_perm_b32 (bytes 0..3 of the second operand are selector values 0..3, of the first 4..7, 0x0c = zero)
+  // instead of four v_and: {m0.b0, m1.b1, 0, 0} ^ {0, 0, m2.b2, m3.b3} ^ k
+  return xor3(__builtin_amdgcn_perm(m1, m0, 0x0c0c0500u), __builtin_amdgcn_perm(m3, m2, 0x07020c0cu), k);
+#else
+  return xor3(xor3(m0 & 0x000000ffu, m1 & 0x0000ff00u, m2 & 0x00ff0000u), m3 & 0xff000000u, k);
+#endif
 }
 
 // One full AES-128 encryption of `in` (FIPS-197; equals _mm_aesenc x9 + _mm_aesenclast, aes_ni.rs:39-54).
