@@ -68,7 +68,11 @@ struct LdsBankedTable {
     const uint32_t v = *reinterpret_cast<const lds_u32*>(uintptr_t(addr + ((K & 2) ? 128u : 0u)));  // Te0 or Te2 half
     return (K & 1) ? __builtin_amdgcn_alignbit(v, v, 24) : v;                                       // Te1 / Te3 = rotl8
   }
-  __device__ __forceinline__ uint32_t rk(int i) const { return *reinterpret_cast<const lds_u32*>(uintptr_t(GSV_LDS_RK_BASE + 4u * uint32_t(i))); }
+  // Round keys of the one-gate-per-lane AES come through the scalar cache (s_load from constant memory): the LDS pipe is
+  // the co-limiter of that loop (364 ds_read per block pair, 44 of them round keys), and although the 44 SGPRs do not all
+  // stay resident (the compiler parks ~90 scalars in VGPR lanes), trading 44 LDS reads for v_readlane is +2.4 %.
+  // The quad form keeps its 11 per-lane round-key words in VGPRs, loaded once from the LDS copy.
+  __device__ __forceinline__ uint32_t rk(int i) const { return c_rk[i]; }
 };
 
 typedef uint32_t GSV_GLB glb_u32;
