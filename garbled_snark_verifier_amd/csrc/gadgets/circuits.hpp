@@ -7,6 +7,7 @@
 //   fq12_square, fq12_cyclotomic_square   Fq12::square_montgomery (fq12.rs:311-324), cyclotomic_square_montgomery (fq12.rs:326-392)
 //   fq12_sqmul, fq12_sqmul_chain:K        square-and-multiply link r <- Fq12::mul(Fq12::square(r), b)
 //   fq_inverse, fq2_inverse, fq12_inverse, fq12_frobenius:I, fq12_conjugate, final_exp   (bn254_ext.hpp)
+//   g2_double, g2_add, g2_mul_by_char, ell_eval, ell_const:K, miller_loop               (bn254_pairing.hpp)
 //   fq_complex          tests/streaming_evaluate.rs:401-407  ((a^2)*b + a)
 //   gate:T              tests/streaming_evaluate.rs:136-213  (one gate of discriminant T at the root)
 //   driver_mix          credits / dead-gate / pass-through / constant edge cases (circuit/mod.rs:419-836 shapes)
@@ -15,7 +16,7 @@
 #include <algorithm>
 #include <string>
 
-#include "bn254_ext.hpp"
+#include "bn254_pairing.hpp"
 
 namespace gsv {
 
@@ -24,6 +25,14 @@ struct NamedCircuit {
   size_t n_outputs = 0;
   CircuitFn fn;
 };
+
+// G2 generator of BN254 (affine, standard form): the constant Q of the pairing test circuits
+inline gadgets::HFq2 test_g2_generator_x() {
+  return gadgets::hfq2_hex("1800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed", "198e9393920d483a7260bfb731fb5d25f1aa493335a9e71297e485b7aef312c2");
+}
+inline gadgets::HFq2 test_g2_generator_y() {
+  return gadgets::hfq2_hex("12c85ea5db8c6deb4aab71808dcb408fe3d1e7690c43d37b4ce6cc0166fa7daa", "090689d0585ff075ec9e99ad690c3395bc4b313370b38ef355acdadcd122975b");
+}
 
 namespace detail {
 inline Wires driver_mix(CircuitContext& c, const Wires& in) {
@@ -217,6 +226,43 @@ inline NamedCircuit make_circuit(const std::string& spec) {
   } else if (name == "final_exp") {  // final_exponentiation_montgomery (final_exponentiation.rs:99-135), ~2.9 B gates
     nc.n_inputs = 3048; nc.n_outputs = 3048;
     nc.fn = [](CircuitContext& c, const Wires& in) { return fq12::final_exponentiation_montgomery(c, Fq12::from_wires(in)).to_wires(); };
+  } else if (name == "g2_double") {  // pairing.rs:359-407: r -> (2r, line coefficients)
+    nc.n_inputs = 1524; nc.n_outputs = 3048;
+    nc.fn = [](CircuitContext& c, const Wires& in) {
+      G2Step s = pairing::double_in_place_circuit_montgomery(c, pairing::g2_from_wires(in));
+      return concat(pairing::g2_to_wires(s.r), s.coeffs.to_wires());
+    };
+  } else if (name == "g2_add") {  // pairing.rs:409-464: (r, q affine) -> (r + q, line coefficients)
+    nc.n_inputs = 3048; nc.n_outputs = 3048;
+    nc.fn = [](CircuitContext& c, const Wires& in) {
+      G2Step s = pairing::add_in_place_montgomery(c, pairing::g2_from_wires(slice(in, 0, 1524)), pairing::g2_from_wires(slice(in, 1524, 3048)));
+      return concat(pairing::g2_to_wires(s.r), s.coeffs.to_wires());
+    };
+  } else if (name == "g2_mul_by_char") {
+    nc.n_inputs = 1524; nc.n_outputs = 1524;
+    nc.fn = [](CircuitContext& c, const Wires& in) { return pairing::g2_to_wires(pairing::mul_by_char_montgomery(c, pairing::g2_from_wires(in))); };
+  } else if (name == "ell_eval") {  // pairing.rs:160-171: f, coeffs (Fq6), p.x, p.y
+    nc.n_inputs = 3048 + 1524 + 508; nc.n_outputs = 3048;
+    nc.fn = [](CircuitContext& c, const Wires& in) {
+      G1Wires p{slice(in, 4572, 4826), slice(in, 4826, 5080), Wires()};
+      return pairing::ell_montgomery(c, Fq12::from_wires(slice(in, 0, 3048)), Fq6::from_wires(slice(in, 3048, 4572)), p).to_wires();
+    };
+  } else if (name == "ell_const") {  // pairing.rs:923-942 with the K-th line coefficient of the G2 generator: ell_const:K
+    const size_t k = has_param ? size_t(param) : 0;
+    nc.n_inputs = 3048 + 762; nc.n_outputs = 3048;
+    nc.fn = [k](CircuitContext& c, const Wires& in) {
+      static const std::vector<HEllCoeff> ell = h_ell_coeffs(test_g2_generator_x(), test_g2_generator_y());
+      if (k >= ell.size()) gsv_panic("ell_const: coefficient index out of range");
+      G1Wires p{slice(in, 3048, 3302), slice(in, 3302, 3556), slice(in, 3556, 3810)};
+      return pairing::ell_by_constant_montgomery(c, Fq12::from_wires(slice(in, 0, 3048)), ell[k], p).to_wires();
+    };
+  } else if (name == "miller_loop") {  // pairing.rs:944-1007 with q1 = G2 generator, q2 = -generator; inputs p1, p2, p3 (x, y, z), q3 (x, y, z)
+    nc.n_inputs = 3 * 762 + 1524; nc.n_outputs = 3048;
+    nc.fn = [](CircuitContext& c, const Wires& in) {
+      auto g1 = [&](size_t o) { return G1Wires{slice(in, o, o + 254), slice(in, o + 254, o + 508), slice(in, o + 508, o + 762)}; };
+      const HFq2 gx = test_g2_generator_x(), gy = test_g2_generator_y();
+      return pairing::multi_miller_loop_groth16_evaluate_montgomery_fast(c, g1(0), g1(762), g1(1524), gx, gy, gx, HFq2::neg(gy), pairing::g2_from_wires(slice(in, 2286, 3810))).to_wires();
+    };
   } else if (name == "fq_addmul") {  // (a + b) * b: glue followed by a component, for the C-ABI plan recorder test
     nc.n_inputs = 508; nc.n_outputs = 254;
     nc.fn = [](CircuitContext& c, const Wires& in) { return fq::mul_montgomery(c, fq::add(c, slice(in, 0, 254), slice(in, 254, 508)), slice(in, 254, 508)); };
