@@ -323,8 +323,9 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
         call.program = -1 - u.external;  // the caller's own program
       } else {
         if (unit_program[size_t(s.unit)] < 0) {
-          Trace copy = u.trace;  // the unit may be called again; keep its trace
-          unit_program[size_t(s.unit)] = add_program(std::move(copy), u.inputs, u.outputs);
+          // later calls of the unit reuse the program index, so the trace can move (178 constant-specialised line
+          // functions of the Miller loop would otherwise exist twice)
+          unit_program[size_t(s.unit)] = add_program(std::move(u.trace), u.inputs, u.outputs);
         }
         call.program = unit_program[size_t(s.unit)];
       }

@@ -572,3 +572,22 @@ def test_plan_recorder_through_the_c_abi(engine):
     s.garble(0)
     assert s.ciphertext_hash(0) == ref.ct_hash.tobytes() and (s.read_outputs()[0] == ref.output_label0).all()
     s.close()
+
+
+@pytest.mark.skipif(not os.environ.get("GSV_SLOW"), reason="building the 522-call Miller-loop plan takes ~7 minutes of host time (178 constant-specialised line programs); set GSV_SLOW=1 or run tools/miller_plan.py")
+def test_miller_loop_as_a_plan(engine):
+    """multi_miller_loop_groth16_evaluate_montgomery_fast (pairing.rs:944-1007): 6,909,061,143 gates, 62 % of the verifier, as a
+    plan; hash + output labels == the oracle's flat-stream fixture (tests/golden/miller_loop_golden.json, 8 minutes of oracle
+    time).  Same check as tools/miller_plan.py, which also measures the device rate (8.1e10 gates/s at 256 instances)."""
+    import hashlib
+    import garbled_snark_verifier_amd as gsv
+    case = json.load(open(os.path.join(os.path.dirname(GOLDEN), "miller_loop_golden.json")))
+    plan = gsv.Plan.from_circuit("miller_loop", ["fq12::square_montgomery", "fq12::mul_by_034_montgomery", "pairing::ell_by_constant_montgomery",
+                                                 "pairing::double_in_place_circuit_montgomery", "pairing::add_in_place_montgomery", "pairing::mul_by_char_montgomery"])
+    assert plan.info["n_gates"] == case["gates"] == 6_909_061_143 and plan.info["n_ciphertexts"] == case["n_ciphertexts"]
+    d, f, t, inp = gsv.labels_from_seed(case["seed"], plan.info["n_inputs"])
+    sess = gsv.Session(engine, plan, 1, retain_stream=False)
+    sess.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
+    hashes = sess.garble_streaming()
+    assert hashes[0].hex() == case["ct_hash"] and hashlib.sha256(sess.read_outputs()[0].tobytes()).hexdigest() == case["output_label0_sha256"]
+    sess.close()
