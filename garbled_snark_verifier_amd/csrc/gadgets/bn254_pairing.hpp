@@ -48,13 +48,27 @@ struct HFq {
     return r;  // callers only use it where the sum fits (a < p, b = p < 2^254)
   }
   static HFq neg(const HFq& a) { return a.is_zero() ? a : sub_raw(p(), a); }
-  static HFq mul(const HFq& a, const HFq& b) {  // double-and-add: constants only, speed is irrelevant
-    HFq r;
-    for (int i = 255; i >= 0; --i) {
-      r = add(r, r);
-      if ((b.l[i / 64] >> (i % 64)) & 1) r = add(r, a);
+  // a * b * 2^-256 mod p (word-serial Montgomery product; p < 2^254 leaves room for the carries)
+  static HFq mont(const HFq& a, const HFq& b) {
+    static const uint64_t n0 = [] { uint64_t p0 = p().l[0], x = 1; for (int i = 0; i < 6; ++i) x *= 2 - p0 * x; return ~x + 1; }();  // -p^-1 mod 2^64
+    const HFq& m = p();
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+      unsigned __int128 acc = 0;
+      for (int j = 0; j < 4; ++j) { acc += (unsigned __int128)a.l[j] * b.l[i] + t[j]; t[j] = uint64_t(acc); acc >>= 64; }
+      acc += t[4]; t[4] = uint64_t(acc); t[5] = uint64_t(acc >> 64);
+      const uint64_t q = t[0] * n0;
+      acc = (unsigned __int128)q * m.l[0] + t[0]; acc >>= 64;
+      for (int j = 1; j < 4; ++j) { acc += (unsigned __int128)q * m.l[j] + t[j]; t[j - 1] = uint64_t(acc); acc >>= 64; }
+      acc += t[4]; t[3] = uint64_t(acc); t[4] = t[5] + uint64_t(acc >> 64);
     }
+    HFq r; for (int i = 0; i < 4; ++i) r.l[i] = t[i];
+    if (t[4] || cmp(r, m) >= 0) r = sub_raw(r, m);
     return r;
+  }
+  static HFq mul(const HFq& a, const HFq& b) {  // standard-form product
+    static const HFq r2 = [] { HFq v = from_u64(1); for (int i = 0; i < 512; ++i) v = add(v, v); return v; }();  // 2^512 mod p
+    return mont(mont(a, b), r2);
   }
   static HFq from_u64(uint64_t v) { HFq r; r.l[0] = v; return r; }
 };

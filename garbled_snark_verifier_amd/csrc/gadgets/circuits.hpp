@@ -8,15 +8,17 @@
 //   fq12_sqmul, fq12_sqmul_chain:K        square-and-multiply link r <- Fq12::mul(Fq12::square(r), b)
 //   fq_inverse, fq2_inverse, fq12_inverse, fq12_frobenius:I, fq12_conjugate, final_exp   (bn254_ext.hpp)
 //   g2_double, g2_add, g2_mul_by_char, ell_eval, ell_const:K, miller_loop               (bn254_pairing.hpp)
+//   g1_add, g1_scalar_mul:W, g1_to_affine, groth16_verify:<vk hex>                      (bn254_groth16.hpp)
 //   fq_complex          tests/streaming_evaluate.rs:401-407  ((a^2)*b + a)
 //   gate:T              tests/streaming_evaluate.rs:136-213  (one gate of discriminant T at the root)
 //   driver_mix          credits / dead-gate / pass-through / constant edge cases (circuit/mod.rs:419-836 shapes)
 //   random_circuit:SEED pseudo-random DAG with nested components for differential tests
 #pragma once
 #include <algorithm>
+#include <memory>
 #include <string>
 
-#include "bn254_pairing.hpp"
+#include "bn254_groth16.hpp"
 
 namespace gsv {
 
@@ -130,8 +132,10 @@ inline NamedCircuit make_circuit(const std::string& spec) {
   size_t colon = spec.find(':');
   if (colon != std::string::npos) {
     name = spec.substr(0, colon);
-    param = std::stoull(spec.substr(colon + 1));
-    has_param = true;
+    if (name != "groth16_verify") {  // (its parameter is a hex blob, parsed below)
+      param = std::stoull(spec.substr(colon + 1));
+      has_param = true;
+    }
   }
   NamedCircuit nc;
   auto two_fq = [&](std::function<Wires(CircuitContext&, const Wires&, const Wires&)> op) {
@@ -262,6 +266,42 @@ inline NamedCircuit make_circuit(const std::string& spec) {
       auto g1 = [&](size_t o) { return G1Wires{slice(in, o, o + 254), slice(in, o + 254, o + 508), slice(in, o + 508, o + 762)}; };
       const HFq2 gx = test_g2_generator_x(), gy = test_g2_generator_y();
       return pairing::multi_miller_loop_groth16_evaluate_montgomery_fast(c, g1(0), g1(762), g1(1524), gx, gy, gx, HFq2::neg(gy), pairing::g2_from_wires(slice(in, 2286, 3810))).to_wires();
+    };
+  } else if (name == "g1_add") {  // g1.rs:159-235
+    nc.n_inputs = 1524; nc.n_outputs = 762;
+    nc.fn = [](CircuitContext& c, const Wires& in) { return g1_to_wires(g1::add_montgomery(c, g1_from_wires(slice(in, 0, 762)), g1_from_wires(slice(in, 762, 1524)))); };
+  } else if (name == "g1_scalar_mul") {  // g1.rs:309-368 with base = the G1 generator (1, 2); window W = param (the verifier uses 10)
+    const size_t W = has_param ? size_t(param) : 10;
+    if (W < 1 || W > 12) gsv_panic("g1_scalar_mul:W needs W in 1..12");
+    nc.n_inputs = 254; nc.n_outputs = 762;
+    nc.fn = [W](CircuitContext& c, const Wires& in) { return g1_to_wires(g1::scalar_mul_by_constant_base_montgomery(c, in, HG1::from_affine(HFq::from_u64(1), HFq::from_u64(2)), W)); };
+  } else if (name == "g1_mux_add") {
+    // plan test shape: constant tables behind multiplexers (unit calls whose inputs are mostly the constant wires), additions of
+    // wire points and of a constant point.  in: 4 selector bits, a point p; out: ((T[s0 s1] + T'[s2 s3]) + p) + G
+    nc.n_inputs = 4 + 762; nc.n_outputs = 762;
+    nc.fn = [](CircuitContext& c, const Wires& in) {
+      const HG1 g = HG1::from_affine(HFq::from_u64(1), HFq::from_u64(2));
+      std::vector<G1Wires> t1, t2;
+      HG1 p = HG1::identity();
+      for (int i = 0; i < 4; ++i) { t1.push_back(g1_new_constant_montgomery(p)); p = HG1::add(p, g); }
+      for (int i = 0; i < 4; ++i) { t2.push_back(g1_new_constant_montgomery(p)); p = HG1::add(p, p); }
+      G1Wires a = g1::multiplexer(c, t1, slice(in, 0, 2), 2), b = g1::multiplexer(c, t2, slice(in, 2, 4), 2);
+      G1Wires r = g1::add_montgomery(c, g1::add_montgomery(c, a, b), g1_from_wires(slice(in, 4, 766)));
+      return g1_to_wires(g1::add_montgomery(c, r, g1_new_constant_montgomery(g)));
+    };
+  } else if (name == "g1_to_affine") {  // groth16.rs:26-48
+    nc.n_inputs = 762; nc.n_outputs = 762;
+    nc.fn = [](CircuitContext& c, const Wires& in) { return g1_to_wires(groth16::projective_to_affine_montgomery(c, g1_from_wires(in))); };
+  } else if (name == "groth16_verify") {  // groth16.rs:58-110; inputs: public scalars, A, B, C (CircuitInput order, groth16.rs:290-318)
+    if (colon == std::string::npos) gsv_panic("groth16_verify needs a verifying key: groth16_verify:<hex>");
+    size_t n_pub = 0;
+    auto vk = std::make_shared<groth16::VerifyingKey>(groth16::vk_from_hex(spec.substr(colon + 1), &n_pub));
+    nc.n_inputs = n_pub * 254 + 762 + 1524 + 762; nc.n_outputs = 1;
+    nc.fn = [vk, n_pub](CircuitContext& c, const Wires& in) {
+      std::vector<Wires> pub;
+      for (size_t i = 0; i < n_pub; ++i) pub.push_back(slice(in, i * 254, i * 254 + 254));
+      const size_t o = n_pub * 254;
+      return Wires{groth16::verify(c, pub, g1_from_wires(slice(in, o, o + 762)), pairing::g2_from_wires(slice(in, o + 762, o + 2286)), g1_from_wires(slice(in, o + 2286, o + 3048)), *vk)};
     };
   } else if (name == "fq_addmul") {  // (a + b) * b: glue followed by a component, for the C-ABI plan recorder test
     nc.n_inputs = 508; nc.n_outputs = 254;

@@ -182,6 +182,7 @@ def test_gate_fusion_shapes_and_unfused_path(monkeypatch):
     ("random_circuit:3", ["test::random_block"], 1),      # 145 calls, 72 distinct unit programs, glue in between
     ("random_circuit:8", ["test::random_block"], 2),
     ("fq_complex", ["fp254::montgomery_reduce", "bigint::mul_karatsuba"], 2),  # two units reused (3 programs for 5 calls)
+    ("g1_mux_add", ["bigint::multiplexer", "g1::add_montgomery"], 3),  # unit inputs that are the constant wires (MSM tables, constant point)
 ])
 def test_plan_builder_matches_flat_stream(spec, units, seed):
     """plan_builder.hpp: the circuit recorded with some components as CALLS of separately compiled programs must give the
