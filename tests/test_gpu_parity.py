@@ -591,3 +591,57 @@ def test_miller_loop_as_a_plan(engine):
     hashes = sess.garble_streaming()
     assert hashes[0].hex() == case["ct_hash"] and hashlib.sha256(sess.read_outputs()[0].tobytes()).hexdigest() == case["output_label0_sha256"]
     sess.close()
+
+
+def test_msm_plan_with_constant_tables(engine):
+    """The verifier's window scalar multiplication (g1.rs:309-368) as a plan: the multiplexer units take the MSM's constant
+    tables as inputs (call operands that are the constant wires), G1 additions are the other unit.  Window 10 as in the verifier:
+    225,290,965 gates in 103 calls of 3 programs; hash / labels == the CPU oracle's flat stream; the evaluator's bits == k * G."""
+    import garbled_snark_verifier_amd as gsv
+    spec = "g1_scalar_mul:10"
+    plan = gsv.Plan.from_circuit(spec, ["bigint::multiplexer", "g1::add_montgomery"])
+    seeds = [31, 32]
+    ref = o.garble(spec, seeds[0], capture_ct=False)
+    assert plan.info["n_gates"] == int(ref.gate_counts.sum()) == 225_290_965 and plan.info["n_ciphertexts"] == ref.n_ciphertexts
+    B, n_in = len(seeds), plan.info["n_inputs"]
+    labs = [gsv.labels_from_seed(s, n_in) for s in seeds]
+    delta = np.stack([x[0] for x in labs]); consts = np.stack([np.stack([x[1], x[2]]) for x in labs]); inputs = np.stack([x[3] for x in labs])
+    sess = gsv.Session(engine, plan, B)
+    sess.set_garble_inputs(delta, consts, inputs)
+    sess.garble(0)
+    out = sess.read_outputs()
+    assert sess.ciphertext_hash(0) == ref.ct_hash.tobytes() and (out[0] == ref.output_label0).all()
+    k = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF
+    bits = np.stack([o.int_to_bits(k, 254), o.int_to_bits(k + 1, 254)])
+    active = np.where(bits[:, :, None] == 1, inputs ^ delta[:, None, :], inputs)
+    sess.set_evaluate_inputs(np.stack([consts[:, 0], consts[:, 1] ^ delta], axis=1), active, bits)
+    sess.evaluate(0)
+    oa, ob = sess.read_outputs(with_bits=True)
+    assert (oa == np.where(ob[:, :, None] == 1, out ^ delta[:, None, :], out)).all()
+    import bn254_ref as T
+    for i, kk in enumerate([k, k + 1]):
+        x, y, z = [o.bits_to_int(ob[i][j * 254:(j + 1) * 254]) * T.RINV % T.P for j in range(3)]
+        zi = pow(z, -1, T.P)
+        assert (x * zi * zi % T.P, y * zi * zi * zi % T.P) == T.g1_mul(kk)
+    sess.close()
+
+
+@pytest.mark.skipif(not os.environ.get("GSV_SLOW"), reason="building the plan of the whole verifier takes ~8 minutes of host time and ~90 GB of host memory; set GSV_SLOW=1 or run tools/groth16_plan.py")
+def test_groth16_verifier_as_a_plan(engine):
+    """groth16_verify (groth16.rs:58-110) — MSM, projective-to-affine, Miller loop, final exponentiation, comparison — for the
+    synthetic instance of tests/groth16_ref.py: 10,914,485,653 gates as one plan; hash + output label == the oracle's flat-stream
+    fixture (tests/golden/make_big_golden.py).  tools/groth16_plan.py runs the same check, evaluates a valid and a tampered
+    proof and measures the device rate."""
+    import hashlib
+    import garbled_snark_verifier_amd as gsv
+    case = json.load(open(os.path.join(os.path.dirname(GOLDEN), "groth16_verify_golden.json")))
+    plan = gsv.Plan.from_circuit(case["circuit"], ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cyclotomic_square_montgomery", "fq12::inverse_montgomery",
+                                                   "fq12::mul_by_034_montgomery", "pairing::ell_by_constant_montgomery", "pairing::double_in_place_circuit_montgomery",
+                                                   "pairing::add_in_place_montgomery", "pairing::mul_by_char_montgomery", "bigint::multiplexer", "g1::add_montgomery", "fp254::inverse"])
+    assert plan.info["n_gates"] == case["gates"] == 10_914_485_653 and plan.info["n_ciphertexts"] == case["n_ciphertexts"]
+    d, f, t, inp = gsv.labels_from_seed(case["seed"], plan.info["n_inputs"])
+    sess = gsv.Session(engine, plan, 1, retain_stream=False)
+    sess.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
+    hashes = sess.garble_streaming()
+    assert hashes[0].hex() == case["ct_hash"] and hashlib.sha256(sess.read_outputs()[0].tobytes()).hexdigest() == case["output_label0_sha256"]
+    sess.close()
