@@ -271,17 +271,23 @@ int gsv_labels_from_seed(uint64_t seed, size_t n_inputs, uint8_t delta[16], uint
 }
 
 // ---------------------------------------------------------------- sessions
+// The half-window variant of a program (two instances per workgroup), compiled on first use.  Throws on failure; p->mu held by the caller.
+static void compile_half_window_variant(gsv_program* p) {
+  if (p->prog2) return;
+  CompileOptions opt = p->src->opt;
+  opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / 2);
+  std::unique_ptr<Program> q(new Program(compile_program(p->src->trace, p->src->inputs, p->src->outputs, p->src->feedback, opt)));
+  for (size_t i = 0; i < q->input_slots.size(); ++i)
+    if (q->input_slots[i] != SLOT_FIRST_INPUT + i) gsv_panic("internal: inputs are not slot-contiguous");
+  p->prog2 = std::move(q);
+}
 static int upload_program(gsv_engine* e, gsv_program* p, uint32_t ni, DevProgram* out) {
   std::lock_guard<std::mutex> lk(p->mu);
   auto it = p->dev.find({e->device, int(ni)});
   if (it != p->dev.end()) { *out = it->second; return GSV_OK; }
   if (ni == 2 && !p->prog2) {  // first session with two instances per workgroup: compile for half of the LDS window
     GSV_TRY
-    CompileOptions opt = p->src->opt;
-    opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / 2);
-    p->prog2.reset(new Program(compile_program(p->src->trace, p->src->inputs, p->src->outputs, p->src->feedback, opt)));
-    for (size_t i = 0; i < p->prog2->input_slots.size(); ++i)
-      if (p->prog2->input_slots[i] != SLOT_FIRST_INPUT + i) return fail(GSV_ERR_CIRCUIT, "internal: inputs are not slot-contiguous");
+    compile_half_window_variant(p);
     GSV_CATCH
   }
   DevProgram d;
@@ -551,6 +557,13 @@ int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_ins
     if (const char* ev = getenv("GSV_INSTANCES_PER_WG")) { int v = atoi(ev); if (v == 1 || (v == 2 && n_instances >= 2)) s->ni = uint32_t(v); }
   }
   s->call_dev.resize(plan->calls.size());
+  if (s->ni == 2) {  // the plan's programs are independent: compile their missing half-window variants in parallel
+    GSV_TRY
+    std::vector<gsv_program*> todo;
+    for (const auto& c : plan->calls) if (std::find(todo.begin(), todo.end(), c.prog) == todo.end()) todo.push_back(c.prog);
+    parallel_for_programs(todo.size(), [&](size_t i) { std::lock_guard<std::mutex> lk(todo[i]->mu); compile_half_window_variant(todo[i]); });
+    GSV_CATCH
+  }
   uint32_t scratch = SLOT_FIRST_INPUT;
   for (size_t k = 0; k < plan->calls.size(); ++k) {
     int rc = upload_program(e, plan->calls[k].prog, s->ni, &s->call_dev[k].dp);

@@ -14,8 +14,13 @@
 // The gates between units ("glue") are collected into segments; when the circuit is complete every wire that crosses a
 // segment boundary becomes a global wire of the plan and each glue segment is compiled as a program of its own.
 #pragma once
+#include <atomic>
+#include <cstdlib>
+#include <exception>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <set>
 #include <string>
 #include <unordered_map>
@@ -263,6 +268,30 @@ class PlanRecordMode final : public CircuitMode, public UnitHook {
 };
 
 // The finished plan in host form: programs (units first, then one per glue segment) and calls over global wire ids.
+// Runs fn(0 .. n-1) on up to GSV_COMPILE_THREADS (default: the hardware's, at most 16) threads; the first exception is rethrown.
+// Programs of a plan are compiled independently of each other (the Miller loop alone has ~190 of them).
+template <class Fn>
+inline void parallel_for_programs(size_t n, Fn&& fn) {
+  size_t nt = std::thread::hardware_concurrency();
+  if (const char* ev = getenv("GSV_COMPILE_THREADS")) nt = size_t(std::max(1, atoi(ev)));
+  nt = std::min<size_t>(std::min<size_t>(nt ? nt : 1, 16), n);
+  if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+  std::atomic<size_t> next{0};
+  std::exception_ptr err;
+  std::mutex mu;
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nt; ++t)
+    th.emplace_back([&] {
+      for (;;) {
+        const size_t i = next.fetch_add(1);
+        if (i >= n) return;
+        try { fn(i); } catch (...) { std::lock_guard<std::mutex> lk(mu); if (!err) err = std::current_exception(); next.store(n); return; }
+      }
+    });
+  for (auto& t : th) t.join();
+  if (err) std::rethrow_exception(err);
+}
+
 struct BuiltPlan {
   struct Call { int program; std::vector<uint32_t> in_globals, out_globals; };  // program < 0: external program -1 - program
   std::vector<Program> programs;
@@ -307,7 +336,7 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
   for (uint32_t w = 2; w < nw; ++w) if (crossing[w] && global_of[w] == DEAD_WIRE) global_of[w] = next_global++;
   const uint32_t trash = next_global;  // outputs nobody reads in this instance still have to land somewhere
   auto add_program = [&](Trace&& t, std::vector<uint32_t> in, std::vector<uint32_t> out) -> int {
-    bp.programs.push_back(compile_program(t, in, out, {}, opt));
+    bp.programs.emplace_back();  // compiled below, all programs in parallel
     bp.traces.push_back(std::move(t));
     bp.prog_inputs.push_back(std::move(in));
     bp.prog_outputs.push_back(std::move(out));
@@ -370,6 +399,7 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
     bp.calls.push_back(std::move(call));
   }
   for (uint32_t w : outputs) bp.outputs.push_back(w == 0 ? PLAN_WIRE_FALSE : w == 1 ? PLAN_WIRE_TRUE : global_of[w]);
+  parallel_for_programs(bp.programs.size(), [&](size_t i) { bp.programs[i] = compile_program(bp.traces[i], bp.prog_inputs[i], bp.prog_outputs[i], {}, opt); });
   return bp;
 }
 

@@ -248,6 +248,56 @@ inline WireId equal_constant(CircuitContext& c, const Fq12& a, const Fq12Const& 
 }
 }  // namespace fq12
 
+// ------------------------------------------------------------------ square roots (fp254impl.rs:691-725, fq.rs:175-192,290-299, fq2.rs:396-446)
+namespace fq {
+// fp254impl.rs:691-725 (#[bn_component(offcircuit_args = "exp")]): left-to-right square-and-multiply over the exponent's bits
+inline Fq exp_by_constant_montgomery(CircuitContext& c, const Fq& a, const BigU& exp) {
+  check_len(a);
+  const std::string kb = exp.key_bytes();
+  return component(c, KeyBuilder("fp254::exp_by_constant_montgomery").param("exp", kb.data(), kb.size()), a, N, [&exp](CircuitContext& cc, const Wires& x) -> Wires {
+    if (exp.is_zero()) return constant_wires(BigU(1), x.size());  // (the plain constant 1, as in the reference)
+    if (exp == BigU(1)) return x;
+    Fq result = x;
+    for (size_t i = exp.bits() - 1; i-- > 0;) {
+      Fq sq = square_montgomery(cc, result);
+      result = exp.bit(i) ? mul_montgomery(cc, x, sq) : sq;
+    }
+    return result;
+  });
+}
+inline const BigU& modulus_add_1_div_4() { static BigU v = BigU::from_hex("0c19139cb84c680a6e14116da060561765e05aa45a1c72a34f082305b61f3f52"); return v; }  // fp254impl.rs:36-37
+inline const BigU& modulus_minus_one_div_two() { static BigU v = BigU::from_hex("183227397098d014dc2822db40c0ac2ecbc0b548b438e5469e10460b6c3e7ea3"); return v; }
+inline Fq sqrt_montgomery(CircuitContext& c, const Fq& a) { return exp_by_constant_montgomery(c, a, modulus_add_1_div_4()); }  // fq.rs:290-299
+inline WireId is_qnr_montgomery(CircuitContext& c, const Fq& x) {  // fq.rs:177-192: x^((p-1)/2) == -1
+  Fq y = exp_by_constant_montgomery(c, x, modulus_minus_one_div_two());
+  const Fq neg_one = constant_wires(fq_as_montgomery_const(bigu_sub(FqConst::modulus(), BigU(1))), N);
+  return gadgets::equal(c, y, neg_one);
+}
+}  // namespace fq
+namespace fq2 {
+// fq2.rs:425-446 (#[component]): the complex method (eprint 2012/685 algorithm 8), general case c1 != 0, the root is assumed to exist
+inline Fq2 sqrt_general_montgomery(CircuitContext& c, const Fq2& a) {
+  Wires out = component(c, KeyBuilder("fq2::sqrt_general_montgomery"), a.to_wires(), 508, [](CircuitContext& cc, const Wires& in) {
+    const Fq a0 = slice(in, 0, 254), a1 = slice(in, 254, 508);
+    Fq c0s = fq::square_montgomery(cc, a0);
+    Fq c1s = fq::square_montgomery(cc, a1);
+    Fq alpha = fq::add(cc, c0s, c1s);  // norm_montgomery, fq2.rs:397-402
+    Fq alpha_sqrt = fq::sqrt_montgomery(cc, alpha);
+    Fq delta_plus = fq::add(cc, alpha_sqrt, a0);
+    Fq delta = fq::half(cc, delta_plus);
+    WireId is_qnr = fq::is_qnr_montgomery(cc, delta);
+    Fq delta_alt = fq::sub(cc, delta, alpha_sqrt);
+    Fq delta_final = select(cc, delta_alt, delta, is_qnr);
+    Fq c0_final = fq::sqrt_montgomery(cc, delta_final);
+    Fq c0_inv = fq::inverse_montgomery(cc, c0_final);
+    Fq c1_half = fq::half(cc, a1);
+    Fq c1_final = fq::mul_montgomery(cc, c0_inv, c1_half);
+    return concat(c0_final, c1_final);
+  });
+  return Fq2::from_wires(out);
+}
+}  // namespace fq2
+
 // ------------------------------------------------------------------ groth16.rs
 namespace groth16 {
 // groth16.rs:26-48 (#[component])
@@ -287,6 +337,54 @@ inline WireId verify(CircuitContext& c, const std::vector<Wires>& pub, const G1W
   Fq12Const ab;
   for (int i = 0; i < 6; ++i) ab.c[i] = Fq2Const{fq_as_montgomery_const(vk.alpha_beta[2 * i].to_bigu()), fq_as_montgomery_const(vk.alpha_beta[2 * i + 1].to_bigu())};
   return fq12::equal_constant(c, f, ab);
+}
+
+// groth16.rs:116-143 (#[component]): y = +-sqrt(x^3 + b), the flag picks the circuit's own root or its negative; z = 1
+inline G1Wires decompress_g1_from_compressed(CircuitContext& c, const Fq& x_m, WireId y_flag) {
+  Wires in = x_m; in.push_back(y_flag);
+  Wires out = component(c, KeyBuilder("groth16::decompress_g1_from_compressed"), in, 762, [](CircuitContext& cc, const Wires& w) {
+    const Fq x = slice(w, 0, 254);
+    const WireId flag = w[254];
+    Fq x2 = fq::square_montgomery(cc, x);
+    Fq x3 = fq::mul_montgomery(cc, x2, x);
+    Fq rhs = fq::add_constant(cc, x3, fq_as_montgomery_const(BigU(3)));  // g1::Config::COEFF_B = 3
+    Fq sy = fq::sqrt_montgomery(cc, rhs);
+    Fq sy_neg = fq::neg(cc, sy);
+    Fq y = select(cc, sy, sy_neg, flag);
+    return concat(concat(x, y), constant_wires(fq_as_montgomery_const(BigU(1)), 254));
+  });
+  return g1_from_wires(out);
+}
+// groth16.rs:145-182 (#[component])
+inline G2Wires decompress_g2_from_compressed(CircuitContext& c, const Fq2& x, WireId y_flag) {
+  Wires in = x.to_wires(); in.push_back(y_flag);
+  Wires out = component(c, KeyBuilder("groth16::decompress_g2_from_compressed"), in, 1524, [](CircuitContext& cc, const Wires& w) {
+    const Fq2 x = Fq2::from_wires(slice(w, 0, 508));
+    const WireId flag = w[508];
+    Fq2 x2 = fq2::square_montgomery(cc, x);
+    Fq2 x3 = fq2::mul_montgomery(cc, x2, x);
+    Fq2 y2 = fq2::add_constant(cc, x3, PairingConst::coeff_b().as_montgomery_const());
+    Fq2 y = fq2::sqrt_general_montgomery(cc, y2);
+    Fq2 neg_y = fq2::neg(cc, y);
+    Fq y0 = select(cc, y.c[0], neg_y.c[0], flag);
+    Fq y1 = select(cc, y.c[1], neg_y.c[1], flag);
+    Wires out = x.to_wires();
+    out.insert(out.end(), y0.begin(), y0.end());
+    out.insert(out.end(), y1.begin(), y1.end());
+    Wires one = constant_wires(fq_as_montgomery_const(BigU(1)), 254), zero = constant_wires(BigU(), 254);
+    out.insert(out.end(), one.begin(), one.end());
+    out.insert(out.end(), zero.begin(), zero.end());
+    return out;
+  });
+  return pairing::g2_from_wires(out);
+}
+// groth16.rs:250-268: decompress A, B, C, then the verifier
+inline WireId verify_compressed(CircuitContext& c, const std::vector<Wires>& pub, const Fq& ax, WireId a_flag, const Fq2& bx, WireId b_flag, const Fq& cx, WireId c_flag,
+                                const VerifyingKey& vk) {
+  G1Wires a = decompress_g1_from_compressed(c, ax, a_flag);
+  G2Wires b = decompress_g2_from_compressed(c, bx, b_flag);
+  G1Wires cp = decompress_g1_from_compressed(c, cx, c_flag);
+  return verify(c, pub, a, b, cp, vk);
 }
 
 // Binary form of a verifying key inside a circuit name ("groth16_verify:<hex>"): n_pub (1 byte), then 32-byte big-endian

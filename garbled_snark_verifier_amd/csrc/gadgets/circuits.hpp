@@ -8,7 +8,7 @@
 //   fq12_sqmul, fq12_sqmul_chain:K        square-and-multiply link r <- Fq12::mul(Fq12::square(r), b)
 //   fq_inverse, fq2_inverse, fq12_inverse, fq12_frobenius:I, fq12_conjugate, final_exp   (bn254_ext.hpp)
 //   g2_double, g2_add, g2_mul_by_char, ell_eval, ell_const:K, miller_loop               (bn254_pairing.hpp)
-//   g1_add, g1_scalar_mul:W, g1_to_affine, groth16_verify:<vk hex>                      (bn254_groth16.hpp)
+//   g1_add, g1_scalar_mul:W, g1_to_affine, fq_sqrt, fq2_sqrt, groth16_verify:<vk hex>, groth16_verify_compressed:<vk hex>   (bn254_groth16.hpp)
 //   fq_complex          tests/streaming_evaluate.rs:401-407  ((a^2)*b + a)
 //   gate:T              tests/streaming_evaluate.rs:136-213  (one gate of discriminant T at the root)
 //   driver_mix          credits / dead-gate / pass-through / constant edge cases (circuit/mod.rs:419-836 shapes)
@@ -132,7 +132,7 @@ inline NamedCircuit make_circuit(const std::string& spec) {
   size_t colon = spec.find(':');
   if (colon != std::string::npos) {
     name = spec.substr(0, colon);
-    if (name != "groth16_verify") {  // (its parameter is a hex blob, parsed below)
+    if (name != "groth16_verify" && name != "groth16_verify_compressed") {  // (its parameter is a hex blob, parsed below)
       param = std::stoull(spec.substr(colon + 1));
       has_param = true;
     }
@@ -303,6 +303,23 @@ inline NamedCircuit make_circuit(const std::string& spec) {
       const size_t o = n_pub * 254;
       return Wires{groth16::verify(c, pub, g1_from_wires(slice(in, o, o + 762)), pairing::g2_from_wires(slice(in, o + 762, o + 2286)), g1_from_wires(slice(in, o + 2286, o + 3048)), *vk)};
     };
+  } else if (name == "groth16_verify_compressed") {  // groth16.rs:250-268; inputs: public scalars, (A.x, flag), (B.x, flag), (C.x, flag) (groth16.rs:410-421)
+    if (colon == std::string::npos) gsv_panic("groth16_verify_compressed needs a verifying key: groth16_verify_compressed:<hex>");
+    size_t n_pub = 0;
+    auto vk = std::make_shared<groth16::VerifyingKey>(groth16::vk_from_hex(spec.substr(colon + 1), &n_pub));
+    nc.n_inputs = n_pub * 254 + 255 + 509 + 255; nc.n_outputs = 1;
+    nc.fn = [vk, n_pub](CircuitContext& c, const Wires& in) {
+      std::vector<Wires> pub;
+      for (size_t i = 0; i < n_pub; ++i) pub.push_back(slice(in, i * 254, i * 254 + 254));
+      const size_t o = n_pub * 254;
+      return Wires{groth16::verify_compressed(c, pub, slice(in, o, o + 254), in[o + 254], Fq2::from_wires(slice(in, o + 255, o + 763)), in[o + 763],
+                                              slice(in, o + 764, o + 1018), in[o + 1018], *vk)};
+    };
+  } else if (name == "fq_sqrt") {  // fq.rs:290-299
+    one_fq([](CircuitContext& c, const Wires& a) { return fq::sqrt_montgomery(c, a); });
+  } else if (name == "fq2_sqrt") {  // fq2.rs:425-446
+    nc.n_inputs = 508; nc.n_outputs = 508;
+    nc.fn = [](CircuitContext& c, const Wires& in) { return fq2::sqrt_general_montgomery(c, Fq2::from_wires(in)).to_wires(); };
   } else if (name == "fq_addmul") {  // (a + b) * b: glue followed by a component, for the C-ABI plan recorder test
     nc.n_inputs = 508; nc.n_outputs = 254;
     nc.fn = [](CircuitContext& c, const Wires& in) { return fq::mul_montgomery(c, fq::add(c, slice(in, 0, 254), slice(in, 254, 508)), slice(in, 254, 508)); };

@@ -89,3 +89,45 @@ def input_bits(inst):
     for v in [A[0], A[1], 1, B[0][0], B[0][1], B[1][0], B[1][1], 1, 0, C[0], C[1], 1]:
         bits.append(o.int_to_bits(m(v), 254))
     return np.concatenate(bits)
+
+
+# ---- point compression as the reference's circuit undoes it (groth16.rs:116-182) ----
+def fq_sqrt_circuit(v):  # fq.rs:290-299: v^((p+1)/4)
+    return pow(v, (P + 1) // 4, P)
+
+
+def fq2_sqrt_circuit(a):  # fq2.rs:425-446 (complex method, general case)
+    c0, c1 = a
+    alpha = (c0 * c0 + c1 * c1) % P
+    alpha_sqrt = fq_sqrt_circuit(alpha)
+    delta = (alpha_sqrt + c0) * T.HALF % P
+    if pow(delta, (P - 1) // 2, P) == P - 1:
+        delta = (delta - alpha_sqrt) % P
+    r0 = fq_sqrt_circuit(delta)
+    r1 = c1 * T.HALF % P * pow(r0, -1, P) % P
+    return (r0, r1)
+
+
+def compressed_input_bits(inst):
+    """Groth16VerifyCompressedInput order (groth16.rs:410-421): public scalars, (A.x, flag), (B.x, flag), (C.x, flag); a flag is 1
+    when the circuit's own square root IS the point's y (0: its negative)."""
+    m = lambda v: (v * RM) % P
+    bits = [o.int_to_bits(x % R, 254) for x in inst["public"]]
+    A, B, C = inst["A"], inst["B"], inst["C"]
+
+    def g1(pt):
+        sy = fq_sqrt_circuit((pt[0] ** 3 + 3) % P)
+        assert sy in (pt[1], P - pt[1])
+        return [o.int_to_bits(m(pt[0]), 254), np.array([int(sy == pt[1])], np.uint8)]
+
+    bits += g1(A)
+    y2 = T.f2_add(T.f2_mul(T.f2_sq(B[0]), B[0]), T.COEFF_B_G2)
+    sy = fq2_sqrt_circuit(y2)
+    assert sy in (B[1], T.f2_neg(B[1]))
+    bits += [o.int_to_bits(m(B[0][0]), 254), o.int_to_bits(m(B[0][1]), 254), np.array([int(sy == B[1])], np.uint8)]
+    bits += g1(C)
+    return np.concatenate(bits)
+
+
+def compressed_circuit_name(inst):
+    return "groth16_verify_compressed:" + vk_blob(inst).hex()

@@ -81,6 +81,29 @@ def test_projective_to_affine():
     assert from_m(ints_of(ob)) == [a[0], a[1], 1]
 
 
+def test_square_roots():
+    """Fq::sqrt_montgomery (fq.rs:290-299) and Fq2::sqrt_general_montgomery (fq2.rs:425-446): a root of the input, the one the
+    mirror of the circuit's algorithm picks — both branches of the quadratic-non-residue test."""
+    random.seed(12)
+    v = random.randrange(1, P)
+    ob, gc, _ = o.execute("fq_sqrt", bits_of(to_m([v * v % P])))
+    r = from_m(ints_of(ob))[0]
+    assert r in (v, P - v) and r == G.fq_sqrt_circuit(v * v % P)
+    seen = set()
+    for _ in range(6):
+        w = (random.randrange(1, P), random.randrange(1, P))
+        sq = T.f2_sq(w)
+        alpha_sqrt = G.fq_sqrt_circuit((sq[0] * sq[0] + sq[1] * sq[1]) % P)
+        branch = pow((alpha_sqrt + sq[0]) * T.HALF % P, (P - 1) // 2, P) == P - 1
+        if branch in seen:
+            continue
+        seen.add(branch)
+        ob, _, _ = o.execute("fq2_sqrt", bits_of(to_m(list(sq))))
+        r = tuple(from_m(ints_of(ob)))
+        assert r in (w, T.f2_neg(w)) and r == G.fq2_sqrt_circuit(sq)
+    assert seen == {True, False}
+
+
 def test_vk_blob_round_trip_and_instance_is_valid():
     inst = G.make_instance(n_pub=2, seed=3)
     assert G.check_instance(inst)  # the pairing equation holds in the Python mirror
@@ -99,4 +122,21 @@ def test_groth16_verify_accepts_valid_and_rejects_tampered():
     print("groth16_verify gates:", int(gc.sum()), "peak live wires:", peak)
     bad = dict(inst, public=[inst["public"][0] + 1, inst["public"][1]])
     ob, _, _ = o.execute(name, G.input_bits(bad))
+    assert ob.tolist() == [0]
+
+
+@pytest.mark.skipif(not os.environ.get("GSV_SLOW"), reason="11 B gates in execute mode: minutes; set GSV_SLOW=1")
+def test_groth16_verify_compressed_accepts_valid_and_rejects_tampered():
+    """groth16_verify_compressed (groth16.rs:250-268): decompression of A, B, C in front of the verifier — the reference's
+    headline circuit (README.md:12 quotes 11,174,708,821 gates for its key; the count depends on the key's constants)."""
+    inst = G.make_instance(n_pub=2, seed=3)
+    name = G.compressed_circuit_name(inst)
+    bits = G.compressed_input_bits(inst)
+    assert o.circuit_info(name) == (bits.size, 1)
+    ob, gc, peak = o.execute(name, bits)
+    assert ob.tolist() == [1]
+    print("groth16_verify_compressed gates:", int(gc.sum()), "peak live wires:", peak)
+    bad = bits.copy()
+    bad[2 * 254 + 254] ^= 1  # A's sign flag: the other root, another point
+    ob, _, _ = o.execute(name, bad)
     assert ob.tolist() == [0]

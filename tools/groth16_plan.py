@@ -7,6 +7,7 @@ projective -> affine, Miller loop, final exponentiation, comparison with the con
 2. garble two instances with the stream retained in HBM (48 GB each) and EVALUATE them: the valid proof decodes to 1, the same
    proof with one public-input bit flipped to 0;
 3. device rate with the ciphertexts discarded.
+`--compressed`: the same for groth16_verify_compressed (point decompression in front: the reference's headline circuit).
 The verifying key / proof are the synthetic instance of tests/groth16_ref.py; the circuit name in the fixture carries the key."""
 import hashlib
 import json
@@ -23,7 +24,10 @@ import garbled_snark_verifier_amd as gsv
 UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cyclotomic_square_montgomery", "fq12::inverse_montgomery", "fq12::mul_by_034_montgomery",
          "pairing::ell_by_constant_montgomery", "pairing::double_in_place_circuit_montgomery", "pairing::add_in_place_montgomery", "pairing::mul_by_char_montgomery",
          "bigint::multiplexer", "g1::add_montgomery", "fp254::inverse"]
-case = json.load(open(os.path.join(ROOT, "tests", "golden", "groth16_verify_golden.json")))
+COMPRESSED = "--compressed" in sys.argv  # groth16_verify_compressed (groth16.rs:250-268): decompression of A, B, C in front of the verifier
+if COMPRESSED:  # the square roots are chains of ~380 Fq multiplications each: the multiplication's two halves are the units
+    UNITS += ["bigint::mul_karatsuba", "fp254::montgomery_reduce"]
+case = json.load(open(os.path.join(ROOT, "tests", "golden", "groth16_verify_compressed_golden.json" if COMPRESSED else "groth16_verify_golden.json")))
 eng = gsv.Engine(0)
 t0 = time.time()
 plan = gsv.Plan.from_circuit(case["circuit"], UNITS)
@@ -47,7 +51,7 @@ sess.close()
 
 if "--no-eval" not in sys.argv:
     bits_ok = np.unpackbits(np.frombuffer(bytes.fromhex(case["input_bits_hex"]), np.uint8), bitorder="little")[:n_in].astype(np.uint8)
-    bits_bad = bits_ok.copy(); bits_bad[0] ^= 1  # another public input: the proof no longer verifies
+    bits_bad = bits_ok.copy(); bits_bad[case.get("tamper_bit", 0)] ^= 1  # another public input (compressed: A's other root): the proof no longer verifies
     bits = np.stack([bits_ok, bits_bad])
     sess = gsv.Session(eng, plan, 2)
     sess.set_garble_inputs(delta, consts, inputs)
