@@ -626,19 +626,27 @@ def test_msm_plan_with_constant_tables(engine):
     sess.close()
 
 
-@pytest.mark.skipif(not os.environ.get("GSV_SLOW"), reason="building the plan of the whole verifier takes ~8 minutes of host time and ~90 GB of host memory; set GSV_SLOW=1 or run tools/groth16_plan.py")
-def test_groth16_verifier_as_a_plan(engine):
-    """groth16_verify (groth16.rs:58-110) — MSM, projective-to-affine, Miller loop, final exponentiation, comparison — for the
-    synthetic instance of tests/groth16_ref.py: 10,914,485,653 gates as one plan; hash + output label == the oracle's flat-stream
-    fixture (tests/golden/make_big_golden.py).  tools/groth16_plan.py runs the same check, evaluates a valid and a tampered
+VERIFIER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cyclotomic_square_montgomery", "fq12::inverse_montgomery", "fq12::mul_by_034_montgomery",
+                  "pairing::ell_by_constant_montgomery", "pairing::double_in_place_circuit_montgomery", "pairing::add_in_place_montgomery", "pairing::mul_by_char_montgomery",
+                  "bigint::multiplexer", "g1::add_montgomery", "fp254::inverse"]
+
+
+@pytest.mark.skipif(not os.environ.get("GSV_SLOW"), reason="building the plan of the whole verifier takes minutes of host time and ~90 GB of host memory; set GSV_SLOW=1 or run tools/groth16_plan.py")
+@pytest.mark.parametrize("fixture,units,gates", [
+    ("groth16_verify_golden.json", VERIFIER_UNITS, 10_914_485_653),
+    ("groth16_verify_compressed_golden.json", VERIFIER_UNITS + ["bigint::mul_karatsuba", "fp254::montgomery_reduce"], 11_687_200_297),
+])
+def test_groth16_verifier_as_a_plan(engine, fixture, units, gates):
+    """groth16_verify (groth16.rs:58-110: MSM, projective-to-affine, Miller loop, final exponentiation, comparison) and
+    groth16_verify_compressed (groth16.rs:250-268: point decompression in front) for the synthetic instance of
+    tests/groth16_ref.py, as one plan each; hash + output label == the oracle's flat-stream fixtures
+    (tests/golden/make_big_golden.py).  tools/groth16_plan.py [--compressed] runs the same check, evaluates a valid and a tampered
     proof and measures the device rate."""
     import hashlib
     import garbled_snark_verifier_amd as gsv
-    case = json.load(open(os.path.join(os.path.dirname(GOLDEN), "groth16_verify_golden.json")))
-    plan = gsv.Plan.from_circuit(case["circuit"], ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cyclotomic_square_montgomery", "fq12::inverse_montgomery",
-                                                   "fq12::mul_by_034_montgomery", "pairing::ell_by_constant_montgomery", "pairing::double_in_place_circuit_montgomery",
-                                                   "pairing::add_in_place_montgomery", "pairing::mul_by_char_montgomery", "bigint::multiplexer", "g1::add_montgomery", "fp254::inverse"])
-    assert plan.info["n_gates"] == case["gates"] == 10_914_485_653 and plan.info["n_ciphertexts"] == case["n_ciphertexts"]
+    case = json.load(open(os.path.join(os.path.dirname(GOLDEN), fixture)))
+    plan = gsv.Plan.from_circuit(case["circuit"], units)
+    assert plan.info["n_gates"] == case["gates"] == gates and plan.info["n_ciphertexts"] == case["n_ciphertexts"]
     d, f, t, inp = gsv.labels_from_seed(case["seed"], plan.info["n_inputs"])
     sess = gsv.Session(engine, plan, 1, retain_stream=False)
     sess.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
