@@ -27,6 +27,102 @@ VERIFIER_GATES = 11_174_708_821  # README.md:12 of the reference
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+VERIFIER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cyclotomic_square_montgomery", "fq12::inverse_montgomery", "fq12::mul_by_034_montgomery",
+                  "pairing::ell_by_constant_montgomery", "pairing::double_in_place_circuit_montgomery", "pairing::add_in_place_montgomery", "pairing::mul_by_char_montgomery",
+                  "bigint::multiplexer", "g1::add_montgomery", "fp254::inverse"]
+
+
+def real_verifier(args):
+    """--workload verifier[_compressed]: the real Groth16 verifier circuit instead of the synthetic chain.  Same
+    contract: a step garbles `--instances` instances per rank (ciphertexts produced on the device and discarded, as in the
+    synthetic step where the ring overwrites them), barrier + synchronize around exactly K steps, max over ranks, one JSON line."""
+    import hashlib
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import garbled_snark_verifier_amd as gsv
+    compressed = args.workload == "verifier_compressed"
+    case = json.load(open(os.path.join(ROOT, "tests", "golden", "groth16_verify_compressed_golden.json" if compressed else "groth16_verify_golden.json")))
+    engine = gsv.Engine(local_rank)
+    t0 = time.time()
+    plan = gsv.Plan.from_circuit(case["circuit"], VERIFIER_UNITS + (["bigint::mul_karatsuba", "fp254::montgomery_reduce"] if compressed else []), half_window=True)
+    build_s = time.time() - t0
+    B, n_in, gates = args.instances, plan.info["n_inputs"], plan.info["n_gates"]
+    f_nf = plan.info["n_ciphertexts"] / gates
+    bytes_per_gate = 64.0 + 16.0 * f_nf
+    seeds = [1_000_003 * (rank + 1) + i for i in range(B)]
+    delta = np.zeros((B, 16), np.uint8); consts = np.zeros((B, 2, 16), np.uint8); inputs = np.zeros((B, n_in, 16), np.uint8)
+    for i, sd in enumerate(seeds):
+        delta[i], consts[i, 0], consts[i, 1], inputs[i] = gsv.labels_from_seed(sd, n_in)
+    sess = gsv.Session(engine, plan, B, retain_stream=False)
+    ni = sess.instances_per_workgroup
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def step():
+        sess.set_garble_inputs(delta, consts, inputs)
+        sess.garble_streaming(discard=True)  # returns when the last call has finished
+        if world > 1:
+            out = torch.from_numpy(sess.read_outputs()).to("cuda")
+            dist.all_gather([torch.empty_like(out) for _ in range(world)], out)
+        return sess.last_kernel_ms()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    gpu_ms = [step() for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    sess.close()
+    result = None
+    if rank == 0:
+        avg_s = sum(gpu_ms) / len(gpu_ms) / 1e3
+        achieved = gates * B * bytes_per_gate / avg_s / 1e9
+        result = {"metric": "gates/sec (garble) on Groth16/BN254 verifier; ciphertext-hash match", "value": gates * B * world * args.steps / elapsed, "unit": "gates/s",
+                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                  "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                  "config": {"workload": "the real %s circuit (synthetic 2-public-input verifying key / proof of tests/groth16_ref.py): %d gates per instance in %d calls of "
+                                         "component programs; %d cut-and-choose instances per GPU" % ("groth16_verify_compressed" if compressed else "groth16_verify", gates, plan.info["n_calls"], B),
+                             "instances_per_gpu": B, "gates_per_instance": gates, "nonfree_fraction": f_nf, "plan_calls": plan.info["n_calls"], "plan_build_s": build_s,
+                             "host_peak_rss_gb": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1e6},
+                  "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "run_program_kernel<false, %d, 0> (all %d launches of one step, stream time between the first and the last)" % (ni, plan.info["n_calls"]),
+                               "kernel_ms_avg": avg_s * 1e3, "bytes_per_gate": bytes_per_gate, "algorithmic_bytes_per_launch": gates * B * bytes_per_gate,
+                               "aes_ceiling_gates_per_s": 4.9e10 / f_nf, "aes_ceiling_frac": (gates * B / avg_s) / (4.9e10 / f_nf)}}
+        if not args.no_check:  # the fixture's seed through the streaming path (stream drained and hashed on the host): oracle's flat-stream hash
+            d, f, t, inp = gsv.labels_from_seed(case["seed"], n_in)
+            chk = gsv.Session(engine, plan, 1, retain_stream=False)
+            chk.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
+            h = chk.garble_streaming()[0].hex()
+            ok = h == case["ct_hash"] and hashlib.sha256(chk.read_outputs()[0].tobytes()).hexdigest() == case["output_label0_sha256"]
+            chk.close()
+            result["ciphertext_hash_match"] = bool(ok)
+            result["hash_check"] = {"circuit": "the whole circuit, seed %d" % case["seed"], "gpu": h, "oracle": case["ct_hash"]}
+        if args.cpu_baseline_chain and world == 1:
+            import oracle_lib as o
+            sec, g, _ = o.bench_garble("g1_scalar_mul:10", seed=0)
+            result["cpu_baseline"] = {"value": g / sec, "unit": "gates/s", "cores": 1, "kind": "port",
+                                      "sample": "g1_scalar_mul:10 (one window-10 scalar multiplication of the verifier's MSM, %d gates) garbled once by the C++ oracle, AES-NI hash + inline CBC-MAC, 1 thread, %.1f s" % (g, sec)}
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -39,7 +135,12 @@ def main():
     ap.add_argument("--component", default="fq12_sqmul", choices=["fq12_sqmul", "fq12_mul"],
                     help="link of the chain: fq12_sqmul = r <- Fq12::mul(Fq12::square(r), b) (33.9 M gates), fq12_mul = r <- Fq12::mul(r, b) (20.3 M)")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "verifier", "verifier_compressed"],
+                    help="synthetic (default): the Groth16-shaped chain; verifier / verifier_compressed: the REAL groth16_verify(_compressed) circuit of the "
+                         "committed fixture as a plan of component programs (2 minutes of plan build and ~90 GB of host memory per rank)")
     args = ap.parse_args()
+    if args.workload != "synthetic":
+        return real_verifier(args)
 
     import numpy as np
     import torch

@@ -257,12 +257,24 @@ class Plan:
         self.n_inputs = self.n_outputs = 0
 
     @classmethod
-    def from_circuit(cls, spec, units):
-        """Record a built-in circuit with the named components (list of names such as "fq12::mul_montgomery") as calls."""
+    def from_circuit(cls, spec, units, half_window=False):
+        """Record a built-in circuit with the named components (list of names such as "fq12::mul_montgomery") as calls.
+        half_window: compile every program once, for the half LDS window (serves one and two instances per workgroup; the
+        recorded traces are not kept) — a third less host memory and one compilation for plans with hundreds of programs."""
         self = cls.__new__(cls)
         self.h = C.c_void_p()
         self.programs = []
-        _chk(lib().gsv_plan_from_circuit(spec.encode(), ",".join(units).encode(), C.byref(self.h)))
+        old = os.environ.get("GSV_PLAN_HALF_WINDOW")
+        if half_window:
+            os.environ["GSV_PLAN_HALF_WINDOW"] = "1"
+        try:
+            _chk(lib().gsv_plan_from_circuit(spec.encode(), ",".join(units).encode(), C.byref(self.h)))
+        finally:
+            if half_window:
+                if old is None:
+                    del os.environ["GSV_PLAN_HALF_WINDOW"]
+                else:
+                    os.environ["GSV_PLAN_HALF_WINDOW"] = old
         g, c, k = C.c_uint64(), C.c_uint64(), C.c_uint64()
         _chk(lib().gsv_plan_counts(self.h, C.byref(g), C.byref(c), C.byref(k)))
         n_in, n_out = C.c_uint64(), C.c_uint64()

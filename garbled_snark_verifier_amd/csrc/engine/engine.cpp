@@ -61,6 +61,8 @@ struct ProgramSource {
 struct gsv_program {
   Program prog;                    // full LDS window: one instance per workgroup
   std::unique_ptr<Program> prog2;  // half window: two instances per workgroup (compiled on demand)
+  bool half_only = false;          // `prog` itself was compiled for the half window and serves both layouts (GSV_PLAN_HALF_WINDOW: no second variant, no trace kept)
+  const Program& variant(uint32_t ni) const { return (ni == 2 && !half_only) ? *prog2 : prog; }
   std::unique_ptr<ProgramSource> src;
   std::mutex mu;
   std::map<std::pair<int, int>, DevProgram> dev;  // per (device, instances per workgroup)
@@ -111,8 +113,8 @@ struct gsv_session {
   struct CallDev { DevProgram dp; void *pre_src = nullptr, *pre_dst = nullptr, *post_src = nullptr, *post_dst = nullptr; };
   std::vector<CallDev> call_dev;
   void* plan_out_slots = nullptr;
-  const Program& prog() const { return plan ? facade : (ni == 2 ? *p->prog2 : p->prog); }
-  const Program& call_prog(size_t k) const { const gsv_program* q = plan->calls[k].prog; return ni == 2 ? *q->prog2 : q->prog; }
+  const Program& prog() const { return plan ? facade : p->variant(ni); }
+  const Program& call_prog(size_t k) const { return plan->calls[k].prog->variant(ni); }
   uint32_t first_input_slot() const { return plan ? global_base : SLOT_FIRST_INPUT; }
   bool ran = false, last_eval = false, garbled = false;
   int hasher = 0;  // 0 AesNiHasher, 1 Blake3Hasher
@@ -273,7 +275,7 @@ int gsv_labels_from_seed(uint64_t seed, size_t n_inputs, uint8_t delta[16], uint
 // ---------------------------------------------------------------- sessions
 // The half-window variant of a program (two instances per workgroup), compiled on first use.  Throws on failure; p->mu held by the caller.
 static void compile_half_window_variant(gsv_program* p) {
-  if (p->prog2) return;
+  if (p->prog2 || p->half_only) return;
   CompileOptions opt = p->src->opt;
   opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / 2);
   std::unique_ptr<Program> q(new Program(compile_program(p->src->trace, p->src->inputs, p->src->outputs, p->src->feedback, opt)));
@@ -285,13 +287,13 @@ static int upload_program(gsv_engine* e, gsv_program* p, uint32_t ni, DevProgram
   std::lock_guard<std::mutex> lk(p->mu);
   auto it = p->dev.find({e->device, int(ni)});
   if (it != p->dev.end()) { *out = it->second; return GSV_OK; }
-  if (ni == 2 && !p->prog2) {  // first session with two instances per workgroup: compile for half of the LDS window
+  if (ni == 2 && !p->prog2 && !p->half_only) {  // first session with two instances per workgroup: compile for half of the LDS window
     GSV_TRY
     compile_half_window_variant(p);
     GSV_CATCH
   }
   DevProgram d;
-  const Program& g = ni == 2 ? *p->prog2 : p->prog;
+  const Program& g = p->variant(ni);
   auto up = [&](void** dst, const void* src, size_t bytes) -> int {
     // +32 bytes of zero padding: the kernel's record prefetch reads 24 bytes wherever a lane's record starts
     HIPCHK(hipMalloc(dst, bytes + 32));
@@ -428,13 +430,20 @@ int gsv_plan_from_circuit(const char* spec, const char* units_csv, gsv_plan** ou
   for (WireId w : run.execute()) out_ssa.push_back(mode.current(w));
   CompileOptions opt;
   if (const char* e = getenv("GSV_FUSE")) opt.fuse = atoi(e) != 0;
+  // GSV_PLAN_HALF_WINDOW=1: compile every program once, for the half LDS window; the same image then serves one and two
+  // instances per workgroup and the recorded traces are not kept (a third less host memory and no second compilation for
+  // plans with hundreds of programs, at a slightly smaller window when sessions have <= 256 instances)
+  const bool half_only = getenv("GSV_PLAN_HALF_WINDOW") && atoi(getenv("GSV_PLAN_HALF_WINDOW")) != 0;
+  if (half_only) opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / 2);
   BuiltPlan bp = finish_plan(mode, in_ssa, out_ssa, opt);
   std::unique_ptr<gsv_plan> plan(new gsv_plan());
   for (size_t k = 0; k < bp.programs.size(); ++k) {
     gsv_program* q = new gsv_program();
     plan->owned.push_back(q);
     q->prog = std::move(bp.programs[k]);
-    q->src.reset(new ProgramSource{std::move(bp.traces[k]), bp.prog_inputs[k], bp.prog_outputs[k], {}, opt});
+    q->half_only = half_only;
+    if (half_only) bp.traces[k] = Trace();
+    else q->src.reset(new ProgramSource{std::move(bp.traces[k]), bp.prog_inputs[k], bp.prog_outputs[k], {}, opt});
     for (size_t i = 0; i < q->prog.input_slots.size(); ++i)
       if (q->prog.input_slots[i] != SLOT_FIRST_INPUT + i) { gsv_plan_destroy(plan.release()); return fail(GSV_ERR_CIRCUIT, "internal: inputs are not slot-contiguous"); }
   }

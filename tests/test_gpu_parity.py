@@ -593,6 +593,28 @@ def test_miller_loop_as_a_plan(engine):
     sess.close()
 
 
+def test_half_window_plan_serves_both_layouts(engine, monkeypatch):
+    """GSV_PLAN_HALF_WINDOW / Plan.from_circuit(half_window=True): every program of the plan is compiled once, for the half LDS
+    window, and the same image runs with one and with two instances per workgroup; hashes and labels == the oracle's."""
+    import garbled_snark_verifier_amd as gsv
+    plan = gsv.Plan.from_circuit("fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"], half_window=True)
+    seeds = [91, 92, 93]
+    B, n_in = len(seeds), plan.info["n_inputs"]
+    labs = [gsv.labels_from_seed(s, n_in) for s in seeds]
+    delta = np.stack([x[0] for x in labs]); consts = np.stack([np.stack([x[1], x[2]]) for x in labs]); inputs = np.stack([x[3] for x in labs])
+    refs = [o.garble("fq12_mix", s, capture_ct=False) for s in seeds]
+    for ni in ("1", "2"):
+        monkeypatch.setenv("GSV_INSTANCES_PER_WG", ni)
+        sess = gsv.Session(engine, plan, B)
+        assert sess.instances_per_workgroup == int(ni)
+        sess.set_garble_inputs(delta, consts, inputs)
+        sess.garble(0)
+        out = sess.read_outputs()
+        for i, ref in enumerate(refs):
+            assert sess.ciphertext_hash(i) == ref.ct_hash.tobytes() and (out[i] == ref.output_label0).all()
+        sess.close()
+
+
 def test_msm_plan_with_constant_tables(engine):
     """The verifier's window scalar multiplication (g1.rs:309-368) as a plan: the multiplexer units take the MSM's constant
     tables as inputs (call operands that are the constant wires), G1 additions are the other unit.  Window 10 as in the verifier:

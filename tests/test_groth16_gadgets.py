@@ -140,3 +140,14 @@ def test_groth16_verify_compressed_accepts_valid_and_rejects_tampered():
     bad[2 * 254 + 254] ^= 1  # A's sign flag: the other root, another point
     ob, _, _ = o.execute(name, bad)
     assert ob.tolist() == [0]
+
+
+@pytest.mark.skipif(not os.environ.get("GSV_SLOW"), reason="11 B gates in execute mode: minutes; set GSV_SLOW=1")
+@pytest.mark.parametrize("n_pub,gates", [(0, 10_457_717_451), (1, 10_684_151_254)])
+def test_groth16_verify_with_fewer_public_inputs(n_pub, gates):
+    """No public input: the MSM is the constant identity (g1.rs:376-383) and only gamma_abc_g1[0] enters; one: a single window
+    scalar multiplication (225 M gates)."""
+    inst = G.make_instance(n_pub=n_pub, seed=5 + n_pub)
+    assert G.check_instance(inst)
+    ob, gc, _ = o.execute(G.circuit_name(inst), G.input_bits(inst))
+    assert ob.tolist() == [1] and int(gc.sum()) == gates
