@@ -424,17 +424,18 @@ int gsv_plan_from_circuit(const char* spec, const char* units_csv, gsv_plan** ou
   }
   NamedCircuit nc = make_circuit(spec);
   PlanRecordMode mode(names);
+  CompileOptions opt;
+  if (const char* e = getenv("GSV_FUSE")) opt.fuse = atoi(e) != 0;
+  // GSV_PLAN_HALF_WINDOW=1: compile every program once, for the half LDS window; the same image then serves one and two
+  // instances per workgroup and the recorded traces are not kept (less host memory and no second compilation for plans with
+  // hundreds of programs, at a slightly smaller window when sessions have <= 256 instances)
+  const bool half_only = getenv("GSV_PLAN_HALF_WINDOW") && atoi(getenv("GSV_PLAN_HALF_WINDOW")) != 0;
+  if (half_only) opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / 2);
+  mode.compile_in_background(opt, half_only);  // units are compiled while the driver records the rest of the circuit
   StreamingRunner run(mode, nc.n_inputs, nc.fn);
   std::vector<uint32_t> in_ssa, out_ssa;
   for (WireId w : run.prepare()) in_ssa.push_back(mode.define_input(w));
   for (WireId w : run.execute()) out_ssa.push_back(mode.current(w));
-  CompileOptions opt;
-  if (const char* e = getenv("GSV_FUSE")) opt.fuse = atoi(e) != 0;
-  // GSV_PLAN_HALF_WINDOW=1: compile every program once, for the half LDS window; the same image then serves one and two
-  // instances per workgroup and the recorded traces are not kept (a third less host memory and no second compilation for
-  // plans with hundreds of programs, at a slightly smaller window when sessions have <= 256 instances)
-  const bool half_only = getenv("GSV_PLAN_HALF_WINDOW") && atoi(getenv("GSV_PLAN_HALF_WINDOW")) != 0;
-  if (half_only) opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / 2);
   BuiltPlan bp = finish_plan(mode, in_ssa, out_ssa, opt);
   std::unique_ptr<gsv_plan> plan(new gsv_plan());
   for (size_t k = 0; k < bp.programs.size(); ++k) {

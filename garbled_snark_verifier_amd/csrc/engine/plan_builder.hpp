@@ -15,6 +15,9 @@
 // segment boundary becomes a global wire of the plan and each glue segment is compiled as a program of its own.
 #pragma once
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <cstdlib>
 #include <exception>
 #include <map>
@@ -38,6 +41,64 @@ struct PlanUnit {  // one compiled (component key, output liveness) pair
   uint64_t n_gates = 0;
   int external = -1;  // >= 0: the program was compiled by the caller (C ABI plan recorder); trace / inputs / outputs are empty
   size_t n_ext_outputs = 0;
+  std::unique_ptr<Program> compiled;  // set by the background compiler (PlanRecordMode::compile_in_background) before finish_plan
+};
+
+inline size_t plan_compile_threads() {  // GSV_COMPILE_THREADS, default: the hardware's, at most 16
+  size_t nt = std::thread::hardware_concurrency();
+  if (const char* ev = getenv("GSV_COMPILE_THREADS")) nt = size_t(std::max(1, atoi(ev)));
+  return std::min<size_t>(nt ? nt : 1, 16);
+}
+
+// A small bounded worker pool: unit programs are compiled while the driver keeps recording (the recording is serial, a
+// compilation takes about as long as recording the unit).  submit() blocks while 2 x threads jobs are pending, which bounds the
+// traces and compiler temporaries in flight; the first exception is rethrown by wait().
+class CompilePool {
+ public:
+  explicit CompilePool(size_t threads) {
+    for (size_t i = 0; i < std::max<size_t>(1, threads); ++i)
+      th_.emplace_back([this] {
+        for (;;) {
+          std::function<void()> job;
+          {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+            if (q_.empty()) return;
+            job = std::move(q_.front());
+            q_.pop_front();
+            ++running_;
+          }
+          try { job(); } catch (...) { std::lock_guard<std::mutex> lk(mu_); if (!err_) err_ = std::current_exception(); }
+          { std::lock_guard<std::mutex> lk(mu_); --running_; }
+          cv_done_.notify_all();
+        }
+      });
+  }
+  ~CompilePool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  void submit(std::function<void()> job) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [this] { return q_.size() < 2 * th_.size(); });
+    q_.push_back(std::move(job));
+    cv_.notify_one();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [this] { return q_.empty() && running_ == 0; });
+    if (err_) { auto e = err_; err_ = nullptr; std::rethrow_exception(e); }
+  }
+
+ private:
+  std::vector<std::thread> th_;
+  std::deque<std::function<void()>> q_;
+  std::mutex mu_;
+  std::condition_variable cv_, cv_done_;
+  size_t running_ = 0;
+  bool stop_ = false;
+  std::exception_ptr err_;
 };
 
 // A glue segment in canonical form: operands are either a wire defined earlier in the same segment (its definition index:
@@ -65,6 +126,14 @@ struct PlanSegment {
 class PlanRecordMode final : public CircuitMode, public UnitHook {
  public:
   explicit PlanRecordMode(std::vector<std::string> unit_names) : unit_names_(std::move(unit_names)) { ver_.assign(2, 0); ver_[1] = 1; written_.assign(2, 1); }
+
+  // Compile every unit as soon as it has been recorded, on a worker pool, with the options finish_plan will be given.
+  // drop_traces: free a unit's trace once its program exists (no other variant of the program will be compiled).
+  void compile_in_background(const CompileOptions& opt, bool drop_traces) {
+    bg_opt_ = opt; bg_drop_ = drop_traces;
+    pool_.reset(new CompilePool(plan_compile_threads()));
+  }
+  void wait_for_compilations() { if (pool_) pool_->wait(); }
 
   // ---- CircuitMode (same rules as RecordMode, program.hpp)
   WireId allocate_wire(Credits credits) override {
@@ -134,6 +203,15 @@ class PlanRecordMode final : public CircuitMode, public UnitHook {
       u->n_gates = u->trace.size();
       it = unit_index_.emplace(cache_key, int(units.size())).first;
       units.push_back(std::move(u));
+      if (pool_) {
+        PlanUnit* pu = units.back().get();  // stable: the vector holds pointers; nothing else touches the trace before finish_plan
+        const CompileOptions opt = bg_opt_;
+        const bool drop = bg_drop_;
+        pool_->submit([pu, opt, drop] {
+          pu->compiled.reset(new Program(compile_program(pu->trace, pu->inputs, pu->outputs, {}, opt)));
+          if (drop) pu->trace = Trace();
+        });
+      }
     }
     const PlanUnit& u = *units[size_t(it->second)];
     (void)tpl; (void)Out::Internal;
@@ -265,6 +343,9 @@ class PlanRecordMode final : public CircuitMode, public UnitHook {
   std::vector<uint8_t> written_;
   uint32_t next_ssa_ = 2;  // 0 / 1 are the constants
   uint64_t n_gates_ = 0;
+  std::unique_ptr<CompilePool> pool_;
+  CompileOptions bg_opt_;
+  bool bg_drop_ = false;
 };
 
 // The finished plan in host form: programs (units first, then one per glue segment) and calls over global wire ids.
@@ -272,9 +353,7 @@ class PlanRecordMode final : public CircuitMode, public UnitHook {
 // Programs of a plan are compiled independently of each other (the Miller loop alone has ~190 of them).
 template <class Fn>
 inline void parallel_for_programs(size_t n, Fn&& fn) {
-  size_t nt = std::thread::hardware_concurrency();
-  if (const char* ev = getenv("GSV_COMPILE_THREADS")) nt = size_t(std::max(1, atoi(ev)));
-  nt = std::min<size_t>(std::min<size_t>(nt ? nt : 1, 16), n);
+  const size_t nt = std::min<size_t>(plan_compile_threads(), n);
   if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
   std::atomic<size_t> next{0};
   std::exception_ptr err;
@@ -306,6 +385,7 @@ struct BuiltPlan {
 // inputs / outputs: global SSA ids of the circuit's inputs / outputs as PlanRecordMode handed them out.
 inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inputs, const std::vector<uint32_t>& outputs, const CompileOptions& opt = CompileOptions()) {
   m.close_glue();
+  m.wait_for_compilations();
   BuiltPlan bp;
   const uint32_t nw = m.n_ssa();
   constexpr int32_t SEG_INPUT = -1, SEG_NONE = -2;
@@ -335,8 +415,10 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
   bp.n_inputs = next_global;
   for (uint32_t w = 2; w < nw; ++w) if (crossing[w] && global_of[w] == DEAD_WIRE) global_of[w] = next_global++;
   const uint32_t trash = next_global;  // outputs nobody reads in this instance still have to land somewhere
+  std::vector<uint8_t> done;
   auto add_program = [&](Trace&& t, std::vector<uint32_t> in, std::vector<uint32_t> out) -> int {
-    bp.programs.emplace_back();  // compiled below, all programs in parallel
+    bp.programs.emplace_back();  // compiled below, all programs in parallel (units may have been compiled while recording)
+    done.push_back(0);
     bp.traces.push_back(std::move(t));
     bp.prog_inputs.push_back(std::move(in));
     bp.prog_outputs.push_back(std::move(out));
@@ -355,6 +437,7 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
           // later calls of the unit reuse the program index, so the trace can move (178 constant-specialised line
           // functions of the Miller loop would otherwise exist twice)
           unit_program[size_t(s.unit)] = add_program(std::move(u.trace), u.inputs, u.outputs);
+          if (u.compiled) { bp.programs.back() = std::move(*u.compiled); u.compiled.reset(); done.back() = 1; }
         }
         call.program = unit_program[size_t(s.unit)];
       }
@@ -399,7 +482,7 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
     bp.calls.push_back(std::move(call));
   }
   for (uint32_t w : outputs) bp.outputs.push_back(w == 0 ? PLAN_WIRE_FALSE : w == 1 ? PLAN_WIRE_TRUE : global_of[w]);
-  parallel_for_programs(bp.programs.size(), [&](size_t i) { bp.programs[i] = compile_program(bp.traces[i], bp.prog_inputs[i], bp.prog_outputs[i], {}, opt); });
+  parallel_for_programs(bp.programs.size(), [&](size_t i) { if (!done[i]) bp.programs[i] = compile_program(bp.traces[i], bp.prog_inputs[i], bp.prog_outputs[i], {}, opt); });
   return bp;
 }
 
