@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
-"""Headline benchmark: gates/s (garble) on the Groth16/BN254-verifier-sized circuit, one rank per GPU.
+"""Headline benchmark: gates/s (garble) on the Groth16/BN254 verifier circuit, one rank per GPU.
 
-Workload (BASELINE.json configs[3]): one garbling instance = 11.17 B gates.  The full verifier's gate
-stream producer (pairing / MSM gadgets) is SURVEY.md §8(f1) "next"; until it lands the circuit is the
-Groth16-SHAPED SYNTHETIC named in SURVEY.md §8(d): a chain of R = 551 `Fq12::mul_montgomery`
-components (r <- r*b), 20,284,982 gates each = 11,177,025,082 gates, garbled exactly as the reference
-would stream it (gate ids and ciphertext indices run through the whole chain; verified bit-exactly
-against the CPU oracle on a short chain in tests/ and below).  Every GPU garbles `--instances`
-independent cut-and-choose instances (own seed => own delta / labels / ciphertext stream) per step.
+Default workload (BASELINE.json configs[3]): the REAL verifier — `groth16_verify_compressed` (reference:
+src/gadgets/groth16.rs:250-268, the circuit src/garbled_groth16.rs garbles): point decompression, window-10 MSM,
+Miller loop, final exponentiation, comparison — 11,687,200,297 gates per instance for the synthetic 2-public-input
+verifying key of tests/groth16_ref.py (the reference quotes 11,174,708,821 for its own key), recorded as a plan of
+component programs and garbled exactly as the reference streams it; the whole stream's CBC-MAC and the
+output label are checked against the fixture the CPU oracle produced from the FLAT stream.  Every GPU garbles
+`--instances` independent cut-and-choose instances (own seed => own delta / labels / ciphertext stream) per step.
 
-One "step" = one pass of the hot path: garble all instances of this rank's batch, ciphertexts written to
-each instance's device-resident stream (ring of `--ct-ring` replays), output labels gathered.
-`value` = total gates garbled by all ranks per second (weak scaling: per-GPU work fixed).
+One "step" = one pass of the hot path: garble all instances of this rank's batch — every call of the plan for all
+instances, ciphertexts produced in HBM (one call block per instance, overwritten by the next call), output labels
+gathered.  `value` = total gates garbled by all ranks per second (weak scaling: per-GPU work fixed).
+
+`--workload synthetic` is the Groth16-SHAPED chain of SURVEY.md §8(d) the engine was tuned on (330 Fq12
+square-and-multiply links = 11.18 B gates, one compiled program replayed with a ciphertext ring; profiles/r01_sqmul);
+`--workload verifier` the uncompressed `groth16_verify` (10.91 B gates).
 """
 import argparse
 import json
@@ -45,6 +49,7 @@ def real_verifier(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     import garbled_snark_verifier_amd as gsv
     compressed = args.workload == "verifier_compressed"
     case = json.load(open(os.path.join(ROOT, "tests", "golden", "groth16_verify_compressed_golden.json" if compressed else "groth16_verify_golden.json")))
@@ -89,7 +94,8 @@ def real_verifier(args):
     sess.close()
     result = None
     if rank == 0:
-        avg_s = sum(gpu_ms) / len(gpu_ms) / 1e3
+        avg_s = sum(gpu_ms) / len(gpu_ms) / 1e3  # stream time of one step: all launches of the plan back to back
+        n_launch = plan.info["n_calls"]
         achieved = gates * B * bytes_per_gate / avg_s / 1e9
         result = {"metric": "gates/sec (garble) on Groth16/BN254 verifier; ciphertext-hash match", "value": gates * B * world * args.steps / elapsed, "unit": "gates/s",
                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -99,8 +105,9 @@ def real_verifier(args):
                              "instances_per_gpu": B, "gates_per_instance": gates, "nonfree_fraction": f_nf, "plan_calls": plan.info["n_calls"], "plan_build_s": build_s,
                              "host_peak_rss_gb": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1e6},
                   "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "kernel": "run_program_kernel<false, %d, 0> (all %d launches of one step, stream time between the first and the last)" % (ni, plan.info["n_calls"]),
-                               "kernel_ms_avg": avg_s * 1e3, "bytes_per_gate": bytes_per_gate, "algorithmic_bytes_per_launch": gates * B * bytes_per_gate,
+                               # one step = n_launch launches of the same kernel over different component programs: averages per launch
+                               "kernel": "run_program_kernel<false, %d, 0>" % ni, "launches_per_step": n_launch, "kernel_ms_avg": avg_s * 1e3 / n_launch,
+                               "step_stream_ms": avg_s * 1e3, "bytes_per_gate": bytes_per_gate, "algorithmic_bytes_per_launch": gates * B * bytes_per_gate / n_launch,
                                "aes_ceiling_gates_per_s": 4.9e10 / f_nf, "aes_ceiling_frac": (gates * B / avg_s) / (4.9e10 / f_nf)}}
         if not args.no_check:  # the fixture's seed through the streaming path (stream drained and hashed on the host): oracle's flat-stream hash
             d, f, t, inp = gsv.labels_from_seed(case["seed"], n_in)
@@ -135,9 +142,9 @@ def main():
     ap.add_argument("--component", default="fq12_sqmul", choices=["fq12_sqmul", "fq12_mul"],
                     help="link of the chain: fq12_sqmul = r <- Fq12::mul(Fq12::square(r), b) (33.9 M gates), fq12_mul = r <- Fq12::mul(r, b) (20.3 M)")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--workload", default="synthetic", choices=["synthetic", "verifier", "verifier_compressed"],
-                    help="synthetic (default): the Groth16-shaped chain; verifier / verifier_compressed: the REAL groth16_verify(_compressed) circuit of the "
-                         "committed fixture as a plan of component programs (2 minutes of plan build and ~90 GB of host memory per rank)")
+    ap.add_argument("--workload", default="verifier_compressed", choices=["synthetic", "verifier", "verifier_compressed"],
+                    help="verifier_compressed (default) / verifier: the REAL groth16_verify_compressed / groth16_verify circuit of the committed fixture as a plan "
+                         "of component programs (~95 s of plan build and ~48 GB of host memory per rank); synthetic: the Groth16-shaped chain")
     args = ap.parse_args()
     if args.workload != "synthetic":
         return real_verifier(args)
