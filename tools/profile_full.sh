@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R
 tail -1 $OUT/bench_stats.log > $OUT/bench.json
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --workload synthetic --steps 1 --warmup 0 --no-check --cpu-baseline-chain 0 > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --workload synthetic --steps 1 --warmup 0 --no-check --cpu-baseline-chain 0 > $OUT/bench_write.log 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $OUT/misc -- python3 $R/bench.py --steps 1 --warmup 0 --replays 8 --no-check --cpu-baseline-chain 0 > $OUT/bench_misc.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $OUT/misc -- python3 $R/bench.py --workload synthetic --steps 1 --warmup 0 --replays 8 --no-check --cpu-baseline-chain 0 > $OUT/bench_misc.log 2>&1
 cd $R
 python3 - <<PY
 import csv, glob, collections, json, os
