@@ -55,7 +55,7 @@ def real_verifier(args):
     case = json.load(open(os.path.join(ROOT, "tests", "golden", "groth16_verify_compressed_golden.json" if compressed else "groth16_verify_golden.json")))
     engine = gsv.Engine(local_rank)
     t0 = time.time()
-    plan = gsv.Plan.from_circuit(case["circuit"], VERIFIER_UNITS + (["bigint::mul_karatsuba", "fp254::montgomery_reduce"] if compressed else []), half_window=True)
+    plan = gsv.Plan.from_circuit(case["circuit"], VERIFIER_UNITS + (["fp254::exp_chunk"] if compressed else []), half_window=True)
     build_s = time.time() - t0
     B, n_in, gates = args.instances, plan.info["n_inputs"], plan.info["n_gates"]
     f_nf = plan.info["n_ciphertexts"] / gates

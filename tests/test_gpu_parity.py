@@ -656,7 +656,7 @@ VERIFIER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cycl
 @pytest.mark.skipif(not os.environ.get("GSV_SLOW"), reason="building the plan of the whole verifier takes minutes of host time and ~90 GB of host memory; set GSV_SLOW=1 or run tools/groth16_plan.py")
 @pytest.mark.parametrize("fixture,units,gates", [
     ("groth16_verify_golden.json", VERIFIER_UNITS, 10_914_485_653),
-    ("groth16_verify_compressed_golden.json", VERIFIER_UNITS + ["bigint::mul_karatsuba", "fp254::montgomery_reduce"], 11_687_200_297),
+    ("groth16_verify_compressed_golden.json", VERIFIER_UNITS + ["fp254::exp_chunk"], 11_687_200_297),
 ])
 def test_groth16_verifier_as_a_plan(engine, fixture, units, gates):
     """groth16_verify (groth16.rs:58-110: MSM, projective-to-affine, Miller loop, final exponentiation, comparison) and

@@ -25,8 +25,8 @@ UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cyclotomic_sq
          "pairing::ell_by_constant_montgomery", "pairing::double_in_place_circuit_montgomery", "pairing::add_in_place_montgomery", "pairing::mul_by_char_montgomery",
          "bigint::multiplexer", "g1::add_montgomery", "fp254::inverse"]
 COMPRESSED = "--compressed" in sys.argv  # groth16_verify_compressed (groth16.rs:250-268): decompression of A, B, C in front of the verifier
-if COMPRESSED:  # the square roots are chains of ~380 Fq multiplications each: the multiplication's two halves are the units
-    UNITS += ["bigint::mul_karatsuba", "fp254::montgomery_reduce"]
+if COMPRESSED:  # the square roots are ladders of ~380 Fq multiplications each: four ladder steps (one fp254::exp_chunk component) are a unit
+    UNITS += ["fp254::exp_chunk"]
 case = json.load(open(os.path.join(ROOT, "tests", "golden", "groth16_verify_compressed_golden.json" if COMPRESSED else "groth16_verify_golden.json")))
 eng = gsv.Engine(0)
 t0 = time.time()
