@@ -202,3 +202,19 @@ def test_plan_builder_matches_flat_stream(spec, units, seed):
     oa, ob = sp.evaluate(np.stack([consts[0], consts[1] ^ delta]), act, bits, cts)
     eo, _, _ = o.execute(spec, bits)
     assert (ob == eo).all() and (oa == np.where(ob[:, None] == 1, out ^ delta[None, :], out)).all()
+
+
+def test_plan_from_circuit_builds_without_a_device_and_in_both_modes():
+    """gsv_plan_from_circuit is host-only work: units are compiled on a worker pool while the driver records (plan_builder.hpp
+    CompilePool), with GSV_PLAN_HALF_WINDOW once for the half LDS window.  Both modes give the reference's counts; the plan of the
+    square-root ladder has one program per distinct four-bit chunk of the exponent (fp254::exp_chunk, <= 16 + tail)."""
+    import garbled_snark_verifier_amd as gsv
+    ref = o.garble("fq12_mix", 1, capture_ct=False)
+    for hw in (False, True):
+        plan = gsv.Plan.from_circuit("fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"], half_window=hw)
+        assert plan.info["n_gates"] == int(ref.gate_counts.sum()) and plan.info["n_ciphertexts"] == ref.n_ciphertexts and plan.info["n_calls"] >= 4
+        plan.close()
+    assert "GSV_PLAN_HALF_WINDOW" not in os.environ
+    plan = gsv.Plan.from_circuit("fq_sqrt", ["fp254::exp_chunk"], half_window=True)
+    assert plan.info["n_gates"] == 148_727_956 and plan.info["n_ciphertexts"] == 36_651_387 and 60 <= plan.info["n_calls"] <= 70
+    plan.close()
