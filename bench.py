@@ -52,6 +52,13 @@ def real_verifier(args):
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     import garbled_snark_verifier_amd as gsv
     compressed = args.workload == "verifier_compressed"
+    try:  # every rank builds its own plan: ~50 GB of host memory each while it is built
+        avail_gb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1e6
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        if rank == 0 and avail_gb < 55 * local_world:
+            print("bench.py: %.0f GB of host memory available for %d ranks, the plan build needs ~50 GB per rank" % (avail_gb, local_world), file=sys.stderr)
+    except (OSError, IndexError, ValueError):
+        pass
     case = json.load(open(os.path.join(ROOT, "tests", "golden", "groth16_verify_compressed_golden.json" if compressed else "groth16_verify_golden.json")))
     engine = gsv.Engine(local_rank)
     t0 = time.time()
