@@ -151,3 +151,18 @@ def test_groth16_verify_with_fewer_public_inputs(n_pub, gates):
     assert G.check_instance(inst)
     ob, gc, _ = o.execute(G.circuit_name(inst), G.input_bits(inst))
     assert ob.tolist() == [1] and int(gc.sum()) == gates
+
+
+def test_malformed_verifying_keys_are_rejected():
+    """The key travels inside the circuit name: wrong length for its public-input count, non-hex text,
+    an unreduced field element and a missing key are errors of the circuit factory (oracle and engine share it), not crashes."""
+    import garbled_snark_verifier_amd as gsv
+    good = G.vk_blob(G.make_instance(n_pub=1, seed=2))
+    bad_len = good[:-32].hex()
+    unreduced = (good[:1] + (P + 1).to_bytes(32, "big") + good[33:]).hex()
+    for name in ["groth16_verify", "groth16_verify:" + bad_len, "groth16_verify:zz" + good.hex()[2:], "groth16_verify_compressed:" + unreduced]:
+        with pytest.raises(Exception):
+            o.circuit_info(name)
+        with pytest.raises(gsv.GsvError):
+            gsv.Plan.from_circuit(name, ["g1::add_montgomery"])
+    assert o.circuit_info("groth16_verify_compressed:" + good.hex()) == (254 + 255 + 509 + 255, 1)
