@@ -49,7 +49,7 @@ EXPORTS = [
     "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_commit_labels",
     "gsv_plan_from_circuit", "gsv_plan_io", "gsv_plan_recorder_create", "gsv_plan_recorder_destroy", "gsv_plan_recorder_allocate_wire",
     "gsv_plan_recorder_declare_input", "gsv_plan_recorder_push_gates", "gsv_plan_recorder_call", "gsv_plan_recorder_finish", "gsv_plan_create", "gsv_plan_destroy", "gsv_plan_add_call", "gsv_plan_finish", "gsv_plan_counts", "gsv_session_create_plan", "gsv_session_create_plan_ex",
-    "gsv_session_garble_streaming", "gsv_session_evaluate_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
+    "gsv_session_garble_streaming", "gsv_session_garble_streaming_calls", "gsv_plan_call_info", "gsv_plan_image_bytes", "gsv_plan_save", "gsv_plan_load", "gsv_session_evaluate_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
 ]
 
 
@@ -114,6 +114,11 @@ def lib():
         L.gsv_session_create_plan_ex.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(vp)]
         L.gsv_session_evaluate_streaming.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_uint64, u8p]
         L.gsv_session_garble_streaming.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_uint64, C.c_int, u8p]
+        L.gsv_session_garble_streaming_calls.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint64, C.c_int, u8p]
+        L.gsv_plan_call_info.argtypes = [vp, C.c_uint64] + [C.POINTER(C.c_uint64)] * 5
+        L.gsv_plan_image_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.gsv_plan_save.argtypes = [vp, C.c_char_p]
+        L.gsv_plan_load.argtypes = [C.c_char_p, vp, C.POINTER(vp)]
         L.gsv_session_instances_per_workgroup.argtypes = [vp, C.POINTER(C.c_int)]
         L.gsv_session_enable_step_clock.argtypes = [vp]
         L.gsv_session_read_step_clock.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -283,6 +288,46 @@ class Plan:
         self.info = {"n_inputs": n_in.value, "n_outputs": n_out.value, "n_gates": g.value, "n_ciphertexts": c.value, "n_calls": k.value, "n_steps": 0}
         return self
 
+    def _read_info(self):
+        g, c, k = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _chk(lib().gsv_plan_counts(self.h, C.byref(g), C.byref(c), C.byref(k)))
+        n_in, n_out = C.c_uint64(), C.c_uint64()
+        _chk(lib().gsv_plan_io(self.h, C.byref(n_in), C.byref(n_out)))
+        self.n_inputs, self.n_outputs = n_in.value, n_out.value
+        self.info = {"n_inputs": n_in.value, "n_outputs": n_out.value, "n_gates": g.value, "n_ciphertexts": c.value, "n_calls": k.value, "n_steps": 0}
+
+    def save(self, path):
+        """Write the finished plan (compiled programs + calls) to `path` (gsv_plan_save)."""
+        _chk(lib().gsv_plan_save(self.h, os.fsencode(path)))
+
+    @classmethod
+    def load(cls, path, engine=None):
+        """Read a plan file.  With `engine` the program records go straight into that GPU's memory and the host keeps
+        only metadata (the ranks of a node share the file through the page cache); without, a complete host copy."""
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        self.programs = []
+        self.engine = engine  # a device-resident plan must not outlive its engine
+        _chk(lib().gsv_plan_load(os.fsencode(path), engine.h if engine is not None else None, C.byref(self.h)))
+        self._read_info()
+        return self
+
+    def image_bytes(self):
+        """(bytes of compiled program records, number of distinct programs)."""
+        b, n = C.c_uint64(), C.c_uint64()
+        _chk(lib().gsv_plan_image_bytes(self.h, C.byref(b), C.byref(n)))
+        return b.value, n.value
+
+    def call_info(self):
+        """Per call: [gate offset, gates, ciphertext offset, ciphertexts, device steps] as a uint64 array [n_calls, 5]."""
+        n = self.info["n_calls"]
+        out = np.zeros((n, 5), np.uint64)
+        v = [C.c_uint64() for _ in range(5)]
+        for k in range(n):
+            _chk(lib().gsv_plan_call_info(self.h, k, *[C.byref(x) for x in v]))
+            out[k] = [x.value for x in v]
+        return out
+
     def add_call(self, program, in_globals, out_globals):
         a = np.ascontiguousarray(in_globals, np.uint32)
         b = np.ascontiguousarray(out_globals, np.uint32)
@@ -405,6 +450,17 @@ class Session:
             return None
         out = np.zeros((self.n, 16), np.uint8)
         _chk(lib().gsv_session_garble_streaming(self.h, gate_id_base, directory.encode() if directory else None, first_index, threads, _p(out)))
+        return [bytes(out[i]) for i in range(self.n)]
+
+    def garble_calls(self, first_call, n_calls, gate_id_base=0, directory=None, first_index=0, threads=0, discard=False):
+        """Plan sessions: garble calls [first_call, first_call + n_calls) only (a slice of the plan).  Wires, gate ids and the
+        CBC-MAC states continue from the previous slice; first_call == 0 starts a new pass.  Returns the MAC states after the
+        slice (the commitments once the last slice has run), or None with discard=True."""
+        if discard:
+            _chk(lib().gsv_session_garble_streaming_calls(self.h, gate_id_base, first_call, n_calls, None, 0, 0, None))
+            return None
+        out = np.zeros((self.n, 16), np.uint8)
+        _chk(lib().gsv_session_garble_streaming_calls(self.h, gate_id_base, first_call, n_calls, directory.encode() if directory else None, first_index, threads, _p(out)))
         return [bytes(out[i]) for i in range(self.n)]
 
     def evaluate_streaming(self, directory, first_index=0, gate_id_base=0):

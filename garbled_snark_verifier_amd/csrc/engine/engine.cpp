@@ -3,6 +3,11 @@
 // garble/evaluate — without a HIP device gsv_engine_create fails with GSV_ERR_DEVICE.
 #include <hip/hip_runtime_api.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
@@ -10,6 +15,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -62,11 +68,14 @@ struct gsv_program {
   Program prog;                    // full LDS window: one instance per workgroup
   std::unique_ptr<Program> prog2;  // half window: two instances per workgroup (compiled on demand)
   bool half_only = false;          // `prog` itself was compiled for the half window and serves both layouts (GSV_PLAN_HALF_WINDOW: no second variant, no trace kept)
+  bool device_only = false;        // loaded by gsv_plan_load straight into device memory: the host keeps the metadata, not the records
+  uint64_t loaded_image_bytes = 0; // size of the records of a device_only program
   const Program& variant(uint32_t ni) const { return (ni == 2 && !half_only) ? *prog2 : prog; }
   std::unique_ptr<ProgramSource> src;
   std::mutex mu;
   std::map<std::pair<int, int>, DevProgram> dev;  // per (device, instances per workgroup)
   size_t image_bytes() const {
+    if (device_only) return size_t(loaded_image_bytes);
     return prog.steps.size() * sizeof(StepDesc) + prog.ands.size() * sizeof(AndRec) + prog.xors.size() * sizeof(XorRec) +
            (prog.fb_src_slot.size() * 2 + prog.output_slots.size() + prog.ct_pos.size()) * sizeof(uint32_t);
   }
@@ -95,6 +104,10 @@ struct gsv_engine {
   void* te = nullptr;  // device T-tables
 };
 
+struct gsv_drain;
+extern "C" {
+static void destroy_drain(gsv_drain* d);
+}
 struct gsv_session {
   gsv_engine* e = nullptr;
   gsv_program* p = nullptr;
@@ -119,6 +132,7 @@ struct gsv_session {
   bool ran = false, last_eval = false, garbled = false;
   int hasher = 0;  // 0 AesNiHasher, 1 Blake3Hasher
   std::vector<uint64_t> ct_uploaded;  // per instance: records supplied by gsv_session_upload_ciphertexts
+  struct gsv_drain* drain = nullptr;   // streaming drain: copy streams, pinned buffers, per-instance MAC states (created on first use)
   uint64_t ct_stride() const { return plan ? (plan_retain ? plan->n_ct : plan_max_block) : ct_cap * p->prog.n_ct; }  // n_ct does not depend on the variant
 };
 
@@ -215,10 +229,11 @@ int gsv_program_compile(gsv_recorder* r, const uint32_t* fb_out_idx, const uint3
 }
 void gsv_program_destroy(gsv_program* p) {
   if (!p) return;
+  std::set<void*> freed;  // a half-window image loaded from a plan file is filed under both layouts
   for (auto& kv : p->dev) {
     (void)hipSetDevice(kv.first.first);
     for (void* q : {kv.second.steps, kv.second.ands, kv.second.xors, kv.second.fb_src, kv.second.fb_dst, kv.second.out_slots, kv.second.ct_pos})
-      if (q) (void)hipFree(q);
+      if (q && freed.insert(q).second) (void)hipFree(q);
   }
   delete p;
 }
@@ -229,7 +244,7 @@ int gsv_program_get_info(const gsv_program* p, gsv_program_info* info) {
   info->n_inputs = g.input_slots.size(); info->n_outputs = g.output_slots.size();
   info->n_gates = g.n_gates; info->n_ciphertexts = g.n_ct; info->n_dead = g.n_dead;
   for (int i = 0; i < 11; ++i) info->gate_count[i] = g.gate_count[i];
-  info->n_steps = g.steps.size(); info->and_depth = g.and_depth; info->n_and_steps = g.n_and_steps; info->max_step_width = g.max_step_width;
+  info->n_steps = g.n_steps; info->and_depth = g.and_depth; info->n_and_steps = g.n_and_steps; info->max_step_width = g.max_step_width;
   info->n_slots = g.n_slots; info->peak_live = g.peak_live; info->device_bytes = p->image_bytes();
   info->n_lds_slots = g.n_lds_slots; info->reads_lds = g.reads_lds; info->reads_hbm = g.reads_hbm; info->writes_lds = g.writes_lds; info->writes_hbm = g.writes_hbm;
   info->n_fused_free = g.n_fused_free;
@@ -276,6 +291,7 @@ int gsv_labels_from_seed(uint64_t seed, size_t n_inputs, uint8_t delta[16], uint
 // The half-window variant of a program (two instances per workgroup), compiled on first use.  Throws on failure; p->mu held by the caller.
 static void compile_half_window_variant(gsv_program* p) {
   if (p->prog2 || p->half_only) return;
+  if (!p->src) gsv_panic("this program was loaded from a plan file compiled for the full LDS window: it cannot serve two instances per workgroup (build the plan with GSV_PLAN_HALF_WINDOW=1)");
   CompileOptions opt = p->src->opt;
   opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / 2);
   std::unique_ptr<Program> q(new Program(compile_program(p->src->trace, p->src->inputs, p->src->outputs, p->src->feedback, opt)));
@@ -356,6 +372,7 @@ void gsv_session_destroy(gsv_session* s) {
   for (void* q : {s->W, s->VB, s->CT, s->delta, s->out, s->out_bits, s->in_bits, s->step_clock, s->ct_stage, s->ct_gate}) if (q) (void)hipFree(q);
   for (auto& cd : s->call_dev) for (void* q : {cd.pre_src, cd.pre_dst, cd.post_src, cd.post_dst}) if (q) (void)hipFree(q);
   if (s->plan_out_slots) (void)hipFree(s->plan_out_slots);
+  destroy_drain(s->drain);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -553,6 +570,199 @@ int gsv_plan_counts(const gsv_plan* p, uint64_t* n_gates, uint64_t* n_ciphertext
   if (n_calls) *n_calls = p->calls.size();
   return GSV_OK;
 }
+// ---- plan files ---------------------------------------------------------------------------------------------------------
+// A built plan (compiled programs + calls) as one file, so that the ~100 s / ~50 GB build of the verifier plan is paid once per
+// machine: rank 0 of a node builds and saves, every other rank (and every later process) loads.  gsv_plan_load with an engine
+// streams each program's records from the (memory-mapped, page-cache shared) file straight into that GPU's memory; the host
+// keeps only the metadata a session needs, so a loading rank's private memory stays small.  Layout (little endian, every array
+// padded to 16 bytes):  PlanFileHeader | per program: PlanFileProgram, steps, ands, xors, ct_pos, input_slots, output_slots |
+// per call: {program, n_in, n_out}, in_globals, out_globals | outputs.
+namespace {
+constexpr char PLAN_MAGIC[8] = {'G', 'S', 'V', 'P', 'L', 'A', 'N', '2'};
+struct PlanFileHeader {
+  char magic[8];
+  uint32_t n_programs, n_calls, n_globals, n_inputs, n_outputs, lds_window_slots;
+  uint64_t n_gates, n_ct, rec_sizes;  // rec_sizes: sizeof(StepDesc) | sizeof(AndRec) << 16 | sizeof(XorRec) << 32 (format guard)
+};
+struct PlanFileProgram {
+  uint64_t n_steps, n_ands, n_xors, n_ct_pos, n_inputs, n_outputs;
+  uint64_t n_gates, n_ct, n_dead, n_fused_free, reads_lds, reads_hbm, writes_lds, writes_hbm;
+  uint64_t gate_count[GATE_TYPE_COUNT];
+  uint32_t n_slots, n_lds_slots, lds_slots_limit, fb_stage_base, and_depth, n_and_steps, max_step_width, peak_live, half_only, pad;
+};
+constexpr uint64_t plan_rec_sizes() { return uint64_t(sizeof(StepDesc)) | (uint64_t(sizeof(AndRec)) << 16) | (uint64_t(sizeof(XorRec)) << 32); }
+inline size_t pad16(size_t n) { return (n + 15) & ~size_t(15); }
+struct FileCloser { FILE* f; ~FileCloser() { if (f) std::fclose(f); } };
+struct Mapping {
+  const uint8_t* base = nullptr; size_t size = 0; int fd = -1;
+  ~Mapping() { if (base) munmap(const_cast<uint8_t*>(base), size); if (fd >= 0) close(fd); }
+};
+}  // namespace
+
+int gsv_plan_image_bytes(const gsv_plan* p, uint64_t* bytes, uint64_t* n_programs) {
+  if (!p) return fail(GSV_ERR_INVALID, "null plan");
+  std::set<const gsv_program*> seen;
+  uint64_t b = 0;
+  for (const PlanCall& c : p->calls) if (seen.insert(c.prog).second) b += c.prog->image_bytes();
+  if (bytes) *bytes = b;
+  if (n_programs) *n_programs = seen.size();
+  return GSV_OK;
+}
+
+int gsv_plan_save(const gsv_plan* p, const char* path) {
+  if (!p || !path || !p->finished) return fail(GSV_ERR_INVALID, "null argument / plan not finished");
+  std::vector<const gsv_program*> progs;
+  std::map<const gsv_program*, uint32_t> index;
+  for (const PlanCall& c : p->calls)
+    if (index.emplace(c.prog, uint32_t(progs.size())).second) {
+      if (c.prog->device_only) return fail(GSV_ERR_INVALID, "a plan loaded straight to the device has no host records to save");
+      progs.push_back(c.prog);
+    }
+  const std::string tmp = std::string(path) + ".tmp." + std::to_string(long(getpid()));
+  FileCloser fc{std::fopen(tmp.c_str(), "wb")};
+  if (!fc.f) return fail(GSV_ERR_INVALID, "cannot create " + tmp);
+  std::setvbuf(fc.f, nullptr, _IOFBF, 8u << 20);
+  bool ok = true;
+  static const uint8_t zeros[16] = {0};
+  auto put = [&](const void* d, size_t n) { if (n) ok = ok && std::fwrite(d, 1, n, fc.f) == n; const size_t r = pad16(n) - n; if (r) ok = ok && std::fwrite(zeros, 1, r, fc.f) == r; };
+  PlanFileHeader h{};
+  std::memcpy(h.magic, PLAN_MAGIC, 8);
+  h.n_programs = uint32_t(progs.size()); h.n_calls = uint32_t(p->calls.size()); h.n_globals = p->n_globals; h.n_inputs = p->n_inputs; h.n_outputs = uint32_t(p->outputs.size());
+  h.lds_window_slots = LDS_WINDOW_SLOTS; h.n_gates = p->n_gates; h.n_ct = p->n_ct; h.rec_sizes = plan_rec_sizes();
+  put(&h, sizeof h);
+  for (const gsv_program* q : progs) {
+    const Program& g = q->prog;
+    PlanFileProgram m{};
+    m.n_steps = g.steps.size(); m.n_ands = g.ands.size(); m.n_xors = g.xors.size(); m.n_ct_pos = g.ct_pos.size(); m.n_inputs = g.input_slots.size(); m.n_outputs = g.output_slots.size();
+    m.n_gates = g.n_gates; m.n_ct = g.n_ct; m.n_dead = g.n_dead; m.n_fused_free = g.n_fused_free;
+    m.reads_lds = g.reads_lds; m.reads_hbm = g.reads_hbm; m.writes_lds = g.writes_lds; m.writes_hbm = g.writes_hbm;
+    for (int i = 0; i < GATE_TYPE_COUNT; ++i) m.gate_count[i] = g.gate_count[i];
+    m.n_slots = g.n_slots; m.n_lds_slots = g.n_lds_slots; m.lds_slots_limit = g.lds_slots_limit; m.fb_stage_base = g.fb_stage_base; m.and_depth = g.and_depth;
+    m.n_and_steps = g.n_and_steps; m.max_step_width = g.max_step_width; m.peak_live = g.peak_live; m.half_only = q->half_only ? 1 : 0;
+    put(&m, sizeof m);
+    put(g.steps.data(), g.steps.size() * sizeof(StepDesc));
+    put(g.ands.data(), g.ands.size() * sizeof(AndRec));
+    put(g.xors.data(), g.xors.size() * sizeof(XorRec));
+    put(g.ct_pos.data(), g.ct_pos.size() * 4);
+    put(g.input_slots.data(), g.input_slots.size() * 4);
+    put(g.output_slots.data(), g.output_slots.size() * 4);
+  }
+  for (const PlanCall& c : p->calls) {
+    const uint32_t hdr[4] = {index[c.prog], uint32_t(c.in_globals.size()), uint32_t(c.out_globals.size()), 0};
+    put(hdr, sizeof hdr);
+    put(c.in_globals.data(), c.in_globals.size() * 4);
+    put(c.out_globals.data(), c.out_globals.size() * 4);
+  }
+  put(p->outputs.data(), p->outputs.size() * 4);
+  ok = ok && std::fflush(fc.f) == 0;
+  std::fclose(fc.f); fc.f = nullptr;
+  if (!ok || std::rename(tmp.c_str(), path) != 0) { std::remove(tmp.c_str()); return fail(GSV_ERR_INVALID, std::string("cannot write ") + path); }
+  return GSV_OK;
+}
+
+int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out) {
+  if (!path || !out) return fail(GSV_ERR_INVALID, "null argument");
+  Mapping mp;
+  mp.fd = open(path, O_RDONLY);
+  if (mp.fd < 0) return fail(GSV_ERR_INVALID, std::string("cannot open ") + path);
+  struct stat st;
+  if (fstat(mp.fd, &st) != 0 || size_t(st.st_size) < sizeof(PlanFileHeader)) return fail(GSV_ERR_INVALID, std::string(path) + ": not a plan file");
+  mp.size = size_t(st.st_size);
+  void* mm = mmap(nullptr, mp.size, PROT_READ, MAP_PRIVATE, mp.fd, 0);
+  if (mm == MAP_FAILED) return fail(GSV_ERR_INVALID, std::string("cannot map ") + path);
+  mp.base = static_cast<const uint8_t*>(mm);
+  (void)madvise(mm, mp.size, MADV_SEQUENTIAL);
+  size_t pos = 0;
+  bool bad = false;
+  auto take = [&](size_t n) -> const uint8_t* { const size_t m = pad16(n); if (m > mp.size - pos) { bad = true; return mp.base; } const uint8_t* q = mp.base + pos; pos += m; return q; };
+  PlanFileHeader h;
+  std::memcpy(&h, take(sizeof h), sizeof h);
+  if (bad || std::memcmp(h.magic, PLAN_MAGIC, 8) != 0 || h.rec_sizes != plan_rec_sizes() || h.lds_window_slots != LDS_WINDOW_SLOTS)
+    return fail(GSV_ERR_INVALID, std::string(path) + ": not a plan file of this engine build");
+  if (e) HIPCHK(hipSetDevice(e->device));
+  struct PlanOwner { gsv_plan* p; ~PlanOwner() { if (p) gsv_plan_destroy(p); } } po{new gsv_plan()};
+  gsv_plan* plan = po.p;
+  GSV_TRY
+  for (uint32_t k = 0; k < h.n_programs; ++k) {
+    PlanFileProgram m;
+    std::memcpy(&m, take(sizeof m), sizeof m);
+    if (bad) break;
+    gsv_program* q = new gsv_program();
+    plan->owned.push_back(q);
+    Program& g = q->prog;
+    g.n_steps = uint32_t(m.n_steps); g.n_gates = m.n_gates; g.n_ct = m.n_ct; g.n_dead = m.n_dead; g.n_fused_free = m.n_fused_free;
+    g.reads_lds = m.reads_lds; g.reads_hbm = m.reads_hbm; g.writes_lds = m.writes_lds; g.writes_hbm = m.writes_hbm;
+    for (int i = 0; i < GATE_TYPE_COUNT; ++i) g.gate_count[i] = m.gate_count[i];
+    g.n_slots = m.n_slots; g.n_lds_slots = m.n_lds_slots; g.lds_slots_limit = m.lds_slots_limit; g.fb_stage_base = m.fb_stage_base; g.and_depth = m.and_depth;
+    g.n_and_steps = m.n_and_steps; g.max_step_width = m.max_step_width; g.peak_live = m.peak_live;
+    q->half_only = m.half_only != 0;
+    const uint8_t* steps = take(m.n_steps * sizeof(StepDesc));
+    const uint8_t* ands = take(m.n_ands * sizeof(AndRec));
+    const uint8_t* xors = take(m.n_xors * sizeof(XorRec));
+    const uint8_t* ctp = take(m.n_ct_pos * 4);
+    const uint8_t* ins = take(m.n_inputs * 4);
+    const uint8_t* outs = take(m.n_outputs * 4);
+    if (bad) break;
+    g.input_slots.assign(reinterpret_cast<const uint32_t*>(ins), reinterpret_cast<const uint32_t*>(ins) + m.n_inputs);
+    g.output_slots.assign(reinterpret_cast<const uint32_t*>(outs), reinterpret_cast<const uint32_t*>(outs) + m.n_outputs);
+    if (!e) {  // host copy: a complete program (hostsim, saving again, uploading to any device later)
+      g.steps.assign(reinterpret_cast<const StepDesc*>(steps), reinterpret_cast<const StepDesc*>(steps) + m.n_steps);
+      g.ands.assign(reinterpret_cast<const AndRec*>(ands), reinterpret_cast<const AndRec*>(ands) + m.n_ands);
+      g.xors.assign(reinterpret_cast<const XorRec*>(xors), reinterpret_cast<const XorRec*>(xors) + m.n_xors);
+      g.ct_pos.assign(reinterpret_cast<const uint32_t*>(ctp), reinterpret_cast<const uint32_t*>(ctp) + m.n_ct_pos);
+      continue;
+    }
+    q->device_only = true;
+    DevProgram d;
+    auto up = [&](void** dst, const void* src, size_t bytes) -> int {  // same padding rule as upload_program
+      HIPCHK(hipMalloc(dst, bytes + 32));
+      HIPCHK(hipMemset(*dst, 0, bytes + 32));
+      if (bytes) HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+      d.bytes += bytes;
+      return GSV_OK;
+    };
+    int rc = GSV_OK;
+    void** dsts[7] = {&d.steps, &d.ands, &d.xors, &d.fb_src, &d.fb_dst, &d.out_slots, &d.ct_pos};
+    const void* srcs[7] = {steps, ands, xors, nullptr, nullptr, outs, ctp};
+    const size_t lens[7] = {size_t(m.n_steps) * sizeof(StepDesc), size_t(m.n_ands) * sizeof(AndRec), size_t(m.n_xors) * sizeof(XorRec), 0, 0, size_t(m.n_outputs) * 4, size_t(m.n_ct_pos) * 4};
+    for (int i = 0; i < 7 && rc == GSV_OK; ++i) rc = up(dsts[i], srcs[i], lens[i]);
+    // file it before checking rc: gsv_plan_destroy then releases whatever was allocated
+    q->dev[{e->device, q->half_only ? 2 : 1}] = d;
+    if (q->half_only) q->dev[{e->device, 1}] = d;
+    if (rc != GSV_OK) return rc;
+    q->loaded_image_bytes = d.bytes;
+    // the pages just read are not needed again by this process (other ranks find them in the page cache)
+    {
+      const uintptr_t lo = (reinterpret_cast<uintptr_t>(steps) + 4095) & ~uintptr_t(4095), hi = reinterpret_cast<uintptr_t>(mp.base + pos) & ~uintptr_t(4095);
+      if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_DONTNEED);
+    }
+  }
+  for (uint32_t k = 0; k < h.n_calls && !bad; ++k) {
+    uint32_t hdr[4];
+    std::memcpy(hdr, take(sizeof hdr), sizeof hdr);
+    if (bad || hdr[0] >= plan->owned.size()) { bad = true; break; }
+    const uint8_t* ig = take(size_t(hdr[1]) * 4);
+    const uint8_t* og = take(size_t(hdr[2]) * 4);
+    if (bad) break;
+    const Program& g = plan->owned[hdr[0]]->prog;
+    if (hdr[1] != g.input_slots.size() || hdr[2] != g.output_slots.size()) { bad = true; break; }
+    int rc = gsv_plan_add_call(plan, plan->owned[hdr[0]], reinterpret_cast<const uint32_t*>(ig), reinterpret_cast<const uint32_t*>(og));
+    if (rc) return rc;
+  }
+  if (!bad) {
+    const uint8_t* og = take(size_t(h.n_outputs) * 4);
+    if (!bad) {
+      int rc = gsv_plan_finish(plan, h.n_inputs, reinterpret_cast<const uint32_t*>(og), h.n_outputs);
+      if (rc) return rc;
+    }
+  }
+  if (bad || plan->n_gates != h.n_gates || plan->n_ct != h.n_ct || plan->n_globals != h.n_globals) return fail(GSV_ERR_INVALID, std::string(path) + ": truncated or inconsistent plan file");
+  po.p = nullptr;
+  *out = plan;
+  return GSV_OK;
+  GSV_CATCH
+}
+
 int gsv_session_create_plan(gsv_engine* e, const gsv_plan* plan, size_t n_instances, gsv_session** out) { return gsv_session_create_plan_ex(e, plan, n_instances, 1, out); }
 int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_instances, int retain_stream, gsv_session** out) {
   if (!e || !plan || !out || n_instances == 0 || !plan->finished || plan->calls.empty()) return fail(GSV_ERR_INVALID, "bad argument / plan not finished");
@@ -730,7 +940,7 @@ static int launch(gsv_session* s, uint64_t gate_id_base, bool eval, uint64_t rep
   ka.delta = static_cast<const uint4*>(s->delta); ka.te = static_cast<const uint32_t*>(s->e->te);
   ka.fb_src = static_cast<const uint32_t*>(s->dp.fb_src); ka.fb_dst = static_cast<const uint32_t*>(s->dp.fb_dst);
   ka.ct_stride = s->ct_stride(); ka.gid_base = gate_id_base; ka.n_gates = g.n_gates; ka.n_ct = g.n_ct;
-  ka.n_steps = uint32_t(g.steps.size()); ka.n_slots = g.n_slots; ka.replays = uint32_t(n_replays ? n_replays : s->replays); ka.rep_base = uint32_t(rep_base); ka.ct_cap_replays = uint32_t(s->ct_cap);
+  ka.n_steps = g.n_steps; ka.n_slots = g.n_slots; ka.replays = uint32_t(n_replays ? n_replays : s->replays); ka.rep_base = uint32_t(rep_base); ka.ct_cap_replays = uint32_t(s->ct_cap);
   ka.n_fb = uint32_t(g.fb_src_slot.size()); ka.fb_stage_base = g.fb_stage_base;
   ka.n_instances = uint32_t(s->n_inst);
   ka.hasher = uint32_t(s->hasher);
@@ -764,7 +974,7 @@ static int launch_plan_call(gsv_session* s, size_t k, uint64_t gate_id_base, boo
   ka.W = static_cast<uint4*>(s->W); ka.VB = static_cast<uint8_t*>(s->VB); ka.CT = static_cast<uint4*>(s->CT);
   ka.delta = static_cast<const uint4*>(s->delta); ka.te = static_cast<const uint32_t*>(s->e->te);
   ka.ct_stride = s->ct_stride(); ka.ct_offset = s->plan_retain ? c.ct_off : 0; ka.gid_base = gate_id_base + c.gid_off; ka.n_gates = g.n_gates; ka.n_ct = g.n_ct;
-  ka.n_steps = uint32_t(g.steps.size()); ka.n_slots = f.n_slots; ka.replays = 1; ka.rep_base = 0; ka.ct_cap_replays = 1;
+  ka.n_steps = g.n_steps; ka.n_slots = f.n_slots; ka.replays = 1; ka.rep_base = 0; ka.ct_cap_replays = 1;
   ka.n_instances = uint32_t(s->n_inst); ka.hasher = uint32_t(s->hasher); ka.instances_per_wg = s->ni;
   if (ka.n_steps) {
     int lrc = gsvk_launch_program(&ka, uint32_t(s->n_inst), eval ? 1 : 0, s->e->stream);
@@ -808,84 +1018,112 @@ int gsv_session_garble(gsv_session* s, uint64_t gate_id_base) {
 // sequential D2H copies (the copy engines work beside the kernel), fold each instance's bytes into its CBC-MAC (strictly
 // serial per instance, hence the host: ciphertext_hasher.rs:23-29) and optionally append them to gc_<index>.bin
 // (ciphertext_repository.rs:94-127).
-int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes) {
-  if (!s) return fail(GSV_ERR_INVALID, "null argument");
-  if (!hashes && !dir) {  // discard the stream: garble only (output labels, device-rate measurements of long plans / chains)
-    HIPCHK(hipSetDevice(s->e->device));
-    HIPCHK(hipEventRecord(s->ev0, s->e->stream));
-    int rc = GSV_OK;
-    if (s->plan) {
-      for (size_t k = 0; k < s->plan->calls.size() && rc == GSV_OK; ++k) rc = launch_plan_call(s, k, gate_id_base, false);
-      if (rc == GSV_OK) { HIPCHK(hipEventRecord(s->ev1, s->e->stream)); rc = gather_plan_outputs(s, false); }
-    } else {
-      rc = launch(s, gate_id_base, false);
-    }
-    if (rc == GSV_OK) { HIPCHK(hipStreamSynchronize(s->e->stream)); s->garbled = !s->plan || s->plan_retain; }
-    return rc;
+//
+// The drain machinery (copy streams, pinned chunk buffers, the per-instance MAC states) lives in the session, so that a plan can
+// be garbled in SLICES of consecutive calls (gsv_session_garble_streaming_calls): the MACs chain from slice to slice and the
+// page-locked buffers are set up once.
+struct gsv_drain {
+  // Many host threads are wanted for the MACs (one serial chain per instance) but only a few D2H copies should be in
+  // flight at once: measured on the MI355X box, 128 concurrent copy streams move 9 GB/s where a handful move 22 GB/s
+  // (and the number of STREAMS matters as much as the number of copies: the copies share a small pool of streams).
+  struct CopyGate {
+    std::mutex mu; std::condition_variable cv; std::vector<hipStream_t> idle;
+    hipStream_t acquire() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !idle.empty(); }); hipStream_t st = idle.back(); idle.pop_back(); return st; }
+    void release(hipStream_t st) { { std::lock_guard<std::mutex> lk(mu); idle.push_back(st); } cv.notify_one(); }
+  } copy_gate;
+  std::vector<hipStream_t> copy_streams;
+  struct Worker { void* pinned[2] = {nullptr, nullptr}; };  // two pinned chunk buffers per worker: copy chunk j+1 while chunk j is hashed
+  std::vector<Worker> workers;
+  uint64_t chunk = 0;  // records per chunk buffer
+  std::vector<CbcMacHost> macs;
+  ~gsv_drain() {
+    for (Worker& w : workers) for (void*& q : w.pinned) if (q) (void)hipHostFree(q);
+    for (hipStream_t st : copy_streams) (void)hipStreamDestroy(st);
   }
+};
+static void destroy_drain(gsv_drain* d) { delete d; }
+static int ensure_drain(gsv_session* s, size_t T, uint64_t seg_records) {
+  const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(seg_records, 1), 256ull << 10);  // records (4 MiB: page-locking large buffers costs more than the copies)
+  if (s->drain && s->drain->workers.size() >= T && s->drain->chunk == chunk) return GSV_OK;
+  std::vector<CbcMacHost> keep;
+  if (s->drain) keep = s->drain->macs;
+  destroy_drain(s->drain);
+  s->drain = new gsv_drain();
+  gsv_drain& d = *s->drain;
+  d.macs = keep;
+  d.chunk = chunk;
+  const int n_copy_streams = getenv("GSV_DRAIN_COPIES") ? std::max(1, atoi(getenv("GSV_DRAIN_COPIES"))) : 6;
+  bool ok = true;
+  for (int k = 0; k < n_copy_streams && ok; ++k) {
+    hipStream_t st;
+    ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    if (ok) { d.copy_streams.push_back(st); d.copy_gate.idle.push_back(st); }
+  }
+  d.workers.resize(T);
+  for (gsv_drain::Worker& w : d.workers) for (void*& q : w.pinned) ok = ok && hipHostMalloc(&q, chunk * 16, hipHostMallocDefault) == hipSuccess;
+  if (!ok) { destroy_drain(s->drain); s->drain = nullptr; return fail(GSV_ERR_DEVICE, "cannot allocate the drain buffers"); }
+  return GSV_OK;
+}
+
+// Discarding form: calls [c0, c1) of a plan (or the whole program launch), ciphertexts stay in / are overwritten on the device.
+static int garble_discard(gsv_session* s, uint64_t gate_id_base, size_t c0, size_t c1) {
+  HIPCHK(hipSetDevice(s->e->device));
+  HIPCHK(hipEventRecord(s->ev0, s->e->stream));
+  int rc = GSV_OK;
+  if (s->plan) {
+    for (size_t k = c0; k < c1 && rc == GSV_OK; ++k) rc = launch_plan_call(s, k, gate_id_base, false);
+    if (rc == GSV_OK) {
+      HIPCHK(hipEventRecord(s->ev1, s->e->stream));
+      if (c1 == s->plan->calls.size()) rc = gather_plan_outputs(s, false); else { s->ran = true; s->last_eval = false; }
+    }
+  } else {
+    rc = launch(s, gate_id_base, false);
+  }
+  if (rc == GSV_OK) { HIPCHK(hipStreamSynchronize(s->e->stream)); s->garbled = !s->plan || s->plan_retain; }
+  return rc;
+}
+
+static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t c0, size_t c1, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes) {
+  if (!hashes && !dir) return garble_discard(s, gate_id_base, c0, c1);  // garble only (output labels, device-rate measurements of long plans / chains)
   if (!hashes) return fail(GSV_ERR_INVALID, "null hash buffer");
   const Program& g = s->prog();
   // program sessions: segments of one ring (ct_cap replays of n_ct records); plan sessions: one call per segment
-  const uint64_t n_ct = s->plan ? s->plan_max_block : g.n_ct, total = s->plan ? s->plan->calls.size() : s->replays, seg = s->plan ? 1 : s->ct_cap;
+  const uint64_t n_ct = s->plan ? s->plan_max_block : g.n_ct, seg = s->plan ? 1 : s->ct_cap;
+  const uint64_t first = s->plan ? c0 : 0, total = s->plan ? c1 : s->replays;
   const size_t n_inst = s->n_inst;
   size_t T = n_threads > 0 ? size_t(n_threads) : std::max<size_t>(1, std::min<size_t>(n_inst, std::thread::hardware_concurrency()));
   T = std::min(T, n_inst);
   HIPCHK(hipSetDevice(s->e->device));
   const uint64_t seg_records = seg * n_ct;  // per instance
   if (!s->ct_gate && seg_records) HIPCHK(hipMalloc(&s->ct_gate, n_inst * seg_records * 16));
-  std::vector<CbcMacHost> macs(n_inst);
+  { int rc = ensure_drain(s, T, seg_records); if (rc) return rc; }
+  gsv_drain& dr = *s->drain;
+  if (first == 0 || dr.macs.size() != n_inst) dr.macs.assign(n_inst, CbcMacHost());  // a new pass starts from h = 0; later slices chain
+  std::vector<CbcMacHost>& macs = dr.macs;
   std::vector<FILE*> files(n_inst, nullptr);
   auto close_files = [&]() { for (FILE*& f : files) if (f) { std::fclose(f); f = nullptr; } };
   if (dir)
     for (size_t i = 0; i < n_inst; ++i) {
       const std::string path = std::string(dir) + "/gc_" + std::to_string(first_index + i) + ".bin";
-      files[i] = std::fopen(path.c_str(), "wb");
+      files[i] = std::fopen(path.c_str(), first == 0 ? "wb" : "ab");
       if (!files[i]) { close_files(); return fail(GSV_ERR_INVALID, "cannot create " + path); }
     }
   std::atomic<int> err{0};
-  // Many host threads are wanted for the MACs (one serial chain per instance) but only a few D2H copies should be in
-  // flight at once: measured on the MI355X box, 128 concurrent copy streams move 9 GB/s where a handful move 22 GB/s.
-  // (and the number of STREAMS matters as much as the number of copies: the copies share a small pool of streams)
-  struct CopyGate {
-    std::mutex mu; std::condition_variable cv; std::vector<hipStream_t> idle;
-    hipStream_t acquire() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !idle.empty(); }); hipStream_t st = idle.back(); idle.pop_back(); return st; }
-    void release(hipStream_t st) { { std::lock_guard<std::mutex> lk(mu); idle.push_back(st); } cv.notify_one(); }
-  } copy_gate;
-  const int n_copy_streams = getenv("GSV_DRAIN_COPIES") ? std::max(1, atoi(getenv("GSV_DRAIN_COPIES"))) : 6;
-  std::vector<hipStream_t> copy_streams;
-  // per-worker copy stream + two pinned chunk buffers (copy chunk j+1 while chunk j is hashed), created once
-  const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(seg_records, 1), 256ull << 10);  // records (4 MiB: page-locking the buffers is part of every call)
-  struct Worker { void* pinned[2] = {nullptr, nullptr}; };
-  std::vector<Worker> workers(T);
-  auto release_workers = [&]() {
-    for (Worker& w : workers) for (void*& q : w.pinned) if (q) { (void)hipHostFree(q); q = nullptr; }
-    for (hipStream_t st : copy_streams) (void)hipStreamDestroy(st);
-    copy_streams.clear();
-  };
-  {
-    bool ok = true;
-    for (int k = 0; k < n_copy_streams && ok; ++k) {
-      hipStream_t st;
-      ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
-      if (ok) { copy_streams.push_back(st); copy_gate.idle.push_back(st); }
-    }
-    for (Worker& w : workers) for (void*& q : w.pinned) ok = ok && hipHostMalloc(&q, chunk * 16, hipHostMallocDefault) == hipSuccess;
-    if (!ok) { release_workers(); close_files(); return fail(GSV_ERR_DEVICE, "cannot allocate the drain buffers"); }
-  }
+  const uint64_t chunk = dr.chunk;
   // one drain = all instances x the `n` records per instance sitting in the gate-order buffer
   auto drain = [&](uint64_t n, std::vector<std::thread>& pool) {
     for (size_t t = 0; t < T; ++t)
       pool.emplace_back([&, t, n]() {
         if (hipSetDevice(s->e->device) != hipSuccess) { err = 1; return; }
-        Worker& w = workers[t];
+        gsv_drain::Worker& w = dr.workers[t];
         for (size_t i = t; i < n_inst && !err && n; i += T) {
           const uint8_t* src = static_cast<const uint8_t*>(s->ct_gate) + i * seg_records * 16;
           // a copy holds a slot of the gate from issue to completion
           auto copy = [&](uint64_t off, int b) {
-            hipStream_t st = copy_gate.acquire();
+            hipStream_t st = dr.copy_gate.acquire();
             const bool ok = hipMemcpyAsync(w.pinned[b], src + off * 16, std::min(chunk, n - off) * 16, hipMemcpyDeviceToHost, st) == hipSuccess &&
                             hipStreamSynchronize(st) == hipSuccess;
-            copy_gate.release(st);
+            dr.copy_gate.release(st);
             return ok;
           };
           int b = 0;
@@ -904,7 +1142,8 @@ int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const ch
   std::vector<std::thread> cur;
   auto join = [](std::vector<std::thread>& p) { for (auto& th : p) th.join(); p.clear(); };
   int rc = GSV_OK;
-  for (uint64_t r0 = 0; r0 < total && rc == GSV_OK; r0 += seg) {
+  HIPCHK(hipEventRecord(s->ev0, s->e->stream));
+  for (uint64_t r0 = first; r0 < total && rc == GSV_OK; r0 += seg) {
     const uint64_t r1 = std::min(total, r0 + seg);
     uint64_t n_records;  // per instance, in this segment
     if (s->plan) {
@@ -934,13 +1173,34 @@ int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const ch
     drain(n_records, cur);
   }
   join(cur);
-  if (rc == GSV_OK && s->plan) rc = gather_plan_outputs(s, false);
-  release_workers();
+  if (rc == GSV_OK && s->plan) {
+    (void)hipEventRecord(s->ev1, s->e->stream);
+    if (c1 == s->plan->calls.size()) rc = gather_plan_outputs(s, false); else { s->ran = true; s->last_eval = false; }
+  }
   close_files();
   if (rc != GSV_OK) return rc;
   if (err) return fail(err == 2 ? GSV_ERR_INVALID : GSV_ERR_DEVICE, err == 2 ? "short write to a gc file" : "device copy failed while draining ciphertexts");
   for (size_t i = 0; i < n_inst; ++i) macs[i].digest(hashes + 16 * i);
   s->garbled = true;
+  return GSV_OK;
+}
+int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes) {
+  if (!s) return fail(GSV_ERR_INVALID, "null argument");
+  return garble_streaming_range(s, gate_id_base, 0, s->plan ? s->plan->calls.size() : 1, dir, first_index, n_threads, hashes);
+}
+int gsv_session_garble_streaming_calls(gsv_session* s, uint64_t gate_id_base, uint64_t first_call, uint64_t n_calls, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes) {
+  if (!s || !s->plan) return fail(GSV_ERR_INVALID, "null session / not a plan session");
+  if (first_call > s->plan->calls.size() || n_calls > s->plan->calls.size() - first_call) return fail(GSV_ERR_INVALID, "call range outside the plan");
+  return garble_streaming_range(s, gate_id_base, size_t(first_call), size_t(first_call + n_calls), dir, first_index, n_threads, hashes);
+}
+int gsv_plan_call_info(const gsv_plan* p, uint64_t call, uint64_t* gate_offset, uint64_t* n_gates, uint64_t* ct_offset, uint64_t* n_ciphertexts, uint64_t* n_steps) {
+  if (!p || call >= p->calls.size()) return fail(GSV_ERR_INVALID, "null plan / call index out of range");
+  const PlanCall& c = p->calls[size_t(call)];
+  if (gate_offset) *gate_offset = c.gid_off;
+  if (n_gates) *n_gates = c.prog->prog.n_gates;
+  if (ct_offset) *ct_offset = c.ct_off;
+  if (n_ciphertexts) *n_ciphertexts = c.prog->prog.n_ct;
+  if (n_steps) *n_steps = c.prog->prog.n_steps;
   return GSV_OK;
 }
 int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base) {
@@ -1029,7 +1289,7 @@ int gsv_session_enable_step_clock(gsv_session* s) {
   if (!s) return fail(GSV_ERR_INVALID, "null session");
   HIPCHK(hipSetDevice(s->e->device));
   if (!s->step_clock) {
-    const size_t bytes = (s->prog().steps.size() + 1) * sizeof(uint64_t);
+    const size_t bytes = (size_t(s->prog().n_steps) + 1) * sizeof(uint64_t);
     HIPCHK(hipMalloc(&s->step_clock, bytes));
     HIPCHK(hipMemset(s->step_clock, 0, bytes));
   }
@@ -1039,7 +1299,7 @@ int gsv_session_read_step_clock(gsv_session* s, uint64_t* out) {
   if (!s || !out || !s->step_clock || !s->ran) return fail(GSV_ERR_INVALID, "step clock not enabled / nothing ran");
   HIPCHK(hipSetDevice(s->e->device));
   HIPCHK(hipStreamSynchronize(s->e->stream));
-  HIPCHK(hipMemcpy(out, s->step_clock, (s->prog().steps.size() + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, s->step_clock, (size_t(s->prog().n_steps) + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return GSV_OK;
 }
 // Diagnostics: per step {and_cnt, xor_cnt, lds_reads, hbm_reads, lds_writes, hbm_writes} decoded from the compiled records.

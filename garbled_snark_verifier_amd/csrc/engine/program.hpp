@@ -123,6 +123,7 @@ struct StepDesc { uint32_t and_off, and_cnt, xor_off, xor_cnt; };  // one depend
 
 struct Program {
   std::vector<StepDesc> steps;
+  uint32_t n_steps = 0;        // == steps.size(); kept separately because a plan loaded straight to the device (gsv_plan_load) has no host copy of the records
   std::vector<AndRec> ands;
   std::vector<XorRec> xors;
   std::vector<uint32_t> input_slots, output_slots;
@@ -487,6 +488,7 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
     if (sd.and_cnt) p.n_and_steps++;
   }
   p.peak_live = peak;
+  p.n_steps = uint32_t(p.steps.size());
   p.n_lds_slots = lds.high();
   p.lds_slots_limit = opt.lds_slots;
   for (uint32_t w : inputs) p.input_slots.push_back(slot[w]);

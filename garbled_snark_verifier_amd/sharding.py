@@ -3,8 +3,17 @@
 The path partitions into independent units: instance i — own seed, own delta, labels and
 ciphertext stream — goes to rank i mod world (reference: `seeds.par_iter()` over a pinned rayon pool,
 src/cut_and_choose/garbler.rs:206-234).  Nothing is exchanged while garbling; the single collective is an
-all-gather of fixed-size commit records at the end (GarbledInstanceCommit, garbler.rs:63-99), which is
-latency-bound (tens of KB) so ring-vs-direct over xGMI is irrelevant.
+all-gather of fixed-size commit records at the end (GarbledInstanceCommit, garbler.rs:61-99), which is
+latency-bound (tens of KB per instance) so ring-vs-direct over xGMI is irrelevant.
+
+Commit record (bytes), one per instance — the fields of GarbledInstanceCommit in declaration order behind the
+instance index:
+    index u64 LE | ciphertext_commit 16 | input_labels_commit: n_in x {commit(label0), commit(label1)} |
+    per output wire {commit(label1), commit(label0)} (output_label1_commit, output_label0_commit) |
+    true_constant_commit = commit(true.label1) | false_constant_commit = commit(false.label0)
+with commit = AesLabelCommitHasher = AES_K(label) (cut_and_choose/mod.rs:41-48).  Only the constants' SEMANTIC labels are
+committed (true.select(true), false.select(false), garbler.rs:94-97): AES_K has a public key and is invertible, so publishing
+both labels of one wire would reveal delta.
 """
 import numpy as np
 import torch
@@ -24,28 +33,46 @@ def shard_instances(total, rank, world):
     return list(range(rank, total, world))
 
 
-def record_len(n_outputs):
-    # index (8 B) | ciphertext hash (16) | commit(false.label0) commit(false.label1) commit(true.label0) commit(true.label1) (64)
-    # | per output: commit(label0), commit(label1) (32 each)
-    return 8 + 16 + 64 + 32 * n_outputs
+def record_len(n_outputs, n_inputs=0):
+    return 8 + 16 + 32 * n_inputs + 32 * n_outputs + 32
 
 
-def commit_record(index, ct_hash, output_label0, delta, false_label0, true_label0):
-    """GarbledInstanceCommit::new (garbler.rs:85-99) with AesLabelCommitHasher = AES_K(label) (cut_and_choose/mod.rs:41-48)."""
+def record_fields(rec, n_outputs, n_inputs):
+    """Views into one record: (index, ct_hash, input_commits[n_in,2,16], output_commits[n_out,2,16] = (label1, label0),
+    true_constant_commit, false_constant_commit)."""
+    rec = np.asarray(rec, np.uint8)
+    assert rec.shape[-1] == record_len(n_outputs, n_inputs)
+    o = 24
+    inp = rec[o:o + 32 * n_inputs].reshape(n_inputs, 2, 16); o += 32 * n_inputs
+    out = rec[o:o + 32 * n_outputs].reshape(n_outputs, 2, 16); o += 32 * n_outputs
+    return int.from_bytes(bytes(rec[:8]), "little"), rec[8:24], inp, out, rec[o:o + 16], rec[o + 16:o + 32]
+
+
+def commit_labels(labels):
+    """AesLabelCommitHasher over an [n,16] array of labels."""
     from . import _chk, _p, lib
+    labels = np.ascontiguousarray(labels, np.uint8).reshape(-1, 16)
+    out = np.zeros_like(labels)
+    _chk(lib().gsv_commit_labels(_p(labels), labels.shape[0], _p(out)))
+    return out
+
+
+def commit_record(index, ct_hash, output_label0, delta, false_label0, true_label0, input_label0=None):
+    """GarbledInstanceCommit::new (garbler.rs:85-99).  `input_label0`: [n_in,16] label0 of the circuit's input wires in
+    EncodeInput order (GarbledInstance.input_wire_values); label1 = label0 ^ delta."""
     out0 = np.ascontiguousarray(output_label0, np.uint8).reshape(-1, 16)
     delta = np.ascontiguousarray(delta, np.uint8).reshape(16)
+    in0 = np.zeros((0, 16), np.uint8) if input_label0 is None else np.ascontiguousarray(input_label0, np.uint8).reshape(-1, 16)
     labels = np.concatenate([
-        np.stack([false_label0, false_label0 ^ delta, true_label0, true_label0 ^ delta]).astype(np.uint8),
-        np.stack([out0, out0 ^ delta[None, :]], axis=1).reshape(-1, 16),
+        np.stack([in0, in0 ^ delta[None, :]], axis=1).reshape(-1, 16),    # per input: label0, label1
+        np.stack([out0 ^ delta[None, :], out0], axis=1).reshape(-1, 16),  # per output: label1, label0
+        (np.asarray(true_label0, np.uint8) ^ delta)[None, :],             # true.select(true)
+        np.asarray(false_label0, np.uint8)[None, :],                      # false.select(false)
     ])
-    labels = np.ascontiguousarray(labels, np.uint8)
-    commits = np.zeros_like(labels)
-    _chk(lib().gsv_commit_labels(_p(labels), labels.shape[0], _p(commits)))
-    rec = np.zeros(record_len(out0.shape[0]), np.uint8)
+    rec = np.zeros(record_len(out0.shape[0], in0.shape[0]), np.uint8)
     rec[:8] = np.frombuffer(int(index).to_bytes(8, "little"), np.uint8)
     rec[8:24] = np.frombuffer(bytes(ct_hash), np.uint8)
-    rec[24:] = commits.reshape(-1)
+    rec[24:] = commit_labels(labels).reshape(-1)
     return rec
 
 
@@ -68,21 +95,21 @@ def all_gather_records(local, total, rank, world, device=None):
             rows.append(gathered[r][:n_r].cpu())
         out = torch.cat(rows)
     # order by the instance index stored in the first 8 bytes
-    idx = np.array([int.from_bytes(bytes(row[:8].tolist()), "little") for row in out.cpu().numpy()])
-    return out.cpu()[torch.from_numpy(np.argsort(idx))]
+    a = out.cpu().numpy()
+    idx = a[:, :8].copy().view("<u8").reshape(-1)
+    return out.cpu()[torch.from_numpy(np.argsort(idx, kind="stable"))]
 
 
 def garble_and_commit(circuit, seeds, indexes, engine=None, program=None, replays=1, gc_dir=None):
     """Garbler::create + commit (garbler.rs:191-257) for the given (index, seed) pairs in ONE launch: returns the
     [len(seeds), record_len] commit records; with gc_dir the ciphertext streams go to gc_<index>.bin
     (ciphertext_repository.rs:94-127).  Indexes must be consecutive when gc_dir is used."""
-    from . import CircuitBuilder, Engine, Program, Session, labels_from_seed
-    import numpy as _np
+    from . import Engine, Program, Session, labels_from_seed
     engine = engine or Engine(0)
     program = program or Program.from_circuit(circuit, chain_feedback=replays > 1)
     n_in = program.info["n_inputs"]
     B = len(seeds)
-    delta = _np.zeros((B, 16), _np.uint8); consts = _np.zeros((B, 2, 16), _np.uint8); inputs = _np.zeros((B, n_in, 16), _np.uint8)
+    delta = np.zeros((B, 16), np.uint8); consts = np.zeros((B, 2, 16), np.uint8); inputs = np.zeros((B, n_in, 16), np.uint8)
     for i, s in enumerate(seeds):
         delta[i], consts[i, 0], consts[i, 1], inputs[i] = labels_from_seed(int(s), n_in)
     sess = Session(engine, program, B, replays, min(replays, 2) if replays > 1 else 1)
@@ -91,7 +118,7 @@ def garble_and_commit(circuit, seeds, indexes, engine=None, program=None, replay
         assert list(indexes) == list(range(indexes[0], indexes[0] + B)), "gc files are numbered first_index + i"
     hashes = sess.garble_streaming(directory=gc_dir, first_index=int(indexes[0]) if B else 0)
     outs = sess.read_outputs()
-    recs = _np.stack([commit_record(indexes[i], hashes[i], outs[i], delta[i], consts[i, 0], consts[i, 1]) for i in range(B)])
+    recs = np.stack([commit_record(indexes[i], hashes[i], outs[i], delta[i], consts[i, 0], consts[i, 1], inputs[i]) for i in range(B)])
     sess.close()
     return recs
 
@@ -129,3 +156,79 @@ def run_regarbling(commits, to_finalize, seeds, circuit, gc_dir, engine=None, pr
             if not (recs[k] == commits[i]).all():
                 errors[i] = "regarbling failed"
     return (not errors), errors
+
+
+class ConsistencyError(Exception):
+    """cut_and_choose/evaluator.rs ConsistencyError: `kind` is the variant name, `index` the instance."""
+
+    def __init__(self, kind, index, **details):
+        super().__init__("%s (instance %d)%s" % (kind, index, (" " + repr(details)) if details else ""))
+        self.kind, self.index, self.details = kind, index, details
+
+
+def _gpu_evaluate(circuit, engine, program, gc_dir):
+    """Default evaluation backend of evaluate_from: EvaluateMode over a FileSource on the GPU (gsv_session_evaluate_streaming)."""
+    from . import Engine, Program, Session
+    eng = engine or Engine(0)
+    prog = program or Program.from_circuit(circuit)
+
+    def run(index, true_active, false_active, input_active, input_bits):
+        sess = Session(eng, prog, 1)
+        try:
+            sess.set_evaluate_inputs(np.stack([false_active, true_active])[None], np.asarray(input_active, np.uint8)[None], np.asarray(input_bits, np.uint8)[None])
+            file_hash = sess.evaluate_streaming(gc_dir, first_index=index)[0]
+            labels, bits = sess.read_outputs(with_bits=True)
+            return labels[0], bits[0], file_hash
+        finally:
+            sess.close()
+    return run
+
+
+def evaluate_from(commits, cases, circuit, gc_dir, n_outputs, engine=None, program=None, evaluate=None):
+    """Evaluator::evaluate_from (cut_and_choose/evaluator.rs:338-476): evaluate the finalized instances from their gc_<i>.bin and
+    check everything the evaluator was handed against the garbler's commit record BEFORE trusting the result.
+    `cases`: list of dicts {index, true_constant_wire[16], false_constant_wire[16], input_active[n_in,16], input_bits[n_in]}
+    (EvaluatorCaseInput).  Raises ConsistencyError with the reference's variants — TrueConstantMismatch,
+    FalseConstantMismatch, MissingCiphertextHash, InputLabelsCountMismatch, InputLabelsMismatch, CiphertextMismatch,
+    OutputLabelMismatch — and returns [(index, output_active[n_out,16], output_bits[n_out])].
+    `evaluate(index, true, false, input_active, input_bits) -> (output_active, output_bits, ciphertext_hash)` defaults to the GPU
+    evaluator; tests without a GPU pass the CPU oracle's."""
+    import os
+    from . import gc_file_name
+    commits = np.asarray(commits, np.uint8)
+    evaluate = evaluate or _gpu_evaluate(circuit, engine, program, gc_dir)
+    results = []
+    for case in cases:
+        index = int(case["index"])
+        t_act = np.asarray(case["true_constant_wire"], np.uint8).reshape(16)
+        f_act = np.asarray(case["false_constant_wire"], np.uint8).reshape(16)
+        in_act = np.asarray(case["input_active"], np.uint8).reshape(-1, 16)
+        in_bits = np.asarray(case["input_bits"], np.uint8).reshape(-1)
+        n_in_committed = (commits.shape[1] - record_len(n_outputs, 0)) // 32
+        _, ct_commit, in_commits, out_commits, true_commit, false_commit = record_fields(commits[index], n_outputs, n_in_committed)
+        got = commit_labels(np.stack([t_act, f_act]))
+        if bytes(got[0]) != bytes(true_commit):
+            raise ConsistencyError("TrueConstantMismatch", index, expected=bytes(true_commit), actual=bytes(got[0]))
+        if bytes(got[1]) != bytes(false_commit):
+            raise ConsistencyError("FalseConstantMismatch", index, expected=bytes(false_commit), actual=bytes(got[1]))
+        if not os.path.exists(os.path.join(gc_dir, gc_file_name(index))):
+            raise ConsistencyError("MissingCiphertextHash", index)
+        out_act, out_bits, file_hash = evaluate(index, t_act, f_act, in_act, in_bits)
+        if in_act.shape[0] != n_in_committed:
+            raise ConsistencyError("InputLabelsCountMismatch", index, expected=n_in_committed, actual=in_act.shape[0])
+        actual = commit_labels(in_act)
+        expected = in_commits[np.arange(n_in_committed), in_bits.astype(np.int64) & 1]  # commit_for_value(value)
+        bad = np.nonzero((actual != expected).any(axis=1))[0]
+        if bad.size:
+            k = int(bad[0])
+            raise ConsistencyError("InputLabelsMismatch", index, label_index=k, expected=bytes(expected[k]), actual=bytes(actual[k]))
+        if bytes(file_hash) != bytes(ct_commit):
+            raise ConsistencyError("CiphertextMismatch", index, expected=bytes(ct_commit), actual=bytes(file_hash))
+        out_act = np.asarray(out_act, np.uint8).reshape(-1, 16)
+        out_bits = np.asarray(out_bits, np.uint8).reshape(-1)
+        oh = commit_labels(out_act)
+        exp_out = out_commits[np.arange(n_outputs), 1 - (out_bits.astype(np.int64) & 1)]  # value 1 -> label1 commit (stored first)
+        if (oh != exp_out).any():
+            raise ConsistencyError("OutputLabelMismatch", index)
+        results.append((index, out_act, out_bits))
+    return results

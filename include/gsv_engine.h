@@ -126,6 +126,20 @@ int gsv_plan_recorder_push_gates(gsv_plan_recorder* r, const gsv_gate* gates, si
 int gsv_plan_recorder_call(gsv_plan_recorder* r, const gsv_program* program, const uint64_t* in_wires, uint64_t* out_wires);
 int gsv_plan_recorder_finish(gsv_plan_recorder* r, const uint64_t* output_wires, size_t n_outputs, gsv_plan** out);
 
+/* Per-call facts of a finished plan: gate ids / ciphertext records consumed by the calls before `call`, and the call's own
+ * gate, ciphertext and device-step counts.  Any pointer may be NULL. */
+int gsv_plan_call_info(const gsv_plan* p, uint64_t call, uint64_t* gate_offset, uint64_t* n_gates, uint64_t* ct_offset, uint64_t* n_ciphertexts, uint64_t* n_steps);
+/* Bytes of compiled program records (what a session uploads to HBM once per GPU) and the number of distinct programs. */
+int gsv_plan_image_bytes(const gsv_plan* p, uint64_t* bytes, uint64_t* n_programs);
+/* Plan files.  Building the verifier's plan takes minutes of host time and tens of GB of host memory (hundreds of
+ * constant-specialised programs): gsv_plan_save writes a finished plan (its compiled programs and calls) to `path` (atomically:
+ * temp file + rename), gsv_plan_load reads one back.  With an engine the program records are streamed from the memory-mapped
+ * file straight into that GPU's memory and the host keeps only the metadata sessions need (the ranks of a node share one file
+ * through the page cache: rank 0 builds and saves, the others load); such a plan serves sessions on that engine only and cannot
+ * be saved again.  With e == NULL the plan is a complete host copy.  The file is specific to the engine build that wrote it. */
+int gsv_plan_save(const gsv_plan* p, const char* path);
+int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out);
+
 /* Call operands naming the constant wires instead of a global wire. */
 #define GSV_PLAN_WIRE_FALSE 0xFFFFFFFEu
 #define GSV_PLAN_WIRE_TRUE 0xFFFFFFFFu
@@ -178,6 +192,12 @@ int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base);
  * are read with gsv_session_read_outputs as after gsv_session_garble.  With hashes == NULL and dir == NULL the stream is
  * discarded (garbling only: output labels, device-rate measurements). */
 int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes);
+
+/* The same for calls [first_call, first_call + n_calls) of a plan session only, so that a long plan can be garbled in slices:
+ * gate ids, wires and (with hashing) the per-instance CBC-MAC states continue from the previous slice; first_call == 0 starts a
+ * new pass (MACs from zero, gc files truncated; later slices append).  `hashes` receives the MAC states after this slice — the
+ * commitments once the last slice has run.  Output labels are gathered by the slice that ends with the plan's last call. */
+int gsv_session_garble_streaming_calls(gsv_session* s, uint64_t gate_id_base, uint64_t first_call, uint64_t n_calls, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes);
 
 /* Evaluate with the ciphertexts streamed from <dir>/gc_<first_index + instance>.bin (EvaluateMode over a FileSource:
  * evaluate_mode.rs:59-196, ciphertext_source.rs:36-107), one ring / one plan call at a time, for streams of any length.  Like

@@ -9,6 +9,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -39,8 +40,8 @@ def _worker(rank, world, port, total, q):
     recs = []
     for i in mine:
         g = o.garble("fq_add", int(seeds[i]))
-        recs.append(sharding.commit_record(i, g.ct_hash.tobytes(), g.output_label0, g.delta, g.false_label0, g.true_label0))
-    local = torch.from_numpy(np.stack(recs)) if recs else torch.zeros((0, sharding.record_len(254)), dtype=torch.uint8)
+        recs.append(sharding.commit_record(i, g.ct_hash.tobytes(), g.output_label0, g.delta, g.false_label0, g.true_label0, g.input_label0))
+    local = torch.from_numpy(np.stack(recs)) if recs else torch.zeros((0, sharding.record_len(254, 508)), dtype=torch.uint8)
     allrec = sharding.all_gather_records(local, total, rank, world, device="cpu")
     q.put((rank, allrec.numpy().copy()))
     dist.barrier()
@@ -66,7 +67,7 @@ def test_shard_and_gather_commits_world2():
     assert len(set(int(s) for s in seeds)) == total
     for i in range(total):
         g = o.garble("fq_add", int(seeds[i]))
-        exp = sharding.commit_record(i, g.ct_hash.tobytes(), g.output_label0, g.delta, g.false_label0, g.true_label0)
+        exp = sharding.commit_record(i, g.ct_hash.tobytes(), g.output_label0, g.delta, g.false_label0, g.true_label0, g.input_label0)
         assert (res[0][i] == exp).all()
 
 
@@ -92,7 +93,7 @@ def test_regarbling_check_file_side_on_cpu(tmp_path):
         g = o.garble("u254_add", seed)
         h = gsv.write_gc_file(os.path.join(str(tmp_path), gsv.gc_file_name(i)), g.ciphertexts)
         assert h == g.ct_hash.tobytes()
-        recs.append(sharding.commit_record(i, h, g.output_label0, g.delta, g.false_label0, g.true_label0))
+        recs.append(sharding.commit_record(i, h, g.output_label0, g.delta, g.false_label0, g.true_label0, g.input_label0))
     commits = np.stack(recs)
     assert sharding.run_regarbling(commits, [0, 1, 2], {}, "u254_add", str(tmp_path)) == (True, {})
     with open(os.path.join(str(tmp_path), gsv.gc_file_name(1)), "r+b") as f:
@@ -103,3 +104,65 @@ def test_regarbling_check_file_side_on_cpu(tmp_path):
     os.remove(os.path.join(str(tmp_path), gsv.gc_file_name(2)))
     ok, errors = sharding.run_regarbling(commits, [0, 1, 2], {}, "u254_add", str(tmp_path))
     assert not ok and errors[1] == "ciphertext corrupted" and errors[2].startswith("failed to get ciphertext source") and 0 not in errors
+
+
+def test_evaluate_from_consistency_checks(tmp_path):
+    """Evaluator::evaluate_from (cut_and_choose/evaluator.rs:338-476): the evaluator checks the constants, the active input labels
+    and the ciphertext file it was handed against the garbler's commit record, and the output label it derives against the output
+    commits.  Honest case passes; every tampering is reported with the reference's ConsistencyError variant.  The evaluation
+    itself is the CPU oracle's here (the GPU path of the same function is covered by test_gpu_parity)."""
+    import garbled_snark_verifier_amd as gsv
+    from garbled_snark_verifier_amd import sharding
+    circuit, n_in, n_out = "u254_add", 508, 255
+    gs, recs = [], []
+    for i, seed in enumerate([21, 22]):
+        g = o.garble(circuit, seed)
+        gs.append(g)
+        h = gsv.write_gc_file(os.path.join(str(tmp_path), gsv.gc_file_name(i)), g.ciphertexts)
+        recs.append(sharding.commit_record(i, h, g.output_label0, g.delta, g.false_label0, g.true_label0, g.input_label0))
+    commits = np.stack(recs)
+    assert commits.shape[1] == sharding.record_len(n_out, n_in)
+    # the record never holds both labels of a constant: publishing AES_K(l) and AES_K(l ^ delta) under a public key reveals delta
+    idx, cth, inc, outc, tc, fc = sharding.record_fields(commits[0], n_out, n_in)
+    assert idx == 0 and bytes(tc) == o.cbcmac((gs[0].true_label0 ^ gs[0].delta).tobytes()) and bytes(fc) == o.cbcmac(gs[0].false_label0.tobytes())
+    assert bytes(inc[3, 1]) == o.cbcmac((gs[0].input_label0[3] ^ gs[0].delta).tobytes()) and bytes(outc[0, 1]) == o.cbcmac(gs[0].output_label0[0].tobytes())
+    rng = np.random.default_rng(5)
+
+    def oracle_eval(index, t_act, f_act, in_act, in_bits):
+        cts, h = gsv.read_gc_file(os.path.join(str(tmp_path), gsv.gc_file_name(index)))
+        e = o.evaluate(circuit, t_act, f_act, in_act, in_bits, cts)
+        return e.output_active, e.output_bits, e.ct_hash.tobytes()
+
+    def case(i, **over):
+        g = gs[i]
+        bits = rng.integers(0, 2, n_in).astype(np.uint8)
+        c = {"index": i, "true_constant_wire": g.true_label0 ^ g.delta, "false_constant_wire": g.false_label0,
+             "input_active": np.where(bits[:, None] == 1, g.input_label0 ^ g.delta[None, :], g.input_label0), "input_bits": bits}
+        c.update(over)
+        return c
+
+    res = sharding.evaluate_from(commits, [case(0), case(1)], circuit, str(tmp_path), n_out, evaluate=oracle_eval)
+    assert [r[0] for r in res] == [0, 1]
+    for (i, act, bits) in res:
+        assert (act == np.where(bits[:, None] == 1, gs[i].output_label0 ^ gs[i].delta[None, :], gs[i].output_label0)).all()
+
+    def kind(c, ev=oracle_eval):
+        with pytest.raises(sharding.ConsistencyError) as ei:
+            sharding.evaluate_from(commits, [c], circuit, str(tmp_path), n_out, evaluate=ev)
+        return ei.value.kind, ei.value.index
+
+    assert kind(case(0, true_constant_wire=gs[0].true_label0)) == ("TrueConstantMismatch", 0)   # label0 of TRUE instead of its label1
+    assert kind(case(1, false_constant_wire=gs[1].false_label0 ^ gs[1].delta)) == ("FalseConstantMismatch", 1)
+    c = case(0)
+    c["input_active"] = c["input_active"].copy(); c["input_active"][7] ^= gs[0].delta          # the garbler's OTHER label for input 7
+    assert kind(c) == ("InputLabelsMismatch", 0)
+    c = case(0)
+    c["input_active"] = c["input_active"][:-1]; c["input_bits"] = c["input_bits"][:-1]
+    assert kind(c, ev=lambda *a: (np.zeros((n_out, 16), np.uint8), np.zeros(n_out, np.uint8), bytes(16))) == ("InputLabelsCountMismatch", 0)
+    path = os.path.join(str(tmp_path), gsv.gc_file_name(1))
+    raw = bytearray(open(path, "rb").read()); raw[-1] ^= 1; open(path, "wb").write(bytes(raw))
+    assert kind(case(1))[0] in ("CiphertextMismatch",)
+    os.remove(path)
+    assert kind(case(1)) == ("MissingCiphertextHash", 1)
+    # a wrong output label (evaluation backend returning garbage) is caught by the output commits
+    assert kind(case(0), ev=lambda i, t, f, a, b: (np.zeros((n_out, 16), np.uint8), np.zeros(n_out, np.uint8), bytes(commits[0, 8:24]))) == ("OutputLabelMismatch", 0)

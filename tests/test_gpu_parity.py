@@ -216,16 +216,18 @@ def test_cut_and_choose_fanout_and_commit_records(engine):
     seeds = [int(x) for x in sharding.instance_seeds(1234, total)]
     prog = gsv.Program.from_circuit("fq_mul")
     g = gsv.CircuitBuilder.streaming_garbling("fq_mul", seeds, engine=engine, program=prog, keep_ciphertexts=False)
-    recs = np.stack([sharding.commit_record(i, g.ciphertext_hash[i], g.output_label0[i], g.delta[i], g.false_label0[i], g.true_label0[i]) for i in range(total)])
+    recs = np.stack([sharding.commit_record(i, g.ciphertext_hash[i], g.output_label0[i], g.delta[i], g.false_label0[i], g.true_label0[i], g.input_label0[i]) for i in range(total)])
     import torch
     table = sharding.all_gather_records(torch.from_numpy(recs), total, 0, 1)
-    assert table.shape == (total, sharding.record_len(254))
+    assert table.shape == (total, sharding.record_len(254, 508))
     for i in (0, 7, 15):
         ref = o.garble("fq_mul", seeds[i], capture_ct=False)
-        exp = sharding.commit_record(i, ref.ct_hash.tobytes(), ref.output_label0, ref.delta, ref.false_label0, ref.true_label0)
+        exp = sharding.commit_record(i, ref.ct_hash.tobytes(), ref.output_label0, ref.delta, ref.false_label0, ref.true_label0, ref.input_label0)
         assert (table[i].numpy() == exp).all()
-    # AES_K(label): one-block CBC-MAC from the zero state
-    assert bytes(table[0].numpy()[24:40]) == o.cbcmac(g.false_label0[0].tobytes())
+    # AES_K(label): one-block CBC-MAC from the zero state; the record ends with commit(true.label1), commit(false.label0)
+    assert bytes(table[0].numpy()[-16:]) == o.cbcmac(g.false_label0[0].tobytes())
+    assert bytes(table[0].numpy()[-32:-16]) == o.cbcmac((g.true_label0[0] ^ g.delta[0]).tobytes())
+    assert bytes(table[0].numpy()[24:40]) == o.cbcmac(g.input_label0[0][0].tobytes())
 
 
 def test_two_instances_per_workgroup(engine, monkeypatch):
@@ -308,7 +310,7 @@ def test_cut_and_choose_regarbling_check(engine, tmp_path):
     # the commit records are the ones the oracle's garbling gives
     for i in (0, 5):
         ref = o.garble("fq_mul", seeds[i], capture_ct=False)
-        assert (commits[i] == sharding.commit_record(i, ref.ct_hash.tobytes(), ref.output_label0, ref.delta, ref.false_label0, ref.true_label0)).all()
+        assert (commits[i] == sharding.commit_record(i, ref.ct_hash.tobytes(), ref.output_label0, ref.delta, ref.false_label0, ref.true_label0, ref.input_label0)).all()
     keep = [1, 4, 6]
     opened = {i: seeds[i] for i in range(total) if i not in keep}
     ok, errors = sharding.run_regarbling(commits, keep, opened, "fq_mul", str(tmp_path), engine=engine, program=prog)
