@@ -136,6 +136,13 @@ struct gsv_session {
   uint64_t ct_stride() const { return plan ? (plan_retain ? plan->n_ct : plan_max_block) : ct_cap * p->prog.n_ct; }  // n_ct does not depend on the variant
 };
 
+// Failure paths release whatever was allocated so far through the public destroy functions (a failed hipMalloc on a
+// multi-GB session must not leave the GPU full).
+struct SessionDeleter { void operator()(gsv_session* s) const { gsv_session_destroy(s); } };
+struct EngineDeleter { void operator()(gsv_engine* e) const { gsv_engine_destroy(e); } };
+typedef std::unique_ptr<gsv_session, SessionDeleter> SessionPtr;
+typedef std::unique_ptr<gsv_engine, EngineDeleter> EnginePtr;
+
 extern "C" {
 
 const char* gsv_last_error(void) { return g_err.c_str(); }
@@ -259,7 +266,7 @@ int gsv_engine_create(int device, gsv_engine** out) {
   if (er != hipSuccess || n <= 0) return fail(GSV_ERR_DEVICE, "no HIP device available: the garbling engine has no CPU fallback");
   if (device < 0 || device >= n) return fail(GSV_ERR_DEVICE, "device index out of range");
   HIPCHK(hipSetDevice(device));
-  std::unique_ptr<gsv_engine> e(new gsv_engine());
+  EnginePtr e(new gsv_engine());
   e->device = device;
   HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   const AesTables& t = AesTables::fixed_key();
@@ -337,7 +344,7 @@ int gsv_session_create(gsv_engine* e, const gsv_program* cp, size_t n_instances,
   if (ct_capacity_replays == 0 || ct_capacity_replays > replays) ct_capacity_replays = replays;
   if (replays > 0xFFFFFFFFull) return fail(GSV_ERR_INVALID, "too many replays");
   HIPCHK(hipSetDevice(e->device));
-  std::unique_ptr<gsv_session> s(new gsv_session());
+  SessionPtr s(new gsv_session());
   s->e = e; s->p = p; s->n_inst = n_instances; s->replays = replays; s->ct_cap = ct_capacity_replays;
   s->ct_uploaded.assign(n_instances, 0);
   // Two instances per workgroup once there are more instances than CUs (each then works with half of the LDS label
@@ -767,7 +774,7 @@ int gsv_session_create_plan(gsv_engine* e, const gsv_plan* plan, size_t n_instan
 int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_instances, int retain_stream, gsv_session** out) {
   if (!e || !plan || !out || n_instances == 0 || !plan->finished || plan->calls.empty()) return fail(GSV_ERR_INVALID, "bad argument / plan not finished");
   HIPCHK(hipSetDevice(e->device));
-  std::unique_ptr<gsv_session> s(new gsv_session());
+  SessionPtr s(new gsv_session());
   s->e = e; s->p = plan->calls[0].prog; s->plan = plan; s->n_inst = n_instances; s->replays = 1; s->ct_cap = 1;
   s->ct_uploaded.assign(n_instances, 0);
   {
@@ -1142,7 +1149,7 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   std::vector<std::thread> cur;
   auto join = [](std::vector<std::thread>& p) { for (auto& th : p) th.join(); p.clear(); };
   int rc = GSV_OK;
-  HIPCHK(hipEventRecord(s->ev0, s->e->stream));
+  if (hipEventRecord(s->ev0, s->e->stream) != hipSuccess) { close_files(); return fail(GSV_ERR_DEVICE, "hipEventRecord failed"); }
   for (uint64_t r0 = first; r0 < total && rc == GSV_OK; r0 += seg) {
     const uint64_t r1 = std::min(total, r0 + seg);
     uint64_t n_records;  // per instance, in this segment
@@ -1237,7 +1244,7 @@ int gsv_session_evaluate_streaming(gsv_session* s, uint64_t gate_id_base, const 
   std::vector<CbcMacHost> macs(n_inst);
   std::vector<uint8_t> host;
   int rc = GSV_OK;
-  HIPCHK(hipEventRecord(s->ev0, s->e->stream));
+  if (hipEventRecord(s->ev0, s->e->stream) != hipSuccess) { close_files(); return fail(GSV_ERR_DEVICE, "hipEventRecord failed"); }
   for (uint64_t r0 = 0; r0 < total && rc == GSV_OK; r0 += seg) {
     const uint64_t r1 = std::min(total, r0 + seg);
     const uint64_t n_records = s->plan ? s->call_prog(size_t(r0)).n_ct : (r1 - r0) * n_ct;  // per instance

@@ -18,6 +18,9 @@
 // No MFMA: the work is byte-table lookups and 128-bit XORs.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+#include <set>
+
 #include "gate_math.hpp"
 #include "kernel_api.h"
 #include "limits.h"
@@ -527,19 +530,27 @@ int gsvk_upload_round_keys(const uint32_t rk[44]) {
 }
 int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, int evaluate, hipStream_t stream) {
   const size_t lds = GSV_LDS_BYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
-    // the kernels address LDS from byte 0: there must be no static LDS in front of the dynamic block
-    hipFuncAttributes fa;
-    const void* kernels[6] = {reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 1, 0>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 1, 0>),
-                              reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 2, 0>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 2, 0>),
-                              reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 1, 1>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 1, 1>)};
-    for (const void* k : kernels) {
-      if (hipFuncGetAttributes(&fa, k) != hipSuccess || fa.sharedSizeBytes != 0) return int(hipErrorInvalidValue);
-      hipError_t e0 = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-      if (e0 != hipSuccess) return int(e0);
+  // The opt-in to 160 KiB of dynamic LDS is a per-device function attribute: done once per device (an engine per GPU may live
+  // in one process, and sessions may be driven from several host threads).
+  {
+    static std::mutex attr_mu;
+    static std::set<int> attr_done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return int(hipErrorInvalidDevice);
+    std::lock_guard<std::mutex> lk(attr_mu);
+    if (!attr_done.count(dev)) {
+      // the kernels address LDS from byte 0: there must be no static LDS in front of the dynamic block
+      hipFuncAttributes fa;
+      const void* kernels[6] = {reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 1, 0>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 1, 0>),
+                                reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 2, 0>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 2, 0>),
+                                reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 1, 1>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 1, 1>)};
+      for (const void* k : kernels) {
+        if (hipFuncGetAttributes(&fa, k) != hipSuccess || fa.sharedSizeBytes != 0) return int(hipErrorInvalidValue);
+        hipError_t e0 = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e0 != hipSuccess) return int(e0);
+      }
+      attr_done.insert(dev);
     }
-    attr_done = true;
   }
   const bool blake3 = ka->hasher == 1;
   const uint32_t ni = (ka->instances_per_wg == 2 && !blake3) ? 2u : 1u;

@@ -218,3 +218,23 @@ def test_plan_from_circuit_builds_without_a_device_and_in_both_modes():
     plan = gsv.Plan.from_circuit("fq_sqrt", ["fp254::exp_chunk"], half_window=True)
     assert plan.info["n_gates"] == 148_727_956 and plan.info["n_ciphertexts"] == 36_651_387 and 60 <= plan.info["n_calls"] <= 70
     plan.close()
+
+
+def test_step_barrier_isa_check():
+    """build.check_step_barrier_isa: the hand-counted `s_waitcnt vmcnt(N); s_barrier` of run_program_kernel is verified on the
+    gfx950 ISA of every instantiation at build time (the record prefetch must stay the youngest vector-memory operation in front
+    of the barrier).  The check passes on the built object and trips on a doctored listing."""
+    from garbled_snark_verifier_amd import build
+    asm = build.disassemble_kernels()
+    res = build.check_step_barrier_isa(asm)
+    assert len(res) == 6 and sorted(res.values()) == [(1, 0)] * 3 + [(1, 1)] * 3
+    # a label store scheduled behind the prefetch
+    lines = asm.splitlines()
+    k = next(i for i, l in enumerate(lines) if "s_waitcnt vmcnt(1) lgkmcnt(0)" in l and "s_barrier" in lines[i + 1])
+    bad = lines[:k] + ["\tglobal_store_dwordx4 v[4:5], v[0:3], off    // doctored"] + lines[k:]
+    with pytest.raises(RuntimeError, match="youngest vector-memory operation"):
+        build.check_step_barrier_isa("\n".join(bad))
+    # a barrier the compiler dropped / duplicated
+    gone = [l for i, l in enumerate(lines) if i != k]
+    with pytest.raises(RuntimeError, match="counted step barriers"):
+        build.check_step_barrier_isa("\n".join(gone))

@@ -576,16 +576,16 @@ def test_plan_recorder_through_the_c_abi(engine):
     s.close()
 
 
-@pytest.mark.skipif(not os.environ.get("GSV_SLOW"), reason="building the 522-call Miller-loop plan takes ~7 minutes of host time (178 constant-specialised line programs); set GSV_SLOW=1 or run tools/miller_plan.py")
 def test_miller_loop_as_a_plan(engine):
     """multi_miller_loop_groth16_evaluate_montgomery_fast (pairing.rs:944-1007): 6,909,061,143 gates, 62 % of the verifier, as a
     plan; hash + output labels == the oracle's flat-stream fixture (tests/golden/miller_loop_golden.json, 8 minutes of oracle
-    time).  Same check as tools/miller_plan.py, which also measures the device rate (8.1e10 gates/s at 256 instances)."""
+    time).  The plan is built for the half LDS window (one compilation per program, traces dropped: ~1-2 minutes of host time for
+    its 178 constant-specialised line programs).  tools/miller_plan.py also measures the device rate."""
     import hashlib
     import garbled_snark_verifier_amd as gsv
     case = json.load(open(os.path.join(os.path.dirname(GOLDEN), "miller_loop_golden.json")))
     plan = gsv.Plan.from_circuit("miller_loop", ["fq12::square_montgomery", "fq12::mul_by_034_montgomery", "pairing::ell_by_constant_montgomery",
-                                                 "pairing::double_in_place_circuit_montgomery", "pairing::add_in_place_montgomery", "pairing::mul_by_char_montgomery"])
+                                                 "pairing::double_in_place_circuit_montgomery", "pairing::add_in_place_montgomery", "pairing::mul_by_char_montgomery"], half_window=True)
     assert plan.info["n_gates"] == case["gates"] == 6_909_061_143 and plan.info["n_ciphertexts"] == case["n_ciphertexts"]
     d, f, t, inp = gsv.labels_from_seed(case["seed"], plan.info["n_inputs"])
     sess = gsv.Session(engine, plan, 1, retain_stream=False)
@@ -593,6 +593,7 @@ def test_miller_loop_as_a_plan(engine):
     hashes = sess.garble_streaming()
     assert hashes[0].hex() == case["ct_hash"] and hashlib.sha256(sess.read_outputs()[0].tobytes()).hexdigest() == case["output_label0_sha256"]
     sess.close()
+    plan.close()
 
 
 def test_half_window_plan_serves_both_layouts(engine, monkeypatch):
@@ -655,10 +656,117 @@ VERIFIER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cycl
                   "bigint::multiplexer", "g1::add_montgomery", "fp254::inverse"]
 
 
-@pytest.mark.skipif(not os.environ.get("GSV_SLOW"), reason="building the plan of the whole verifier takes minutes of host time and ~90 GB of host memory; set GSV_SLOW=1 or run tools/groth16_plan.py")
+@pytest.fixture(scope="module")
+def compressed_verifier_plan():
+    """The plan of the reference's headline circuit, groth16_verify_compressed (groth16.rs:250-268), built ONCE for the tests below
+    (what bench.py builds: half LDS window, ~100 s of host time and ~50 GB of host memory on the GPU box)."""
+    import garbled_snark_verifier_amd as gsv
+    case = json.load(open(os.path.join(os.path.dirname(GOLDEN), "groth16_verify_compressed_golden.json")))
+    plan = gsv.Plan.from_circuit(case["circuit"], VERIFIER_UNITS + ["fp254::exp_chunk"], half_window=True)
+    yield case, plan
+    plan.close()
+
+
+def test_compressed_verifier_as_a_plan_in_slices(engine, compressed_verifier_plan):
+    """BASELINE config 4.  groth16_verify_compressed (groth16.rs:250-268: decompression of A, B, C; MSM; projective-to-affine;
+    Miller loop; final exponentiation; comparison) for the synthetic instance of tests/groth16_ref.py as one plan, garbled the way
+    bench.py steps through it — in slices of consecutive calls, the stream drained and CBC-MAC'ed slice by slice: the final MAC
+    and the output label == the fixture the CPU oracle produced from the FLAT 11,687,200,297-gate stream
+    (tests/golden/make_big_golden.py).  tools/groth16_plan.py --compressed also evaluates a valid and a tampered proof."""
+    import hashlib
+    import bench
+    import garbled_snark_verifier_amd as gsv
+    case, plan = compressed_verifier_plan
+    assert plan.info["n_gates"] == case["gates"] == 11_687_200_297 and plan.info["n_ciphertexts"] == case["n_ciphertexts"]
+    ci = plan.call_info()
+    slices = bench.plan_slices(ci[:, 1], 10)
+    assert sum(s[2] for s in slices) == case["gates"] and max(s[2] for s in slices) < 1.1 * case["gates"] / 10
+    d, f, t, inp = gsv.labels_from_seed(case["seed"], plan.info["n_inputs"])
+    sess = gsv.Session(engine, plan, 1, retain_stream=False)
+    sess.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
+    for first, n, _ in slices:
+        hashes = sess.garble_calls(first, n)
+    assert hashes[0].hex() == case["ct_hash"] and hashlib.sha256(sess.read_outputs()[0].tobytes()).hexdigest() == case["output_label0_sha256"]
+    sess.close()
+
+
+def test_verifier_lockstep_two_instances_per_workgroup(engine, compressed_verifier_plan):
+    """The bench's configuration on real verifier programs: 512 instances, two per workgroup (the kernel instantiation
+    run_program_kernel<false, 2, 0> and its hand-counted step barrier), all with the SAME seed, through the first slice of the
+    plan with the ciphertexts drained: every instance must produce the same CBC-MAC state, and a second run the same again."""
+    import bench
+    import garbled_snark_verifier_amd as gsv
+    case, plan = compressed_verifier_plan
+    ci = plan.call_info()
+    first, n, _ = bench.plan_slices(ci[:, 1], 100)[0]  # decompression ladders: thousands of narrow steps (~30 M ciphertexts per instance)
+    B = 512
+    d, f, t, inp = gsv.labels_from_seed(7, plan.info["n_inputs"])
+    sess = gsv.Session(engine, plan, B, retain_stream=False)
+    assert sess.instances_per_workgroup == 2
+    seen = []
+    for _ in range(2):
+        sess.set_garble_inputs(np.tile(d, (B, 1)), np.tile(np.stack([f, t]), (B, 1, 1)), np.tile(inp, (B, 1, 1)))
+        hashes = sess.garble_calls(first, n)
+        assert len(set(hashes)) == 1, "identical instances produced different ciphertext streams"
+        seen.append(hashes[0])
+    assert seen[0] == seen[1]
+    sess.close()
+    # the same slice for ONE instance (one per workgroup, run_program_kernel<false, 1, 0>) gives the same stream
+    one = gsv.Session(engine, plan, 1, retain_stream=False)
+    one.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
+    assert one.garble_calls(first, n)[0] == seen[0]
+    one.close()
+
+
+def test_plan_slices_and_plan_file_on_the_device(engine, tmp_path):
+    """gsv_session_garble_streaming_calls + gsv_plan_save / gsv_plan_load: a plan garbled slice by slice (MACs chained, gc files
+    appended) equals the whole pass and the oracle; the same plan loaded from its file straight into device memory (no host
+    records) gives the same stream again, with one and with two instances per workgroup."""
+    import garbled_snark_verifier_amd as gsv
+    plan = gsv.Plan.from_circuit("fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"], half_window=True)
+    seeds = [91, 92, 93]
+    B, n_in, n_calls = len(seeds), plan.info["n_inputs"], plan.info["n_calls"]
+    labs = [gsv.labels_from_seed(s, n_in) for s in seeds]
+    delta = np.stack([x[0] for x in labs]); consts = np.stack([np.stack([x[1], x[2]]) for x in labs]); inputs = np.stack([x[3] for x in labs])
+    refs = [o.garble("fq12_mix", s, capture_ct=True) for s in seeds]
+    path = os.path.join(str(tmp_path), "mix.gsvplan")
+    plan.save(path)
+    loaded = gsv.Plan.load(path, engine)
+    assert loaded.info == plan.info and loaded.image_bytes() == plan.image_bytes()
+    with pytest.raises(gsv.GsvError):
+        loaded.save(os.path.join(str(tmp_path), "again.gsvplan"))  # no host records to write
+    for pl, ni in ((plan, "1"), (loaded, "1"), (loaded, "2")):
+        os.environ["GSV_INSTANCES_PER_WG"] = ni
+        try:
+            sess = gsv.Session(engine, pl, B, retain_stream=False)
+        finally:
+            del os.environ["GSV_INSTANCES_PER_WG"]
+        assert sess.instances_per_workgroup == int(ni)
+        gc = os.path.join(str(tmp_path), "gc_%s_%s" % (ni, pl is loaded))
+        os.makedirs(gc)
+        sess.set_garble_inputs(delta, consts, inputs)
+        for first in range(0, n_calls, 2):  # slices of two calls
+            hashes = sess.garble_calls(first, min(2, n_calls - first), directory=gc, first_index=5)
+        out = sess.read_outputs()
+        for i, ref in enumerate(refs):
+            assert hashes[i] == ref.ct_hash.tobytes() and (out[i] == ref.output_label0).all()
+            cts, h = gsv.read_gc_file(os.path.join(gc, gsv.gc_file_name(5 + i)))
+            assert h == ref.ct_hash.tobytes() and (cts == ref.ciphertexts).all()
+        # discarding slices leave the same output labels
+        sess.set_garble_inputs(delta, consts, inputs)
+        sess.garble_calls(0, 1, discard=True)
+        sess.garble_calls(1, n_calls - 1, discard=True)
+        assert (sess.read_outputs() == out).all()
+        with pytest.raises(gsv.GsvError):
+            sess.garble_calls(n_calls, 1, discard=True)
+        sess.close()
+    loaded.close()
+    plan.close()
+
+
+@pytest.mark.skipif(not os.environ.get("GSV_SLOW"), reason="the uncompressed variant is a sub-circuit of groth16_verify_compressed, which the default run covers; GSV_SLOW=1 builds this second plan too")
 @pytest.mark.parametrize("fixture,units,gates", [
-    ("groth16_verify_golden.json", VERIFIER_UNITS, 10_914_485_653),
-    ("groth16_verify_compressed_golden.json", VERIFIER_UNITS + ["fp254::exp_chunk"], 11_687_200_297),
+    ("groth16_verify_golden.json", VERIFIER_UNITS, 10_914_485_653),  # the compressed circuit (tests above, always run) contains this one
 ])
 def test_groth16_verifier_as_a_plan(engine, fixture, units, gates):
     """groth16_verify (groth16.rs:58-110: MSM, projective-to-affine, Miller loop, final exponentiation, comparison) and
