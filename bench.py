@@ -41,9 +41,13 @@ VERIFIER_GATES = 11_174_708_821  # README.md:12 of the reference (its own 1-publ
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s
 AES_CEILING_AND_PER_S = 4.9e10   # 741 VALU + 364 LDS wave-instructions per 64 garbled ANDs -> ~5 us per 1024 ANDs per CU
 
-VERIFIER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cyclotomic_square_montgomery", "fq12::inverse_montgomery", "fq12::mul_by_034_montgomery",
+VERIFIER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cyclotomic_square_montgomery", "fq12::mul_by_034_montgomery",
                   "pairing::ell_by_constant_montgomery", "pairing::double_in_place_circuit_montgomery", "pairing::add_in_place_montgomery", "pairing::mul_by_char_montgomery",
-                  "bigint::multiplexer", "g1::add_montgomery", "fp254::inverse"]
+                  "bigint::multiplexer", "g1::add_montgomery",
+                  # the Fq inversions (binary extended Euclid, fp254impl.rs:333-690) enter as their own 4-iteration components: as ONE unit an
+                  # inversion (11 M ciphertexts) — or the Fq12 inversion around it (21 M) — would set the size of every instance's device
+                  # ciphertext block (340 MB x 512 instances); their chunks keep the largest block at an Fq12 multiplication's 5.4 M records
+                  "inverse_iteration", "inverse::divide_result_by_2^k::chunk", "inverse::divide_result_by_even_part::chunk"]
 
 
 # ---------------------------------------------------------------------------------------------------------- rank logic (no GPU)
@@ -261,38 +265,93 @@ def get_plan(gsv, engine, args, circuit, units, rank, local_rank, local_world, d
     return plan, info, save_later
 
 
-def cpu_baseline(np, o, log):
-    """The restated CPU path (C++ oracle: AES-NI gate hash + inline CBC-MAC, the reference's loop) on this host: one core, then one
-    instance per core on all cores (reference: cut_and_choose/mod.rs:131-186).  Sample: verifier components, ~0.5 B gates per core."""
-    specs = ["g1_scalar_mul:10", "fq12_sqmul_chain:8"]  # MSM window scalar multiplication + 8 square-and-multiply links of the pairing core
+def physical_cores():
+    """One logical CPU per physical core of this process's affinity mask (the reference pins one garbling task per physical core,
+    cut_and_choose/mod.rs:131-186)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = list(range(os.cpu_count() or 1))
+    seen, picks = set(), []
+    for c in allowed:
+        try:
+            sib = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            picks.append(c)
+    return picks
+
+
+def cpu_quota_cores():
+    """CPU bandwidth limit of this container in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+_CPU_WORKER = """
+import json, os, sys
+sys.path.insert(0, %r)
+cpu = int(sys.argv[1])
+try:
+    os.sched_setaffinity(0, {cpu})
+except (AttributeError, OSError):
+    pass
+import oracle_lib as o
+res = [o.bench_garble(s, seed=0) for s in %r]
+print(json.dumps({"seconds": sum(r[0] for r in res), "gates": sum(r[1] for r in res), "hashes": [r[2].hex() for r in res]}))
+"""
+
+
+def cpu_baseline(np, o, log, budget_s=75.0):
+    """The restated CPU path (C++ oracle: AES-NI gate hash + inline CBC-MAC, the reference's per-gate loop) on this host: one core,
+    then one instance per physical core, each in its own process pinned to its core (reference: one garbling task per physical
+    core, cut_and_choose/mod.rs:131-186).  Sample per core: verifier components, ~0.36 B gates (~15 s)."""
+    specs = ["g1_scalar_mul:10", "fq12_sqmul_chain:4"]  # the MSM's window scalar multiplication + 4 square-and-multiply links of the pairing core
     t0 = time.time()
     ref = [o.bench_garble(s, seed=0) for s in specs]
     one_s, one_g = sum(r[0] for r in ref), sum(r[1] for r in ref)
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        pass
-    res = [None] * cores
-
-    def worker(k):
-        res[k] = [o.bench_garble(s, seed=0) for s in specs]  # ctypes releases the GIL: `cores` garblings run concurrently
-    th = [threading.Thread(target=worker, args=(k,)) for k in range(cores)]
+    out = {"value": one_g / one_s, "unit": "gates/s", "cores": 1, "kind": "port",
+           "sample": "%s garbled back to back by the C++ restatement of the reference's loop (AES-NI hash, inline CBC-MAC): %d gates per core" % (" + ".join(specs), one_g),
+           "cpu_1core": {"value": one_g / one_s, "unit": "gates/s", "cores": 1, "seconds": one_s, "gates": one_g},
+           "reference_published": {"cpu_1core": 32e6, "cpu_8cores": 249e6, "source": "README.md:12-13 of the reference (developer laptop)"}}
+    cpus = physical_cores()
+    quota = cpu_quota_cores()
+    out["host"] = {"physical_cores_in_affinity_mask": len(cpus), "cgroup_cpu_quota_cores": quota}
+    if quota is not None and quota < len(cpus):  # more processes than the container may run at once would only time-slice
+        cpus = cpus[: max(1, int(quota))]
+    code = _CPU_WORKER % (os.path.join(ROOT, "tests"), specs)
     t1 = time.perf_counter()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(c)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for c in cpus]
+    done, ok = [], True
+    for p in procs:
+        try:
+            so, _ = p.communicate(timeout=max(1.0, budget_s - (time.perf_counter() - t1)))
+            r = json.loads(so.strip().splitlines()[-1])
+            ok = ok and r["hashes"] == [x[2].hex() for x in ref]  # same seed -> same ciphertext hashes on every core
+            done.append(r)
+        except (subprocess.TimeoutExpired, ValueError, IndexError):
+            p.kill()
+            ok = False
     wall = time.perf_counter() - t1
-    ok = all(r is not None and [x[2] for x in r] == [x[2] for x in ref] for r in res)  # same seed -> same hashes on every core
-    all_g = one_g * cores
-    return {"value": all_g / wall, "unit": "gates/s", "cores": cores, "kind": "port",
-            "sample": "%s garbled back to back by the C++ restatement of the reference's loop (AES-NI hash, inline CBC-MAC), one instance per core on %d cores: %d gates per core, %.1f s wall"
-                      % (" + ".join(specs), cores, one_g, wall),
-            "cpu_1core": {"value": one_g / one_s, "unit": "gates/s", "cores": 1, "seconds": one_s, "gates": one_g},
-            "cpu_allcores": {"value": all_g / wall, "unit": "gates/s", "cores": cores, "seconds": wall, "gates": all_g, "hashes_equal_single_core": bool(ok)},
-            "reference_published": {"cpu_1core": 32e6, "cpu_8cores": 249e6, "source": "README.md:12-13 of the reference (developer laptop)"},
-            "seconds_total": time.time() - t0}
+    if done:
+        g = sum(r["gates"] for r in done)
+        out["cpu_allcores"] = {"value": g / wall, "unit": "gates/s", "cores": len(done), "seconds": wall, "gates": g, "hashes_equal_single_core": bool(ok),
+                               "per_core_rate_mean": sum(r["gates"] / r["seconds"] for r in done) / len(done)}
+        out.update({"value": g / wall, "cores": len(done)})
+        out["sample"] += "; all-cores leg: one process per physical core on %d cores, %.1f s wall (process start included)" % (len(done), wall)
+    out["seconds_total"] = time.time() - t0
+    return out
 
 
 def run_verifier(args):
@@ -321,8 +380,11 @@ def run_verifier(args):
     ci = plan.call_info()
     slices = plan_slices(ci[:, 1], args.slices)
     image_bytes, n_programs = plan.image_bytes()
+    n_glob, n_prog_slots = plan.wire_file()
+    max_block = int(ci[:, 3].max())
     if rank == 0:
-        log("bench.py: plan %s in %.1f s (%d calls of %d programs, %.1f GB of program records), %d slices" % (plan_info["how"], plan_info["seconds"], n_calls, n_programs, image_bytes / 1e9, len(slices)))
+        log("bench.py: plan %s in %.1f s (%d calls of %d programs, %.1f GB of program records), %d slices; per instance: wire file %.1f MB (%d + %d slots), ciphertext block %.1f MB"
+            % (plan_info["how"], plan_info["seconds"], n_calls, n_programs, image_bytes / 1e9, len(slices), (n_glob + n_prog_slots) * 16 / 1e6, n_prog_slots, n_glob, max_block * 16 / 1e6))
 
     result = {}
     # ---- whole-stream check on the fixture's seed, BEFORE the timed loop: one instance, stream drained and hashed on the host

@@ -49,7 +49,7 @@ EXPORTS = [
     "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_commit_labels",
     "gsv_plan_from_circuit", "gsv_plan_io", "gsv_plan_recorder_create", "gsv_plan_recorder_destroy", "gsv_plan_recorder_allocate_wire",
     "gsv_plan_recorder_declare_input", "gsv_plan_recorder_push_gates", "gsv_plan_recorder_call", "gsv_plan_recorder_finish", "gsv_plan_create", "gsv_plan_destroy", "gsv_plan_add_call", "gsv_plan_finish", "gsv_plan_counts", "gsv_session_create_plan", "gsv_session_create_plan_ex",
-    "gsv_session_garble_streaming", "gsv_session_garble_streaming_calls", "gsv_plan_call_info", "gsv_plan_image_bytes", "gsv_plan_save", "gsv_plan_load", "gsv_session_evaluate_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
+    "gsv_session_garble_streaming", "gsv_session_garble_streaming_calls", "gsv_plan_call_info", "gsv_plan_image_bytes", "gsv_plan_wire_file", "gsv_plan_save", "gsv_plan_load", "gsv_session_evaluate_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
 ]
 
 
@@ -117,6 +117,7 @@ def lib():
         L.gsv_session_garble_streaming_calls.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint64, C.c_int, u8p]
         L.gsv_plan_call_info.argtypes = [vp, C.c_uint64] + [C.POINTER(C.c_uint64)] * 5
         L.gsv_plan_image_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.gsv_plan_wire_file.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.gsv_plan_save.argtypes = [vp, C.c_char_p]
         L.gsv_plan_load.argtypes = [C.c_char_p, vp, C.POINTER(vp)]
         L.gsv_session_instances_per_workgroup.argtypes = [vp, C.POINTER(C.c_int)]
@@ -317,6 +318,12 @@ class Plan:
         b, n = C.c_uint64(), C.c_uint64()
         _chk(lib().gsv_plan_image_bytes(self.h, C.byref(b), C.byref(n)))
         return b.value, n.value
+
+    def wire_file(self):
+        """(global wire slots, largest program's own slots): a session's wire file is their sum x 16 bytes per instance."""
+        g, m = C.c_uint64(), C.c_uint64()
+        _chk(lib().gsv_plan_wire_file(self.h, C.byref(g), C.byref(m)))
+        return g.value, m.value
 
     def call_info(self):
         """Per call: [gate offset, gates, ciphertext offset, ciphertexts, device steps] as a uint64 array [n_calls, 5]."""

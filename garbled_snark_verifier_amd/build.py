@@ -53,8 +53,8 @@ def check_step_barrier_isa(asm=None):
     vector-memory store was a ciphertext, for that store (N = 2).  That is only right while the compiler keeps the prefetch load
     the YOUNGEST vector-memory operation in front of the barrier.  Checked on the ISA of every instantiation, so that a compiler
     bump cannot silently break it:
-      * each kernel holds exactly one `s_waitcnt vmcnt(1) lgkmcnt(0)` + `s_barrier` pair, garbling kernels also exactly one
-        vmcnt(2) pair, each immediately followed by its s_barrier;
+      * each kernel holds exactly two `s_waitcnt vmcnt(1) lgkmcnt(0)` + `s_barrier` pairs (the step loop is unrolled by two:
+        ping-pong record registers), garbling kernels also exactly two vmcnt(2) pairs, each immediately followed by its s_barrier;
       * walking back from the vmcnt(1) pair, the first vector-memory instruction is the 16-byte record prefetch
         (global_load_dwordx4) and no label store (global_store / ds_write) sits between it and the barrier.
     Returns {kernel symbol: (n_vmcnt1, n_vmcnt2)}; raises RuntimeError on a violation."""
@@ -91,8 +91,8 @@ def check_step_barrier_isa(asm=None):
                     j -= 1
                 if j < 0 or not ins[j].startswith("global_load_dwordx4"):
                     raise RuntimeError("%s: the youngest vector-memory operation before the step barrier is `%s`, not the record prefetch" % (name, ins[j] if j >= 0 else "none"))
-        if n[1] != 1 or n[2] != (1 if garble else 0):
-            raise RuntimeError("%s: found %d / %d counted step barriers (vmcnt 1 / 2), expected 1 / %d" % (name, n[1], n[2], 1 if garble else 0))
+        if n[1] != 2 or n[2] != (2 if garble else 0):
+            raise RuntimeError("%s: found %d / %d counted step barriers (vmcnt 1 / 2), expected 2 / %d" % (name, n[1], n[2], 2 if garble else 0))
         out[name] = (n[1], n[2])
     return out
 

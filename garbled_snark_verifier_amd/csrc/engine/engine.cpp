@@ -38,11 +38,30 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
   catch (const std::exception& e) { return fail(GSV_ERR_CIRCUIT, e.what()); }     \
   catch (...) { return fail(GSV_ERR_CIRCUIT, "unknown exception"); }
 
+// A failed HIP call leaves its error behind for hipGetLastError(); the kernel launchers report hipGetLastError(), so the stale
+// error of e.g. an out-of-memory hipMalloc would make every later launch of the process look failed: clear it here.
 #define HIPCHK(expr)                                                                                         \
   do {                                                                                                       \
     hipError_t _e = (expr);                                                                                  \
-    if (_e != hipSuccess) return fail(GSV_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+    if (_e != hipSuccess) {                                                                                  \
+      (void)hipGetLastError();                                                                               \
+      return fail(GSV_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));                        \
+    }                                                                                                        \
   } while (0)
+
+// Large device allocations report what was asked for and what the device had left.
+static int dev_alloc(void** p, size_t bytes, const char* what) {
+  hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+  if (e == hipSuccess) return GSV_OK;
+  (void)hipGetLastError();
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  char msg[256];
+  std::snprintf(msg, sizeof msg, "hipMalloc of %.2f GB for %s failed (%s): device has %.2f of %.2f GB free", double(bytes) / 1e9, what, hipGetErrorString(e), double(free_b) / 1e9,
+                double(total_b) / 1e9);
+  return fail(GSV_ERR_DEVICE, msg);
+}
+#define DEVALLOC(p, bytes, what) do { int _rc = dev_alloc(reinterpret_cast<void**>(p), (bytes), (what)); if (_rc) return _rc; } while (0)
 
 struct gsv_recorder {
   RecordMode mode;
@@ -310,6 +329,10 @@ static int upload_program(gsv_engine* e, gsv_program* p, uint32_t ni, DevProgram
   std::lock_guard<std::mutex> lk(p->mu);
   auto it = p->dev.find({e->device, int(ni)});
   if (it != p->dev.end()) { *out = it->second; return GSV_OK; }
+  if (p->half_only) {  // one compiled image serves both layouts: one copy in HBM (the verifier plan's images are 42 GB)
+    auto other = p->dev.find({e->device, int(ni == 2 ? 1 : 2)});
+    if (other != p->dev.end()) { p->dev[{e->device, int(ni)}] = other->second; *out = other->second; return GSV_OK; }
+  }
   if (ni == 2 && !p->prog2 && !p->half_only) {  // first session with two instances per workgroup: compile for half of the LDS window
     GSV_TRY
     compile_half_window_variant(p);
@@ -358,11 +381,11 @@ int gsv_session_create(gsv_engine* e, const gsv_program* cp, size_t n_instances,
   int rc = upload_program(e, p, s->ni, &s->dp);
   if (rc) return rc;
   const Program& g = s->prog();
-  HIPCHK(hipMalloc(&s->W, n_instances * size_t(g.n_slots) * 16));
+  DEVALLOC(&s->W, n_instances * size_t(g.n_slots) * 16, "the wire files");
   HIPCHK(hipMalloc(&s->VB, n_instances * size_t(g.n_slots)));
   HIPCHK(hipMemset(s->VB, 0, n_instances * size_t(g.n_slots)));
   size_t ct_bytes = n_instances * size_t(s->ct_stride()) * 16;
-  HIPCHK(hipMalloc(&s->CT, ct_bytes ? ct_bytes : 16));
+  DEVALLOC(&s->CT, ct_bytes, "the ciphertext blocks");
   HIPCHK(hipMalloc(&s->delta, n_instances * 16));
   HIPCHK(hipMalloc(&s->out, n_instances * g.output_slots.size() * 16 + 16));
   HIPCHK(hipMalloc(&s->out_bits, n_instances * g.output_slots.size() + 16));
@@ -606,6 +629,14 @@ struct Mapping {
 };
 }  // namespace
 
+int gsv_plan_wire_file(const gsv_plan* p, uint64_t* n_global_wires, uint64_t* max_program_slots) {
+  if (!p || !p->finished) return fail(GSV_ERR_INVALID, "plan not finished");
+  uint64_t mx = SLOT_FIRST_INPUT;
+  for (const PlanCall& c : p->calls) mx = std::max<uint64_t>(mx, c.prog->prog.n_slots);
+  if (n_global_wires) *n_global_wires = p->n_globals;
+  if (max_program_slots) *max_program_slots = mx;
+  return GSV_OK;
+}
 int gsv_plan_image_bytes(const gsv_plan* p, uint64_t* bytes, uint64_t* n_programs) {
   if (!p) return fail(GSV_ERR_INVALID, "null plan");
   std::set<const gsv_program*> seen;
@@ -824,11 +855,11 @@ int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_ins
     if ((rc = up32(&s->call_dev[k].post_src, src)) || (rc = up32(&s->call_dev[k].post_dst, dst))) return rc;
   }
   { int rc = up32(&s->plan_out_slots, f.output_slots); if (rc) return rc; }
-  HIPCHK(hipMalloc(&s->W, n_instances * size_t(f.n_slots) * 16));
+  DEVALLOC(&s->W, n_instances * size_t(f.n_slots) * 16, "the wire files");
   HIPCHK(hipMalloc(&s->VB, n_instances * size_t(f.n_slots)));
   HIPCHK(hipMemset(s->VB, 0, n_instances * size_t(f.n_slots)));
   const size_t ct_bytes = n_instances * size_t(s->ct_stride()) * 16;
-  HIPCHK(hipMalloc(&s->CT, ct_bytes ? ct_bytes : 16));
+  DEVALLOC(&s->CT, ct_bytes, "the ciphertext blocks");
   HIPCHK(hipMalloc(&s->delta, n_instances * 16));
   HIPCHK(hipMalloc(&s->out, n_instances * f.output_slots.size() * 16 + 16));
   HIPCHK(hipMalloc(&s->out_bits, n_instances * f.output_slots.size() + 16));
@@ -1102,7 +1133,7 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   T = std::min(T, n_inst);
   HIPCHK(hipSetDevice(s->e->device));
   const uint64_t seg_records = seg * n_ct;  // per instance
-  if (!s->ct_gate && seg_records) HIPCHK(hipMalloc(&s->ct_gate, n_inst * seg_records * 16));
+  if (!s->ct_gate && seg_records) DEVALLOC(&s->ct_gate, n_inst * seg_records * 16, "the gate-order ciphertext buffer");
   { int rc = ensure_drain(s, T, seg_records); if (rc) return rc; }
   gsv_drain& dr = *s->drain;
   if (first == 0 || dr.macs.size() != n_inst) dr.macs.assign(n_inst, CbcMacHost());  // a new pass starts from h = 0; later slices chain
@@ -1233,7 +1264,7 @@ int gsv_session_evaluate_streaming(gsv_session* s, uint64_t gate_id_base, const 
   const size_t n_inst = s->n_inst;
   HIPCHK(hipSetDevice(s->e->device));
   const uint64_t seg_records = seg * n_ct;
-  if (!s->ct_gate && seg_records) HIPCHK(hipMalloc(&s->ct_gate, n_inst * seg_records * 16));
+  if (!s->ct_gate && seg_records) DEVALLOC(&s->ct_gate, n_inst * seg_records * 16, "the gate-order ciphertext buffer");
   std::vector<FILE*> files(n_inst, nullptr);
   auto close_files = [&]() { for (FILE*& f : files) if (f) { std::fclose(f); f = nullptr; } };
   for (size_t i = 0; i < n_inst; ++i) {

@@ -61,6 +61,9 @@ typedef uint8_t GSV_LDS lds_u8;
 typedef u32x4 GSV_GLB glb_u128;
 typedef u32x2 GSV_GLB glb_u64;
 typedef uint8_t GSV_GLB glb_u8;
+#define GSV_CST __attribute__((address_space(4)))
+typedef const u32x4 GSV_CST cst_u128;   // read-only data behind a wave-uniform address: s_load (scalar cache), not a vector load
+typedef const uint32_t GSV_CST cst_u32;
 
 struct LdsBankedTable {
   uint32_t lane4;  // (lane & 31) * 4
@@ -75,7 +78,9 @@ struct LdsBankedTable {
   // the co-limiter of that loop (364 ds_read per block pair, 44 of them round keys), and although the 44 SGPRs do not all
   // stay resident (the compiler parks ~90 scalars in VGPR lanes), trading 44 LDS reads for v_readlane is +2.4 %.
   // The quad form keeps its 11 per-lane round-key words in VGPRs, loaded once from the LDS copy.
-  __device__ __forceinline__ uint32_t rk(int i) const { return c_rk[i]; }
+  cst_u32* rkp;  // = c_rk; laundered (asm volatile) at the top of every one-gate-per-lane AES pass so that the 44 s_loads are
+                 // issued THERE and their SGPRs are live only across the pass, not across the whole step loop
+  __device__ __forceinline__ uint32_t rk(int i) const { return rkp[i]; }
 };
 
 typedef uint32_t GSV_GLB glb_u32;
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   // address below then lives in SGPRs instead of costing a VGPR each
   const uint32_t sub = NI == 1 ? 0u : uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / BT)));
   const uint32_t tid = threadIdx.x - sub * BT;      // lane index inside the instance's thread group
-  const LdsBankedTable aes{(tid & 31u) * 4u};
+  const LdsBankedTable aes{(tid & 31u) * 4u, (cst_u32*)c_rk};
   // narrow-step mode: LPG lanes per AND gate (garble: two blocks x 4 columns; evaluate: one block x 4 columns)
   constexpr uint32_t LPG = EVAL ? 4u : 8u;
   const uint32_t col = tid & 3u, blk = (tid >> 2) & 1u;
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   if (!EVAL) { const u32x4 d = ((const glb_u128*)ka.delta)[inst]; delta = Label{{d.x, d.y, d.z, d.w}}; }
   // this lane's column of delta (selects, not a runtime-indexed array: that would be promoted to static LDS)
   const uint32_t dq = col == 0 ? delta.w[0] : col == 1 ? delta.w[1] : col == 2 ? delta.w[2] : delta.w[3];
-  const glb_u128* __restrict__ step_q = (const glb_u128*)ka.steps;
+  cst_u128* const step_q = (cst_u128*)ka.steps;
   const bool no_store = (ka.diag & 8u) != 0, no_load = (ka.diag & 4u) != 0, no_aes = (ka.diag & 1u) != 0, no_narrow = (ka.diag & 16u) != 0;
 
   for (uint32_t rep = 0; rep < ka.replays; ++rep) {
@@ -246,11 +251,12 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     };
     auto load_and_rec = [&](uint32_t k) -> Rec { return *(const glb_u128*)(and_bytes + size_t(k) * 32u); };      // record k of the AND array, first half
     auto load_and_hi = [&](uint32_t k) -> u32x2 { return *(const glb_u64*)(and_bytes + size_t(k) * 32u + 16u); };  // second half
-    Rec r0, n0;
-    u32x4 sd = load_desc(0);
-    r0 = load_rec(sd);
-    u32x4 nsd = load_desc(1);
-    n0 = load_rec(nsd);
+    // Two record registers in ping-pong: step s consumes one (loaded at the end of step s-2) and, once it is done with it,
+    // refills the SAME registers with the record of step s+2.  No in-flight load is ever copied to another register: a copy
+    // would make the compiler wait for the load it has just issued at the top of every step (which is what a rotating
+    // r0 <- n0 <- n2r form did, exposing a full L2 round trip per step).
+    u32x4 sdA = load_desc(0), sdB = load_desc(1);
+    Rec recA = load_rec(sdA), recB = load_rec(sdB);
     const uint32_t wave_first = __builtin_amdgcn_readfirstlane(tid);  // index of the wave's first lane inside its instance group
     // decoded AND record
     struct AndOp { uint32_t a1, a2, b1, b2, p, c, t; uint64_t gid; };
@@ -310,10 +316,11 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       o.c = ((r.z >> 21) | (r.w << 11)) & GSV_SLOT_MASK;
       return o;
     };
-    for (uint32_t s = 0; s < ka.n_steps; ++s) {
+    // One step.  sd: its descriptor; r0: this lane's first record of it — consumed here and refilled, as the wave's youngest
+    // vector-memory operation, with the record of step s+2 (descriptor n2sd, a scalar load issued at the top of this step).
+    auto run_step = [&](const uint32_t s, const u32x4& sd, Rec& r0, const u32x4& n2sd) __attribute__((always_inline)) {
       const uint32_t and_off = sd.x, and_cnt = sd.y, xor_off = sd.z, total = sd.y + sd.w;
       (void)total;
-      const u32x4 n2sd = load_desc(s + 2);  // lands during this step; its record load is issued at the end
       bool young_ct = false;                 // did this wave issue a ciphertext store AFTER its last label store?
       if (ka.step_clock && blockIdx.x == 0 && threadIdx.x == 0 && rep + 1 == ka.replays) ka.step_clock[s] = wall_clock64();  // older than this step's stores
       if (is_narrow(sd)) {
@@ -389,6 +396,8 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         const uint32_t and_full = small_rem(and_cnt) ? and_cnt - and_rem : and_cnt;
         Rec qnext = r0;
         for (uint32_t i = tid; i < and_full; i += BT) {
+          LdsBankedTable aes_pass = aes;
+          asm volatile("" : "+s"(aes_pass.rkp));
           const Rec q = qnext;
           if (i + BT < and_full) qnext = load_and_rec(and_off + i + BT);
           const uint32_t cti = and_off + i;
@@ -405,12 +414,12 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           if (!EVAL) {
             if (no_aes) { c0 = lxor(a, b); ct = lxor(a, tweak_of(o.gid)); }
             else if (HASH == 1) garble_and_blake3(t, a, b, delta, o.gid, c0, ct);
-            else garble_and(aes, t, a, b, delta, o.gid, c0, ct);
+            else garble_and(aes_pass, t, a, b, delta, o.gid, c0, ct);
           } else {
             const uint32_t va = (wf.ld_bit(o.a1) ^ wf.ld_bit(o.a2)) & 1u, vb = (wf.ld_bit(o.b1) ^ wf.ld_bit(o.b2)) & 1u, vp = wf.ld_bit(o.p) & 1u;
             const u32x4 cv = CT[ct_base + cti];
             if (HASH == 1) c0 = degarble_and_blake3(t, Label{{cv.x, cv.y, cv.z, cv.w}}, a, va, b, o.gid);
-            else c0 = degarble_and(aes, t, Label{{cv.x, cv.y, cv.z, cv.w}}, a, va, b, o.gid);
+            else c0 = degarble_and(aes_pass, t, Label{{cv.x, cv.y, cv.z, cv.w}}, a, va, b, o.gid);
             vc = (gate_eval_bit(t, va, vb) ^ vp) & 1u;
           }
           c0 = lxor(c0, pl);
@@ -440,13 +449,22 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         young_ct = !EVAL && !no_store && xor_cnt == 0 && and_full == and_cnt && wave_first < and_cnt &&
                    (wave_first + ((and_cnt - 1u - wave_first) / BT) * BT) < and_cnt;
       }
-      asm volatile("" ::: "memory");
-      const Rec n2r = load_rec(n2sd);  // the wave's youngest load: may stay in flight across the barrier
+      // keep r0's registers reserved through the step: were they handed to a store's data in between, the refill below would
+      // have to wait for that store (vmcnt(0) in front of the prefetch) before it could overwrite them
+      asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w)::"memory");
+      r0 = load_rec(n2sd);  // the wave's youngest load: stays in flight across the barrier and the whole next step
       asm volatile("" ::: "memory");
       if (young_ct) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      sd = nsd; r0 = n0;
-      nsd = n2sd; n0 = n2r;
+    };
+    for (uint32_t s = 0; s < ka.n_steps; s += 2) {
+      const u32x4 sdA2 = load_desc(s + 2);  // lands during the step; the record load that needs it is issued at the step's end
+      run_step(s, sdA, recA, sdA2);
+      sdA = sdA2;
+      if (s + 1 >= ka.n_steps) break;        // wave-uniform: every wave passes the same number of barriers
+      const u32x4 sdB2 = load_desc(s + 3);
+      run_step(s + 1, sdB, recB, sdB2);
+      sdB = sdB2;
     }
     __syncthreads();
     if (ka.step_clock && blockIdx.x == 0 && threadIdx.x == 0 && rep + 1 == ka.replays) ka.step_clock[ka.n_steps] = wall_clock64();

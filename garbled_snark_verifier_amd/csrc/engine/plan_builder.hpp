@@ -380,6 +380,8 @@ struct BuiltPlan {
   uint32_t n_inputs = 0;
   std::vector<uint32_t> outputs;  // global ids (or PLAN_WIRE_*)
   uint64_t n_gates = 0;
+  uint32_t n_global_ids = 0;      // recycled pool size (without the trash ids behind it)
+  uint32_t n_crossing_wires = 0;  // wires that cross calls (what the pool would be without recycling)
 };
 
 // inputs / outputs: global SSA ids of the circuit's inputs / outputs as PlanRecordMode handed them out.
@@ -409,12 +411,29 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
     GlueClass& g = *m.glue_classes[size_t(s.glue_class)];
     for (uint32_t d = 0; d < g.n_defs; ++d) if (crossing[s.base_ssa + d]) g.out_mark[d] = 1;
   }
+  // Global wire ids with RECYCLING: a global is live from the call that writes it to the last call that reads it (circuit inputs
+  // and outputs are pinned), and its id returns to a free list after that call — the verifier's plan crosses ~2 x 10^7 wires
+  // between calls, of which only a small fraction is alive at any point (the reference's Storage does the same with credits,
+  // storage.rs:119-198).  A call's pre-copy (globals -> program inputs) runs before its kernel and its post-copy (program outputs
+  // -> globals) after it, so an id freed by the call's own last read may be handed to one of its outputs.
+  constexpr int32_t NEVER_FREED = 0x7FFFFFFF;
+  std::vector<int32_t> last_use(nw, -1);
+  for (size_t si = 0; si < m.segments.size(); ++si)
+    for (uint32_t w : m.segments[si].in_ssa) if (w < PLAN_WIRE_FALSE && w > 1) last_use[w] = int32_t(si);
+  for (uint32_t w : inputs) last_use[w] = NEVER_FREED;
+  for (uint32_t w : outputs) if (w > 1) last_use[w] = NEVER_FREED;
   std::vector<uint32_t> global_of(nw, DEAD_WIRE);
   uint32_t next_global = 0;
   for (uint32_t w : inputs) global_of[w] = next_global++;
   bp.n_inputs = next_global;
-  for (uint32_t w = 2; w < nw; ++w) if (crossing[w] && global_of[w] == DEAD_WIRE) global_of[w] = next_global++;
-  const uint32_t trash = next_global;  // outputs nobody reads in this instance still have to land somewhere
+  std::vector<uint32_t> free_ids;
+  auto alloc_global = [&]() -> uint32_t { if (!free_ids.empty()) { uint32_t g = free_ids.back(); free_ids.pop_back(); return g; } return next_global++; };
+  // released after segment si has read its inputs; each wire once even when a call names it several times
+  auto release_dead_inputs = [&](size_t si) {
+    for (uint32_t w : m.segments[si].in_ssa)
+      if (w < PLAN_WIRE_FALSE && w > 1 && last_use[w] == int32_t(si) && global_of[w] != DEAD_WIRE) { free_ids.push_back(global_of[w]); last_use[w] = -2; }
+  };
+  constexpr uint32_t TRASH_FLAG = 0x80000000u;  // patched to ids behind the pool's high-water mark once that is known
   std::vector<uint8_t> done;
   auto add_program = [&](Trace&& t, std::vector<uint32_t> in, std::vector<uint32_t> out) -> int {
     bp.programs.emplace_back();  // compiled below, all programs in parallel (units may have been compiled while recording)
@@ -426,7 +445,8 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
   };
   std::vector<int> unit_program(m.units.size(), -1), class_program(m.glue_classes.size(), -1);
   std::vector<std::vector<uint32_t>> class_outputs(m.glue_classes.size());  // exported definition indices
-  for (const PlanSegment& s : m.segments) {
+  for (size_t si = 0; si < m.segments.size(); ++si) {
+    const PlanSegment& s = m.segments[si];
     BuiltPlan::Call call;
     if (s.unit >= 0) {
       PlanUnit& u = *m.units[size_t(s.unit)];
@@ -442,10 +462,11 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
         call.program = unit_program[size_t(s.unit)];
       }
       for (uint32_t w : s.in_ssa) call.in_globals.push_back(w == PLAN_WIRE_FALSE || w == 0 ? PLAN_WIRE_FALSE : w == PLAN_WIRE_TRUE || w == 1 ? PLAN_WIRE_TRUE : global_of[w]);
+      release_dead_inputs(si);
       uint32_t t_used = 0;
       for (uint32_t w : s.out_ssa) {
-        if (w != DEAD_WIRE && global_of[w] != DEAD_WIRE) call.out_globals.push_back(global_of[w]);
-        else call.out_globals.push_back(trash + t_used++);
+        if (w != DEAD_WIRE && crossing[w]) { if (global_of[w] == DEAD_WIRE) global_of[w] = alloc_global(); call.out_globals.push_back(global_of[w]); }
+        else call.out_globals.push_back(TRASH_FLAG | t_used++);
       }
       bp.n_gates += u.n_gates;
     } else {
@@ -472,15 +493,22 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
       }
       call.program = class_program[ci];
       for (uint32_t w : s.in_ssa) call.in_globals.push_back(global_of[w]);
+      release_dead_inputs(si);
       uint32_t t_used = 0;
       for (uint32_t k : class_outputs[ci]) {
         const uint32_t w = s.base_ssa + k;
-        call.out_globals.push_back(crossing[w] ? global_of[w] : trash + t_used++);
+        if (crossing[w]) { if (global_of[w] == DEAD_WIRE) global_of[w] = alloc_global(); call.out_globals.push_back(global_of[w]); }
+        else call.out_globals.push_back(TRASH_FLAG | t_used++);
       }
       bp.n_gates += s.n_gates;
     }
     bp.calls.push_back(std::move(call));
   }
+  // outputs nobody reads in their instance still have to land somewhere: a few ids behind the recycled pool
+  for (BuiltPlan::Call& c : bp.calls) for (uint32_t& g : c.out_globals) if (g < PLAN_WIRE_FALSE && (g & TRASH_FLAG)) g = next_global + (g & ~TRASH_FLAG);
+  bp.n_global_ids = next_global;
+  for (uint32_t w = 2; w < nw; ++w) if (crossing[w]) ++bp.n_crossing_wires;
+  if (getenv("GSV_PLAN_DEBUG")) std::fprintf(stderr, "plan: %zu segments, %u wires cross calls, %u global ids after recycling (%u inputs pinned)\n", m.segments.size(), bp.n_crossing_wires, next_global, bp.n_inputs);
   for (uint32_t w : outputs) bp.outputs.push_back(w == 0 ? PLAN_WIRE_FALSE : w == 1 ? PLAN_WIRE_TRUE : global_of[w]);
   parallel_for_programs(bp.programs.size(), [&](size_t i) { if (!done[i]) bp.programs[i] = compile_program(bp.traces[i], bp.prog_inputs[i], bp.prog_outputs[i], {}, opt); });
   return bp;

@@ -129,6 +129,9 @@ int gsv_plan_recorder_finish(gsv_plan_recorder* r, const uint64_t* output_wires,
 /* Per-call facts of a finished plan: gate ids / ciphertext records consumed by the calls before `call`, and the call's own
  * gate, ciphertext and device-step counts.  Any pointer may be NULL. */
 int gsv_plan_call_info(const gsv_plan* p, uint64_t call, uint64_t* gate_offset, uint64_t* n_gates, uint64_t* ct_offset, uint64_t* n_ciphertexts, uint64_t* n_steps);
+/* Wire file of a plan session, in 16-byte slots per instance: the global region (wires that cross calls; ids are recycled once
+ * their last reader has run) behind the largest program's own slots. */
+int gsv_plan_wire_file(const gsv_plan* p, uint64_t* n_global_wires, uint64_t* max_program_slots);
 /* Bytes of compiled program records (what a session uploads to HBM once per GPU) and the number of distinct programs. */
 int gsv_plan_image_bytes(const gsv_plan* p, uint64_t* bytes, uint64_t* n_programs);
 /* Plan files.  Building the verifier's plan takes minutes of host time and tens of GB of host memory (hundreds of

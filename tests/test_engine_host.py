@@ -227,7 +227,7 @@ def test_step_barrier_isa_check():
     from garbled_snark_verifier_amd import build
     asm = build.disassemble_kernels()
     res = build.check_step_barrier_isa(asm)
-    assert len(res) == 6 and sorted(res.values()) == [(1, 0)] * 3 + [(1, 1)] * 3
+    assert len(res) == 6 and sorted(res.values()) == [(2, 0)] * 3 + [(2, 2)] * 3
     # a label store scheduled behind the prefetch
     lines = asm.splitlines()
     k = next(i for i, l in enumerate(lines) if "s_waitcnt vmcnt(1) lgkmcnt(0)" in l and "s_barrier" in lines[i + 1])

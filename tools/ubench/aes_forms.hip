@@ -1,0 +1,222 @@
+// SURVEY.md §7 hard part (vi): "T-table in LDS vs bitsliced — choose by measurement".
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/aes_forms.hip -o tools/ubench/aes_forms
+//   tools/ubench/aes_forms
+//
+// Two complete, validated fixed-key AES-128 encryptions on gfx950, both run with every CU full, in blocks per second:
+//   T-table   the production form (kernels.hip / gate_math.hpp): Te0 / Te2 replicated once per LDS bank with a 256-byte entry
+//             stride, lookup address = one v_perm_b32, Te1 / Te3 by v_alignbit, columns summed with V_BITOP3 — two interleaved
+//             blocks per lane, 1024-thread workgroups (16 waves per CU), round keys through the scalar cache.
+//   bitsliced no tables, no LDS: every lane holds 32 blocks as 128 bit-planes in VGPRs; SubBytes is the Boyar-Peralta
+//             113-gate S-box circuit (32 AND + 81 XOR/XNOR) on 16 byte positions, ShiftRows is register renaming, MixColumns
+//             and AddRoundKey are XOR networks; the compiler is free to fuse pairs of gates into V_BITOP3.  The transposition
+//             into and out of bit-plane form is NOT timed (it would only add to this form's cost).
+// Both kernels chain ITER encryptions (output feeds the next input) and are checked against the host's byte-oriented AES.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../garbled_snark_verifier_amd/csrc/engine/host_crypto.hpp"
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+__constant__ uint32_t c_rk[44];
+__constant__ uint8_t c_rkb[176];
+
+// ---------------------------------------------------------------- T-table form (as in kernels.hip)
+#define LDS_U32 __attribute__((address_space(3))) uint32_t
+struct Banked {
+  uint32_t lane4;
+  template <int K, int BYTE>
+  __device__ __forceinline__ uint32_t lk(uint32_t s) const {
+    const uint32_t addr = __builtin_amdgcn_perm(s, lane4, 0x0c0c0000u | (uint32_t(4 + BYTE) << 8));
+    const uint32_t v = *reinterpret_cast<const LDS_U32*>(uintptr_t(addr + ((K & 2) ? 128u : 0u)));
+    return (K & 1) ? __builtin_amdgcn_alignbit(v, v, 24) : v;
+  }
+  __device__ __forceinline__ uint32_t rk(int i) const { return c_rk[i]; }
+};
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+template <class T>
+__device__ __forceinline__ uint32_t col(const T& t, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t k) {
+  return xor3(xor3(t.template lk<0, 0>(x0), t.template lk<1, 1>(x1), t.template lk<2, 2>(x2)), t.template lk<3, 3>(x3), k);
+}
+template <class T>
+__device__ __forceinline__ uint32_t last(const T& t, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t k) {
+  const uint32_t m0 = t.template lk<2, 0>(x0), m1 = t.template lk<0, 1>(x1), m2 = t.template lk<0, 2>(x2), m3 = t.template lk<2, 3>(x3);
+  return xor3(__builtin_amdgcn_perm(m1, m0, 0x0c0c0500u), __builtin_amdgcn_perm(m3, m2, 0x07020c0cu), k);
+}
+__global__ __launch_bounds__(1024) void ttable_kernel(const uint32_t* te, uint4* io, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  (void)smem;
+  for (uint32_t i = threadIdx.x; i < 65536 / 4; i += 1024) *reinterpret_cast<LDS_U32*>(uintptr_t(i * 4u)) = te[((i & 32u) ? 512u : 0u) + (i >> 6)];
+  __syncthreads();
+  const Banked T{(threadIdx.x & 31u) * 4u};
+  const size_t g = size_t(blockIdx.x) * 1024 + threadIdx.x;
+  uint4 x = io[2 * g], y = io[2 * g + 1];
+  uint32_t a0 = x.x, a1 = x.y, a2 = x.z, a3 = x.w, b0 = y.x, b1 = y.y, b2 = y.z, b3 = y.w;
+  for (int it = 0; it < iters; ++it) {
+    a0 ^= T.rk(0); a1 ^= T.rk(1); a2 ^= T.rk(2); a3 ^= T.rk(3);
+    b0 ^= T.rk(0); b1 ^= T.rk(1); b2 ^= T.rk(2); b3 ^= T.rk(3);
+#pragma unroll
+    for (int r = 1; r < 10; ++r) {
+      const uint32_t k0 = T.rk(4 * r), k1 = T.rk(4 * r + 1), k2 = T.rk(4 * r + 2), k3 = T.rk(4 * r + 3);
+      uint32_t t0 = col(T, a0, a1, a2, a3, k0), u0 = col(T, b0, b1, b2, b3, k0);
+      uint32_t t1 = col(T, a1, a2, a3, a0, k1), u1 = col(T, b1, b2, b3, b0, k1);
+      uint32_t t2 = col(T, a2, a3, a0, a1, k2), u2 = col(T, b2, b3, b0, b1, k2);
+      uint32_t t3 = col(T, a3, a0, a1, a2, k3), u3 = col(T, b3, b0, b1, b2, k3);
+      a0 = t0; a1 = t1; a2 = t2; a3 = t3; b0 = u0; b1 = u1; b2 = u2; b3 = u3;
+    }
+    uint32_t t0 = last(T, a0, a1, a2, a3, T.rk(40)), u0 = last(T, b0, b1, b2, b3, T.rk(40));
+    uint32_t t1 = last(T, a1, a2, a3, a0, T.rk(41)), u1 = last(T, b1, b2, b3, b0, T.rk(41));
+    uint32_t t2 = last(T, a2, a3, a0, a1, T.rk(42)), u2 = last(T, b2, b3, b0, b1, T.rk(42));
+    uint32_t t3 = last(T, a3, a0, a1, a2, T.rk(43)), u3 = last(T, b3, b0, b1, b2, T.rk(43));
+    a0 = t0; a1 = t1; a2 = t2; a3 = t3; b0 = u0; b1 = u1; b2 = u2; b3 = u3;
+  }
+  io[2 * g] = uint4{a0, a1, a2, a3};
+  io[2 * g + 1] = uint4{b0, b1, b2, b3};
+}
+
+// ---------------------------------------------------------------- bitsliced form
+// state bit-plane index: 8 * (state byte: 4 * column + row) + bit (0 = LSB); every uint32 holds that bit of 32 blocks
+__device__ __forceinline__ void sbox_bp(uint32_t* b) {  // Boyar-Peralta; U0 = MSB ... U7 = LSB, S0 = MSB ... S7 = LSB
+  const uint32_t U0 = b[7], U1 = b[6], U2 = b[5], U3 = b[4], U4 = b[3], U5 = b[2], U6 = b[1], U7 = b[0];
+  const uint32_t T1 = U0 ^ U3, T2 = U0 ^ U5, T3 = U0 ^ U6, T4 = U3 ^ U5, T5 = U4 ^ U6, T6 = T1 ^ T5, T7 = U1 ^ U2, T8 = U7 ^ T6, T9 = U7 ^ T7, T10 = T6 ^ T7, T11 = U1 ^ U5, T12 = U2 ^ U5,
+                 T13 = T3 ^ T4, T14 = T6 ^ T11, T15 = T5 ^ T11, T16 = T5 ^ T12, T17 = T9 ^ T16, T18 = U3 ^ U7, T19 = T7 ^ T18, T20 = T1 ^ T19, T21 = U6 ^ U7, T22 = T7 ^ T21, T23 = T2 ^ T22,
+                 T24 = T2 ^ T10, T25 = T20 ^ T17, T26 = T3 ^ T16, T27 = T1 ^ T12;
+  const uint32_t M1 = T13 & T6, M2 = T23 & T8, M3 = T14 ^ M1, M4 = T19 & U7, M5 = M4 ^ M1, M6 = T3 & T16, M7 = T22 & T9, M8 = T26 ^ M6, M9 = T20 & T17, M10 = M9 ^ M6, M11 = T1 & T15,
+                 M12 = T4 & T27, M13 = M12 ^ M11, M14 = T2 & T10, M15 = M14 ^ M11, M16 = M3 ^ M2, M17 = M5 ^ T24, M18 = M8 ^ M7, M19 = M10 ^ M15, M20 = M16 ^ M13, M21 = M17 ^ M15,
+                 M22 = M18 ^ M13, M23 = M19 ^ T25, M24 = M22 ^ M23, M25 = M22 & M20, M26 = M21 ^ M25, M27 = M20 ^ M21, M28 = M23 ^ M25, M29 = M28 & M27, M30 = M26 & M24, M31 = M20 & M23,
+                 M32 = M27 & M31, M33 = M27 ^ M25, M34 = M21 & M22, M35 = M24 & M34, M36 = M24 ^ M25, M37 = M21 ^ M29, M38 = M32 ^ M33, M39 = M23 ^ M30, M40 = M35 ^ M36, M41 = M38 ^ M40,
+                 M42 = M37 ^ M39, M43 = M37 ^ M38, M44 = M39 ^ M40, M45 = M42 ^ M41;
+  const uint32_t M46 = M44 & T6, M47 = M40 & T8, M48 = M39 & U7, M49 = M43 & T16, M50 = M38 & T9, M51 = M37 & T17, M52 = M42 & T15, M53 = M45 & T27, M54 = M41 & T10, M55 = M44 & T13,
+                 M56 = M40 & T23, M57 = M39 & T19, M58 = M43 & T3, M59 = M38 & T22, M60 = M37 & T20, M61 = M42 & T1, M62 = M45 & T4, M63 = M41 & T2;
+  const uint32_t L0 = M61 ^ M62, L1 = M50 ^ M56, L2 = M46 ^ M48, L3 = M47 ^ M55, L4 = M54 ^ M58, L5 = M49 ^ M61, L6 = M62 ^ L5, L7 = M46 ^ L3, L8 = M51 ^ M59, L9 = M52 ^ M53, L10 = M53 ^ L4,
+                 L11 = M60 ^ L2, L12 = M48 ^ M51, L13 = M50 ^ L0, L14 = M52 ^ M61, L15 = M55 ^ L1, L16 = M56 ^ L0, L17 = M57 ^ L1, L18 = M58 ^ L8, L19 = M63 ^ L4, L20 = L0 ^ L1, L21 = L1 ^ L7,
+                 L22 = L3 ^ L12, L23 = L18 ^ L2, L24 = L15 ^ L9, L25 = L6 ^ L10, L26 = L7 ^ L9, L27 = L8 ^ L10, L28 = L11 ^ L14, L29 = L11 ^ L17;
+  b[7] = L6 ^ L24; b[6] = ~(L16 ^ L26); b[5] = ~(L19 ^ L28); b[4] = L6 ^ L21; b[3] = L20 ^ L22; b[2] = L25 ^ L29; b[1] = ~(L13 ^ L27); b[0] = ~(L6 ^ L23);
+}
+__device__ __forceinline__ void add_round_key(uint32_t* s, int r) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[8 * i + k] ^= 0u - uint32_t((c_rkb[16 * r + i] >> k) & 1u);
+}
+__device__ __forceinline__ void round_bs(uint32_t* s, int r, bool mix) {
+  uint32_t t[128];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sbox_bp(s + 8 * i);
+  // ShiftRows: new byte (col c, row w) = old byte (col (c + w) % 4, row w)
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[8 * (4 * c + w) + k] = s[8 * (4 * ((c + w) & 3) + w) + k];
+  if (mix) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint32_t* a = t + 32 * c;
+      uint32_t o[32];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t *x = a + 8 * w, *y = a + 8 * ((w + 1) & 3), *z = a + 8 * ((w + 2) & 3), *u = a + 8 * ((w + 3) & 3);
+        uint32_t v[8];  // v = x ^ y ; out = xtime(v) ^ y ^ z ^ u
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = x[k] ^ y[k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          uint32_t xt = k ? v[k - 1] : v[7];
+          if (k == 1 || k == 3 || k == 4) xt ^= v[7];
+          o[8 * w + k] = xt ^ y[k] ^ z[k] ^ u[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 32; ++k) s[32 * c + k] = o[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 128; ++k) s[k] = t[k];
+  }
+  add_round_key(s, r);
+}
+__global__ __launch_bounds__(256) void bitsliced_kernel(uint32_t* io, int iters) {
+  const size_t g = size_t(blockIdx.x) * 256 + threadIdx.x;
+  uint32_t s[128];
+#pragma unroll
+  for (int k = 0; k < 128; ++k) s[k] = io[g * 128 + k];
+  for (int it = 0; it < iters; ++it) {
+    add_round_key(s, 0);
+#pragma unroll
+    for (int r = 1; r < 10; ++r) round_bs(s, r, true);
+    round_bs(s, 10, false);
+  }
+#pragma unroll
+  for (int k = 0; k < 128; ++k) io[g * 128 + k] = s[k];
+}
+
+int main() {
+  const gsv::AesTables& t = gsv::AesTables::fixed_key();
+  CHK(hipMemcpyToSymbol(HIP_SYMBOL(c_rk), t.rk, sizeof t.rk));
+  CHK(hipMemcpyToSymbol(HIP_SYMBOL(c_rkb), t.rk_bytes, sizeof t.rk_bytes));
+  hipDeviceProp_t prop;
+  CHK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount, iters = 64;
+  auto host_chain = [&](uint8_t* blk, int n) { for (int i = 0; i < n; ++i) { uint8_t o[16]; gsv::CbcMacHost::encrypt_portable(t, blk, o); std::memcpy(blk, o, 16); } };
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+  // ---- T-table
+  {
+    void* te; CHK(hipMalloc(&te, sizeof t.te)); CHK(hipMemcpy(te, t.te, sizeof t.te, hipMemcpyHostToDevice));
+    const int wgs = cus * 8;
+    const size_t n_blocks = size_t(wgs) * 1024 * 2;
+    std::vector<uint8_t> h(n_blocks * 16);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = uint8_t(i * 131 + (i >> 9));
+    uint4* d; CHK(hipMalloc(&d, h.size())); CHK(hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice));
+    CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(ttable_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    hipLaunchKernelGGL(ttable_kernel, dim3(wgs), dim3(1024), 65536, 0, static_cast<const uint32_t*>(te), d, iters);  // warm-up + validation
+    std::vector<uint8_t> out(h.size());
+    CHK(hipMemcpy(out.data(), d, h.size(), hipMemcpyDeviceToHost));
+    bool ok = true;
+    for (size_t b : {size_t(0), size_t(1), size_t(12345), n_blocks - 1}) { uint8_t ref[16]; std::memcpy(ref, &h[b * 16], 16); host_chain(ref, iters); ok = ok && std::memcmp(ref, &out[b * 16], 16) == 0; }
+    CHK(hipEventRecord(e0));
+    for (int k = 0; k < 5; ++k) hipLaunchKernelGGL(ttable_kernel, dim3(wgs), dim3(1024), 65536, 0, static_cast<const uint32_t*>(te), d, iters);
+    CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+    float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+    const double rate = 5.0 * double(n_blocks) * iters / (ms * 1e-3);
+    std::printf("T-table  (LDS, 2 blocks per lane, 16 waves per CU): %.3e blocks/s on %d CUs = %.3e per CU  [%s]\n", rate, cus, rate / cus, ok ? "matches host AES" : "MISMATCH");
+  }
+  // ---- bitsliced
+  {
+    const int wgs = cus * 8;
+    const size_t lanes = size_t(wgs) * 256, n_blocks = lanes * 32;
+    std::vector<uint8_t> blocks(n_blocks * 16);
+    for (size_t i = 0; i < blocks.size(); ++i) blocks[i] = uint8_t(i * 29 + (i >> 11));
+    std::vector<uint32_t> bs(lanes * 128, 0);
+    for (size_t l = 0; l < lanes; ++l)
+      for (int j = 0; j < 32; ++j)
+        for (int i = 0; i < 16; ++i)
+          for (int k = 0; k < 8; ++k) bs[l * 128 + 8 * i + k] |= uint32_t((blocks[(l * 32 + j) * 16 + i] >> k) & 1u) << j;
+    uint32_t* d; CHK(hipMalloc(&d, bs.size() * 4)); CHK(hipMemcpy(d, bs.data(), bs.size() * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(bitsliced_kernel, dim3(wgs), dim3(256), 0, 0, d, iters);
+    std::vector<uint32_t> out(bs.size());
+    CHK(hipMemcpy(out.data(), d, bs.size() * 4, hipMemcpyDeviceToHost));
+    bool ok = true;
+    for (size_t b : {size_t(0), size_t(33), size_t(777777), n_blocks - 1}) {
+      uint8_t ref[16], got[16] = {0};
+      std::memcpy(ref, &blocks[b * 16], 16); host_chain(ref, iters);
+      const size_t l = b / 32; const int j = int(b % 32);
+      for (int i = 0; i < 16; ++i) for (int k = 0; k < 8; ++k) got[i] |= uint8_t(((out[l * 128 + 8 * i + k] >> j) & 1u) << k);
+      ok = ok && std::memcmp(ref, got, 16) == 0;
+    }
+    CHK(hipEventRecord(e0));
+    for (int k = 0; k < 5; ++k) hipLaunchKernelGGL(bitsliced_kernel, dim3(wgs), dim3(256), 0, 0, d, iters);
+    CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+    float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+    const double rate = 5.0 * double(n_blocks) * iters / (ms * 1e-3);
+    hipFuncAttributes fa; CHK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(bitsliced_kernel)));
+    std::printf("bitsliced (no LDS, 32 blocks per lane in %d VGPRs):        %.3e blocks/s on %d CUs = %.3e per CU  [%s]\n", fa.numRegs, rate, cus, rate / cus, ok ? "matches host AES" : "MISMATCH");
+  }
+  return 0;
+}
