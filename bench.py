@@ -206,6 +206,8 @@ class VerifierWork:
 def _plan_cache_path(args, circuit, units):
     if args.no_plan_cache:
         return None
+    if os.environ.get("GSV_PLAN_FILE"):  # experiments: one plan file for several engine builds (the key below includes the library)
+        return os.environ["GSV_PLAN_FILE"]
     import garbled_snark_verifier_amd.build as b
     h = hashlib.sha256()
     with open(b.build(), "rb") as f:
@@ -459,7 +461,7 @@ def run_verifier(args):
                                    "full verifier pass per instance" % ("groth16_verify_compressed" if compressed else "groth16_verify", gates, B, len(slices), n_calls, len(slices)),
                        "instances_per_gpu": B, "instances_per_workgroup": ni, "gates_per_instance": gates, "nonfree_fraction": f_nf, "plan_calls": n_calls, "plan_programs": n_programs,
                        "slices_per_pass": len(slices), "gates_per_step_per_instance": [s[2] for s in slices], "steps_requested": args.steps,
-                       "passes_timed": r["gates_per_instance"] / gates, "plan": plan_info, "plan_image_gb": image_bytes / 1e9, "seconds_to_first_launch": t_first_launch,
+                       "passes_timed": r["gates_per_instance"] / gates, "step_device_ms": [round(x, 1) for x in r["step_ms"]], "plan": plan_info, "plan_image_gb": image_bytes / 1e9, "seconds_to_first_launch": t_first_launch,
                        "host_peak_rss_gb": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1e6},
             "commit_records_gathered": None if r["commit_table"] is None else list(r["commit_table"].shape),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -479,6 +481,7 @@ def run_verifier(args):
                 log("bench.py: plan not saved: %r" % (e,))
     dist.barrier()
     dist.close()
+    plan.close()
 
 
 def run_synthetic(args):
@@ -582,8 +585,13 @@ def main():
         print("bench.py: --gpus %d but WORLD_SIZE=%s: launch with --nproc-per-node == --gpus" % (args.gpus, world_env), file=sys.stderr)
         sys.exit(2)
     if args.workload == "synthetic":
-        return run_synthetic(args)
-    return run_verifier(args)
+        run_synthetic(args)
+    else:
+        run_verifier(args)
+    # everything is closed and the result line is out: leave without the interpreter's teardown (HIP / RCCL destructors at exit are
+    # not ours to debug, and a crash there would turn a finished run into a failed one)
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":

@@ -11,14 +11,17 @@ reference's entry points for the hot path
 
 There is no CPU fallback: every garble/evaluate call runs on a HIP device or raises ``GsvError``.
 """
+import atexit
 import ctypes as C
 import os
+import sys
+import weakref
 
 import numpy as np
 
 from . import build as _build
 
-__all__ = ["GsvError", "lib", "Program", "Engine", "Session", "CircuitBuilder", "StreamingResult", "labels_from_seed", "GATE_NAMES", "cbcmac",
+__all__ = ["GsvError", "lib", "Program", "Engine", "Session", "CircuitBuilder", "StreamingResult", "labels_from_seed", "GATE_NAMES", "cbcmac", "cbcmac_many",
            "write_gc_file", "read_gc_file", "gc_file_name"]
 
 GATE_NAMES = ["And", "Nand", "Nimp", "Imp", "Ncimp", "Cimp", "Nor", "Or", "Xor", "Xnor", "Not"]
@@ -28,6 +31,21 @@ _lib = None
 
 class GsvError(RuntimeError):
     pass
+
+
+# Device objects are released in dependency order BEFORE the interpreter tears down: a session collected during interpreter
+# shutdown would call into a HIP runtime that has already destroyed its own state (observed: std::bad_variant_access inside hipFree).
+_live = {"session": weakref.WeakSet(), "plan": weakref.WeakSet(), "program": weakref.WeakSet(), "engine": weakref.WeakSet()}
+
+
+@atexit.register
+def _close_everything():
+    for kind in ("session", "plan", "program", "engine"):
+        for obj in list(_live[kind]):
+            try:
+                obj.close()
+            except Exception:
+                pass
 
 
 class _ProgramInfo(C.Structure):
@@ -46,7 +64,7 @@ EXPORTS = [
     "gsv_program_get_info", "gsv_engine_create", "gsv_engine_destroy", "gsv_labels_from_seed", "gsv_session_create", "gsv_session_destroy",
     "gsv_session_set_garble_inputs", "gsv_session_garble", "gsv_session_set_evaluate_inputs", "gsv_session_upload_ciphertexts",
     "gsv_session_evaluate", "gsv_session_set_hasher", "gsv_session_sync", "gsv_session_last_kernel_ms", "gsv_session_read_outputs", "gsv_session_read_ciphertexts",
-    "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_commit_labels",
+    "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_cbcmac_update_many", "gsv_commit_labels",
     "gsv_plan_from_circuit", "gsv_plan_io", "gsv_plan_recorder_create", "gsv_plan_recorder_destroy", "gsv_plan_recorder_allocate_wire",
     "gsv_plan_recorder_declare_input", "gsv_plan_recorder_push_gates", "gsv_plan_recorder_call", "gsv_plan_recorder_finish", "gsv_plan_create", "gsv_plan_destroy", "gsv_plan_add_call", "gsv_plan_finish", "gsv_plan_counts", "gsv_session_create_plan", "gsv_session_create_plan_ex",
     "gsv_session_garble_streaming", "gsv_session_garble_streaming_calls", "gsv_plan_call_info", "gsv_plan_image_bytes", "gsv_plan_wire_file", "gsv_plan_save", "gsv_plan_load", "gsv_session_evaluate_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
@@ -94,6 +112,7 @@ def lib():
         L.gsv_session_ciphertext_hash.argtypes = [vp, C.c_size_t, u8p]
         L.gsv_cbcmac_update.argtypes = [u8p, u8p, C.c_uint64]
         L.gsv_commit_labels.argtypes = [u8p, C.c_uint64, u8p]
+        L.gsv_cbcmac_update_many.argtypes = [u8p, C.POINTER(C.c_void_p), C.c_size_t, C.c_uint64]
         L.gsv_plan_from_circuit.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
         L.gsv_plan_io.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.gsv_plan_recorder_create.argtypes = [C.POINTER(vp)]
@@ -159,11 +178,23 @@ def cbcmac(cts, state=None):
     return st.tobytes()
 
 
+def cbcmac_many(streams, states=None):
+    """AESAccumulatingHash of several equally long streams at once (gsv_cbcmac_update_many: four chains side by side per step)."""
+    arrs = [_u8(a).reshape(-1) for a in streams]
+    n = arrs[0].size // 16
+    assert all(a.size == n * 16 for a in arrs)
+    st = np.zeros((len(arrs), 16), np.uint8) if states is None else _u8(states, (len(arrs), 16)).copy()
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    _chk(lib().gsv_cbcmac_update_many(_p(st), ptrs, len(arrs), n))
+    return [bytes(st[i]) for i in range(len(arrs))]
+
+
 class Program:
     """A recorded circuit compiled to device steps (gsv_recorder + gsv_program)."""
 
     def __init__(self, handle):
         self.h = handle
+        _live["program"].add(self)
         info = _ProgramInfo()
         _chk(lib().gsv_program_get_info(self.h, C.byref(info)))
         self.info = {n: (list(getattr(info, n)) if n == "gate_count" else int(getattr(info, n))) for n, _ in _ProgramInfo._fields_}
@@ -233,10 +264,12 @@ class Program:
             _chk(L.gsv_program_compile(r, None, None, 0, C.byref(h)))
         return cls(h)
 
-    def __del__(self):
-        if getattr(self, "h", None) is not None and _lib is not None:
+    def close(self):
+        if getattr(self, "h", None) is not None and _lib is not None and not sys.is_finalizing():
             _lib.gsv_program_destroy(self.h)
-            self.h = None
+        self.h = None
+
+    __del__ = close
 
 
 class Engine:
@@ -246,11 +279,14 @@ class Engine:
         self.h = C.c_void_p()
         _chk(lib().gsv_engine_create(device, C.byref(self.h)))
         self.device = device
+        _live["engine"].add(self)
 
-    def __del__(self):
-        if getattr(self, "h", None) is not None and _lib is not None and self.h:
+    def close(self):
+        if getattr(self, "h", None) is not None and _lib is not None and self.h and not sys.is_finalizing():
             _lib.gsv_engine_destroy(self.h)
-            self.h = None
+        self.h = None
+
+    __del__ = close
 
 
 class Plan:
@@ -259,6 +295,7 @@ class Plan:
     def __init__(self):
         self.h = C.c_void_p()
         _chk(lib().gsv_plan_create(C.byref(self.h)))
+        _live["plan"].add(self)
         self.programs = []  # keep the programs alive
         self.n_inputs = self.n_outputs = 0
 
@@ -270,6 +307,7 @@ class Plan:
         self = cls.__new__(cls)
         self.h = C.c_void_p()
         self.programs = []
+        _live["plan"].add(self)
         old = os.environ.get("GSV_PLAN_HALF_WINDOW")
         if half_window:
             os.environ["GSV_PLAN_HALF_WINDOW"] = "1"
@@ -308,6 +346,7 @@ class Plan:
         self = cls.__new__(cls)
         self.h = C.c_void_p()
         self.programs = []
+        _live["plan"].add(self)
         self.engine = engine  # a device-resident plan must not outlive its engine
         _chk(lib().gsv_plan_load(os.fsencode(path), engine.h if engine is not None else None, C.byref(self.h)))
         self._read_info()
@@ -351,9 +390,9 @@ class Plan:
         self.info = {"n_inputs": n_inputs, "n_outputs": int(o.size), "n_gates": g.value, "n_ciphertexts": c.value, "n_calls": k.value, "n_steps": 0}
 
     def close(self):
-        if self.h:
-            lib().gsv_plan_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None and not sys.is_finalizing():
+            _lib.gsv_plan_destroy(self.h)
+        self.h = None
 
     def __del__(self):
         try:
@@ -403,6 +442,7 @@ class PlanRecorder:
     def finish(self, output_wires):
         plan = Plan.__new__(Plan)
         plan.h = C.c_void_p()
+        _live["plan"].add(plan)
         plan.programs = list(self.programs)
         o = (C.c_uint64 * max(1, len(output_wires)))(*output_wires)
         _chk(lib().gsv_plan_recorder_finish(self.h, o, len(output_wires), C.byref(plan.h)))
@@ -438,6 +478,7 @@ class Session:
         else:
             _chk(lib().gsv_session_create(engine.h, program.h, n_instances, replays, self.ct_cap, C.byref(self.h)))
         self.n_in, self.n_out = program.info["n_inputs"], program.info["n_outputs"]
+        _live["session"].add(self)
 
     def set_garble_inputs(self, delta, const_label0, input_label0):
         d = _u8(delta, (self.n, 16))
@@ -535,9 +576,9 @@ class Session:
         return h.tobytes()
 
     def close(self):
-        if getattr(self, "h", None) is not None and _lib is not None and self.h:
+        if getattr(self, "h", None) is not None and _lib is not None and self.h and not sys.is_finalizing():
             _lib.gsv_session_destroy(self.h)
-            self.h = None
+        self.h = None
 
     __del__ = close
 

@@ -1070,18 +1070,28 @@ struct gsv_drain {
     void release(hipStream_t st) { { std::lock_guard<std::mutex> lk(mu); idle.push_back(st); } cv.notify_one(); }
   } copy_gate;
   std::vector<hipStream_t> copy_streams;
-  struct Worker { void* pinned[2] = {nullptr, nullptr}; };  // two pinned chunk buffers per worker: copy chunk j+1 while chunk j is hashed
+  static constexpr int GROUP = 4;  // instances whose MAC chains one worker advances side by side (CbcMacHost::update_interleaved)
+  struct Worker {
+    void* pinned[2][GROUP] = {};  // two sets of pinned chunk buffers: copy set j+1 while set j is hashed
+    hipEvent_t done = nullptr;    // blocking-sync event: a worker waiting for its copies sleeps instead of spinning on a core
+  };
   std::vector<Worker> workers;
   uint64_t chunk = 0;  // records per chunk buffer
   std::vector<CbcMacHost> macs;
   ~gsv_drain() {
-    for (Worker& w : workers) for (void*& q : w.pinned) if (q) (void)hipHostFree(q);
+    for (Worker& w : workers) {
+      for (auto& set : w.pinned) for (void*& q : set) if (q) (void)hipHostFree(q);
+      if (w.done) (void)hipEventDestroy(w.done);
+    }
     for (hipStream_t st : copy_streams) (void)hipStreamDestroy(st);
   }
 };
 static void destroy_drain(gsv_drain* d) { delete d; }
 static int ensure_drain(gsv_session* s, size_t T, uint64_t seg_records) {
-  const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(seg_records, 1), 256ull << 10);  // records (4 MiB: page-locking large buffers costs more than the copies)
+  // records per chunk: 16 MiB by default — measured on the MI355X box (tools/d2h_bw.py) a D2H copy stream moves 39-48 GB/s in 4 MiB
+  // pieces and 54-57 GB/s from 16 MiB up; the buffers are page-locked once per session, not per call as in round 1
+  const uint64_t chunk_mb = getenv("GSV_DRAIN_CHUNK_MB") ? std::max(1, atoi(getenv("GSV_DRAIN_CHUNK_MB"))) : 16;
+  const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(seg_records, 1), (chunk_mb << 20) / 16);
   if (s->drain && s->drain->workers.size() >= T && s->drain->chunk == chunk) return GSV_OK;
   std::vector<CbcMacHost> keep;
   if (s->drain) keep = s->drain->macs;
@@ -1098,7 +1108,10 @@ static int ensure_drain(gsv_session* s, size_t T, uint64_t seg_records) {
     if (ok) { d.copy_streams.push_back(st); d.copy_gate.idle.push_back(st); }
   }
   d.workers.resize(T);
-  for (gsv_drain::Worker& w : d.workers) for (void*& q : w.pinned) ok = ok && hipHostMalloc(&q, chunk * 16, hipHostMallocDefault) == hipSuccess;
+  for (gsv_drain::Worker& w : d.workers) {
+    for (auto& set : w.pinned) for (void*& q : set) ok = ok && hipHostMalloc(&q, chunk * 16, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&w.done, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
+  }
   if (!ok) { destroy_drain(s->drain); s->drain = nullptr; return fail(GSV_ERR_DEVICE, "cannot allocate the drain buffers"); }
   return GSV_OK;
 }
@@ -1129,8 +1142,12 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   const uint64_t n_ct = s->plan ? s->plan_max_block : g.n_ct, seg = s->plan ? 1 : s->ct_cap;
   const uint64_t first = s->plan ? c0 : 0, total = s->plan ? c1 : s->replays;
   const size_t n_inst = s->n_inst;
-  size_t T = n_threads > 0 ? size_t(n_threads) : std::max<size_t>(1, std::min<size_t>(n_inst, std::thread::hardware_concurrency()));
-  T = std::min(T, n_inst);
+  constexpr size_t GROUP = size_t(gsv_drain::GROUP);
+  const size_t n_groups = (n_inst + GROUP - 1) / GROUP;
+  // a worker MACs GROUP streams side by side at ~3e8 blocks/s (AES-NI): a dozen of them keep up with the PCIe link, 32 leave
+  // room for slow cores without page-locking more than 4 GB of chunk buffers
+  size_t T = n_threads > 0 ? size_t(n_threads) : std::max<size_t>(1, std::min<size_t>(std::min<size_t>(n_groups, 32), std::thread::hardware_concurrency()));
+  T = std::min(T, n_groups);
   HIPCHK(hipSetDevice(s->e->device));
   const uint64_t seg_records = seg * n_ct;  // per instance
   if (!s->ct_gate && seg_records) DEVALLOC(&s->ct_gate, n_inst * seg_records * 16, "the gate-order ciphertext buffer");
@@ -1154,13 +1171,16 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
       pool.emplace_back([&, t, n]() {
         if (hipSetDevice(s->e->device) != hipSuccess) { err = 1; return; }
         gsv_drain::Worker& w = dr.workers[t];
-        for (size_t i = t; i < n_inst && !err && n; i += T) {
-          const uint8_t* src = static_cast<const uint8_t*>(s->ct_gate) + i * seg_records * 16;
-          // a copy holds a slot of the gate from issue to completion
+        for (size_t grp = t; grp < n_groups && !err && n; grp += T) {
+          const size_t i0 = grp * GROUP, ng = std::min(GROUP, n_inst - i0);  // instances i0 .. i0+ng-1 advance together
+          // the copies of one chunk set share a stream of the pool (a set holds a slot of the gate from issue to completion)
           auto copy = [&](uint64_t off, int b) {
             hipStream_t st = dr.copy_gate.acquire();
-            const bool ok = hipMemcpyAsync(w.pinned[b], src + off * 16, std::min(chunk, n - off) * 16, hipMemcpyDeviceToHost, st) == hipSuccess &&
-                            hipStreamSynchronize(st) == hipSuccess;
+            bool ok = true;
+            for (size_t g = 0; g < ng && ok; ++g)
+              ok = hipMemcpyAsync(w.pinned[b][g], static_cast<const uint8_t*>(s->ct_gate) + ((i0 + g) * seg_records + off) * 16, std::min(chunk, n - off) * 16,
+                                  hipMemcpyDeviceToHost, st) == hipSuccess;
+            ok = ok && hipEventRecord(w.done, st) == hipSuccess && hipEventSynchronize(w.done) == hipSuccess;
             dr.copy_gate.release(st);
             return ok;
           };
@@ -1168,8 +1188,18 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
           if (!copy(0, 0)) { err = 1; break; }
           for (uint64_t off = 0; off < n; off += chunk, b ^= 1) {
             const uint64_t m = std::min(chunk, n - off);
-            macs[i].update(static_cast<const uint8_t*>(w.pinned[b]), m);
-            if (dir && std::fwrite(w.pinned[b], 16, m, files[i]) != m) { err = 2; break; }
+            if (ng == GROUP) {
+              CbcMacHost* const mp[GROUP] = {&macs[i0], &macs[i0 + 1], &macs[i0 + 2], &macs[i0 + 3]};
+              const uint8_t* const cp[GROUP] = {static_cast<const uint8_t*>(w.pinned[b][0]), static_cast<const uint8_t*>(w.pinned[b][1]),
+                                                static_cast<const uint8_t*>(w.pinned[b][2]), static_cast<const uint8_t*>(w.pinned[b][3])};
+              CbcMacHost::update_interleaved<int(GROUP)>(mp, cp, m);
+            } else {
+              for (size_t g = 0; g < ng; ++g) macs[i0 + g].update(static_cast<const uint8_t*>(w.pinned[b][g]), m);
+            }
+            if (dir)
+              for (size_t g = 0; g < ng; ++g)
+                if (std::fwrite(w.pinned[b][g], 16, m, files[i0 + g]) != m) { err = 2; break; }
+            if (err) break;
             if (off + chunk < n && !copy(off + chunk, b ^ 1)) { err = 1; break; }
           }
         }
@@ -1429,6 +1459,27 @@ int gsv_cbcmac_update(uint8_t state[16], const uint8_t* cts, uint64_t n_records)
   mac.update(first, 1);
   mac.update(cts + 16, n_records - 1);
   mac.digest(state);
+  return GSV_OK;
+}
+int gsv_cbcmac_update_many(uint8_t* states, const uint8_t* const* cts, size_t n_chains, uint64_t n_records) {
+  if ((!states || !cts) && n_chains) return fail(GSV_ERR_INVALID, "null argument");
+  for (size_t i = 0; i < n_chains; ++i) if (!cts[i] && n_records) return fail(GSV_ERR_INVALID, "null stream");
+  // CbcMacHost starts from zero: chain by XOR-ing the state into a copy of the first block (h ^ ct), as gsv_cbcmac_update does
+  if (n_records == 0) return GSV_OK;
+  std::vector<CbcMacHost> macs(n_chains);
+  for (size_t i = 0; i < n_chains; ++i) {
+    uint8_t first[16];
+    for (int k = 0; k < 16; ++k) first[k] = cts[i][k] ^ states[16 * i + k];
+    macs[i].update(first, 1);
+  }
+  size_t i = 0;
+  for (; i + 4 <= n_chains; i += 4) {
+    CbcMacHost* const mp[4] = {&macs[i], &macs[i + 1], &macs[i + 2], &macs[i + 3]};
+    const uint8_t* const cp[4] = {cts[i] + 16, cts[i + 1] + 16, cts[i + 2] + 16, cts[i + 3] + 16};
+    CbcMacHost::update_interleaved<4>(mp, cp, n_records - 1);
+  }
+  for (; i < n_chains; ++i) macs[i].update(cts[i] + 16, n_records - 1);
+  for (size_t k = 0; k < n_chains; ++k) macs[k].digest(states + 16 * k);
   return GSV_OK;
 }
 int gsv_commit_labels(const uint8_t* labels, uint64_t n, uint8_t* out) {

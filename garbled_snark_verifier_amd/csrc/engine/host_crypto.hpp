@@ -122,6 +122,34 @@ class CbcMacHost {
     for (uint64_t i = 0; i < n; ++i) update(base + size_t(pos[i]) * 16, 1);
 #endif
   }
+  // Several independent chains advanced together: one chain is bound by the latency of 10 dependent AESENC (~40 cycles per
+  // block) while the AES unit accepts a new instruction every cycle, so a host thread that MACs the streams of G instances side
+  // by side gets close to G times the blocks per second (the commitment stage has fewer cores than instances to work with).
+  // All chains advance by the same n records.
+  template <int G>
+  static void update_interleaved(CbcMacHost* const (&mac)[G], const uint8_t* const (&cts)[G], uint64_t n) {
+#if GSV_HOST_AESNI
+    const AesTables& t = AesTables::fixed_key();
+    __m128i rk[11], h[G];
+    for (int r = 0; r < 11; ++r) rk[r] = _mm_loadu_si128(reinterpret_cast<const __m128i*>(t.rk_bytes + 16 * r));
+    for (int g = 0; g < G; ++g) h[g] = _mm_loadu_si128(reinterpret_cast<const __m128i*>(mac[g]->h_));
+    for (uint64_t i = 0; i < n; ++i) {
+      __m128i s[G];
+#pragma GCC unroll 8
+      for (int g = 0; g < G; ++g) s[g] = _mm_xor_si128(_mm_xor_si128(h[g], _mm_loadu_si128(reinterpret_cast<const __m128i*>(cts[g] + 16 * i))), rk[0]);
+#pragma GCC unroll 16
+      for (int r = 1; r < 10; ++r) {
+#pragma GCC unroll 8
+        for (int g = 0; g < G; ++g) s[g] = _mm_aesenc_si128(s[g], rk[r]);
+      }
+#pragma GCC unroll 8
+      for (int g = 0; g < G; ++g) h[g] = _mm_aesenclast_si128(s[g], rk[10]);
+    }
+    for (int g = 0; g < G; ++g) _mm_storeu_si128(reinterpret_cast<__m128i*>(mac[g]->h_), h[g]);
+#else
+    for (int g = 0; g < G; ++g) mac[g]->update(cts[g], n);
+#endif
+  }
   void digest(uint8_t out[16]) const { std::memcpy(out, h_, 16); }
 
   static void encrypt_portable(const AesTables& t, const uint8_t in[16], uint8_t out[16]) {

@@ -190,7 +190,8 @@ int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base);
  * cut_and_choose/ciphertext_repository.rs:94-127).  The launch is cut into segments of one device ring
  * (ct_capacity_replays replays); each finished segment is brought into gate order on the device (second buffer of the
  * ring's size, allocated on first use), copied out while the next segment is garbled, folded into every instance's CBC-MAC
- * by n_threads host threads (0 = one per instance up to the core count; the chain is serial per instance) and, if dir is
+ * by n_threads host threads (0 = up to 32; every thread advances the chains of four instances side by side, one chain alone
+ * being bound by the latency of its dependent AES rounds) and, if dir is
  * not NULL, appended to <dir>/gc_<first_index + instance>.bin.  hashes receives n_instances x 16 bytes.  Output labels
  * are read with gsv_session_read_outputs as after gsv_session_garble.  With hashes == NULL and dir == NULL the stream is
  * discarded (garbling only: output labels, device-rate measurements). */
@@ -239,6 +240,10 @@ int gsv_session_read_ciphertexts(gsv_session* s, size_t instance, uint64_t first
 int gsv_session_ciphertext_hash(gsv_session* s, size_t instance, uint8_t hash[16]);
 /* Stand-alone host CBC-MAC (AESAccumulatingHash) over a byte stream, chaining from `state`. */
 int gsv_cbcmac_update(uint8_t state[16], const uint8_t* cts, uint64_t n_records);
+/* The same for n_chains independent streams of n_records records each (states: n_chains x 16 bytes): chains are advanced four at
+ * a time side by side — one chain is bound by the latency of its dependent AES rounds, four fill the AES unit — which is how the
+ * engine's own drain hashes the instances' streams. */
+int gsv_cbcmac_update_many(uint8_t* states, const uint8_t* const* cts, size_t n_chains, uint64_t n_records);
 /* AesLabelCommitHasher: AES_K(label) for n labels (cut_and_choose/mod.rs:41-48). */
 int gsv_commit_labels(const uint8_t* labels, uint64_t n, uint8_t* out);
 

@@ -3,7 +3,7 @@
 # AFTER a bench.py run of the same call has left the plan file in /dev/shm (the profiled processes then load the plan in seconds
 # instead of building it with 16 compile threads under the profiler).  Outputs under gpurun_out/prof_<tag>/:
 #   1. rocprofv3 --kernel-trace --stats over one full pass (10 slices);
-#   2. rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, over the first two slices.
+#   2. rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, each over one full pass (10 slices).
 TAG=${1:-r02_verifier}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
@@ -12,8 +12,8 @@ cd /tmp && export TMPDIR=/tmp
 FLAGS="--no-check --no-cpu-baseline --no-e2e"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 10 --warmup 0 $FLAGS > $OUT/bench_stats.log 2> $OUT/bench_stats.err
 tail -1 $OUT/bench_stats.log > $OUT/bench_profiled.json
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 2 --warmup 0 $FLAGS > $OUT/bench_fetch.log 2> $OUT/bench_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 2 --warmup 0 $FLAGS > $OUT/bench_write.log 2> $OUT/bench_write.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 10 --warmup 0 $FLAGS > $OUT/bench_fetch.log 2> $OUT/bench_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 10 --warmup 0 $FLAGS > $OUT/bench_write.log 2> $OUT/bench_write.err
 cd $R
 python3 - <<PY
 import csv, glob, collections, json, os
