@@ -48,12 +48,16 @@ def disassemble_kernels(obj=None):
 
 
 def check_step_barrier_isa(asm=None):
-    """Every barrier of run_program_kernel must be a FULL one: the step barrier is a hand-written
-    `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier` (kernels.hip) — all label stores of the step, LDS and HBM, have completed before any
-    wave reads them in the next step.  (Round 1 used counted waits, vmcnt(1|2), that relied on the compiler's instruction order;
-    they are gone, and this check keeps them gone.)  On the ISA of every instantiation: the step loop, unrolled by two, shows at
-    least two such pairs, and no `s_barrier` is directly preceded by a partial `s_waitcnt vmcnt(N > 0)`.
-    Returns {kernel symbol: number of full step barriers}; raises RuntimeError on a violation."""
+    """The step barrier of run_program_kernel is a hand-counted `s_waitcnt vmcnt(N) lgkmcnt(0); s_barrier` (kernels.hip): it
+    waits for the step's label stores but not for the record prefetch issued just before it (N = 1) nor, when the wave's last
+    vector-memory store was a ciphertext, for that store (N = 2).  That is only right while the compiler keeps the prefetch load
+    the YOUNGEST vector-memory operation in front of the barrier.  Checked on the ISA of every instantiation, so that a compiler
+    bump cannot silently break it:
+      * each kernel holds exactly two `s_waitcnt vmcnt(1) lgkmcnt(0)` + `s_barrier` pairs (the step loop is unrolled by two:
+        ping-pong record registers), garbling kernels also exactly two vmcnt(2) pairs, each immediately followed by its s_barrier;
+      * walking back from the vmcnt(1) pair, the first vector-memory instruction is the 16-byte record prefetch
+        (global_load_dwordx4) and no label store (global_store / ds_write) sits between it and the barrier.
+    Returns {kernel symbol: (n_vmcnt1, n_vmcnt2)}; raises RuntimeError on a violation."""
     import re
     asm = asm if asm is not None else disassemble_kernels()
     funcs, cur = {}, None
@@ -69,18 +73,27 @@ def check_step_barrier_isa(asm=None):
     if len(kernels) != 6:
         raise RuntimeError("expected 6 instantiations of run_program_kernel, found %d" % len(kernels))
     for name, ins in kernels.items():
-        full = 0
+        garble = "ILb0E" in name  # run_program_kernel<false, ...>
+        n = {1: 0, 2: 0}
         for i, t in enumerate(ins):
-            if t != "s_barrier" or i == 0:
+            m = re.match(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)$", t)
+            if not m or int(m.group(1)) not in (1, 2):
                 continue
-            m = re.match(r"s_waitcnt vmcnt\((\d+)\)", ins[i - 1])
-            if m and int(m.group(1)) != 0:
-                raise RuntimeError("%s: a barrier behind a partial wait `%s`" % (name, ins[i - 1]))
-            if ins[i - 1] == "s_waitcnt vmcnt(0) lgkmcnt(0)":
-                full += 1
-        if full < 2:
-            raise RuntimeError("%s: found %d full step barriers, expected at least 2" % (name, full))
-        out[name] = full
+            k = int(m.group(1))
+            if i + 1 >= len(ins) or ins[i + 1] != "s_barrier":
+                continue  # an ordinary compiler-generated wait
+            n[k] += 1
+            if k == 1:
+                j = i - 1
+                while j >= 0 and not re.match(r"(global_|buffer_|scratch_|flat_)", ins[j]):
+                    if re.match(r"ds_write|ds_store", ins[j]):
+                        raise RuntimeError("%s: an LDS label store sits between the record prefetch and the step barrier" % name)
+                    j -= 1
+                if j < 0 or not ins[j].startswith("global_load_dwordx4"):
+                    raise RuntimeError("%s: the youngest vector-memory operation before the step barrier is `%s`, not the record prefetch" % (name, ins[j] if j >= 0 else "none"))
+        if n[1] != 2 or n[2] != (2 if garble else 0):
+            raise RuntimeError("%s: found %d / %d counted step barriers (vmcnt 1 / 2), expected 2 / %d" % (name, n[1], n[2], 2 if garble else 0))
+        out[name] = (n[1], n[2])
     return out
 
 

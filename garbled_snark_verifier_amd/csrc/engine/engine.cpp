@@ -718,6 +718,20 @@ int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out) {
   if (bad || std::memcmp(h.magic, PLAN_MAGIC, 8) != 0 || h.rec_sizes != plan_rec_sizes() || h.lds_window_slots != LDS_WINDOW_SLOTS)
     return fail(GSV_ERR_INVALID, std::string(path) + ": not a plan file of this engine build");
   if (e) HIPCHK(hipSetDevice(e->device));
+  const size_t bounce_bytes = 64u << 20;
+  struct Bounce {
+    void* buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr};
+    ~Bounce() { for (void* q : buf) if (q) (void)hipHostFree(q); for (hipEvent_t x : ev) if (x) (void)hipEventDestroy(x); }
+  } bounce_owner;
+  void** bounce = bounce_owner.buf;
+  hipEvent_t* bounce_ev = bounce_owner.ev;
+  int bounce_next = 0;
+  if (e)
+    for (int b = 0; b < 2; ++b) {
+      HIPCHK(hipHostMalloc(&bounce[b], bounce_bytes, hipHostMallocDefault));
+      HIPCHK(hipEventCreateWithFlags(&bounce_ev[b], hipEventDisableTiming));
+      HIPCHK(hipEventRecord(bounce_ev[b], e->stream));
+    }
   struct PlanOwner { gsv_plan* p; ~PlanOwner() { if (p) gsv_plan_destroy(p); } } po{new gsv_plan()};
   gsv_plan* plan = po.p;
   GSV_TRY
@@ -752,11 +766,30 @@ int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out) {
     }
     q->device_only = true;
     DevProgram d;
+    // Records go from the file to the device through two page-locked bounce buffers (pread + async copy): the process never
+    // holds more than the buffers, whatever the size of the plan (the mapping above is only dereferenced for the metadata).
     auto up = [&](void** dst, const void* src, size_t bytes) -> int {  // same padding rule as upload_program
       HIPCHK(hipMalloc(dst, bytes + 32));
-      HIPCHK(hipMemset(*dst, 0, bytes + 32));
-      if (bytes) HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+      HIPCHK(hipMemsetAsync(*dst, 0, bytes + 32, e->stream));
       d.bytes += bytes;
+      if (!bytes) return GSV_OK;
+      if (!src) return fail(GSV_ERR_INVALID, "internal: missing source");
+      size_t off = size_t(static_cast<const uint8_t*>(src) - mp.base);
+      for (size_t done_b = 0; done_b < bytes;) {
+        const size_t nb = std::min(bounce_bytes, bytes - done_b);
+        const int b = bounce_next;
+        bounce_next ^= 1;
+        HIPCHK(hipEventSynchronize(bounce_ev[b]));  // the previous copy out of this buffer has finished
+        size_t got = 0;
+        while (got < nb) {
+          const ssize_t r = pread(mp.fd, static_cast<uint8_t*>(bounce[b]) + got, nb - got, off_t(off + done_b + got));
+          if (r <= 0) return fail(GSV_ERR_INVALID, std::string(path) + ": short read");
+          got += size_t(r);
+        }
+        HIPCHK(hipMemcpyAsync(static_cast<uint8_t*>(*dst) + done_b, bounce[b], nb, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipEventRecord(bounce_ev[b], e->stream));
+        done_b += nb;
+      }
       return GSV_OK;
     };
     int rc = GSV_OK;
@@ -769,12 +802,8 @@ int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out) {
     if (q->half_only) q->dev[{e->device, 1}] = d;
     if (rc != GSV_OK) return rc;
     q->loaded_image_bytes = d.bytes;
-    // the pages just read are not needed again by this process (other ranks find them in the page cache)
-    {
-      const uintptr_t lo = (reinterpret_cast<uintptr_t>(steps) + 4095) & ~uintptr_t(4095), hi = reinterpret_cast<uintptr_t>(mp.base + pos) & ~uintptr_t(4095);
-      if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_DONTNEED);
-    }
   }
+  if (e) HIPCHK(hipStreamSynchronize(e->stream));
   for (uint32_t k = 0; k < h.n_calls && !bad; ++k) {
     uint32_t hdr[4];
     std::memcpy(hdr, take(sizeof hdr), sizeof hdr);

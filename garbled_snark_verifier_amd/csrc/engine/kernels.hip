@@ -216,9 +216,13 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     // Absent operands name window entry 0 (an all-zero label), so every lane runs the same instruction stream.
     // The ciphertext of AND record k goes to position k of the replay's block of the stream.
     //
-    // Software pipeline, two steps deep: while step s computes, the descriptors of the next steps (scalar loads: the whole
-    // step bookkeeping stays on the scalar unit, which matters because all 16 waves run it even when only one has gates) and
-    // this lane's first record of step s+2 are in flight (program records stream from HBM / L2).
+    // Software pipeline, two steps deep: while step s computes, the descriptor (scalar load: the whole
+    // step bookkeeping stays on the scalar unit, which matters because all 16 waves run it even when only one
+    // has gates) + this lane's first record of step s+2 are in flight (program records stream from HBM).  The step
+    // barrier must only wait for what other waves will read — this step's label stores — so it is a hand-counted
+    // `s_waitcnt vmcnt(N)`: vector-memory ops retire in issue order and the N youngest ops of the wave are, by
+    // construction (compiler barriers pin the order), the record prefetch load and, when the wave's last pass
+    // held AND gates, the ciphertext store.
     const uint32_t last_step = ka.n_steps - 1;
     auto is_narrow = [&](const u32x4& d) -> bool { return HASH == 0 && !no_narrow && d.y != 0 && d.y * LPG + d.w <= BT; };
     // wide steps: is the AND remainder small enough for the multi-lane form?
@@ -228,14 +232,13 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       if (!inst_active) { d.y = 0; d.w = 0; }
       return d;
     };
-    // This lane's first (or only) record of step d: two vector loads (16 + 8 bytes).  Lanes without a gate read the step
-    // table's first entry (always present).
+    // First 16 bytes (the operand / output slots) of this lane's first (or only) record of step d.  ALWAYS exactly one
+    // vector load per lane and per wave, whatever the lane has to do: the step barrier's counted vmcnt relies on it.
+    // Lanes without a gate read the step table's first entry (always present).  The second half of an AND record
+    // (gate id, third type bit) is only needed when the AES starts: it is loaded together with the operands.
     const glb_u8* const and_bytes = (const glb_u8*)ka.ands;
     const glb_u8* const xor_bytes = (const glb_u8*)ka.xors;
-    // A prefetched record: the first 16 bytes (operand / output slots) and the next 8 (AND records: gate id + third type bit; free
-    // records: the head of the next record, unused).  Both halves are prefetched — the gate id feeds the tweak, and loading it when
-    // the step starts put an L2 round trip in front of the AES of every narrow step.
-    struct Rec { u32x4 lo; u32x2 hi; };
+    typedef u32x4 Rec;
     auto load_rec = [&](const u32x4& d) -> Rec {
       const glb_u8* p = (const glb_u8*)ka.steps;
       if (is_narrow(d)) {
@@ -244,23 +247,20 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         else if (tid < na + d.w) p = xor_bytes + size_t(d.z + (tid - na)) * 16u;
       } else if (d.y >= BT || !small_rem(d.y)) { if (tid < d.y) p = and_bytes + size_t(d.x + tid) * 32u; }  // wide: first one-per-lane pass
       else if (tid / LPG < d.y) p = and_bytes + size_t(d.x + tid / LPG) * 32u;  // wide with only a small remainder: first multi-lane pass
-      Rec r;
-      r.lo = *(const glb_u128*)p;         // every array is padded by 32 bytes: the 24-byte read is in bounds wherever p points
-      r.hi = *(const glb_u64*)(p + 16);
-      return r;
+      return *(const glb_u128*)p;
     };
-    auto load_and_rec = [&](uint32_t k) -> Rec { Rec r; r.lo = *(const glb_u128*)(and_bytes + size_t(k) * 32u); r.hi = *(const glb_u64*)(and_bytes + size_t(k) * 32u + 16u); return r; };  // record k of the AND array
+    auto load_and_rec = [&](uint32_t k) -> Rec { return *(const glb_u128*)(and_bytes + size_t(k) * 32u); };      // record k of the AND array, first half
+    auto load_and_hi = [&](uint32_t k) -> u32x2 { return *(const glb_u64*)(and_bytes + size_t(k) * 32u + 16u); };  // second half
     // Two record registers in ping-pong: step s consumes one (loaded at the end of step s-2) and, once it is done with it,
     // refills the SAME registers with the record of step s+2.  No in-flight load is ever copied to another register: a copy
     // would make the compiler wait for the load it has just issued at the top of every step (which is what a rotating
     // r0 <- n0 <- n2r form did, exposing a full L2 round trip per step).
     u32x4 sdA = load_desc(0), sdB = load_desc(1);
     Rec recA = load_rec(sdA), recB = load_rec(sdB);
+    const uint32_t wave_first = __builtin_amdgcn_readfirstlane(tid);  // index of the wave's first lane inside its instance group
     // decoded AND record
     struct AndOp { uint32_t a1, a2, b1, b2, p, c, t; uint64_t gid; };
-    auto decode_and = [&](const Rec& rec) -> AndOp {
-      const u32x4& q = rec.lo;
-      const u32x2& hi = rec.hi;
+    auto decode_and = [&](const Rec& q, const u32x2& hi) -> AndOp {
       AndOp o;
       o.a1 = q.x & GSV_SLOT_MASK;
       o.a2 = ((q.x >> 21) | (q.y << 11)) & GSV_SLOT_MASK;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     // Called with LPG-aligned groups of active lanes; `q` is the gate's record (same in all lanes of the group), `cti`
     // its index in the program's AND array.
     auto and_multilane = [&](const Rec& q, uint32_t cti) {
-      const AndOp o = decode_and(q);
+      const AndOp o = decode_and(q, load_and_hi(cti));
       const uint32_t t = o.t;
       uint32_t a_c = dq, b_c = dq, p_c = 0;
       if (!no_load) {
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         const uint32_t ct_c = h ^ o2 ^ b_c ^ (alpha_b(t) ? dq : 0u);
         if (!blk && !no_store) wf.st_word(o.c, col, c0_c);
         asm volatile("" ::: "memory");
-        if (!blk && !no_store) __builtin_nontemporal_store(ct_c, &CTw[(ct_base + cti) * 4u + col]);  // write-once stream: `nt`
+        if (!blk && !no_store) CTw[(ct_base + cti) * 4u + col] = ct_c;
       } else {
         const uint32_t va = (wf.ld_bit(o.a1) ^ wf.ld_bit(o.a2)) & 1u, vb = (wf.ld_bit(o.b1) ^ wf.ld_bit(o.b2)) & 1u, vp = wf.ld_bit(o.p) & 1u;
         const uint32_t ct_c = CTw[(ct_base + cti) * 4u + col];
@@ -318,16 +318,10 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     };
     // One step.  sd: its descriptor; r0: this lane's first record of it — consumed here and refilled, as the wave's youngest
     // vector-memory operation, with the record of step s+2 (descriptor n2sd, a scalar load issued at the top of this step).
-    auto run_step = [&](const uint32_t s, const u32x4& sd, Rec& rec, const u32x4& n2sd) __attribute__((always_inline)) {
+    auto run_step = [&](const uint32_t s, const u32x4& sd, Rec& r0, const u32x4& n2sd) __attribute__((always_inline)) {
       const uint32_t and_off = sd.x, and_cnt = sd.y, xor_off = sd.z, total = sd.y + sd.w;
       (void)total;
-      // The record registers are read once, here, and refilled right away with the record of step s+2: the refill is then the
-      // OLDEST vector-memory operation of the step and has two whole steps to land.  (Issued at the END of the step — the
-      // round-1 order — it was the youngest operation when the next step began, and the compiler's wait for the OTHER record
-      // register, in-order counter that vmcnt is, had to sit out its full L2 round trip at the top of every step.)
-      const Rec r0 = rec;
-      rec = load_rec(n2sd);
-      asm volatile("" ::: "memory");
+      bool young_ct = false;                 // did this wave issue a ciphertext store AFTER its last label store?
       if (ka.step_clock && blockIdx.x == 0 && threadIdx.x == 0 && rep + 1 == ka.replays) ka.step_clock[s] = wall_clock64();  // older than this step's stores
       if (is_narrow(sd)) {
         // ------------------------------------------------------------------ narrow step: one pass
@@ -335,7 +329,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         if (tid < na) {
           and_multilane(r0, and_off + tid / LPG);
         } else if (tid < na + sd.w) {
-          const XorOp o = decode_xor(r0.lo);
+          const XorOp o = decode_xor(r0);
           Label c0 = delta;
           if (!no_load) c0 = lxor(lxor(wf.ld(o.x1), wf.ld(o.x2)), lxor(wf.ld(o.x3), wf.ld(o.x4)));
           if (!EVAL) c0 = lxor_if(c0, delta, o.par);
@@ -344,6 +338,9 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
             if (EVAL) wf.st_bit(o.c, (wf.ld_bit(o.x1) ^ wf.ld_bit(o.x2) ^ wf.ld_bit(o.x3) ^ wf.ld_bit(o.x4) ^ o.par) & 1u);
           }
         }
+        // the AND lanes come first, so a wave holding any AND lane issued its ciphertext store last... unless it
+        // also holds free-gate lanes (boundary wave), whose label store is issued after it in program order.
+        young_ct = !EVAL && !no_store && wave_first + 64u <= na;
       } else {
         // ------------------------------------------------------------------ wide step
         // AND-family gates: passes of 1024 gates, one per lane (two interleaved AES blocks each).
@@ -404,7 +401,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           const Rec q = qnext;
           if (i + BT < and_full) qnext = load_and_rec(and_off + i + BT);
           const uint32_t cti = and_off + i;
-          const AndOp o = decode_and(q);
+          const AndOp o = decode_and(q, load_and_hi(cti));
           const uint32_t t = o.t;
           Label a = delta, b = delta, pl{{0, 0, 0, 0}};
           if (!no_load) {
@@ -430,7 +427,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
             wf.st(o.c, c0);
             if (EVAL) wf.st_bit(o.c, vc);
           }
-          if (!EVAL && !no_store) __builtin_nontemporal_store(u32x4{ct.w[0], ct.w[1], ct.w[2], ct.w[3]}, &CT[ct_base + cti]);
+          if (!EVAL && !no_store) CT[ct_base + cti] = u32x4{ct.w[0], ct.w[1], ct.w[2], ct.w[3]};
         }
         for (uint32_t g = and_full + tid / LPG; g < and_cnt; g += BT / LPG) {
           // the first remainder record was prefetched two steps ago when the step has no whole pass
@@ -449,23 +446,25 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
             load_xor_recs(nb + XB * BT, xrn);
           }
         }
+        young_ct = !EVAL && !no_store && xor_cnt == 0 && and_full == and_cnt && wave_first < and_cnt &&
+                   (wave_first + ((and_cnt - 1u - wave_first) / BT) * BT) < and_cnt;
       }
-      // The step barrier: every label store of the step (LDS and HBM) has completed before any wave goes on.  Round 1 counted
-      // vmcnt by hand to let a trailing ciphertext store (which nobody reads inside the launch) stay in flight across the barrier;
-      // with vmcnt in order the very next wait of the wave — for its record registers — retired that store anyway, so the plain
-      // full wait costs nothing and needs no assumption about the compiler's instruction order.
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // keep r0's registers reserved through the step: were they handed to a store's data in between, the refill below would
+      // have to wait for that store (vmcnt(0) in front of the prefetch) before it could overwrite them
+      asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w)::"memory");
+      r0 = load_rec(n2sd);  // the wave's youngest load: stays in flight across the barrier and the whole next step
+      asm volatile("" ::: "memory");
+      if (young_ct) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
-    // descriptors run further ahead than records: the refill at the top of step s needs the descriptor of step s+2
-    u32x4 sdA2 = load_desc(2), sdB2 = load_desc(3);
     for (uint32_t s = 0; s < ka.n_steps; s += 2) {
-      const u32x4 sdA4 = load_desc(s + 4);   // scalar loads: they land during the step
+      const u32x4 sdA2 = load_desc(s + 2);  // lands during the step; the record load that needs it is issued at the step's end
       run_step(s, sdA, recA, sdA2);
-      sdA = sdA2; sdA2 = sdA4;
+      sdA = sdA2;
       if (s + 1 >= ka.n_steps) break;        // wave-uniform: every wave passes the same number of barriers
-      const u32x4 sdB4 = load_desc(s + 5);
+      const u32x4 sdB2 = load_desc(s + 3);
       run_step(s + 1, sdB, recB, sdB2);
-      sdB = sdB2; sdB2 = sdB4;
+      sdB = sdB2;
     }
     __syncthreads();
     if (ka.step_clock && blockIdx.x == 0 && threadIdx.x == 0 && rep + 1 == ka.replays) ka.step_clock[ka.n_steps] = wall_clock64();

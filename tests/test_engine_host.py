@@ -221,20 +221,22 @@ def test_plan_from_circuit_builds_without_a_device_and_in_both_modes():
 
 
 def test_step_barrier_isa_check():
-    """build.check_step_barrier_isa: every barrier of run_program_kernel is a full one (`s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`),
-    verified on the gfx950 ISA of every instantiation at build time.  The check passes on the built object and trips on a doctored
-    listing (a counted partial wait in front of a barrier, or the step barriers missing)."""
+    """build.check_step_barrier_isa: the hand-counted `s_waitcnt vmcnt(N); s_barrier` of run_program_kernel is verified on the
+    gfx950 ISA of every instantiation at build time (the record prefetch must stay the youngest vector-memory operation in front
+    of the barrier).  The check passes on the built object and trips on a doctored listing."""
     from garbled_snark_verifier_amd import build
     asm = build.disassemble_kernels()
     res = build.check_step_barrier_isa(asm)
-    assert len(res) == 6 and all(v >= 2 for v in res.values())
+    assert len(res) == 6 and sorted(res.values()) == [(2, 0)] * 3 + [(2, 2)] * 3
+    # a label store scheduled behind the prefetch
     lines = asm.splitlines()
-    k = next(i for i, l in enumerate(lines) if "s_waitcnt vmcnt(0) lgkmcnt(0)" in l and "s_barrier" in lines[i + 1])
-    bad = lines[:k] + [lines[k].replace("vmcnt(0)", "vmcnt(1)")] + lines[k + 1:]
-    with pytest.raises(RuntimeError, match="partial wait"):
+    k = next(i for i, l in enumerate(lines) if "s_waitcnt vmcnt(1) lgkmcnt(0)" in l and "s_barrier" in lines[i + 1])
+    bad = lines[:k] + ["\tglobal_store_dwordx4 v[4:5], v[0:3], off    // doctored"] + lines[k:]
+    with pytest.raises(RuntimeError, match="youngest vector-memory operation"):
         build.check_step_barrier_isa("\n".join(bad))
-    gone = [l for l in lines if "s_waitcnt vmcnt(0) lgkmcnt(0)" not in l]
-    with pytest.raises(RuntimeError, match="full step barriers"):
+    # a barrier the compiler dropped / duplicated
+    gone = [l for i, l in enumerate(lines) if i != k]
+    with pytest.raises(RuntimeError, match="counted step barriers"):
         build.check_step_barrier_isa("\n".join(gone))
 
 
