@@ -482,6 +482,7 @@ def run_verifier(args):
     dist.barrier()
     dist.close()
     plan.close()
+    engine.close()
 
 
 def run_synthetic(args):
@@ -588,10 +589,9 @@ def main():
         run_synthetic(args)
     else:
         run_verifier(args)
-    # everything is closed and the result line is out: leave without the interpreter's teardown (HIP / RCCL destructors at exit are
-    # not ours to debug, and a crash there would turn a finished run into a failed one)
+    # sessions, plan and engine are closed in order by now (and the package's atexit hook closes whatever is left before the
+    # interpreter tears down); a normal exit also lets a profiler's own exit handlers write their output
     sys.stdout.flush(); sys.stderr.flush()
-    os._exit(0)
 
 
 if __name__ == "__main__":

@@ -1209,7 +1209,9 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
             for (size_t g = 0; g < ng && ok; ++g)
               ok = hipMemcpyAsync(w.pinned[b][g], static_cast<const uint8_t*>(s->ct_gate) + ((i0 + g) * seg_records + off) * 16, std::min(chunk, n - off) * 16,
                                   hipMemcpyDeviceToHost, st) == hipSuccess;
-            ok = ok && hipEventRecord(w.done, st) == hipSuccess && hipEventSynchronize(w.done) == hipSuccess;
+            // many workers: sleep on the blocking-sync event (spinning workers eat the cores the MACs need); a handful of
+            // workers (one instance: the whole-stream check) spin instead, a blocking wait's wake-up latency would be paid per chunk
+            ok = ok && (T > 8 ? hipEventRecord(w.done, st) == hipSuccess && hipEventSynchronize(w.done) == hipSuccess : hipStreamSynchronize(st) == hipSuccess);
             dr.copy_gate.release(st);
             return ok;
           };
