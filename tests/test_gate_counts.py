@@ -1,0 +1,57 @@
+"""DESIGN.md §2 "Gate count against the reference's published figure": the per-component table is produced by
+tools/gate_counts.cpp (the gadget headers under a memoising counting context).  Pinned here: the counter agrees with the real
+two-pass driver (oracle, Execute mode) on whole sub-circuits, and the one-public-input compressed verifier — the configuration the
+reference quotes 11,174,708,821 gates for (README.md:12, examples/groth16_cut_and_choose.rs:83,117) — has the totals of the table."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import groth16_ref as G
+import oracle_lib as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def counter(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("gate_counts") / "gate_counts")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "garbled_snark_verifier_amd", "csrc"), os.path.join(ROOT, "tools", "gate_counts.cpp"), "-o", exe])
+
+    def run(spec, depth=2):
+        out = subprocess.check_output([exe, spec, str(depth)], text=True)
+        total, nonfree = map(int, re.search(r"total gates (\d+)\s+non-free (\d+)", out).groups())
+        tree = {}
+        for m in re.finditer(r"^( *)(\S+) +calls +(\d+) +gates +(\d+)", out[out.index("call tree"):], re.M):
+            tree.setdefault((len(m.group(1)) // 2, m.group(2)), (int(m.group(3)), int(m.group(4))))
+        return total, nonfree, tree
+    return run
+
+
+@pytest.mark.parametrize("spec", ["fq_mul", "fq12_mul", "fq12_cyclotomic_square", "g1_add", "fq_inverse", "g2_add"])
+def test_counter_equals_the_two_pass_driver(counter, spec):
+    n_in, _ = o.circuit_info(spec)
+    _, gc, _ = o.execute(spec, np.zeros(n_in, np.uint8))
+    total, nonfree, _ = counter(spec)
+    assert total == int(gc.sum()) and nonfree == int(gc[:8].sum())  # non-free = the eight AND-family types
+
+
+def test_one_public_input_compressed_verifier_table(counter):
+    inst = G.make_instance(n_pub=1, seed=6)
+    total, nonfree, tree = counter(G.compressed_circuit_name(inst), 2)
+    assert total == 11_456_865_898 and total - 11_174_708_821 == 282_157_077  # restated vs the reference's published figure
+    top = {name: v for (depth, name), v in tree.items() if depth == 1}
+    assert top["groth16::decompress_g1_from_compressed"] == (2, 299_125_232)
+    assert top["groth16::decompress_g2_from_compressed"] == (1, 473_589_412)
+    assert top["g1::msm_with_constant_bases_montgomery"] == (1, 225_290_965)
+    assert top["g1::add_montgomery"] == (1, 6_671_689)
+    assert top["groth16::projective_to_affine_montgomery"] == (1, 24_857_679)
+    assert top["pairing::multi_miller_loop_groth16_evaluate_montgomery_fast"] == (1, 6_907_999_657)
+    assert top["final_exponentiation_montgomery"] == (1, 3_519_328_217)
+    assert sum(g for _, g in top.values()) + 11 == total  # 11 root-level AND gates of Fq12::equal_constant's tree
+    second = {name: v for (depth, name), v in tree.items() if depth == 2}
+    assert second["pairing::ell_by_constant_montgomery"][0] == 182 and second["fq12::mul_by_034_montgomery"] == (91, 1_530_187_022)
+    assert second["pairing::double_in_place_circuit_montgomery"] == (64, 64 * 10_124_254) and second["pairing::add_in_place_montgomery"] == (27, 27 * 15_683_482)
+    assert second["fq12::cyclotomic_square_montgomery"] == (186, 186 * 8_032_850) and second["fq12::inverse_montgomery"] == (4, 4 * 61_993_136)

@@ -722,6 +722,34 @@ def test_verifier_lockstep_two_instances_per_workgroup(engine, compressed_verifi
     one.close()
 
 
+def test_compressed_verifier_evaluates_valid_and_tampered_proof(engine, compressed_verifier_plan):
+    """BASELINE config 4, evaluator side (EvaluateMode over the whole circuit, evaluate_mode.rs:123-158): two instances of the
+    verifier are garbled with their 49 GB ciphertext streams retained in HBM and evaluated — one with the valid proof's input bits,
+    one with A's sign flag flipped (another point: the proof must no longer verify).  The plaintext output bits are (1, 0), every
+    active output label is select(label0, bit), and the retained streams' CBC-MAC equals the oracle's flat-stream fixture."""
+    import garbled_snark_verifier_amd as gsv
+    case, plan = compressed_verifier_plan
+    n_in = plan.info["n_inputs"]
+    seeds = [case["seed"], case["seed"] + 1]
+    labs = [gsv.labels_from_seed(s, n_in) for s in seeds]
+    delta = np.stack([x[0] for x in labs]); consts = np.stack([np.stack([x[1], x[2]]) for x in labs]); inputs = np.stack([x[3] for x in labs])
+    bits_ok = np.unpackbits(np.frombuffer(bytes.fromhex(case["input_bits_hex"]), np.uint8), bitorder="little")[:n_in].astype(np.uint8)
+    bits_bad = bits_ok.copy(); bits_bad[case["tamper_bit"]] ^= 1
+    bits = np.stack([bits_ok, bits_bad])
+    sess = gsv.Session(engine, plan, 2)  # whole stream retained
+    sess.set_garble_inputs(delta, consts, inputs)
+    sess.garble(0); sess.sync()
+    out0 = sess.read_outputs()
+    assert sess.ciphertext_hash(0).hex() == case["ct_hash"]
+    active = np.where(bits[:, :, None] == 1, inputs ^ delta[:, None, :], inputs)
+    sess.set_evaluate_inputs(np.stack([consts[:, 0], consts[:, 1] ^ delta], axis=1), active, bits)
+    sess.evaluate(0); sess.sync()
+    oa, ob = sess.read_outputs(with_bits=True)
+    assert case["expected_output"] == 1 and ob[:, 0].tolist() == [1, 0]
+    assert (oa == np.where(ob[:, :, None] == 1, out0 ^ delta[:, None, :], out0)).all()
+    sess.close()
+
+
 def test_plan_slices_and_plan_file_on_the_device(engine, tmp_path):
     """gsv_session_garble_streaming_calls + gsv_plan_save / gsv_plan_load: a plan garbled slice by slice (MACs chained, gc files
     appended) equals the whole pass and the oracle; the same plan loaded from its file straight into device memory (no host
@@ -768,20 +796,18 @@ def test_plan_slices_and_plan_file_on_the_device(engine, tmp_path):
     plan.close()
 
 
-@pytest.mark.skipif(not os.environ.get("GSV_SLOW"), reason="the uncompressed variant is a sub-circuit of groth16_verify_compressed, which the default run covers; GSV_SLOW=1 builds this second plan too")
 @pytest.mark.parametrize("fixture,units,gates", [
-    ("groth16_verify_golden.json", VERIFIER_UNITS, 10_914_485_653),  # the compressed circuit (tests above, always run) contains this one
+    ("groth16_verify_golden.json", VERIFIER_UNITS, 10_914_485_653),
 ])
 def test_groth16_verifier_as_a_plan(engine, fixture, units, gates):
-    """groth16_verify (groth16.rs:58-110: MSM, projective-to-affine, Miller loop, final exponentiation, comparison) and
-    groth16_verify_compressed (groth16.rs:250-268: point decompression in front) for the synthetic instance of
-    tests/groth16_ref.py, as one plan each; hash + output label == the oracle's flat-stream fixtures
-    (tests/golden/make_big_golden.py).  tools/groth16_plan.py [--compressed] runs the same check, evaluates a valid and a tampered
-    proof and measures the device rate."""
+    """groth16_verify (groth16.rs:58-110: MSM, projective-to-affine, Miller loop, final exponentiation, comparison; uncompressed
+    A, B, C) for the synthetic instance of tests/groth16_ref.py as a plan of its own: hash + output label == the oracle's
+    flat-stream fixture (tests/golden/make_big_golden.py).  (The compressed circuit — the reference's headline — is covered by the
+    tests above; tools/groth16_plan.py runs both end to end and measures the device rate.)"""
     import hashlib
     import garbled_snark_verifier_amd as gsv
     case = json.load(open(os.path.join(os.path.dirname(GOLDEN), fixture)))
-    plan = gsv.Plan.from_circuit(case["circuit"], units)
+    plan = gsv.Plan.from_circuit(case["circuit"], units, half_window=True)
     assert plan.info["n_gates"] == case["gates"] == gates and plan.info["n_ciphertexts"] == case["n_ciphertexts"]
     d, f, t, inp = gsv.labels_from_seed(case["seed"], plan.info["n_inputs"])
     sess = gsv.Session(engine, plan, 1, retain_stream=False)
@@ -789,3 +815,4 @@ def test_groth16_verifier_as_a_plan(engine, fixture, units, gates):
     hashes = sess.garble_streaming()
     assert hashes[0].hex() == case["ct_hash"] and hashlib.sha256(sess.read_outputs()[0].tobytes()).hexdigest() == case["output_label0_sha256"]
     sess.close()
+    plan.close()
