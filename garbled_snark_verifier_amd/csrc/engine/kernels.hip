@@ -294,7 +294,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         const uint32_t ct_c = h ^ o2 ^ b_c ^ (alpha_b(t) ? dq : 0u);
         if (!blk && !no_store) wf.st_word(o.c, col, c0_c);
         asm volatile("" ::: "memory");
-        if (!blk && !no_store) CTw[(ct_base + cti) * 4u + col] = ct_c;
+        if (!blk && !no_store) __builtin_nontemporal_store(ct_c, &CTw[(ct_base + cti) * 4u + col]);
       } else {
         const uint32_t va = (wf.ld_bit(o.a1) ^ wf.ld_bit(o.a2)) & 1u, vb = (wf.ld_bit(o.b1) ^ wf.ld_bit(o.b2)) & 1u, vp = wf.ld_bit(o.p) & 1u;
         const uint32_t ct_c = CTw[(ct_base + cti) * 4u + col];
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
             wf.st(o.c, c0);
             if (EVAL) wf.st_bit(o.c, vc);
           }
-          if (!EVAL && !no_store) CT[ct_base + cti] = u32x4{ct.w[0], ct.w[1], ct.w[2], ct.w[3]};
+          if (!EVAL && !no_store) __builtin_nontemporal_store(u32x4{ct.w[0], ct.w[1], ct.w[2], ct.w[3]}, &CT[ct_base + cti]);
         }
         for (uint32_t g = and_full + tid / LPG; g < and_cnt; g += BT / LPG) {
           // the first remainder record was prefetched two steps ago when the step has no whole pass
