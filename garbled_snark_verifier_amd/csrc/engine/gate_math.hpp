@@ -70,6 +70,7 @@ GSV_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
 }
 
 struct PlainTables {
+  static constexpr bool kPairedRotation = false;  // four tables, plain round keys
   const uint32_t* te[4];
   const uint32_t* rkp;  // 44 round-key words
   template <int K, int BYTE>
@@ -78,9 +79,17 @@ struct PlainTables {
 };
 
 // One middle round for one column: T0[b0 of x0] ^ T1[b1 of x1] ^ T2[b2 of x2] ^ T3[b3 of x3] ^ k
+// A table set that keeps only Te0 and Te2 (kPairedRotation) pays ONE rotation per column instead of one per rotated term:
+//   Te1[b] ^ Te3[d] ^ k = rotl8(Te0[b] ^ Te2[d] ^ rotr8(k)),
+// and its rk(4..39) — the middle rounds' keys — are stored as rotr8(k), so the key rides in the same three-input XOR.
 template <class Tab>
 GSV_HD uint32_t aes_col(const Tab& T, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t k) {
-  return xor3(xor3(T.template lk<0, 0>(x0), T.template lk<1, 1>(x1), T.template lk<2, 2>(x2)), T.template lk<3, 3>(x3), k);
+  if constexpr (Tab::kPairedRotation) {
+    const uint32_t odd = xor3(T.template lk<0, 1>(x1), T.template lk<2, 3>(x3), k);
+    return xor3(T.template lk<0, 0>(x0), T.template lk<2, 2>(x2), (odd << 8) | (odd >> 24));
+  } else {
+    return xor3(xor3(T.template lk<0, 0>(x0), T.template lk<1, 1>(x1), T.template lk<2, 2>(x2)), T.template lk<3, 3>(x3), k);
+  }
 }
 // Final round column: SubBytes + ShiftRows + AddRoundKey; the plain S-box byte sits in Te2 byte0 and byte3
 // and in Te0 byte1 and byte2 (only the two tables the device keeps un-rotated are used).

@@ -66,6 +66,7 @@ typedef const u32x4 GSV_CST cst_u128;   // read-only data behind a wave-uniform 
 typedef const uint32_t GSV_CST cst_u32;
 
 struct LdsBankedTable {
+  static constexpr bool kPairedRotation = true;  // Te0 / Te2 only; c_rk[4..39] hold rotr8 of the middle rounds' keys (gate_math.hpp, aes_col)
   uint32_t lane4;  // (lane & 31) * 4
   template <int K, int BYTE>
   __device__ __forceinline__ uint32_t lk(uint32_t s) const {
@@ -138,8 +139,10 @@ __device__ __forceinline__ uint32_t aes128_quad(const LdsBankedTable& T, const u
   s ^= rkc[0];
 #pragma unroll
   for (int r = 1; r < 10; ++r) {
-    const uint32_t u0 = T.lk<0, 0>(s), u1 = T.lk<1, 1>(s), u2 = T.lk<2, 2>(s), u3 = T.lk<3, 3>(s);
-    s = u0 ^ quad_from<GSV_QP_NEXT1>(u1) ^ quad_from<GSV_QP_NEXT2>(u2) ^ quad_from<GSV_QP_NEXT3>(u3) ^ rkc[r];
+    // rotated terms paired under one rotation (aes_col): rkc[1..9] are rotr8 of the round keys
+    const uint32_t u0 = T.lk<0, 0>(s), u1 = T.lk<0, 1>(s), u2 = T.lk<2, 2>(s), u3 = T.lk<2, 3>(s);
+    const uint32_t odd = rkc[r] ^ quad_from<GSV_QP_NEXT1>(u1) ^ quad_from<GSV_QP_NEXT3>(u3);
+    s = __builtin_amdgcn_alignbit(odd, odd, 24) ^ (u0 ^ quad_from<GSV_QP_NEXT2>(u2));
   }
   const uint32_t m0 = T.lk<2, 0>(s) & 0x000000ffu, m1 = T.lk<0, 1>(s) & 0x0000ff00u;  // S-box byte from the un-rotated tables
   const uint32_t m2 = T.lk<0, 2>(s) & 0x00ff0000u, m3 = T.lk<2, 3>(s) & 0xff000000u;
@@ -544,7 +547,9 @@ __global__ void gather_segment_kernel(uint4* ring, uint64_t ring_stride, const u
 extern "C" {
 
 int gsvk_upload_round_keys(const uint32_t rk[44]) {
-  return int(hipMemcpyToSymbol(HIP_SYMBOL(gsv::dev::c_rk), rk, 44 * sizeof(uint32_t)));
+  uint32_t dev_rk[44];  // LdsBankedTable::kPairedRotation: the nine middle rounds' keys rotated right by one byte
+  for (int i = 0; i < 44; ++i) dev_rk[i] = (i >= 4 && i < 40) ? ((rk[i] >> 8) | (rk[i] << 24)) : rk[i];
+  return int(hipMemcpyToSymbol(HIP_SYMBOL(gsv::dev::c_rk), dev_rk, 44 * sizeof(uint32_t)));
 }
 int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, int evaluate, hipStream_t stream) {
   const size_t lds = GSV_LDS_BYTES;

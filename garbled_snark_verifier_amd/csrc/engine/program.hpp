@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <string>
+#include <queue>
 #include <vector>
 
 #include "../circuit/circuit.hpp"
@@ -150,6 +151,7 @@ struct CompileOptions {
   uint32_t hbm_arena_factor = 4;          // HBM wire file = factor x peak live wires (next-fit then sweeps mostly free space)
   bool fuse = true;                       // fold free gates into their readers / into the AND that feeds them
   uint32_t fuse_dup_fanout = 2;           // a free gate of <= 2 operands is also folded (recomputed) when it has up to this many readers
+  uint32_t and_cap = 0, xor_cap = 0;      // most AND-family / free gates in one step (0 = no cap: ASAP levels); see compile_program 1b
 };
 
 // next-fit slot pool over a bitmap: consecutive allocations get ascending (mostly consecutive) slots, so the
@@ -310,7 +312,10 @@ inline FusedOps fuse_trace(const Trace& t, const std::vector<uint32_t>& inputs, 
 // inputs / outputs: SSA ids of the circuit's input and output wires.
 // feedback: pairs (output index -> input index) copied at the end of every replay (chained circuits).
 inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inputs, const std::vector<uint32_t>& outputs,
-                               const std::vector<std::pair<uint32_t, uint32_t>>& feedback = {}, const CompileOptions& opt = CompileOptions()) {
+                               const std::vector<std::pair<uint32_t, uint32_t>>& feedback = {}, const CompileOptions& opt_in = CompileOptions()) {
+  CompileOptions opt = opt_in;
+  if (const char* e = getenv("GSV_AND_CAP")) opt.and_cap = uint32_t(atoi(e));  // tuning knobs (the defaults are the measured best)
+  if (const char* e = getenv("GSV_XOR_CAP")) opt.xor_cap = uint32_t(atoi(e));
   const uint32_t nw = t.n_wires;
   Program p;
   p.n_gates = t.size();
@@ -334,7 +339,51 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
     n_steps = std::max(n_steps, lev[c]);
     p.and_depth = std::max(p.and_depth, ad[c]);
   }
-  auto step_of = [&](size_t i) -> uint32_t { return lev[f.out[i]] - 1; };
+  // 1b. Width-capped list scheduling.  ASAP levels put every independent sub-circuit's multiplier array into the same few
+  // steps (an Fq12 multiplication: 740 of 8197 levels hold 59 % of the gates, 7000+ each) and leave thousands of levels
+  // on the carry chains with a few dozen gates.  The wide levels overflow the LDS label window into the HBM wire file, the
+  // narrow ones cost a barrier for a handful of gates.  With a cap on the AND-family and free gates of a step, the ready
+  // gates with the longest path to a sink go first and the rest wait for a later step: work with slack moves under the
+  // carry chains.  The schedule is at least as long as the critical path, steps become uniform, live ranges shrink.
+  // Labels do not depend on the schedule (only on gate ids and dataflow), so the result is the same stream.
+  std::vector<uint32_t> stp;
+  if (opt.and_cap || opt.xor_cap) {
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    std::vector<uint32_t> prod(nw, NONE), pending(n, 0), height(n, 0), succ_off(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) prod[f.out[i]] = uint32_t(i);
+    for (size_t i = 0; i < n; ++i)
+      for (int k = 0; k < 5; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE && prod[w] != NONE) { succ_off[prod[w] + 1]++; pending[i]++; } }
+    for (size_t i = 0; i < n; ++i) succ_off[i + 1] += succ_off[i];
+    std::vector<uint32_t> succ(succ_off[n]);
+    {
+      std::vector<uint32_t> cur(succ_off.begin(), succ_off.end() - 1);
+      for (size_t i = 0; i < n; ++i)
+        for (int k = 0; k < 5; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE && prod[w] != NONE) succ[cur[prod[w]]++] = uint32_t(i); }
+    }
+    for (size_t i = n; i-- > 0;)  // the fused list is in stream order: producers precede their readers
+      for (int k = 0; k < 5; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE && prod[w] != NONE) height[prod[w]] = std::max(height[prod[w]], height[i] + 1); }
+    auto key = [&](uint32_t i) -> uint64_t { return (uint64_t(height[i]) << 32) | (0xFFFFFFFFu - i); };  // longest path first, then stream order
+    std::priority_queue<uint64_t> ready[2];
+    for (size_t i = 0; i < n; ++i) if (pending[i] == 0) ready[is_and(i) ? 0 : 1].push(key(uint32_t(i)));
+    const uint32_t cap[2] = {opt.and_cap ? opt.and_cap : 0xFFFFFFFFu, opt.xor_cap ? opt.xor_cap : 0xFFFFFFFFu};
+    stp.assign(n, 0);
+    std::vector<uint32_t> batch;
+    size_t done = 0;
+    uint32_t s = 0;
+    while (done < n) {
+      batch.clear();
+      for (int kind = 0; kind < 2; ++kind)
+        for (uint32_t c = 0; c < cap[kind] && !ready[kind].empty(); ++c) { batch.push_back(0xFFFFFFFFu - uint32_t(ready[kind].top())); ready[kind].pop(); }
+      if (batch.empty()) gsv_panic("internal: list scheduler found no ready gate");
+      for (uint32_t i : batch) stp[i] = s;
+      for (uint32_t i : batch)
+        for (uint32_t q = succ_off[i]; q < succ_off[i + 1]; ++q) { const uint32_t j = succ[q]; if (--pending[j] == 0) ready[is_and(j) ? 0 : 1].push(key(j)); }
+      done += batch.size();
+      ++s;
+    }
+    n_steps = s;
+  }
+  auto step_of = [&](size_t i) -> uint32_t { return stp.empty() ? lev[f.out[i]] - 1 : stp[i]; };
   // 2. counting sort of the ops by (step, kind): AND-family first, then free gates
   std::vector<uint32_t> cnt(2 * size_t(n_steps) + 1, 0);
   for (size_t i = 0; i < n; ++i) cnt[2 * size_t(step_of(i)) + (is_and(i) ? 0 : 1) + 1]++;
@@ -486,6 +535,41 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
     p.steps.push_back(sd);
     p.max_step_width = std::max(p.max_step_width, sd.and_cnt + sd.xor_cnt);
     if (sd.and_cnt) p.n_and_steps++;
+  }
+  if (getenv("GSV_SCHED_STATS")) {
+    // coalescing of the wire-file accesses: distinct 128-byte lines (8 slots) per wave-wide access (64 consecutive records of a step)
+    uint64_t acc[2] = {0, 0}, lines[2] = {0, 0}, lanes[2] = {0, 0};
+    std::vector<uint32_t> ls;
+    auto tally = [&](int rw) { if (ls.empty()) return; std::sort(ls.begin(), ls.end()); acc[rw]++; lanes[rw] += ls.size(); lines[rw] += uint64_t(std::unique(ls.begin(), ls.end()) - ls.begin()); };
+    for (const StepDesc& sd : p.steps) {
+      for (uint32_t w0 = 0; w0 < sd.and_cnt; w0 += 64) {
+        const uint32_t w1 = std::min(sd.and_cnt, w0 + 64);
+        for (int q = 0; q < 6; ++q) {
+          ls.clear();
+          for (uint32_t k = w0; k < w1; ++k) {
+            const AndRec& r = p.ands[sd.and_off + k];
+            const uint32_t sl[6] = {uint32_t(r.w0 & 0x1FFFFF), uint32_t((r.w0 >> 21) & 0x1FFFFF), uint32_t((r.w0 >> 42) & 0x1FFFFF), uint32_t(r.w1 & 0x1FFFFF), uint32_t((r.w1 >> 21) & 0x1FFFFF), uint32_t((r.w1 >> 42) & 0x1FFFFF)};
+            if (!(sl[q] & SLOT_LDS_FLAG) && sl[q] != SLOT_ZERO) ls.push_back(sl[q] / 8);
+          }
+          tally(q == 5 ? 1 : 0);
+        }
+      }
+      for (uint32_t w0 = 0; w0 < sd.xor_cnt; w0 += 64) {
+        const uint32_t w1 = std::min(sd.xor_cnt, w0 + 64);
+        for (int q = 0; q < 5; ++q) {
+          ls.clear();
+          for (uint32_t k = w0; k < w1; ++k) {
+            const XorRec& r = p.xors[sd.xor_off + k];
+            const uint32_t sl[5] = {uint32_t(r.w0 & 0x1FFFFF), uint32_t((r.w0 >> 21) & 0x1FFFFF), uint32_t((r.w0 >> 42) & 0x1FFFFF), uint32_t(r.w1 & 0x1FFFFF), uint32_t((r.w1 >> 21) & 0x1FFFFF)};
+            if (!(sl[q] & SLOT_LDS_FLAG) && sl[q] != SLOT_ZERO) ls.push_back(sl[q] / 8);
+          }
+          tally(q == 4 ? 1 : 0);
+        }
+      }
+    }
+    fprintf(stderr, "[sched] wire-file loads: %llu wave accesses, %.1f lanes and %.1f lines each (%.2f lanes per line); stores: %llu wave accesses, %.1f lanes, %.1f lines (%.2f per line)\n",
+            (unsigned long long)acc[0], double(lanes[0]) / std::max<uint64_t>(1, acc[0]), double(lines[0]) / std::max<uint64_t>(1, acc[0]), double(lanes[0]) / std::max<uint64_t>(1, lines[0]),
+            (unsigned long long)acc[1], double(lanes[1]) / std::max<uint64_t>(1, acc[1]), double(lines[1]) / std::max<uint64_t>(1, acc[1]), double(lanes[1]) / std::max<uint64_t>(1, lines[1]));
   }
   p.peak_live = peak;
   p.n_steps = uint32_t(p.steps.size());
