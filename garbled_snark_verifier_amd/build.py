@@ -47,19 +47,8 @@ def disassemble_kernels(obj=None):
         return subprocess.check_output([objdump, "-d", os.path.join(td, co[0])], text=True)
 
 
-def check_step_barrier_isa(asm=None):
-    """The step barrier of run_program_kernel is a hand-counted `s_waitcnt vmcnt(N) lgkmcnt(0); s_barrier` (kernels.hip): it
-    waits for the step's label stores but not for the record prefetch issued just before it (N = 1) nor, when the wave's last
-    vector-memory store was a ciphertext, for that store (N = 2).  That is only right while the compiler keeps the prefetch load
-    the YOUNGEST vector-memory operation in front of the barrier.  Checked on the ISA of every instantiation, so that a compiler
-    bump cannot silently break it:
-      * each kernel holds exactly two `s_waitcnt vmcnt(1) lgkmcnt(0)` + `s_barrier` pairs (the step loop is unrolled by two:
-        ping-pong record registers), garbling kernels also exactly two vmcnt(2) pairs, each immediately followed by its s_barrier;
-      * walking back from the vmcnt(1) pair, the first vector-memory instruction is the 16-byte record prefetch
-        (global_load_dwordx4) and no label store (global_store / ds_write) sits between it and the barrier.
-    Returns {kernel symbol: (n_vmcnt1, n_vmcnt2)}; raises RuntimeError on a violation."""
+def _functions(asm):
     import re
-    asm = asm if asm is not None else disassemble_kernels()
     funcs, cur = {}, None
     for line in asm.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
@@ -68,33 +57,68 @@ def check_step_barrier_isa(asm=None):
             funcs[cur] = []
         elif cur is not None and line.startswith("\t"):
             funcs[cur].append(line.split("//")[0].strip())
+    return funcs
+
+
+def check_step_barrier_isa(asm=None):
+    """The step barrier of run_program_kernel is `s_waitcnt lgkmcnt(0); s_barrier` (kernels.hip): it waits for the wave's LDS
+    label stores and scalar loads but for NO vector-memory operation — label stores to the HBM wire file are visible to the
+    other waves of the workgroup in issue order (workgroup-scope release/acquire of the AMDGPU memory model outside
+    threadgroup-split mode; check_workgroup_release_model pins that on the compiler).  Checked on the ISA of every
+    instantiation, so that a compiler bump cannot silently put the store-acknowledgement wait back:
+      * each kernel holds exactly two `s_waitcnt lgkmcnt(0)` + `s_barrier` pairs (the step loop is unrolled by two: ping-pong
+        record registers);
+      * in each of them the instruction right in front of the wait is the 16-byte record prefetch (global_load_dwordx4): the
+        prefetch crosses the barrier in flight and nothing waits for vector memory in between.  (Other lgkmcnt(0) + s_barrier
+        pairs are the compiler's own __syncthreads of the prologue / replay epilogue.)
+    Returns {kernel symbol: number of step barriers}; raises RuntimeError on a violation."""
+    asm = asm if asm is not None else disassemble_kernels()
     out = {}
-    kernels = {k: v for k, v in funcs.items() if "run_program_kernel" in k}
+    kernels = {k: v for k, v in _functions(asm).items() if "run_program_kernel" in k}
     if len(kernels) != 6:
         raise RuntimeError("expected 6 instantiations of run_program_kernel, found %d" % len(kernels))
     for name, ins in kernels.items():
-        garble = "ILb0E" in name  # run_program_kernel<false, ...>
-        n = {1: 0, 2: 0}
-        for i, t in enumerate(ins):
-            m = re.match(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)$", t)
-            if not m or int(m.group(1)) not in (1, 2):
-                continue
-            k = int(m.group(1))
-            if i + 1 >= len(ins) or ins[i + 1] != "s_barrier":
-                continue  # an ordinary compiler-generated wait
-            n[k] += 1
-            if k == 1:
-                j = i - 1
-                while j >= 0 and not re.match(r"(global_|buffer_|scratch_|flat_)", ins[j]):
-                    if re.match(r"ds_write|ds_store", ins[j]):
-                        raise RuntimeError("%s: an LDS label store sits between the record prefetch and the step barrier" % name)
-                    j -= 1
-                if j < 0 or not ins[j].startswith("global_load_dwordx4"):
-                    raise RuntimeError("%s: the youngest vector-memory operation before the step barrier is `%s`, not the record prefetch" % (name, ins[j] if j >= 0 else "none"))
-        if n[1] != 2 or n[2] != (2 if garble else 0):
-            raise RuntimeError("%s: found %d / %d counted step barriers (vmcnt 1 / 2), expected 2 / %d" % (name, n[1], n[2], 2 if garble else 0))
-        out[name] = (n[1], n[2])
+        n = sum(1 for i, t in enumerate(ins) if t == "s_waitcnt lgkmcnt(0)" and 0 < i < len(ins) - 1 and ins[i + 1] == "s_barrier" and ins[i - 1].startswith("global_load_dwordx4"))
+        if n != 2:
+            raise RuntimeError("%s: found %d step barriers with the record prefetch issued right in front of them, expected 2" % (name, n))
+        if any(t.startswith("s_waitcnt vmcnt") and i + 1 < len(ins) and ins[i + 1] == "s_barrier" for i, t in enumerate(ins)):
+            raise RuntimeError("%s: a barrier waits for vector memory" % name)
+        out[name] = n
     return out
+
+
+_RELEASE_PROBE = r"""
+#include <hip/hip_runtime.h>
+__global__ void gsv_probe(unsigned* __restrict__ a, unsigned* __restrict__ out) {
+  a[threadIdx.x] = threadIdx.x * 3u;
+  __syncthreads();
+  out[threadIdx.x] = a[(threadIdx.x + 64) & 1023];
+}
+"""
+
+
+def check_workgroup_release_model():
+    """What the step barrier relies on, pinned on the compiler: for `global store; __syncthreads(); global load of another
+    wave's element` hipcc emits, on gfx950, no `s_waitcnt vmcnt` between the store and s_barrier and no cache invalidate
+    (buffer_inv / buffer_wbl2) around it — i.e. the toolchain's own workgroup-scope release/acquire does not wait for
+    store acknowledgements.  Returns the instructions of the probe kernel; raises RuntimeError if the toolchain stops doing so
+    (then the step barrier of kernels.hip must wait for vmcnt as well)."""
+    import re
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        src, obj = os.path.join(td, "probe.hip"), os.path.join(td, "kernels.o")
+        open(src, "w").write(_RELEASE_PROBE)
+        subprocess.check_call([os.path.join(ROCM, "bin", "hipcc"), "--offload-arch=gfx950", "-O3", "-c", src, "-o", obj], stderr=subprocess.DEVNULL)
+        ins = [v for k, v in _functions(disassemble_kernels(obj)).items() if "gsv_probe" in k][0]
+    st = [i for i, t in enumerate(ins) if t.startswith("global_store")][0]
+    ba = ins.index("s_barrier")
+    ld = [i for i, t in enumerate(ins) if t.startswith("global_load")][0]
+    if not st < ba < ld:
+        raise RuntimeError("probe kernel: unexpected order of store / barrier / load")
+    for t in ins[st:ld]:
+        if re.match(r"s_waitcnt .*vmcnt", t) or t.startswith(("buffer_inv", "buffer_wbl2")):
+            raise RuntimeError("hipcc now emits `%s` inside a workgroup release/acquire on gfx950: the step barrier's memory model no longer holds" % t)
+    return ins[: ins.index("s_endpgm") + 1]
 
 
 def build(force=False, verbose=False):
@@ -116,7 +140,7 @@ def build(force=False, verbose=False):
             print(" ".join(c), file=sys.stderr)
         subprocess.check_call(c)
         if i == 0:
-            check_step_barrier_isa()  # refuse to link a kernel whose hand-counted step barrier the compiler has rearranged
+            check_step_barrier_isa()  # refuse to link a kernel whose step barrier the compiler has rearranged
     return OUT
 
 

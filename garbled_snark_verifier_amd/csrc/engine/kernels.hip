@@ -221,11 +221,17 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     //
     // Software pipeline, two steps deep: while step s computes, the descriptor (scalar load: the whole
     // step bookkeeping stays on the scalar unit, which matters because all 16 waves run it even when only one
-    // has gates) + this lane's first record of step s+2 are in flight (program records stream from HBM).  The step
-    // barrier must only wait for what other waves will read — this step's label stores — so it is a hand-counted
-    // `s_waitcnt vmcnt(N)`: vector-memory ops retire in issue order and the N youngest ops of the wave are, by
-    // construction (compiler barriers pin the order), the record prefetch load and, when the wave's last pass
-    // held AND gates, the ciphertext store.
+    // has gates) + this lane's first record of step s+2 are in flight (program records stream from HBM).
+    //
+    // The step barrier is `s_waitcnt lgkmcnt(0); s_barrier`: it waits for the wave's LDS stores (window labels) and scalar
+    // loads, NOT for its vector-memory operations.  The waves of a workgroup share their CU's vector L1 (this code object is
+    // not built for threadgroup-split mode), which serves their global accesses in issue order: a label stored to the HBM
+    // wire file before the barrier is seen by any wave of the workgroup that loads it after the barrier, whether or not the
+    // store has been acknowledged by L2.  That is the AMDGPU memory model's workgroup-scope release/acquire on gfx90a+,
+    // and exactly what hipcc emits for `global store; __syncthreads(); global load` on gfx950 (no vmcnt wait in front of
+    // s_barrier, no cache invalidate behind it; tests/test_engine_host.py pins that on the compiler's output).  So a step
+    // never waits for store acknowledgements (~1 us each), and the record prefetch and the ciphertext stores stay in
+    // flight across the barrier by themselves.
     const uint32_t last_step = ka.n_steps - 1;
     auto is_narrow = [&](const u32x4& d) -> bool { return HASH == 0 && !no_narrow && d.y != 0 && d.y * LPG + d.w <= BT; };
     // wide steps: is the AND remainder small enough for the multi-lane form?
@@ -235,9 +241,8 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       if (!inst_active) { d.y = 0; d.w = 0; }
       return d;
     };
-    // First 16 bytes (the operand / output slots) of this lane's first (or only) record of step d.  ALWAYS exactly one
-    // vector load per lane and per wave, whatever the lane has to do: the step barrier's counted vmcnt relies on it.
-    // Lanes without a gate read the step table's first entry (always present).  The second half of an AND record
+    // First 16 bytes (the operand / output slots) of this lane's first (or only) record of step d.  Lanes without a gate
+    // read the step table's first entry (always present): one unconditional load, no divergence.  The second half of an AND record
     // (gate id, third type bit) is only needed when the AES starts: it is loaded together with the operands.
     const glb_u8* const and_bytes = (const glb_u8*)ka.ands;
     const glb_u8* const xor_bytes = (const glb_u8*)ka.xors;
@@ -260,7 +265,6 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     // r0 <- n0 <- n2r form did, exposing a full L2 round trip per step).
     u32x4 sdA = load_desc(0), sdB = load_desc(1);
     Rec recA = load_rec(sdA), recB = load_rec(sdB);
-    const uint32_t wave_first = __builtin_amdgcn_readfirstlane(tid);  // index of the wave's first lane inside its instance group
     // decoded AND record
     struct AndOp { uint32_t a1, a2, b1, b2, p, c, t; uint64_t gid; };
     auto decode_and = [&](const Rec& q, const u32x2& hi) -> AndOp {
@@ -324,7 +328,6 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     auto run_step = [&](const uint32_t s, const u32x4& sd, Rec& r0, const u32x4& n2sd) __attribute__((always_inline)) {
       const uint32_t and_off = sd.x, and_cnt = sd.y, xor_off = sd.z, total = sd.y + sd.w;
       (void)total;
-      bool young_ct = false;                 // did this wave issue a ciphertext store AFTER its last label store?
       if (ka.step_clock && blockIdx.x == 0 && threadIdx.x == 0 && rep + 1 == ka.replays) ka.step_clock[s] = wall_clock64();  // older than this step's stores
       if (is_narrow(sd)) {
         // ------------------------------------------------------------------ narrow step: one pass
@@ -341,9 +344,6 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
             if (EVAL) wf.st_bit(o.c, (wf.ld_bit(o.x1) ^ wf.ld_bit(o.x2) ^ wf.ld_bit(o.x3) ^ wf.ld_bit(o.x4) ^ o.par) & 1u);
           }
         }
-        // the AND lanes come first, so a wave holding any AND lane issued its ciphertext store last... unless it
-        // also holds free-gate lanes (boundary wave), whose label store is issued after it in program order.
-        young_ct = !EVAL && !no_store && wave_first + 64u <= na;
       } else {
         // ------------------------------------------------------------------ wide step
         // AND-family gates: passes of 1024 gates, one per lane (two interleaved AES blocks each).
@@ -449,16 +449,12 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
             load_xor_recs(nb + XB * BT, xrn);
           }
         }
-        young_ct = !EVAL && !no_store && xor_cnt == 0 && and_full == and_cnt && wave_first < and_cnt &&
-                   (wave_first + ((and_cnt - 1u - wave_first) / BT) * BT) < and_cnt;
       }
       // keep r0's registers reserved through the step: were they handed to a store's data in between, the refill below would
       // have to wait for that store (vmcnt(0) in front of the prefetch) before it could overwrite them
       asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w)::"memory");
-      r0 = load_rec(n2sd);  // the wave's youngest load: stays in flight across the barrier and the whole next step
-      asm volatile("" ::: "memory");
-      if (young_ct) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      r0 = load_rec(n2sd);  // stays in flight across the barrier and the whole next step
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     for (uint32_t s = 0; s < ka.n_steps; s += 2) {
       const u32x4 sdA2 = load_desc(s + 2);  // lands during the step; the record load that needs it is issued at the step's end
