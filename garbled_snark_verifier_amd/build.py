@@ -121,28 +121,32 @@ def check_workgroup_release_model():
     return ins[: ins.index("s_endpgm") + 1]
 
 
-def build(force=False, verbose=False):
-    if os.environ.get("GSV_ENGINE_SO"):  # experiments: load a differently built library
+def build(force=False, verbose=False, diag=False):
+    """diag=True builds libgsv_engine_diag.so instead: the same library with the kernel's timing ablations compiled in
+    (-DGSV_DIAG_BUILD; GSV_DIAG=<bits> then takes effect, see kernel_api.h) — load it with GSV_ENGINE_SO for experiments."""
+    if os.environ.get("GSV_ENGINE_SO") and not diag:  # experiments: load a differently built library
         return os.environ["GSV_ENGINE_SO"]
-    if not force and not _newer(OUT, _all_sources()):
-        return OUT
+    out = OUT.replace(".so", "_diag.so") if diag else OUT
+    if not force and not _newer(out, _all_sources()):
+        return out
     hipcc = os.path.join(ROCM, "bin", "hipcc")
-    k_o = os.path.join(ENG, "kernels.o")
+    k_o = os.path.join(ENG, "kernels_diag.o" if diag else "kernels.o")
     e_o = os.path.join(ENG, "engine.o")
     cmds = [
-        [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-promote-alloca-to-lds", "-c", os.path.join(ENG, "kernels.hip"), "-o", k_o],
+        [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-promote-alloca-to-lds"] + (["-DGSV_DIAG_BUILD"] if diag else []) +
+        ["-c", os.path.join(ENG, "kernels.hip"), "-o", k_o],
         ["g++", "-O2", "-std=c++17", "-fPIC", "-maes", "-msse2", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include"),
          "-Wall", "-Wno-unused-parameter", "-c", os.path.join(ENG, "engine.cpp"), "-o", e_o],
-        [hipcc, "-shared", "-o", OUT, k_o, e_o],
+        [hipcc, "-shared", "-o", out, k_o, e_o],
     ]
     for i, c in enumerate(cmds):
         if verbose:
             print(" ".join(c), file=sys.stderr)
         subprocess.check_call(c)
         if i == 0:
-            check_step_barrier_isa()  # refuse to link a kernel whose step barrier the compiler has rearranged
-    return OUT
+            check_step_barrier_isa(disassemble_kernels(k_o))  # refuse to link a kernel whose step barrier the compiler has rearranged
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))

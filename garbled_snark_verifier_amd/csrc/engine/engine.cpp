@@ -1013,7 +1013,7 @@ static int launch(gsv_session* s, uint64_t gate_id_base, bool eval, uint64_t rep
   ka.hasher = uint32_t(s->hasher);
   ka.step_clock = static_cast<unsigned long long*>(s->step_clock);
   ka.instances_per_wg = s->ni;
-  if (const char* dg = getenv("GSV_DIAG")) ka.diag = uint32_t(atoi(dg));  // timing experiments: outputs are wrong when set
+  if (const char* dg = getenv("GSV_DIAG")) ka.diag = uint32_t(atoi(dg));  // timing experiments (libgsv_engine_diag.so only): outputs are wrong when set
   HIPCHK(hipEventRecord(s->ev0, s->e->stream));
   if (ka.n_steps) {
     int lrc = gsvk_launch_program(&ka, uint32_t(s->n_inst), eval ? 1 : 0, s->e->stream);

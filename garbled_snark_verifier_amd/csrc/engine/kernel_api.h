@@ -37,7 +37,8 @@ struct KernelArgs {
   uint32_t instances_per_wg;  // 1 or 2 (2 needs a program compiled for half the LDS window)
   uint32_t hasher;            // 0 = AesNiHasher, 1 = Blake3Hasher
   unsigned long long* step_clock;  // diagnostics: workgroup 0 stamps the 100 MHz wall clock at the start of every step of the last replay (null = off)
-  uint32_t diag;  // timing experiments only (GSV_DIAG env): 1 = skip AES, 2 = no record prefetch, 4 = skip label loads, 8 = skip stores
+  uint32_t diag;  // timing experiments only (GSV_DIAG env; honoured by a library built with -DGSV_DIAG_BUILD = `build.py --diag`, ignored by
+                  // the production build): 1 = skip AES, 4 = skip label loads, 8 = skip stores, 16 = no multi-lane narrow form
 };
 
 }  // namespace dev

@@ -91,26 +91,28 @@ struct WireFile {
   glb_u8* hbm_bits;   // evaluate: plaintext bits
   uint32_t win_base;  // LDS byte address of this instance's label window
   uint32_t bit_base;  // LDS byte address of this instance's window plaintext bits
-  __device__ __forceinline__ lds_u128* win(uint32_t idx) const { return reinterpret_cast<lds_u128*>(uintptr_t(win_base + idx * 16u)); }
-  __device__ __forceinline__ lds_u32* win_word(uint32_t idx, uint32_t c) const { return reinterpret_cast<lds_u32*>(uintptr_t(win_base + idx * 16u + c * 4u)); }
+  // `slot` still carries GSV_SLOT_LDS_FLAG: (slot << 4) + (win_base - FLAG * 16) is ONE v_lshl_add_u32 (mod 2^32), where masking
+  // the flag off first costs an AND and a separate shift
+  __device__ __forceinline__ lds_u128* win(uint32_t slot) const { return reinterpret_cast<lds_u128*>(uintptr_t((slot << 4) + (win_base - (GSV_SLOT_LDS_FLAG << 4)))); }
+  __device__ __forceinline__ lds_u32* win_word(uint32_t slot, uint32_t c) const { return reinterpret_cast<lds_u32*>(uintptr_t((slot << 4) + (win_base - (GSV_SLOT_LDS_FLAG << 4)) + c * 4u)); }
   __device__ __forceinline__ lds_u8* win_bit(uint32_t idx) const { return reinterpret_cast<lds_u8*>(uintptr_t(bit_base + idx)); }
   __device__ __forceinline__ Label ld(uint32_t slot) const {
     u32x4 v;
-    if (slot & GSV_SLOT_LDS_FLAG) v = *win(slot & GSV_SLOT_INDEX_MASK); else v = hbm[slot];
+    if (slot & GSV_SLOT_LDS_FLAG) v = *win(slot); else v = hbm[slot];
     return Label{{v.x, v.y, v.z, v.w}};
   }
   __device__ __forceinline__ void st(uint32_t slot, const Label& l) const {
     const u32x4 v = {l.w[0], l.w[1], l.w[2], l.w[3]};
-    if (slot & GSV_SLOT_LDS_FLAG) *win(slot & GSV_SLOT_INDEX_MASK) = v; else hbm[slot] = v;
+    if (slot & GSV_SLOT_LDS_FLAG) *win(slot) = v; else hbm[slot] = v;
   }
   // one 32-bit column of a label (narrow-step mode: a label is spread over the 4 lanes of a quad)
   __device__ __forceinline__ uint32_t ld_word(uint32_t slot, uint32_t c) const {
     uint32_t v;
-    if (slot & GSV_SLOT_LDS_FLAG) v = *win_word(slot & GSV_SLOT_INDEX_MASK, c); else v = ((const glb_u32*)hbm)[slot * 4u + c];
+    if (slot & GSV_SLOT_LDS_FLAG) v = *win_word(slot, c); else v = ((const glb_u32*)hbm)[slot * 4u + c];
     return v;
   }
   __device__ __forceinline__ void st_word(uint32_t slot, uint32_t c, uint32_t v) const {
-    if (slot & GSV_SLOT_LDS_FLAG) *win_word(slot & GSV_SLOT_INDEX_MASK, c) = v; else ((glb_u32*)hbm)[slot * 4u + c] = v;
+    if (slot & GSV_SLOT_LDS_FLAG) *win_word(slot, c) = v; else ((glb_u32*)hbm)[slot * 4u + c] = v;
   }
   __device__ __forceinline__ uint32_t ld_bit(uint32_t slot) const {
     uint32_t b;
@@ -202,7 +204,13 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   // this lane's column of delta (selects, not a runtime-indexed array: that would be promoted to static LDS)
   const uint32_t dq = col == 0 ? delta.w[0] : col == 1 ? delta.w[1] : col == 2 ? delta.w[2] : delta.w[3];
   cst_u128* const step_q = (cst_u128*)ka.steps;
+  // Timing ablations (GSV_DIAG, kernel_api.h) exist only in a library built with -DGSV_DIAG_BUILD (build.py --diag): as run-time
+  // flags they cost the production loop a dozen register initialisations and several branches per gate.
+#ifdef GSV_DIAG_BUILD
   const bool no_store = (ka.diag & 8u) != 0, no_load = (ka.diag & 4u) != 0, no_aes = (ka.diag & 1u) != 0, no_narrow = (ka.diag & 16u) != 0;
+#else
+  constexpr bool no_store = false, no_load = false, no_aes = false, no_narrow = false;
+#endif
 
   for (uint32_t rep = 0; rep < ka.replays; ++rep) {
     const uint64_t gid_base = ka.gid_base + uint64_t(ka.rep_base + rep) * ka.n_gates;

@@ -3,8 +3,8 @@
   wide    fq12_sqmul chain replayed (the Miller-loop / final-exponentiation shape), 512 instances
   narrow  fq_sqrt as a plan of exp_chunk units (the decompression ladders: thousands of narrow steps), 512 instances
   inverse fq12_inverse (one Fq inversion inside: binary extended Euclid), 512 instances
-plus a hash check of each against the CPU oracle on one instance (KAB_NOCHECK=1 skips it: timing experiments under GSV_DIAG,
-whose outputs are wrong by design).  GSV_ENGINE_SO selects the library (garbled_snark_verifier_amd/build.py).
+plus a hash check of each against the CPU oracle on one instance (KAB_NOCHECK=1 skips it: timing experiments under GSV_DIAG —
+which only the diagnostic library honours, `build.py --diag` -> libgsv_engine_diag.so — give wrong outputs by design).  GSV_ENGINE_SO selects the library (garbled_snark_verifier_amd/build.py).
 usage: kernel_ab.py [instances]"""
 import os
 import sys

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-step latency probe: times narrow programs (u254_add: 760 steps of 1-2 gates; fq_mul: 2812 steps, mean 147
-gates) replayed many times on one instance, optionally under GSV_DIAG ablations.  Diagnostic tool, not a benchmark."""
+gates) replayed many times on one instance, optionally under GSV_DIAG ablations (those need the diagnostic library:
+`python garbled_snark_verifier_amd/build.py --diag`, then GSV_ENGINE_SO=.../libgsv_engine_diag.so).  Diagnostic tool, not a benchmark."""
 import os
 import sys
 
