@@ -446,7 +446,7 @@ def run_verifier(args):
         g_rank = r["gates_per_instance"] * B
         achieved = g_rank * bytes_per_gate / stream_s / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_verifier", "traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_final", "traffic.json")
         if os.path.exists(tpath) and B == 512 and compressed:
             try:
                 traffic = float(json.load(open(tpath))["hbm_bytes_per_launch"])

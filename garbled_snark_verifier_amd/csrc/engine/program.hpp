@@ -316,6 +316,7 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
   CompileOptions opt = opt_in;
   if (const char* e = getenv("GSV_AND_CAP")) opt.and_cap = uint32_t(atoi(e));  // tuning knobs (the defaults are the measured best)
   if (const char* e = getenv("GSV_XOR_CAP")) opt.xor_cap = uint32_t(atoi(e));
+  if (const char* e = getenv("GSV_LDS_SLOTS_CAP")) opt.lds_slots = std::min<uint32_t>(opt.lds_slots, uint32_t(atoi(e)));  // experiments: more instances per workgroup
   const uint32_t nw = t.n_wires;
   Program p;
   p.n_gates = t.size();

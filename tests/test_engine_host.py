@@ -175,6 +175,22 @@ def test_gate_fusion_shapes_and_unfused_path(monkeypatch):
     _hostsim_check("fq_add", 4)
 
 
+def test_width_capped_list_schedule_matches_oracle(monkeypatch):
+    """compile_program's width-capped list scheduler (CompileOptions::and_cap / xor_cap, GSV_AND_CAP / GSV_XOR_CAP; off by default:
+    measured slower on the GPU, profiles/r02_verifier): labels depend on gate ids and dataflow, never on the schedule, so every
+    cap must interpret to the oracle's ciphertexts, labels and bits — including the degenerate one gate of each kind per step."""
+    asap = {spec: h.SimProgram(spec).info["n_steps"] for spec in ("fq_mul", "random_circuit:5")}
+    for cap_and, cap_xor in ((64, 64), (1, 1), (0, 16)):
+        monkeypatch.setenv("GSV_AND_CAP", str(cap_and))
+        monkeypatch.setenv("GSV_XOR_CAP", str(cap_xor))
+        for spec, seed in (("fq_mul", 1), ("random_circuit:5", 3), ("driver_mix", 2)):
+            sp = _hostsim_check(spec, seed)
+            if spec in asap:
+                assert sp.info["n_steps"] >= asap[spec]  # never shorter than the critical path
+                if cap_and == 1:
+                    assert sp.info["n_steps"] >= max(sp.info["n_ct"], sp.info["n_fused_free"])
+
+
 @pytest.mark.parametrize("spec,units,seed", [
     ("driver_mix", ["test::mixed_outputs"], 5),           # unit with pass-through / constant / internal outputs, nested child flattened
     ("driver_mix", ["test::inner"], 5),                   # unit nested inside a flattened component; one of its outputs is dead

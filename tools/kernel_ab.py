@@ -31,7 +31,7 @@ def tiled(n_in, seed=1):
 # wide
 prog = gsv.Program.from_circuit("fq12_sqmul", chain_feedback=True)
 R = 6
-sess = gsv.Session(eng, prog, B, R, 2)
+sess = gsv.Session(eng, prog, B, R, int(os.environ.get("KAB_CT_CAP", "2")))
 D, K, I = tiled(prog.info["n_inputs"])
 best = 1e9
 for _ in range(3):

@@ -5,8 +5,9 @@
 //
 // Two complete, validated fixed-key AES-128 encryptions on gfx950, both run with every CU full, in blocks per second:
 //   T-table   the production form (kernels.hip / gate_math.hpp): Te0 / Te2 replicated once per LDS bank with a 256-byte entry
-//             stride, lookup address = one v_perm_b32, Te1 / Te3 by v_alignbit, columns summed with V_BITOP3 — two interleaved
-//             blocks per lane, 1024-thread workgroups (16 waves per CU), round keys through the scalar cache.
+//             stride, lookup address = one v_perm_b32, ONE v_alignbit per column for both rotated terms (Te1[b] ^ Te3[d] ^ k =
+//             rotl8(Te0[b] ^ Te2[d] ^ rotr8 k), middle-round keys stored pre-rotated), columns summed with V_BITOP3 — two
+//             interleaved blocks per lane, 1024-thread workgroups (16 waves per CU), round keys through the scalar cache.
 //   bitsliced no tables, no LDS: every lane holds 32 blocks as 128 bit-planes in VGPRs; SubBytes is the Boyar-Peralta
 //             113-gate S-box circuit (32 AND + 81 XOR/XNOR) on 16 byte positions, ShiftRows is register renaming, MixColumns
 //             and AddRoundKey are XOR networks; the compiler is free to fuse pairs of gates into V_BITOP3.  The transposition
@@ -33,14 +34,15 @@ struct Banked {
   __device__ __forceinline__ uint32_t lk(uint32_t s) const {
     const uint32_t addr = __builtin_amdgcn_perm(s, lane4, 0x0c0c0000u | (uint32_t(4 + BYTE) << 8));
     const uint32_t v = *reinterpret_cast<const LDS_U32*>(uintptr_t(addr + ((K & 2) ? 128u : 0u)));
-    return (K & 1) ? __builtin_amdgcn_alignbit(v, v, 24) : v;
+    return v;  // K = 0 / 2 only: the rotated tables are folded into the column sum (col)
   }
   __device__ __forceinline__ uint32_t rk(int i) const { return c_rk[i]; }
 };
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 template <class T>
 __device__ __forceinline__ uint32_t col(const T& t, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t k) {
-  return xor3(xor3(t.template lk<0, 0>(x0), t.template lk<1, 1>(x1), t.template lk<2, 2>(x2)), t.template lk<3, 3>(x3), k);
+  const uint32_t odd = xor3(t.template lk<0, 1>(x1), t.template lk<2, 3>(x3), k);  // k = rotr8(round key) for the middle rounds
+  return xor3(t.template lk<0, 0>(x0), t.template lk<2, 2>(x2), __builtin_amdgcn_alignbit(odd, odd, 24));
 }
 template <class T>
 __device__ __forceinline__ uint32_t last(const T& t, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t k) {
@@ -158,7 +160,9 @@ __global__ __launch_bounds__(256) void bitsliced_kernel(uint32_t* io, int iters)
 
 int main() {
   const gsv::AesTables& t = gsv::AesTables::fixed_key();
-  CHK(hipMemcpyToSymbol(HIP_SYMBOL(c_rk), t.rk, sizeof t.rk));
+  uint32_t dev_rk[44];  // middle rounds' keys rotated right by one byte (see col)
+  for (int i = 0; i < 44; ++i) dev_rk[i] = (i >= 4 && i < 40) ? ((t.rk[i] >> 8) | (t.rk[i] << 24)) : t.rk[i];
+  CHK(hipMemcpyToSymbol(HIP_SYMBOL(c_rk), dev_rk, sizeof dev_rk));
   CHK(hipMemcpyToSymbol(HIP_SYMBOL(c_rkb), t.rk_bytes, sizeof t.rk_bytes));
   hipDeviceProp_t prop;
   CHK(hipGetDeviceProperties(&prop, 0));
