@@ -6,11 +6,12 @@ the circuit src/garbled_groth16.rs garbles and examples/groth16_garble.rs:116-12
 Miller loop, final exponentiation, comparison — 11,687,200,297 gates per instance for the synthetic 2-public-input verifying
 key of tests/groth16_ref.py (the reference quotes 11,174,708,821 for its 1-public-input key; DESIGN.md §2 has the
 component-by-component reconciliation), recorded as a plan of component programs and garbled exactly as the reference streams
-it.  Every GPU garbles `--instances` independent cut-and-choose instances (own seed => own delta / labels / ciphertext stream).
+it.  Every GPU garbles `--instances` (default 1024 = four per workgroup on 256 CUs) independent cut-and-choose instances (own seed => own
+delta / labels / ciphertext stream).
 
 A "step" is one SLICE of that pass: the plan's calls are cut into `--slices` consecutive groups of (nearly) equal gate count and
 step i garbles slice i mod slices for all instances of the rank — wires, gate ids and the ciphertext stream continue from step
-to step, so `--slices` consecutive steps are exactly one full verifier pass per instance (a whole pass is ~80 s per step at 512
+to step, so `--slices` consecutive steps are exactly one full verifier pass per instance (a whole pass is ~130 s at 1024
 instances, which no driver budget fits 25 times).  `value` = gates garbled by all ranks in the timed steps / elapsed, with the
 ciphertexts produced into HBM (one call block per instance, overwritten by the next call: inputs and outputs resident in HBM).
 The PCIe-inclusive rate — every ciphertext copied out and folded into the per-instance CBC-MAC commitment
@@ -148,7 +149,7 @@ def timed_steps(work, slices, warmup, steps, dist, sync, time_budget_s=None, t_s
     warm_s = time.perf_counter() - t0
     steps_run = steps
     if time_budget_s is not None:
-        # projected duration of the timed steps from the warm-up's gate rate (5e10 gates/s per 512 instances when there was no warm-up)
+        # projected duration of the timed steps from the warm-up's gate rate (no projection when there was no warm-up)
         wg = sum(slices[i % S][2] for i in range(warmup))
         rate = wg / warm_s if warmup and warm_s > 0 else None
         left = time_budget_s - (time.time() - (t_start or T_START))
@@ -212,7 +213,7 @@ def _plan_cache_path(args, circuit, units):
     h = hashlib.sha256()
     with open(b.build(), "rb") as f:
         h.update(f.read())  # the file format and the compiler live in the library: any rebuild invalidates the cache
-    h.update(("|".join([circuit, ",".join(units), "half"])).encode())
+    h.update(("|".join([circuit, ",".join(units), "window/4"])).encode())
     name = "plan_%s.gsvplan" % h.hexdigest()[:24]
     cands = [args.plan_cache] if args.plan_cache else [os.environ.get("GSV_PLAN_CACHE"), "/dev/shm", "/tmp"]
     for d in cands:
@@ -250,7 +251,7 @@ def get_plan(gsv, engine, args, circuit, units, rank, local_rank, local_world, d
                     log("bench.py: %.0f GB of host memory available, the plan build needs ~50 GB" % avail_gb)
             except (OSError, IndexError, ValueError):
                 pass
-            plan = gsv.Plan.from_circuit(circuit, units, half_window=True)
+            plan = gsv.Plan.from_circuit(circuit, units, window_div=4)  # one image per program, good for 1, 2 and 4 instances per workgroup
             info["how"] = "built"
             if local_world > 1:
                 if not path:
@@ -411,27 +412,35 @@ def run_verifier(args):
         except Exception as e:  # the baseline must not cost the run its result line
             result["cpu_baseline"] = {"error": repr(e)}
 
-    work = VerifierWork(gsv, engine, plan, B, instance_seeds(rank, B))
-    ni = work.sess.instances_per_workgroup
-    # ---- PCIe-inclusive rate with the commitment: calls from the middle of the plan for all B instances, every ciphertext copied
-    # out and folded into its instance's CBC-MAC while the next call is garbled (correctness of this path: the check above)
+    # ---- PCIe-inclusive rate with the commitment: calls from the middle of the plan, every ciphertext copied out and folded into its
+    # instance's CBC-MAC while the next call is garbled (correctness of this path: the check above).  In a session of its own, closed
+    # before the timed one is created: the drain keeps a gate-order copy of the ciphertext blocks (twice their HBM).
     if rank == 0 and world == 1 and not args.no_e2e:
         try:
-            first = slices[len(slices) // 2][0]
-            n, g_acc = 0, 0
-            while first + n < n_calls and g_acc * B < args.e2e_gates:
-                g_acc += int(ci[first + n, 1]); n += 1
-            work.new_pass()
-            t0 = time.perf_counter()
-            work.sess.garble_calls(first, n, discard=False)
-            dt = time.perf_counter() - t0
-            ct = int(ci[first:first + n, 3].sum())
-            result["e2e_with_commitment"] = {"value": g_acc * B / dt, "unit": "gates/s", "instances": B, "seconds": dt, "ciphertext_gb_per_s": ct * B * 16 / dt / 1e9,
-                                             "sample": "calls %d..%d of the plan (%d gates, %d ciphertexts per instance) for %d instances: garbled, drained over PCIe and CBC-MAC'ed per instance on the host (gsv_session_garble_streaming_calls)"
-                                                       % (first, first + n - 1, g_acc, ct, B)}
-            log("bench.py: e2e with commitment %.3g gates/s (%.1f GB/s of ciphertexts)" % (g_acc * B / dt, ct * B * 16 / dt / 1e9))
+            Be = max(1, min(B, args.e2e_instances))
+            e2e = VerifierWork(gsv, engine, plan, Be, instance_seeds(rank, Be))
+            try:
+                first = slices[len(slices) // 2][0]
+                n, g_acc = 0, 0
+                while first + n < n_calls and g_acc * Be < args.e2e_gates:
+                    g_acc += int(ci[first + n, 1]); n += 1
+                e2e.new_pass()
+                t0 = time.perf_counter()
+                e2e.sess.garble_calls(first, n, discard=False)
+                dt = time.perf_counter() - t0
+                ct = int(ci[first:first + n, 3].sum())
+                result["e2e_with_commitment"] = {"value": g_acc * Be / dt, "unit": "gates/s", "instances": Be, "instances_per_workgroup": e2e.sess.instances_per_workgroup, "seconds": dt,
+                                                 "ciphertext_gb_per_s": ct * Be * 16 / dt / 1e9,
+                                                 "sample": "calls %d..%d of the plan (%d gates, %d ciphertexts per instance) for %d instances: garbled, drained over PCIe and CBC-MAC'ed per instance on the host (gsv_session_garble_streaming_calls)"
+                                                           % (first, first + n - 1, g_acc, ct, Be)}
+                log("bench.py: e2e with commitment %.3g gates/s (%.1f GB/s of ciphertexts)" % (g_acc * Be / dt, ct * Be * 16 / dt / 1e9))
+            finally:
+                e2e.close()
         except Exception as e:
             result["e2e_with_commitment"] = {"error": repr(e)}
+
+    work = VerifierWork(gsv, engine, plan, B, instance_seeds(rank, B))
+    ni = work.sess.instances_per_workgroup
 
     def sync():
         torch.cuda.synchronize()
@@ -447,9 +456,11 @@ def run_verifier(args):
         achieved = g_rank * bytes_per_gate / stream_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r02_final", "traffic.json")
-        if os.path.exists(tpath) and B == 512 and compressed:
+        if os.path.exists(tpath) and compressed:
             try:
-                traffic = float(json.load(open(tpath))["hbm_bytes_per_launch"])
+                tj = json.load(open(tpath))
+                if int(tj.get("instances_per_gpu", 512)) == B:  # PMC passes of this very configuration (tools/profile_r02.sh)
+                    traffic = float(tj["hbm_bytes_per_launch"])
             except (KeyError, ValueError):
                 pass
         result.update({
@@ -559,7 +570,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--instances", type=int, default=512, help="cut-and-choose instances per GPU (more than the 256 CUs: two per workgroup)")
+    ap.add_argument("--instances", type=int, default=1024, help="cut-and-choose instances per GPU (4 x the 256 CUs: four per workgroup; 257..512: two per workgroup)")
+    ap.add_argument("--e2e-instances", type=int, default=512, help="instances of the e2e_with_commitment measurement (its gate-order copy of the ciphertext blocks doubles their HBM)")
     ap.add_argument("--slices", type=int, default=10, help="steps per full verifier pass: the plan's calls are cut into this many slices of equal gate count")
     ap.add_argument("--workload", default="verifier_compressed", choices=["synthetic", "verifier", "verifier_compressed"],
                     help="verifier_compressed (default) / verifier: the restated groth16_verify_compressed / groth16_verify circuit of the committed fixture as a plan of "

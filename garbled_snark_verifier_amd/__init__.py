@@ -300,25 +300,31 @@ class Plan:
         self.n_inputs = self.n_outputs = 0
 
     @classmethod
-    def from_circuit(cls, spec, units, half_window=False):
+    def from_circuit(cls, spec, units, half_window=False, window_div=None):
         """Record a built-in circuit with the named components (list of names such as "fq12::mul_montgomery") as calls.
-        half_window: compile every program once, for the half LDS window (serves one and two instances per workgroup; the
-        recorded traces are not kept) — a third less host memory and one compilation for plans with hundreds of programs."""
+        window_div = 2 | 4 (half_window=True is window_div=2): compile every program once, for half / a quarter of the LDS label
+        window; the one image then serves every layout of up to that many instances per workgroup and the recorded traces are not
+        kept — a third less host memory and one compilation for plans with hundreds of programs."""
         self = cls.__new__(cls)
         self.h = C.c_void_p()
         self.programs = []
         _live["plan"].add(self)
-        old = os.environ.get("GSV_PLAN_HALF_WINDOW")
-        if half_window:
-            os.environ["GSV_PLAN_HALF_WINDOW"] = "1"
+        div = int(window_div) if window_div else (2 if half_window else 1)
+        if div not in (1, 2, 4):
+            raise ValueError("window_div must be 1, 2 or 4")
+        saved = {k: os.environ.get(k) for k in ("GSV_PLAN_WINDOW_DIV", "GSV_PLAN_HALF_WINDOW")}
+        if div > 1:
+            os.environ["GSV_PLAN_WINDOW_DIV"] = str(div)
+            os.environ.pop("GSV_PLAN_HALF_WINDOW", None)
         try:
             _chk(lib().gsv_plan_from_circuit(spec.encode(), ",".join(units).encode(), C.byref(self.h)))
         finally:
-            if half_window:
-                if old is None:
-                    del os.environ["GSV_PLAN_HALF_WINDOW"]
-                else:
-                    os.environ["GSV_PLAN_HALF_WINDOW"] = old
+            if div > 1:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
         g, c, k = C.c_uint64(), C.c_uint64(), C.c_uint64()
         _chk(lib().gsv_plan_counts(self.h, C.byref(g), C.byref(c), C.byref(k)))
         n_in, n_out = C.c_uint64(), C.c_uint64()

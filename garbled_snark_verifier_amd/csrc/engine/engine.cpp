@@ -84,12 +84,14 @@ struct ProgramSource {
 };
 
 struct gsv_program {
-  Program prog;                    // full LDS window: one instance per workgroup
-  std::unique_ptr<Program> prog2;  // half window: two instances per workgroup (compiled on demand)
-  bool half_only = false;          // `prog` itself was compiled for the half window and serves both layouts (GSV_PLAN_HALF_WINDOW: no second variant, no trace kept)
+  Program prog;                    // compiled for 1/window_div of the LDS label window: serves every layout of up to window_div instances per workgroup
+  std::map<uint32_t, std::unique_ptr<Program>> variants;  // instances per workgroup (2, 4) -> the program compiled for that share of the window, on demand, from `src`
+  uint32_t window_div = 1;         // 1: full window (the other layouts are compiled on demand); 2 / 4: `prog` itself was compiled for half / a quarter of the
+                                   // window and is the only image (GSV_PLAN_WINDOW_DIV: no second variant, no trace kept)
   bool device_only = false;        // loaded by gsv_plan_load straight into device memory: the host keeps the metadata, not the records
   uint64_t loaded_image_bytes = 0; // size of the records of a device_only program
-  const Program& variant(uint32_t ni) const { return (ni == 2 && !half_only) ? *prog2 : prog; }
+  uint32_t image_key(uint32_t ni) const { return ni <= window_div ? 1u : ni; }  // which compiled image a layout runs
+  const Program& variant(uint32_t ni) const { return ni <= window_div ? prog : *variants.at(ni); }
   std::unique_ptr<ProgramSource> src;
   std::mutex mu;
   std::map<std::pair<int, int>, DevProgram> dev;  // per (device, instances per workgroup)
@@ -314,28 +316,36 @@ int gsv_labels_from_seed(uint64_t seed, size_t n_inputs, uint8_t delta[16], uint
 }
 
 // ---------------------------------------------------------------- sessions
-// The half-window variant of a program (two instances per workgroup), compiled on first use.  Throws on failure; p->mu held by the caller.
-static void compile_half_window_variant(gsv_program* p) {
-  if (p->prog2 || p->half_only) return;
-  if (!p->src) gsv_panic("this program was loaded from a plan file compiled for the full LDS window: it cannot serve two instances per workgroup (build the plan with GSV_PLAN_HALF_WINDOW=1)");
+// The variant of a program for `ni` instances per workgroup (1/ni of the LDS window each), compiled on first use.  Throws on failure; p->mu held by the caller.
+static void compile_window_variant(gsv_program* p, uint32_t ni) {
+  if (ni <= p->window_div || p->variants.count(ni)) return;
+  if (!p->src) gsv_panic("this program was compiled for 1/" + std::to_string(p->window_div) + " of the LDS window and its trace was not kept: it cannot serve " + std::to_string(ni) +
+                         " instances per workgroup (build the plan with GSV_PLAN_WINDOW_DIV=" + std::to_string(ni) + ")");
   CompileOptions opt = p->src->opt;
-  opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / 2);
+  opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / ni);
   std::unique_ptr<Program> q(new Program(compile_program(p->src->trace, p->src->inputs, p->src->outputs, p->src->feedback, opt)));
   for (size_t i = 0; i < q->input_slots.size(); ++i)
     if (q->input_slots[i] != SLOT_FIRST_INPUT + i) gsv_panic("internal: inputs are not slot-contiguous");
-  p->prog2 = std::move(q);
+  p->variants[ni] = std::move(q);
+}
+// Instances per workgroup of a session: as many (1, 2, 4) as keep every CU busy — the latency-bound narrow steps then cost their fixed
+// time once for all of them (kernels.hip) — limited to what the programs can serve; GSV_INSTANCES_PER_WG=1|2|4 overrides.
+static uint32_t choose_instances_per_wg(size_t n_instances, int n_cus, uint32_t max_servable) {
+  uint32_t ni = n_instances > 2 * size_t(n_cus) ? 4u : n_instances > size_t(n_cus) ? 2u : 1u;
+  if (const char* ev = getenv("GSV_INSTANCES_PER_WG")) { int v = atoi(ev); if (v == 1 || v == 2 || v == 4) ni = uint32_t(v); }
+  while (ni > 1 && (ni > max_servable || ni > n_instances)) ni /= 2;
+  return ni;
 }
 static int upload_program(gsv_engine* e, gsv_program* p, uint32_t ni, DevProgram* out) {
   std::lock_guard<std::mutex> lk(p->mu);
-  auto it = p->dev.find({e->device, int(ni)});
+  // one image per compiled variant: a program compiled for a share of the window serves every layout up to it from ONE copy in HBM
+  // (the verifier plan's images are 41 GB)
+  const int key = int(p->image_key(ni));
+  auto it = p->dev.find({e->device, key});
   if (it != p->dev.end()) { *out = it->second; return GSV_OK; }
-  if (p->half_only) {  // one compiled image serves both layouts: one copy in HBM (the verifier plan's images are 42 GB)
-    auto other = p->dev.find({e->device, int(ni == 2 ? 1 : 2)});
-    if (other != p->dev.end()) { p->dev[{e->device, int(ni)}] = other->second; *out = other->second; return GSV_OK; }
-  }
-  if (ni == 2 && !p->prog2 && !p->half_only) {  // first session with two instances per workgroup: compile for half of the LDS window
+  if (ni > p->window_div) {  // first session with this many instances per workgroup: compile for that share of the LDS window
     GSV_TRY
-    compile_half_window_variant(p);
+    compile_window_variant(p, ni);
     GSV_CATCH
   }
   DevProgram d;
@@ -356,7 +366,7 @@ static int upload_program(gsv_engine* e, gsv_program* p, uint32_t ni, DevProgram
   if ((rc = up(&d.fb_dst, g.fb_dst_slot.data(), g.fb_dst_slot.size() * 4))) return rc;
   if ((rc = up(&d.out_slots, g.output_slots.data(), g.output_slots.size() * 4))) return rc;
   if ((rc = up(&d.ct_pos, g.ct_pos.data(), g.ct_pos.size() * 4))) return rc;
-  p->dev[{e->device, int(ni)}] = d;
+  p->dev[{e->device, key}] = d;
   *out = d;
   return GSV_OK;
 }
@@ -375,8 +385,7 @@ int gsv_session_create(gsv_engine* e, const gsv_program* cp, size_t n_instances,
   {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, e->device));
-    s->ni = n_instances > size_t(prop.multiProcessorCount) ? 2u : 1u;
-    if (const char* ev = getenv("GSV_INSTANCES_PER_WG")) { int v = atoi(ev); if (v == 1 || (v == 2 && n_instances >= 2)) s->ni = uint32_t(v); }
+    s->ni = choose_instances_per_wg(n_instances, prop.multiProcessorCount, p->src ? 4u : p->window_div);
   }
   int rc = upload_program(e, p, s->ni, &s->dp);
   if (rc) return rc;
@@ -473,12 +482,16 @@ int gsv_plan_from_circuit(const char* spec, const char* units_csv, gsv_plan** ou
   PlanRecordMode mode(names);
   CompileOptions opt;
   if (const char* e = getenv("GSV_FUSE")) opt.fuse = atoi(e) != 0;
-  // GSV_PLAN_HALF_WINDOW=1: compile every program once, for the half LDS window; the same image then serves one and two
-  // instances per workgroup and the recorded traces are not kept (less host memory and no second compilation for plans with
-  // hundreds of programs, at a slightly smaller window when sessions have <= 256 instances)
-  const bool half_only = getenv("GSV_PLAN_HALF_WINDOW") && atoi(getenv("GSV_PLAN_HALF_WINDOW")) != 0;
-  if (half_only) opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / 2);
-  mode.compile_in_background(opt, half_only);  // units are compiled while the driver records the rest of the circuit
+  // GSV_PLAN_WINDOW_DIV=2|4: compile every program once, for half / a quarter of the LDS window; the same image then serves every
+  // layout of up to that many instances per workgroup and the recorded traces are not kept (less host memory and no second
+  // compilation for plans with hundreds of programs, at a smaller window when sessions have few instances).
+  // GSV_PLAN_HALF_WINDOW=1 is the older spelling of GSV_PLAN_WINDOW_DIV=2.
+  uint32_t window_div = 1;
+  if (getenv("GSV_PLAN_HALF_WINDOW") && atoi(getenv("GSV_PLAN_HALF_WINDOW")) != 0) window_div = 2;
+  if (const char* e = getenv("GSV_PLAN_WINDOW_DIV")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) window_div = uint32_t(v); else return fail(GSV_ERR_INVALID, "GSV_PLAN_WINDOW_DIV must be 1, 2 or 4"); }
+  const bool single_image = window_div > 1;
+  if (single_image) opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / window_div);
+  mode.compile_in_background(opt, single_image);  // units are compiled while the driver records the rest of the circuit
   StreamingRunner run(mode, nc.n_inputs, nc.fn);
   std::vector<uint32_t> in_ssa, out_ssa;
   for (WireId w : run.prepare()) in_ssa.push_back(mode.define_input(w));
@@ -489,8 +502,8 @@ int gsv_plan_from_circuit(const char* spec, const char* units_csv, gsv_plan** ou
     gsv_program* q = new gsv_program();
     plan->owned.push_back(q);
     q->prog = std::move(bp.programs[k]);
-    q->half_only = half_only;
-    if (half_only) bp.traces[k] = Trace();
+    q->window_div = window_div;
+    if (single_image) bp.traces[k] = Trace();
     else q->src.reset(new ProgramSource{std::move(bp.traces[k]), bp.prog_inputs[k], bp.prog_outputs[k], {}, opt});
     for (size_t i = 0; i < q->prog.input_slots.size(); ++i)
       if (q->prog.input_slots[i] != SLOT_FIRST_INPUT + i) { gsv_plan_destroy(plan.release()); return fail(GSV_ERR_CIRCUIT, "internal: inputs are not slot-contiguous"); }
@@ -608,7 +621,7 @@ int gsv_plan_counts(const gsv_plan* p, uint64_t* n_gates, uint64_t* n_ciphertext
 // padded to 16 bytes):  PlanFileHeader | per program: PlanFileProgram, steps, ands, xors, ct_pos, input_slots, output_slots |
 // per call: {program, n_in, n_out}, in_globals, out_globals | outputs.
 namespace {
-constexpr char PLAN_MAGIC[8] = {'G', 'S', 'V', 'P', 'L', 'A', 'N', '2'};
+constexpr char PLAN_MAGIC[8] = {'G', 'S', 'V', 'P', 'L', 'A', 'N', '3'};
 struct PlanFileHeader {
   char magic[8];
   uint32_t n_programs, n_calls, n_globals, n_inputs, n_outputs, lds_window_slots;
@@ -618,7 +631,7 @@ struct PlanFileProgram {
   uint64_t n_steps, n_ands, n_xors, n_ct_pos, n_inputs, n_outputs;
   uint64_t n_gates, n_ct, n_dead, n_fused_free, reads_lds, reads_hbm, writes_lds, writes_hbm;
   uint64_t gate_count[GATE_TYPE_COUNT];
-  uint32_t n_slots, n_lds_slots, lds_slots_limit, fb_stage_base, and_depth, n_and_steps, max_step_width, peak_live, half_only, pad;
+  uint32_t n_slots, n_lds_slots, lds_slots_limit, fb_stage_base, and_depth, n_and_steps, max_step_width, peak_live, window_div, pad;
 };
 constexpr uint64_t plan_rec_sizes() { return uint64_t(sizeof(StepDesc)) | (uint64_t(sizeof(AndRec)) << 16) | (uint64_t(sizeof(XorRec)) << 32); }
 inline size_t pad16(size_t n) { return (n + 15) & ~size_t(15); }
@@ -676,7 +689,7 @@ int gsv_plan_save(const gsv_plan* p, const char* path) {
     m.reads_lds = g.reads_lds; m.reads_hbm = g.reads_hbm; m.writes_lds = g.writes_lds; m.writes_hbm = g.writes_hbm;
     for (int i = 0; i < GATE_TYPE_COUNT; ++i) m.gate_count[i] = g.gate_count[i];
     m.n_slots = g.n_slots; m.n_lds_slots = g.n_lds_slots; m.lds_slots_limit = g.lds_slots_limit; m.fb_stage_base = g.fb_stage_base; m.and_depth = g.and_depth;
-    m.n_and_steps = g.n_and_steps; m.max_step_width = g.max_step_width; m.peak_live = g.peak_live; m.half_only = q->half_only ? 1 : 0;
+    m.n_and_steps = g.n_and_steps; m.max_step_width = g.max_step_width; m.peak_live = g.peak_live; m.window_div = q->window_div;
     put(&m, sizeof m);
     put(g.steps.data(), g.steps.size() * sizeof(StepDesc));
     put(g.ands.data(), g.ands.size() * sizeof(AndRec));
@@ -747,7 +760,8 @@ int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out) {
     for (int i = 0; i < GATE_TYPE_COUNT; ++i) g.gate_count[i] = m.gate_count[i];
     g.n_slots = m.n_slots; g.n_lds_slots = m.n_lds_slots; g.lds_slots_limit = m.lds_slots_limit; g.fb_stage_base = m.fb_stage_base; g.and_depth = m.and_depth;
     g.n_and_steps = m.n_and_steps; g.max_step_width = m.max_step_width; g.peak_live = m.peak_live;
-    q->half_only = m.half_only != 0;
+    if (m.window_div != 1 && m.window_div != 2 && m.window_div != 4) { bad = true; break; }
+    q->window_div = m.window_div;
     const uint8_t* steps = take(m.n_steps * sizeof(StepDesc));
     const uint8_t* ands = take(m.n_ands * sizeof(AndRec));
     const uint8_t* xors = take(m.n_xors * sizeof(XorRec));
@@ -798,8 +812,7 @@ int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out) {
     const size_t lens[7] = {size_t(m.n_steps) * sizeof(StepDesc), size_t(m.n_ands) * sizeof(AndRec), size_t(m.n_xors) * sizeof(XorRec), 0, 0, size_t(m.n_outputs) * 4, size_t(m.n_ct_pos) * 4};
     for (int i = 0; i < 7 && rc == GSV_OK; ++i) rc = up(dsts[i], srcs[i], lens[i]);
     // file it before checking rc: gsv_plan_destroy then releases whatever was allocated
-    q->dev[{e->device, q->half_only ? 2 : 1}] = d;
-    if (q->half_only) q->dev[{e->device, 1}] = d;
+    q->dev[{e->device, 1}] = d;  // image key 1 = `prog` itself (gsv_program::image_key)
     if (rc != GSV_OK) return rc;
     q->loaded_image_bytes = d.bytes;
   }
@@ -840,15 +853,17 @@ int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_ins
   {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, e->device));
-    s->ni = n_instances > size_t(prop.multiProcessorCount) ? 2u : 1u;
-    if (const char* ev = getenv("GSV_INSTANCES_PER_WG")) { int v = atoi(ev); if (v == 1 || (v == 2 && n_instances >= 2)) s->ni = uint32_t(v); }
+    uint32_t servable = 4;
+    for (const auto& c : plan->calls) if (!c.prog->src) servable = std::min(servable, c.prog->window_div);
+    s->ni = choose_instances_per_wg(n_instances, prop.multiProcessorCount, servable);
   }
   s->call_dev.resize(plan->calls.size());
-  if (s->ni == 2) {  // the plan's programs are independent: compile their missing half-window variants in parallel
+  if (s->ni > 1) {  // the plan's programs are independent: compile their missing window variants in parallel
     GSV_TRY
     std::vector<gsv_program*> todo;
     for (const auto& c : plan->calls) if (std::find(todo.begin(), todo.end(), c.prog) == todo.end()) todo.push_back(c.prog);
-    parallel_for_programs(todo.size(), [&](size_t i) { std::lock_guard<std::mutex> lk(todo[i]->mu); compile_half_window_variant(todo[i]); });
+    const uint32_t ni = s->ni;
+    parallel_for_programs(todo.size(), [&](size_t i) { std::lock_guard<std::mutex> lk(todo[i]->mu); compile_window_variant(todo[i], ni); });
     GSV_CATCH
   }
   uint32_t scratch = SLOT_FIRST_INPUT;

@@ -34,7 +34,7 @@ struct KernelArgs {
   uint32_t n_fb;
   uint32_t fb_stage_base;
   uint32_t n_instances;
-  uint32_t instances_per_wg;  // 1 or 2 (2 needs a program compiled for half the LDS window)
+  uint32_t instances_per_wg;  // 1, 2 or 4 (n needs a program compiled for 1/n of the LDS window)
   uint32_t hasher;            // 0 = AesNiHasher, 1 = Blake3Hasher
   unsigned long long* step_clock;  // diagnostics: workgroup 0 stamps the 100 MHz wall clock at the start of every step of the last replay (null = off)
   uint32_t diag;  // timing experiments only (GSV_DIAG env; honoured by a library built with -DGSV_DIAG_BUILD = `build.py --diag`, ignored by

@@ -156,13 +156,14 @@ __device__ __forceinline__ uint32_t tweak_word(uint64_t gate_id, uint32_t c) {  
   return (c & 1u) ? uint32_t(t >> 32) : uint32_t(t);
 }
 
-// NI = instances per workgroup.  NI = 2 splits the 1024 threads into two halves that garble two instances of the
-// same program in lockstep (they share the step barrier and the AES table; each has half of the label window):
-// the many steps that are narrower than half a workgroup then cost their fixed latency once for two instances.
-// The host picks NI = 2 when a launch holds more instances than the GPU has CUs (+16 % at 512 instances; with
-// <= 256 instances NI = 1 keeps every CU busy instead).  Measured and rejected: per-instance software barriers
-// (LDS arrival counters) that let the two halves drift into different phases (no gain over lockstep: waves of the
-// two halves already overlap each other's latencies) and NI = 4 (quarter windows: -6 %).
+// NI = instances per workgroup (1, 2 or 4).  NI > 1 splits the 1024 threads into NI groups that garble NI instances of the
+// same program in lockstep (they share the step barrier and the AES table; each has 1/NI of the label window): the many
+// steps that are narrower than a group then cost their fixed latency once for NI instances.  The host picks the largest NI
+// that still gives every CU a workgroup (2 above 256 instances: +16 %; 4 above 512: at 1024 instances the same rate on wide
+// programs as NI = 2, +21 % on the decompression ladders and +29 % on the inversions, profiles/r02_final/ni4_vs_ni2.txt).
+// Measured and rejected: per-group software barriers (LDS arrival counters) that let the groups drift into different
+// phases, with and without a start skew (no gain over lockstep: the waves of the groups already overlap each other's
+// latencies).
 // HASH = 0: AesNiHasher (fixed-key AES, the hot path); HASH = 1: Blake3Hasher (src/hashers/mod.rs:22-51; the PRF most of
 // the reference's own tests use) — pure 32-bit add/xor/rotate, one gate per lane in every step (no multi-lane form).
 template <bool EVAL, int NI, int HASH>
@@ -568,8 +569,9 @@ int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, in
     if (!attr_done.count(dev)) {
       // the kernels address LDS from byte 0: there must be no static LDS in front of the dynamic block
       hipFuncAttributes fa;
-      const void* kernels[6] = {reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 1, 0>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 1, 0>),
+      const void* kernels[8] = {reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 1, 0>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 1, 0>),
                                 reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 2, 0>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 2, 0>),
+                                reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 4, 0>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 4, 0>),
                                 reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 1, 1>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 1, 1>)};
       for (const void* k : kernels) {
         if (hipFuncGetAttributes(&fa, k) != hipSuccess || fa.sharedSizeBytes != 0) return int(hipErrorInvalidValue);
@@ -580,11 +582,14 @@ int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, in
     }
   }
   const bool blake3 = ka->hasher == 1;
-  const uint32_t ni = (ka->instances_per_wg == 2 && !blake3) ? 2u : 1u;
+  const uint32_t ni = blake3 ? 1u : (ka->instances_per_wg == 4 ? 4u : ka->instances_per_wg == 2 ? 2u : 1u);
   const dim3 grid((n_instances + ni - 1) / ni);
   if (blake3) {
     if (evaluate) hipLaunchKernelGGL((gsv::dev::run_program_kernel<true, 1, 1>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
     else hipLaunchKernelGGL((gsv::dev::run_program_kernel<false, 1, 1>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
+  } else if (ni == 4) {
+    if (evaluate) hipLaunchKernelGGL((gsv::dev::run_program_kernel<true, 4, 0>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
+    else hipLaunchKernelGGL((gsv::dev::run_program_kernel<false, 4, 0>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
   } else if (ni == 2) {
     if (evaluate) hipLaunchKernelGGL((gsv::dev::run_program_kernel<true, 2, 0>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
     else hipLaunchKernelGGL((gsv::dev::run_program_kernel<false, 2, 0>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);

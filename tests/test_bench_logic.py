@@ -137,7 +137,7 @@ def test_plan_file_roundtrip_without_device(tmp_path):
     """gsv_plan_save / gsv_plan_load: a built plan survives the file byte for byte (save -> load -> save), with the same calls,
     counts and program images; truncated or foreign files are rejected; a plan loaded without an engine is a host copy."""
     import garbled_snark_verifier_amd as gsv
-    plan = gsv.Plan.from_circuit("fq_complex", ["fp254::montgomery_reduce", "bigint::mul_karatsuba"], half_window=True)
+    plan = gsv.Plan.from_circuit("fq_complex", ["fp254::montgomery_reduce", "bigint::mul_karatsuba"], window_div=4)  # as bench.py builds its plan
     a, b = os.path.join(str(tmp_path), "a.gsvplan"), os.path.join(str(tmp_path), "b.gsvplan")
     plan.save(a)
     p2 = gsv.Plan.load(a)

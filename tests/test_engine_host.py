@@ -222,15 +222,17 @@ def test_plan_builder_matches_flat_stream(spec, units, seed):
 
 def test_plan_from_circuit_builds_without_a_device_and_in_both_modes():
     """gsv_plan_from_circuit is host-only work: units are compiled on a worker pool while the driver records (plan_builder.hpp
-    CompilePool), with GSV_PLAN_HALF_WINDOW once for the half LDS window.  Both modes give the reference's counts; the plan of the
-    square-root ladder has one program per distinct four-bit chunk of the exponent (fp254::exp_chunk, <= 16 + tail)."""
+    CompilePool), with GSV_PLAN_WINDOW_DIV once for half / a quarter of the LDS window.  Every mode gives the reference's counts; the
+    plan of the square-root ladder has one program per distinct four-bit chunk of the exponent (fp254::exp_chunk, <= 16 + tail)."""
     import garbled_snark_verifier_amd as gsv
     ref = o.garble("fq12_mix", 1, capture_ct=False)
-    for hw in (False, True):
-        plan = gsv.Plan.from_circuit("fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"], half_window=hw)
+    for kw in ({}, {"half_window": True}, {"window_div": 4}):
+        plan = gsv.Plan.from_circuit("fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"], **kw)
         assert plan.info["n_gates"] == int(ref.gate_counts.sum()) and plan.info["n_ciphertexts"] == ref.n_ciphertexts and plan.info["n_calls"] >= 4
         plan.close()
-    assert "GSV_PLAN_HALF_WINDOW" not in os.environ
+    assert "GSV_PLAN_HALF_WINDOW" not in os.environ and "GSV_PLAN_WINDOW_DIV" not in os.environ
+    with pytest.raises(ValueError):
+        gsv.Plan.from_circuit("fq12_mix", ["fq12::mul_montgomery"], window_div=3)
     plan = gsv.Plan.from_circuit("fq_sqrt", ["fp254::exp_chunk"], half_window=True)
     assert plan.info["n_gates"] == 148_727_956 and plan.info["n_ciphertexts"] == 36_651_387 and 60 <= plan.info["n_calls"] <= 70
     plan.close()
@@ -245,7 +247,7 @@ def test_step_barrier_isa_check():
     from garbled_snark_verifier_amd import build
     asm = build.disassemble_kernels()
     res = build.check_step_barrier_isa(asm)
-    assert len(res) == 6 and set(res.values()) == {2}
+    assert len(res) == 8 and set(res.values()) == {2}  # garble / evaluate x 1, 2, 4 instances per workgroup + the two Blake3 kernels
     lines = asm.splitlines()
     k = next(i for i, l in enumerate(lines) if "s_waitcnt lgkmcnt(0)" in l and "s_barrier" in lines[i + 1] and "global_load_dwordx4" in lines[i - 1])
     # something scheduled between the prefetch and the barrier

@@ -236,12 +236,13 @@ def test_two_instances_per_workgroup(engine, monkeypatch):
     garble and evaluate, against the oracle; then a >256-instance batch where the engine picks it by itself, checked
     through lock-step determinism (identical seeds -> identical streams) and spot instances against the oracle."""
     import garbled_snark_verifier_amd as gsv
-    monkeypatch.setenv("GSV_INSTANCES_PER_WG", "2")
-    for spec, seeds in (("fq_mul", [5, 6, 7]), ("driver_mix", [1, 2]), ("fq_complex", [9, 10, 11, 12, 13])):
-        g, prog = _garble_and_check(gsv, engine, spec, seeds)
-        _evaluate_and_check(gsv, engine, spec, g, prog, seeds)
-    g, prog = _garble_and_check(gsv, engine, "fq12_mul", [21, 22, 23], replays=2, oracle_spec="fq12_mul_chain:2")
-    _evaluate_and_check(gsv, engine, "fq12_mul", g, prog, [21, 22, 23], replays=2, oracle_spec="fq12_mul_chain:2")
+    for ni in ("2", "4"):  # four per workgroup: a quarter of the window each (run_program_kernel<*, 4, 0>); batches that leave groups idle
+        monkeypatch.setenv("GSV_INSTANCES_PER_WG", ni)
+        for spec, seeds in (("fq_mul", [5, 6, 7]), ("driver_mix", [1, 2]), ("fq_complex", [9, 10, 11, 12, 13])):
+            g, prog = _garble_and_check(gsv, engine, spec, seeds)
+            _evaluate_and_check(gsv, engine, spec, g, prog, seeds)
+        g, prog = _garble_and_check(gsv, engine, "fq12_mul", [21, 22, 23], replays=2, oracle_spec="fq12_mul_chain:2")
+        _evaluate_and_check(gsv, engine, "fq12_mul", g, prog, [21, 22, 23], replays=2, oracle_spec="fq12_mul_chain:2")
     monkeypatch.delenv("GSV_INSTANCES_PER_WG")
     total = 300  # > 256 CUs
     seeds = [1000 + (i % 50) for i in range(total)]
@@ -597,16 +598,22 @@ def test_miller_loop_as_a_plan(engine):
 
 
 def test_half_window_plan_serves_both_layouts(engine, monkeypatch):
-    """GSV_PLAN_HALF_WINDOW / Plan.from_circuit(half_window=True): every program of the plan is compiled once, for the half LDS
-    window, and the same image runs with one and with two instances per workgroup; hashes and labels == the oracle's."""
+    """GSV_PLAN_WINDOW_DIV / Plan.from_circuit(window_div=4): every program of the plan is compiled once, for a quarter of the LDS
+    window, and the same image runs with one, two and four instances per workgroup; hashes and labels == the oracle's.  (A
+    half-window plan, window_div=2, cannot serve four: the session falls back to two.)"""
     import garbled_snark_verifier_amd as gsv
-    plan = gsv.Plan.from_circuit("fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"], half_window=True)
-    seeds = [91, 92, 93]
+    plan2 = gsv.Plan.from_circuit("fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"], half_window=True)
+    monkeypatch.setenv("GSV_INSTANCES_PER_WG", "4")
+    sess = gsv.Session(engine, plan2, 5)
+    assert sess.instances_per_workgroup == 2
+    sess.close(); plan2.close()
+    plan = gsv.Plan.from_circuit("fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"], window_div=4)
+    seeds = [91, 92, 93, 94, 95]
     B, n_in = len(seeds), plan.info["n_inputs"]
     labs = [gsv.labels_from_seed(s, n_in) for s in seeds]
     delta = np.stack([x[0] for x in labs]); consts = np.stack([np.stack([x[1], x[2]]) for x in labs]); inputs = np.stack([x[3] for x in labs])
     refs = [o.garble("fq12_mix", s, capture_ct=False) for s in seeds]
-    for ni in ("1", "2"):
+    for ni in ("1", "2", "4"):
         monkeypatch.setenv("GSV_INSTANCES_PER_WG", ni)
         sess = gsv.Session(engine, plan, B)
         assert sess.instances_per_workgroup == int(ni)
@@ -663,10 +670,11 @@ VERIFIER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cycl
 @pytest.fixture(scope="module")
 def compressed_verifier_plan():
     """The plan of the reference's headline circuit, groth16_verify_compressed (groth16.rs:250-268), built ONCE for the tests below
-    (what bench.py builds: half LDS window, ~100 s of host time and ~50 GB of host memory on the GPU box)."""
+    (what bench.py builds: one image per program, compiled for a quarter of the LDS window; ~100 s of host time and ~50 GB of host
+    memory on the GPU box)."""
     import garbled_snark_verifier_amd as gsv
     case = json.load(open(os.path.join(os.path.dirname(GOLDEN), "groth16_verify_compressed_golden.json")))
-    plan = gsv.Plan.from_circuit(case["circuit"], VERIFIER_UNITS + ["fp254::exp_chunk"], half_window=True)
+    plan = gsv.Plan.from_circuit(case["circuit"], VERIFIER_UNITS + ["fp254::exp_chunk"], window_div=4)
     yield case, plan
     plan.close()
 
@@ -695,26 +703,27 @@ def test_compressed_verifier_as_a_plan_in_slices(engine, compressed_verifier_pla
 
 
 def test_verifier_lockstep_two_instances_per_workgroup(engine, compressed_verifier_plan):
-    """The bench's configuration on real verifier programs: 512 instances, two per workgroup (the kernel instantiation
-    run_program_kernel<false, 2, 0> and its hand-counted step barrier), all with the SAME seed, through the first slice of the
-    plan with the ciphertexts drained: every instance must produce the same CBC-MAC state, and a second run the same again."""
+    """The bench's configuration on real verifier programs: 1024 instances, four per workgroup (the kernel instantiation
+    run_program_kernel<false, 4, 0>, groups in lockstep on the LDS-only step barrier), then 512 instances, two per workgroup
+    (<false, 2, 0>), all with the SAME seed, through the first slice of the plan with the ciphertexts drained: every instance
+    must produce the same CBC-MAC state, a second run the same again, and both layouts the same as one instance alone."""
     import bench
     import garbled_snark_verifier_amd as gsv
     case, plan = compressed_verifier_plan
     ci = plan.call_info()
     first, n, _ = bench.plan_slices(ci[:, 1], 100)[0]  # decompression ladders: thousands of narrow steps (~30 M ciphertexts per instance)
-    B = 512
     d, f, t, inp = gsv.labels_from_seed(7, plan.info["n_inputs"])
-    sess = gsv.Session(engine, plan, B, retain_stream=False)
-    assert sess.instances_per_workgroup == 2
     seen = []
-    for _ in range(2):
-        sess.set_garble_inputs(np.tile(d, (B, 1)), np.tile(np.stack([f, t]), (B, 1, 1)), np.tile(inp, (B, 1, 1)))
-        hashes = sess.garble_calls(first, n)
-        assert len(set(hashes)) == 1, "identical instances produced different ciphertext streams"
-        seen.append(hashes[0])
-    assert seen[0] == seen[1]
-    sess.close()
+    for B, ni in ((1024, 4), (512, 2)):
+        sess = gsv.Session(engine, plan, B, retain_stream=False)
+        assert sess.instances_per_workgroup == ni
+        for _ in range(2):
+            sess.set_garble_inputs(np.tile(d, (B, 1)), np.tile(np.stack([f, t]), (B, 1, 1)), np.tile(inp, (B, 1, 1)))
+            hashes = sess.garble_calls(first, n)
+            assert len(set(hashes)) == 1, "identical instances produced different ciphertext streams"
+            seen.append(hashes[0])
+        sess.close()
+    assert len(set(seen)) == 1
     # the same slice for ONE instance (one per workgroup, run_program_kernel<false, 1, 0>) gives the same stream
     one = gsv.Session(engine, plan, 1, retain_stream=False)
     one.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])

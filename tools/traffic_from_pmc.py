@@ -3,7 +3,7 @@
 rocprofv3 --pmc passes) -> profiles/<dir>/traffic.json with HBM bytes per launch as MI355X_MICROARCH.md prescribes: both
 counters are in KiB; on gfx950 FETCH_SIZE reads half of the bytes of wide coalesced 16-byte-per-lane reads, so it is doubled
 before it is compared with a byte count (the kernel's reads are record streams and 16-byte label reads: the doubled figure is an
-upper bound, the raw one a lower bound; both are kept).  usage: traffic_from_pmc.py profiles/r02_verifier [algorithmic bytes per launch]"""
+upper bound, the raw one a lower bound; both are kept).  usage: traffic_from_pmc.py profiles/r02_final [algorithmic bytes per launch [instances per GPU]]"""
 import json
 import os
 import sys
@@ -12,11 +12,13 @@ d = sys.argv[1]
 p = json.load(open(os.path.join(d, "pmc_counters.json")))
 f, w = p["fetch"]["sum"]["FETCH_SIZE"] * 1024.0, p["write"]["sum"]["WRITE_SIZE"] * 1024.0
 nf, nw = p["fetch"]["dispatches"]["FETCH_SIZE"], p["write"]["dispatches"]["WRITE_SIZE"]
-out = {"kernel": "run_program_kernel<false, 2, 0>", "launches_fetch_pass": nf, "launches_write_pass": nw,
+out = {"kernel": "run_program_kernel (garble)", "launches_fetch_pass": nf, "launches_write_pass": nw,
        "fetch_bytes_raw_per_launch": f / nf, "write_bytes_per_launch": w / nw,
        "hbm_bytes_per_launch_raw": f / nf + w / nw, "hbm_bytes_per_launch": 2 * f / nf + w / nw,
-       "note": "FETCH_SIZE / WRITE_SIZE (KiB) summed over the run_program_kernel dispatches of separate rocprofv3 --pmc passes of `bench.py` (512 instances), divided by the "
+       "note": "FETCH_SIZE / WRITE_SIZE (KiB) summed over the run_program_kernel dispatches of separate rocprofv3 --pmc passes of `bench.py`, divided by the "
                "dispatch count; hbm_bytes_per_launch applies the guide's gfx950 correction (FETCH_SIZE x 2)"}
+if len(sys.argv) > 3:
+    out["instances_per_gpu"] = int(sys.argv[3])  # bench.py quotes the figure only for a run of the same configuration
 if len(sys.argv) > 2:
     out["algorithmic_bytes_per_launch"] = float(sys.argv[2])
     out["traffic_over_algorithmic"] = out["hbm_bytes_per_launch"] / float(sys.argv[2])
