@@ -40,7 +40,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 VERIFIER_GATES = 11_174_708_821  # README.md:12 of the reference (its own 1-public-input key)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s
-AES_CEILING_AND_PER_S = 4.9e10   # 741 VALU + 364 LDS wave-instructions per 64 garbled ANDs -> ~5 us per 1024 ANDs per CU
+AES_CEILING_AND_PER_S = 4.82e10  # tools/ubench/aes_forms.hip on MI355X (profiles/r02_final/aes_forms.txt): 9.65e10 T-table AES blocks/s with every CU full, two blocks per garbled AND
 
 VERIFIER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cyclotomic_square_montgomery", "fq12::mul_by_034_montgomery",
                   "pairing::ell_by_constant_montgomery", "pairing::double_in_place_circuit_montgomery", "pairing::add_in_place_montgomery", "pairing::mul_by_char_montgomery",

@@ -149,7 +149,10 @@ int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out);
 /* Stand-alone harness: record one of the built-in restated circuits under the two-pass driver with the named components
  * (comma separated, e.g. "fq12::mul_montgomery,fq12::square_montgomery") turned into calls; each distinct (component key,
  * output liveness) pair is recorded and compiled once, the gates between units become glue programs.  The plan owns its
- * programs.  (A Rust host reaches the same through a with_named_child hook; see INTEGRATION.md.) */
+ * programs.  (A Rust host reaches the same through a with_named_child hook; see INTEGRATION.md.)
+ * Environment: GSV_PLAN_WINDOW_DIV=2|4 compiles every program ONCE, for half / a quarter of the LDS label window — the one image
+ * then serves sessions with up to that many instances per workgroup and the recorded traces are freed (the verifier plan: 50 GB
+ * of host memory instead of 92); unset, programs are compiled for the full window and the other layouts on first use. */
 int gsv_plan_from_circuit(const char* spec, const char* units_csv, gsv_plan** out);
 
 /* ---- engine --------------------------------------------------------------------------------- */
@@ -216,9 +219,10 @@ int gsv_session_evaluate_streaming(gsv_session* s, uint64_t gate_id_base, const 
 int gsv_session_set_hasher(gsv_session* s, int kind);
 
 int gsv_session_sync(gsv_session* s);
-/* 1 or 2: how many instances share a workgroup (= a CU) in this session's launches.  Chosen at creation: 2 once the
- * session holds more instances than the device has CUs (each instance then works with half of the LDS label window;
- * the program variant for it is compiled on first use), else 1.  Results do not depend on it. */
+/* 1, 2 or 4: how many instances share a workgroup (= a CU) in this session's launches.  Chosen at creation: 2 once the
+ * session holds more instances than the device has CUs, 4 once it holds more than twice as many (each instance then works
+ * with half / a quarter of the LDS label window; the program variant for that share is compiled on first use, or the plan was
+ * built for it: GSV_PLAN_WINDOW_DIV), else 1; GSV_INSTANCES_PER_WG=1|2|4 overrides.  Results do not depend on it. */
 int gsv_session_instances_per_workgroup(const gsv_session* s, int* n);
 /* seconds of device time of the last garble/evaluate launch (HIP events on the engine stream) */
 int gsv_session_last_kernel_ms(gsv_session* s, double* ms);
