@@ -110,6 +110,10 @@ def check_workgroup_release_model():
         open(src, "w").write(_RELEASE_PROBE)
         subprocess.check_call([os.path.join(ROCM, "bin", "hipcc"), "--offload-arch=gfx950", "-O3", "-c", src, "-o", obj], stderr=subprocess.DEVNULL)
         ins = [v for k, v in _functions(disassemble_kernels(obj)).items() if "gsv_probe" in k][0]
+        # the model holds outside threadgroup-split mode only: the default, which build() never changes (no -mtgsplit)
+        asm_text = subprocess.check_output([os.path.join(ROCM, "bin", "hipcc"), "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only", src, "-o", "-"], stderr=subprocess.DEVNULL, text=True)
+        if ".amdhsa_tg_split 0" not in asm_text or ".amdhsa_tg_split 1" in asm_text:
+            raise RuntimeError("hipcc builds gfx950 kernels in threadgroup-split mode by default now: the step barrier must wait for vmcnt")
     st = [i for i, t in enumerate(ins) if t.startswith("global_store")][0]
     ba = ins.index("s_barrier")
     ld = [i for i, t in enumerate(ins) if t.startswith("global_load")][0]
