@@ -54,6 +54,18 @@ class _ProgramInfo(C.Structure):
                                  "reads_lds", "reads_hbm", "writes_lds", "writes_hbm", "n_fused_free")]
 
 
+class _PlanSessionOpts(C.Structure):
+    _fields_ = [("retain_stream", C.c_int), ("max_concurrent_calls", C.c_uint32), ("window_ct_records", C.c_uint64), ("max_scratch_slots", C.c_uint64),
+                ("max_window_calls", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+_SCHED_FIELDS = ["n_calls", "n_windows", "n_batches", "max_batch_calls", "scratch_slots", "wire_file_slots", "window_ct_records", "critical_steps", "total_steps"]
+
+
+class _PlanScheduleInfo(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in _SCHED_FIELDS]
+
+
 class _Gate(C.Structure):
     _fields_ = [("wire_a", C.c_uint64), ("wire_b", C.c_uint64), ("wire_c", C.c_uint64), ("gate_type", C.c_uint8), ("pad", C.c_uint8 * 7)]
 
@@ -68,6 +80,7 @@ EXPORTS = [
     "gsv_plan_from_circuit", "gsv_plan_io", "gsv_plan_recorder_create", "gsv_plan_recorder_destroy", "gsv_plan_recorder_allocate_wire",
     "gsv_plan_recorder_declare_input", "gsv_plan_recorder_push_gates", "gsv_plan_recorder_call", "gsv_plan_recorder_finish", "gsv_plan_create", "gsv_plan_destroy", "gsv_plan_add_call", "gsv_plan_finish", "gsv_plan_counts", "gsv_session_create_plan", "gsv_session_create_plan_ex",
     "gsv_session_garble_streaming", "gsv_session_garble_streaming_calls", "gsv_plan_call_info", "gsv_plan_image_bytes", "gsv_plan_wire_file", "gsv_plan_save", "gsv_plan_load", "gsv_session_evaluate_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
+    "gsv_session_create_plan_opts", "gsv_session_plan_schedule_info", "gsv_session_plan_window", "gsv_session_set_unchecked_slices",
 ]
 
 
@@ -143,6 +156,10 @@ def lib():
         L.gsv_session_enable_step_clock.argtypes = [vp]
         L.gsv_session_read_step_clock.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.gsv_program_step_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
+        L.gsv_session_create_plan_opts.argtypes = [vp, vp, C.c_size_t, C.POINTER(_PlanSessionOpts), C.POINTER(vp)]
+        L.gsv_session_plan_schedule_info.argtypes = [vp, C.POINTER(_PlanScheduleInfo)]
+        L.gsv_session_plan_window.argtypes = [vp, C.c_uint64] + [C.POINTER(C.c_uint64)] * 3
+        L.gsv_session_set_unchecked_slices.argtypes = [vp, C.c_int]
         _lib = L
     return _lib
 
@@ -473,14 +490,18 @@ class PlanRecorder:
 class Session:
     """A batch of instances on one program (gsv_session) or, with a Plan, on a sequence of component programs."""
 
-    def __init__(self, engine, program, n_instances=1, replays=1, ct_capacity_replays=None, retain_stream=True):
+    def __init__(self, engine, program, n_instances=1, replays=1, ct_capacity_replays=None, retain_stream=True, concurrent_calls=0, window_ct_records=0,
+                 max_scratch_slots=0, max_window_calls=0):
+        """Plan sessions: concurrent_calls = how many independent calls of the plan may run side by side (0: as many as give every CU a
+        workgroup, 1: sequential); window_ct_records / max_scratch_slots / max_window_calls: see gsv_plan_session_opts (0 = automatic)."""
         self.engine, self.program = engine, program
         self.n, self.replays = n_instances, replays
         self.ct_cap = replays if ct_capacity_replays is None else ct_capacity_replays
         self.h = C.c_void_p()
         if isinstance(program, Plan):
             assert replays == 1
-            _chk(lib().gsv_session_create_plan_ex(engine.h, program.h, n_instances, int(bool(retain_stream)), C.byref(self.h)))
+            o = _PlanSessionOpts(int(bool(retain_stream)), int(concurrent_calls), int(window_ct_records), int(max_scratch_slots), int(max_window_calls), 0)
+            _chk(lib().gsv_session_create_plan_opts(engine.h, program.h, n_instances, C.byref(o), C.byref(self.h)))
         else:
             _chk(lib().gsv_session_create(engine.h, program.h, n_instances, replays, self.ct_cap, C.byref(self.h)))
         self.n_in, self.n_out = program.info["n_inputs"], program.info["n_outputs"]
@@ -516,6 +537,26 @@ class Session:
         out = np.zeros((self.n, 16), np.uint8)
         _chk(lib().gsv_session_garble_streaming_calls(self.h, gate_id_base, first_call, n_calls, directory.encode() if directory else None, first_index, threads, _p(out)))
         return [bytes(out[i]) for i in range(self.n)]
+
+    def schedule_info(self):
+        """Plan sessions: the call-level schedule this session executes (windows, batches of calls side by side, wire-file layout,
+        depth in device steps)."""
+        i = _PlanScheduleInfo()
+        _chk(lib().gsv_session_plan_schedule_info(self.h, C.byref(i)))
+        return {k: int(getattr(i, k)) for k in _SCHED_FIELDS}
+
+    def windows(self):
+        """[(first_call, n_calls, n_batches)] of the schedule: slices handed to garble_calls start and end on these boundaries."""
+        out = []
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        for w in range(self.schedule_info()["n_windows"]):
+            _chk(lib().gsv_session_plan_window(self.h, w, C.byref(a), C.byref(b), C.byref(c)))
+            out.append((a.value, b.value, c.value))
+        return out
+
+    def set_unchecked_slices(self, on=True):
+        """Timing harnesses only: allow garble_calls slices that do not continue the previous one (stale wires, meaningless MACs)."""
+        _chk(lib().gsv_session_set_unchecked_slices(self.h, int(bool(on))))
 
     def evaluate_streaming(self, directory, first_index=0, gate_id_base=0):
         """Evaluate with the ciphertexts read from gc_<first_index+i>.bin segment by segment; returns the files' CBC-MACs."""

@@ -25,6 +25,7 @@
 #include "host_crypto.hpp"
 #include "kernel_api.h"
 #include "plan_builder.hpp"
+#include "schedule.hpp"
 #include "program.hpp"
 
 using namespace gsv;
@@ -117,6 +118,7 @@ struct gsv_plan {
   std::vector<uint32_t> outputs;
   uint64_t n_gates = 0, n_ct = 0;
   bool finished = false;
+  int device = -1;  // >= 0: loaded by gsv_plan_load straight into that device's memory (device_only programs): serves that device only
 };
 
 struct gsv_engine {
@@ -143,9 +145,17 @@ struct gsv_session {
   Program facade;
   uint32_t global_base = 0;  // first slot of the plan's global region
   bool plan_retain = true;   // plan sessions: whole ciphertext stream kept on the device (else one call block: streaming only)
-  uint64_t plan_max_block = 0;
-  struct CallDev { DevProgram dp; void *pre_src = nullptr, *pre_dst = nullptr, *post_src = nullptr, *post_dst = nullptr; };
+  uint64_t plan_max_block = 0;  // ciphertext records per instance of the device block: the largest WINDOW of the schedule
+  struct CallDev { DevProgram dp; };
   std::vector<CallDev> call_dev;
+  // Call-level schedule (schedule.hpp): windows of consecutive calls, cut into batches of independent calls that run side by side.
+  // Everything below is laid out in EXECUTION order (sched.order): the call descriptors the kernel indexes with blockIdx.y and the
+  // concatenated pre / post copy lists (globals -> the call's scratch region -> globals), so that a batch is one contiguous range.
+  Schedule sched;
+  void *d_calls = nullptr, *d_pre_src = nullptr, *d_pre_dst = nullptr, *d_post_src = nullptr, *d_post_dst = nullptr;
+  std::vector<uint64_t> pre_off, post_off;  // per execution position (+1): offsets into the concatenated copy lists
+  uint64_t next_call = 0;                   // streaming slices: the call the next slice must start with
+  bool unchecked_slices = false;            // benchmarks may garble slices out of order (results are then meaningless)
   void* plan_out_slots = nullptr;
   const Program& prog() const { return plan ? facade : p->variant(ni); }
   const Program& call_prog(size_t k) const { return plan->calls[k].prog->variant(ni); }
@@ -343,6 +353,8 @@ static int upload_program(gsv_engine* e, gsv_program* p, uint32_t ni, DevProgram
   const int key = int(p->image_key(ni));
   auto it = p->dev.find({e->device, key});
   if (it != p->dev.end()) { *out = it->second; return GSV_OK; }
+  // a program loaded by gsv_plan_load(path, engine) has no host copy of its records: there is nothing to upload to another device
+  if (p->device_only) return fail(GSV_ERR_INVALID, "this program was loaded straight into another device's memory (gsv_plan_load with an engine): it has no image for device " + std::to_string(e->device));
   if (ni > p->window_div) {  // first session with this many instances per workgroup: compile for that share of the LDS window
     GSV_TRY
     compile_window_variant(p, ni);
@@ -409,7 +421,7 @@ void gsv_session_destroy(gsv_session* s) {
   (void)hipSetDevice(s->e->device);
   (void)hipStreamSynchronize(s->e->stream);
   for (void* q : {s->W, s->VB, s->CT, s->delta, s->out, s->out_bits, s->in_bits, s->step_clock, s->ct_stage, s->ct_gate}) if (q) (void)hipFree(q);
-  for (auto& cd : s->call_dev) for (void* q : {cd.pre_src, cd.pre_dst, cd.post_src, cd.post_dst}) if (q) (void)hipFree(q);
+  for (void* q : {s->d_calls, s->d_pre_src, s->d_pre_dst, s->d_post_src, s->d_post_dst}) if (q) (void)hipFree(q);
   if (s->plan_out_slots) (void)hipFree(s->plan_out_slots);
   destroy_drain(s->drain);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -816,7 +828,7 @@ int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out) {
     if (rc != GSV_OK) return rc;
     q->loaded_image_bytes = d.bytes;
   }
-  if (e) HIPCHK(hipStreamSynchronize(e->stream));
+  if (e) { HIPCHK(hipStreamSynchronize(e->stream)); plan->device = e->device; }
   for (uint32_t k = 0; k < h.n_calls && !bad; ++k) {
     uint32_t hdr[4];
     std::memcpy(hdr, take(sizeof hdr), sizeof hdr);
@@ -845,14 +857,65 @@ int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out) {
 
 int gsv_session_create_plan(gsv_engine* e, const gsv_plan* plan, size_t n_instances, gsv_session** out) { return gsv_session_create_plan_ex(e, plan, n_instances, 1, out); }
 int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_instances, int retain_stream, gsv_session** out) {
+  gsv_plan_session_opts o{};
+  o.retain_stream = retain_stream;
+  return gsv_session_create_plan_opts(e, plan, n_instances, &o, out);
+}
+// The call-level schedule of a plan session (schedule.hpp) for `n_wg` workgroups per call on a device with `n_cus` CUs.
+static Schedule make_schedule(const gsv_plan* plan, uint32_t ni, size_t n_instances, int n_cus, size_t free_bytes, const gsv_plan_session_opts& o, uint64_t* max_call_ct) {
+  std::vector<SchedCall> calls(plan->calls.size());
+  uint64_t max_block = 0;
+  uint32_t max_slots = 0;
+  for (size_t k = 0; k < plan->calls.size(); ++k) {
+    const PlanCall& c = plan->calls[k];
+    const Program& g = c.prog->variant(ni);
+    calls[k].in = c.in_globals.data(); calls[k].n_in = c.in_globals.size();
+    calls[k].out = c.out_globals.data(); calls[k].n_out = c.out_globals.size();
+    calls[k].n_slots = g.n_slots; calls[k].n_ct = g.n_ct; calls[k].n_steps = g.n_steps;
+    max_block = std::max<uint64_t>(max_block, g.n_ct);
+    max_slots = std::max(max_slots, g.n_slots);
+  }
+  *max_call_ct = max_block;
+  SchedParams sp;
+  const size_t n_wg = (n_instances + ni - 1) / ni;
+  // calls side by side: as many as it takes to give every CU a workgroup (GSV_PLAN_CONCURRENCY / opts override)
+  uint32_t conc = o.max_concurrent_calls ? o.max_concurrent_calls : uint32_t(std::max<size_t>(1, size_t(n_cus) / std::max<size_t>(1, n_wg)));
+  if (!o.max_concurrent_calls) if (const char* ev = getenv("GSV_PLAN_CONCURRENCY")) conc = uint32_t(std::max(1, atoi(ev)));
+  sp.max_calls_per_batch = std::min<uint32_t>(conc, 65535u);
+  // scratch regions of a batch: at most ~1/16 of the free device memory over all instances, and 2^30 slots (slot offsets are 32 bits)
+  uint64_t slots = o.max_scratch_slots ? o.max_scratch_slots : uint64_t(free_bytes / 16 / 16 / std::max<size_t>(1, n_instances));
+  sp.max_batch_slots = std::min<uint64_t>(std::max<uint64_t>(slots, max_slots), 1ull << 30);
+  if (conc == 1) sp.max_batch_slots = max_slots;
+  // ciphertext window: the whole stream when it is retained, else about a quarter of the free memory for the two window buffers
+  if (o.retain_stream) sp.max_window_ct = ~0ull;
+  else {
+    uint64_t w = o.window_ct_records ? o.window_ct_records : uint64_t(free_bytes / 4 / 32 / std::max<size_t>(1, n_instances));
+    if (!o.window_ct_records && conc == 1) w = 0;  // sequential sessions keep the one-call block of rounds 1-2 (smallest footprint)
+    sp.max_window_ct = std::max<uint64_t>(w, max_block);
+  }
+  sp.max_window_calls = o.max_window_calls ? o.max_window_calls : 4096u;
+  Schedule sc = schedule_calls(calls, plan->n_globals, plan->outputs, sp);
+  if (getenv("GSV_PLAN_DEBUG") || getenv("GSV_VERIFY_SCHEDULE")) {
+    const std::string err = verify_schedule(calls, plan->n_globals, plan->outputs, sc);
+    if (!err.empty()) gsv_panic("internal: plan schedule violates a hazard: " + err);
+    std::fprintf(stderr, "plan schedule: %zu calls, %zu windows, %zu batches (<= %u calls), scratch %llu slots, depth %llu of %llu steps\n", calls.size(), sc.windows.size(),
+                 sc.batches.size(), sp.max_calls_per_batch, (unsigned long long)sc.scratch_slots, (unsigned long long)sc.critical_steps, (unsigned long long)sc.total_steps);
+  }
+  return sc;
+}
+int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_instances, const gsv_plan_session_opts* opts, gsv_session** out) {
   if (!e || !plan || !out || n_instances == 0 || !plan->finished || plan->calls.empty()) return fail(GSV_ERR_INVALID, "bad argument / plan not finished");
+  gsv_plan_session_opts o{};
+  o.retain_stream = 1;
+  if (opts) o = *opts;
   HIPCHK(hipSetDevice(e->device));
+  if (plan->device >= 0 && plan->device != e->device) return fail(GSV_ERR_INVALID, "this plan was loaded into device " + std::to_string(plan->device) + " (gsv_plan_load with an engine): it serves sessions on that device only");
   SessionPtr s(new gsv_session());
   s->e = e; s->p = plan->calls[0].prog; s->plan = plan; s->n_inst = n_instances; s->replays = 1; s->ct_cap = 1;
   s->ct_uploaded.assign(n_instances, 0);
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, e->device));
   {
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, e->device));
     uint32_t servable = 4;
     for (const auto& c : plan->calls) if (!c.prog->src) servable = std::min(servable, c.prog->window_div);
     s->ni = choose_instances_per_wg(n_instances, prop.multiProcessorCount, servable);
@@ -866,15 +929,21 @@ int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_ins
     parallel_for_programs(todo.size(), [&](size_t i) { std::lock_guard<std::mutex> lk(todo[i]->mu); compile_window_variant(todo[i], ni); });
     GSV_CATCH
   }
-  uint32_t scratch = SLOT_FIRST_INPUT;
   for (size_t k = 0; k < plan->calls.size(); ++k) {
     int rc = upload_program(e, plan->calls[k].prog, s->ni, &s->call_dev[k].dp);
     if (rc) return rc;
-    scratch = std::max(scratch, s->call_prog(k).n_slots);
   }
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  uint64_t max_call_ct = 0;
+  GSV_TRY
+  s->sched = make_schedule(plan, s->ni, n_instances, prop.multiProcessorCount, free_b, o, &max_call_ct);
+  GSV_CATCH
+  const Schedule& sc = s->sched;
+  const uint32_t scratch = uint32_t((std::max<uint64_t>(sc.scratch_slots, SLOT_FIRST_INPUT) + 7) / 8 * 8);
   s->global_base = scratch;
-  s->plan_retain = retain_stream != 0;
-  for (size_t k = 0; k < plan->calls.size(); ++k) s->plan_max_block = std::max<uint64_t>(s->plan_max_block, s->call_prog(k).n_ct);
+  s->plan_retain = o.retain_stream != 0;
+  s->plan_max_block = sc.max_window_ct;
   if (uint64_t(scratch) + plan->n_globals > 0xFFFFFFF0ull) return fail(GSV_ERR_CIRCUIT, "plan wire file too large");
   Program& f = s->facade;
   f.n_slots = scratch + plan->n_globals;
@@ -882,23 +951,44 @@ int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_ins
   for (uint32_t i = 0; i < plan->n_inputs; ++i) f.input_slots.push_back(scratch + i);
   auto global_slot = [&](uint32_t w) -> uint32_t { return w == PLAN_WIRE_FALSE ? SLOT_FALSE : w == PLAN_WIRE_TRUE ? SLOT_TRUE : scratch + w; };
   for (uint32_t w : plan->outputs) f.output_slots.push_back(global_slot(w));
-  auto up32 = [&](void** dst, const std::vector<uint32_t>& v) -> int {
-    HIPCHK(hipMalloc(dst, v.size() * 4 + 16));
-    if (!v.empty()) HIPCHK(hipMemcpy(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+  auto up = [&](void** dst, const void* src, size_t bytes) -> int {
+    HIPCHK(hipMalloc(dst, bytes + 64));
+    if (bytes) HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
     return GSV_OK;
   };
-  for (size_t k = 0; k < plan->calls.size(); ++k) {
-    const PlanCall& c = plan->calls[k];
-    const Program& g = s->call_prog(k);
-    std::vector<uint32_t> src, dst;
-    for (size_t i = 0; i < c.in_globals.size(); ++i) { src.push_back(global_slot(c.in_globals[i])); dst.push_back(g.input_slots[i]); }
+  // descriptors and copy lists in execution order
+  {
+    const size_t n = plan->calls.size();
+    std::vector<dev::CallDesc> cds(n);
+    std::vector<uint32_t> pre_src, pre_dst, post_src, post_dst;
+    s->pre_off.assign(n + 1, 0); s->post_off.assign(n + 1, 0);
+    std::vector<uint64_t> window_ct0(n, 0);
+    for (const Schedule::Window& w : sc.windows) for (uint32_t k = w.call0; k < w.call1; ++k) window_ct0[k] = w.ct0;
+    for (size_t pos = 0; pos < n; ++pos) {
+      const uint32_t k = sc.order[pos];
+      const PlanCall& c = plan->calls[k];
+      const Program& g = s->call_prog(k);
+      const uint32_t base = sc.scratch_base[k];
+      dev::CallDesc& d = cds[pos];
+      d.steps = s->call_dev[k].dp.steps; d.ands = s->call_dev[k].dp.ands; d.xors = s->call_dev[k].dp.xors;
+      d.gid_off = c.gid_off; d.ct_off = s->plan_retain ? c.ct_off : c.ct_off - window_ct0[k];
+      d.w_base = base; d.n_steps = g.n_steps;
+      s->pre_off[pos] = pre_src.size(); s->post_off[pos] = post_src.size();
+      if (base != 0)  // the call's own copies of the constant labels (FALSE, TRUE, the all-zero label) in front of its scratch region
+        for (uint32_t q = 0; q < SLOT_FIRST_INPUT; ++q) { pre_src.push_back(q); pre_dst.push_back(base + q); }
+      for (size_t i = 0; i < c.in_globals.size(); ++i) { pre_src.push_back(global_slot(c.in_globals[i])); pre_dst.push_back(base + g.input_slots[i]); }
+      for (size_t i = 0; i < c.out_globals.size(); ++i) {
+        if (g.output_slots[i] & SLOT_LDS_FLAG) return fail(GSV_ERR_CIRCUIT, "internal: a program output lives in the LDS window");
+        post_src.push_back(base + g.output_slots[i]); post_dst.push_back(scratch + c.out_globals[i]);
+      }
+    }
+    s->pre_off[n] = pre_src.size(); s->post_off[n] = post_src.size();
     int rc;
-    if ((rc = up32(&s->call_dev[k].pre_src, src)) || (rc = up32(&s->call_dev[k].pre_dst, dst))) return rc;
-    src.clear(); dst.clear();
-    for (size_t i = 0; i < c.out_globals.size(); ++i) { src.push_back(g.output_slots[i]); dst.push_back(scratch + c.out_globals[i]); }
-    if ((rc = up32(&s->call_dev[k].post_src, src)) || (rc = up32(&s->call_dev[k].post_dst, dst))) return rc;
+    if ((rc = up(&s->d_calls, cds.data(), cds.size() * sizeof(dev::CallDesc))) || (rc = up(&s->d_pre_src, pre_src.data(), pre_src.size() * 4)) || (rc = up(&s->d_pre_dst, pre_dst.data(), pre_dst.size() * 4)) ||
+        (rc = up(&s->d_post_src, post_src.data(), post_src.size() * 4)) || (rc = up(&s->d_post_dst, post_dst.data(), post_dst.size() * 4)))
+      return rc;
+    if ((rc = up(&s->plan_out_slots, f.output_slots.data(), f.output_slots.size() * 4))) return rc;
   }
-  { int rc = up32(&s->plan_out_slots, f.output_slots); if (rc) return rc; }
   DEVALLOC(&s->W, n_instances * size_t(f.n_slots) * 16, "the wire files");
   HIPCHK(hipMalloc(&s->VB, n_instances * size_t(f.n_slots)));
   HIPCHK(hipMemset(s->VB, 0, n_instances * size_t(f.n_slots)));
@@ -911,6 +1001,29 @@ int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_ins
   HIPCHK(hipEventCreate(&s->ev0));
   HIPCHK(hipEventCreate(&s->ev1));
   *out = s.release();
+  return GSV_OK;
+}
+int gsv_session_plan_schedule_info(const gsv_session* s, gsv_plan_schedule_info* info) {
+  if (!s || !s->plan || !info) return fail(GSV_ERR_INVALID, "null argument / not a plan session");
+  const Schedule& sc = s->sched;
+  info->n_calls = s->plan->calls.size(); info->n_windows = sc.windows.size(); info->n_batches = sc.batches.size();
+  info->max_batch_calls = 0;
+  for (const Schedule::Batch& b : sc.batches) info->max_batch_calls = std::max<uint64_t>(info->max_batch_calls, b.count);
+  info->scratch_slots = s->global_base; info->wire_file_slots = s->facade.n_slots; info->window_ct_records = sc.max_window_ct;
+  info->critical_steps = sc.critical_steps; info->total_steps = sc.total_steps;
+  return GSV_OK;
+}
+int gsv_session_plan_window(const gsv_session* s, uint64_t window, uint64_t* first_call, uint64_t* n_calls, uint64_t* n_batches) {
+  if (!s || !s->plan || window >= s->sched.windows.size()) return fail(GSV_ERR_INVALID, "null argument / window index out of range");
+  const Schedule::Window& w = s->sched.windows[size_t(window)];
+  if (first_call) *first_call = w.call0;
+  if (n_calls) *n_calls = w.call1 - w.call0;
+  if (n_batches) *n_batches = w.batch1 - w.batch0;
+  return GSV_OK;
+}
+int gsv_session_set_unchecked_slices(gsv_session* s, int on) {
+  if (!s) return fail(GSV_ERR_INVALID, "null session");
+  s->unchecked_slices = on != 0;
   return GSV_OK;
 }
 
@@ -1043,27 +1156,62 @@ static int launch(gsv_session* s, uint64_t gate_id_base, bool eval, uint64_t rep
   s->ran = true; s->last_eval = eval;
   return GSV_OK;
 }
-// One kernel launch per call (a component runs for >100 ms, a launch costs ~10 us), wire hand-over by two small copy kernels.
-static int launch_plan_call(gsv_session* s, size_t k, uint64_t gate_id_base, bool eval) {
+// One BATCH of a plan session: the pre-copies of its calls (globals -> each call's scratch region), ONE kernel launch with
+// grid.y = calls (run_program_kernel picks its call's descriptor with blockIdx.y), the post-copies (program outputs -> globals).
+// A sequential schedule has one call per batch: a component runs for >100 ms, a launch costs ~10 us.
+static int launch_plan_batch(gsv_session* s, size_t b, uint64_t gate_id_base, bool eval) {
   const Program& f = s->facade;
-  const PlanCall& c = s->plan->calls[k];
-  const Program& g = s->call_prog(k);
-  const gsv_session::CallDev& cd = s->call_dev[k];
-  if (gsvk_copy_slots(s->W, eval ? s->VB : nullptr, f.n_slots, static_cast<const uint32_t*>(cd.pre_src), static_cast<const uint32_t*>(cd.pre_dst), uint32_t(c.in_globals.size()),
+  const Schedule::Batch& bt = s->sched.batches[b];
+  const uint64_t p0 = s->pre_off[bt.first], p1 = s->pre_off[bt.first + bt.count], q0 = s->post_off[bt.first], q1 = s->post_off[bt.first + bt.count];
+  if (gsvk_copy_slots(s->W, eval ? s->VB : nullptr, f.n_slots, static_cast<const uint32_t*>(s->d_pre_src) + p0, static_cast<const uint32_t*>(s->d_pre_dst) + p0, uint32_t(p1 - p0),
                       uint32_t(s->n_inst), s->e->stream) != 0) return fail(GSV_ERR_DEVICE, "copy launch failed");
   dev::KernelArgs ka{};
-  ka.steps = cd.dp.steps; ka.ands = cd.dp.ands; ka.xors = cd.dp.xors;
+  ka.calls = static_cast<const dev::CallDesc*>(s->d_calls) + bt.first;
   ka.W = static_cast<uint4*>(s->W); ka.VB = static_cast<uint8_t*>(s->VB); ka.CT = static_cast<uint4*>(s->CT);
   ka.delta = static_cast<const uint4*>(s->delta); ka.te = static_cast<const uint32_t*>(s->e->te);
-  ka.ct_stride = s->ct_stride(); ka.ct_offset = s->plan_retain ? c.ct_off : 0; ka.gid_base = gate_id_base + c.gid_off; ka.n_gates = g.n_gates; ka.n_ct = g.n_ct;
-  ka.n_steps = g.n_steps; ka.n_slots = f.n_slots; ka.replays = 1; ka.rep_base = 0; ka.ct_cap_replays = 1;
+  ka.ct_stride = s->ct_stride(); ka.gid_base = gate_id_base; ka.n_gates = 0; ka.n_ct = 0;
+  ka.n_steps = 0; ka.n_slots = f.n_slots; ka.replays = 1; ka.rep_base = 0; ka.ct_cap_replays = 1;
   ka.n_instances = uint32_t(s->n_inst); ka.hasher = uint32_t(s->hasher); ka.instances_per_wg = s->ni;
-  if (ka.n_steps) {
-    int lrc = gsvk_launch_program(&ka, uint32_t(s->n_inst), eval ? 1 : 0, s->e->stream);
+  if (bt.max_steps) {  // (calls without steps — pure wire shuffles — only copy)
+    int lrc = gsvk_launch_batch(&ka, uint32_t(s->n_inst), bt.count, eval ? 1 : 0, s->e->stream);
     if (lrc != 0) return fail(GSV_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipError_t(lrc)));
   }
-  if (gsvk_copy_slots(s->W, eval ? s->VB : nullptr, f.n_slots, static_cast<const uint32_t*>(cd.post_src), static_cast<const uint32_t*>(cd.post_dst), uint32_t(c.out_globals.size()),
+  if (gsvk_copy_slots(s->W, eval ? s->VB : nullptr, f.n_slots, static_cast<const uint32_t*>(s->d_post_src) + q0, static_cast<const uint32_t*>(s->d_post_dst) + q0, uint32_t(q1 - q0),
                       uint32_t(s->n_inst), s->e->stream) != 0) return fail(GSV_ERR_DEVICE, "copy launch failed");
+  return GSV_OK;
+}
+static int launch_plan_window(gsv_session* s, size_t w, uint64_t gate_id_base, bool eval) {
+  const Schedule::Window& win = s->sched.windows[w];
+  for (size_t b = win.batch0; b < win.batch1; ++b) {
+    int rc = launch_plan_batch(s, b, gate_id_base, eval);
+    if (rc) return rc;
+  }
+  return GSV_OK;
+}
+// Gate order <-> program order for the calls of one window: ct_gate (window-relative, gate order) <-> the window's device block.
+static int permute_plan_window(gsv_session* s, size_t w, uint64_t gate_stride, int scatter) {
+  const Schedule::Window& win = s->sched.windows[w];
+  for (uint32_t k = win.call0; k < win.call1; ++k) {
+    const Program& cp = s->call_prog(k);
+    if (!cp.n_ct) continue;
+    const uint64_t rel = s->plan->calls[k].ct_off - win.ct0;
+    uint8_t* block = static_cast<uint8_t*>(s->CT) + (s->plan_retain ? s->plan->calls[k].ct_off : rel) * 16;
+    if (gsvk_gather_segment(block, s->ct_stride(), s->call_dev[k].dp.ct_pos, cp.n_ct, 1, uint32_t(s->n_inst), static_cast<uint8_t*>(s->ct_gate) + rel * 16, gate_stride, scatter, s->e->stream) != 0)
+      return fail(GSV_ERR_DEVICE, scatter ? "ciphertext scatter launch failed" : "ciphertext gather launch failed");
+  }
+  return GSV_OK;
+}
+// windows [w0, w1) that cover exactly the calls [c0, c1), or an error: a slice of a plan starts and ends on window boundaries
+static int window_range(const gsv_session* s, size_t c0, size_t c1, size_t* w0, size_t* w1) {
+  const auto& ws = s->sched.windows;
+  size_t a = 0;
+  while (a < ws.size() && ws[a].call0 < c0) ++a;
+  size_t b = a;
+  while (b < ws.size() && ws[b].call1 <= c1) ++b;
+  if (c0 == c1) { *w0 = *w1 = a; return GSV_OK; }
+  if (a >= ws.size() || ws[a].call0 != c0 || b == a || ws[b - 1].call1 != c1)
+    return fail(GSV_ERR_INVALID, "a slice of a plan session must start and end on window boundaries of its schedule (gsv_session_plan_window)");
+  *w0 = a; *w1 = b;
   return GSV_OK;
 }
 static int gather_plan_outputs(gsv_session* s, bool eval) {
@@ -1075,13 +1223,12 @@ static int gather_plan_outputs(gsv_session* s, bool eval) {
   s->ran = true; s->last_eval = eval;
   return GSV_OK;
 }
-// One kernel launch per call (a component runs for >100 ms, a launch costs ~10 us), wire hand-over by two small copy kernels.
 static int launch_plan(gsv_session* s, uint64_t gate_id_base, bool eval) {
-  if (!s->plan_retain) return fail(GSV_ERR_INVALID, "this plan session keeps one call block of ciphertexts only: use gsv_session_garble_streaming");
+  if (!s->plan_retain) return fail(GSV_ERR_INVALID, "this plan session keeps one window of ciphertexts only: use gsv_session_garble_streaming");
   HIPCHK(hipSetDevice(s->e->device));
   HIPCHK(hipEventRecord(s->ev0, s->e->stream));
-  for (size_t k = 0; k < s->plan->calls.size(); ++k) {
-    int rc = launch_plan_call(s, k, gate_id_base, eval);
+  for (size_t w = 0; w < s->sched.windows.size(); ++w) {
+    int rc = launch_plan_window(s, w, gate_id_base, eval);
     if (rc) return rc;
   }
   HIPCHK(hipEventRecord(s->ev1, s->e->stream));
@@ -1166,7 +1313,9 @@ static int garble_discard(gsv_session* s, uint64_t gate_id_base, size_t c0, size
   HIPCHK(hipEventRecord(s->ev0, s->e->stream));
   int rc = GSV_OK;
   if (s->plan) {
-    for (size_t k = c0; k < c1 && rc == GSV_OK; ++k) rc = launch_plan_call(s, k, gate_id_base, false);
+    size_t w0 = 0, w1 = 0;
+    rc = window_range(s, c0, c1, &w0, &w1);
+    for (size_t w = w0; w < w1 && rc == GSV_OK; ++w) rc = launch_plan_window(s, w, gate_id_base, false);
     if (rc == GSV_OK) {
       HIPCHK(hipEventRecord(s->ev1, s->e->stream));
       if (c1 == s->plan->calls.size()) rc = gather_plan_outputs(s, false); else { s->ran = true; s->last_eval = false; }
@@ -1182,9 +1331,12 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   if (!hashes && !dir) return garble_discard(s, gate_id_base, c0, c1);  // garble only (output labels, device-rate measurements of long plans / chains)
   if (!hashes) return fail(GSV_ERR_INVALID, "null hash buffer");
   const Program& g = s->prog();
-  // program sessions: segments of one ring (ct_cap replays of n_ct records); plan sessions: one call per segment
+  // program sessions: segments of one ring (ct_cap replays of n_ct records); plan sessions: one WINDOW of the schedule per segment
+  size_t pw0 = 0, pw1 = 0;
+  if (s->plan) { int wrc = window_range(s, c0, c1, &pw0, &pw1); if (wrc) return wrc; }
   const uint64_t n_ct = s->plan ? s->plan_max_block : g.n_ct, seg = s->plan ? 1 : s->ct_cap;
-  const uint64_t first = s->plan ? c0 : 0, total = s->plan ? c1 : s->replays;
+  const uint64_t first = s->plan ? pw0 : 0, total = s->plan ? pw1 : s->replays;
+  const bool new_pass = s->plan ? c0 == 0 : true;
   const size_t n_inst = s->n_inst;
   constexpr size_t GROUP = size_t(gsv_drain::GROUP);
   const size_t n_groups = (n_inst + GROUP - 1) / GROUP;
@@ -1197,14 +1349,14 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   if (!s->ct_gate && seg_records) DEVALLOC(&s->ct_gate, n_inst * seg_records * 16, "the gate-order ciphertext buffer");
   { int rc = ensure_drain(s, T, seg_records); if (rc) return rc; }
   gsv_drain& dr = *s->drain;
-  if (first == 0 || dr.macs.size() != n_inst) dr.macs.assign(n_inst, CbcMacHost());  // a new pass starts from h = 0; later slices chain
+  if (new_pass || dr.macs.size() != n_inst) dr.macs.assign(n_inst, CbcMacHost());  // a new pass starts from h = 0; later slices chain
   std::vector<CbcMacHost>& macs = dr.macs;
   std::vector<FILE*> files(n_inst, nullptr);
   auto close_files = [&]() { for (FILE*& f : files) if (f) { std::fclose(f); f = nullptr; } };
   if (dir)
     for (size_t i = 0; i < n_inst; ++i) {
       const std::string path = std::string(dir) + "/gc_" + std::to_string(first_index + i) + ".bin";
-      files[i] = std::fopen(path.c_str(), first == 0 ? "wb" : "ab");
+      files[i] = std::fopen(path.c_str(), new_pass ? "wb" : "ab");
       if (!files[i]) { close_files(); return fail(GSV_ERR_INVALID, "cannot create " + path); }
     }
   std::atomic<int> err{0};
@@ -1261,17 +1413,13 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
     const uint64_t r1 = std::min(total, r0 + seg);
     uint64_t n_records;  // per instance, in this segment
     if (s->plan) {
-      const size_t k = size_t(r0);
-      rc = launch_plan_call(s, k, gate_id_base, false);
+      const size_t w = size_t(r0);
+      rc = launch_plan_window(s, w, gate_id_base, false);
       if (rc != GSV_OK) break;
       join(cur);
-      const Program& cp = s->call_prog(k);
-      n_records = cp.n_ct;
-      uint8_t* block = static_cast<uint8_t*>(s->CT) + (s->plan_retain ? s->plan->calls[k].ct_off : 0) * 16;
-      if (gsvk_gather_segment(block, s->ct_stride(), s->call_dev[k].dp.ct_pos, cp.n_ct, 1, uint32_t(n_inst), s->ct_gate, seg_records, 0, s->e->stream) != 0) {
-        rc = fail(GSV_ERR_DEVICE, "ciphertext gather launch failed");
-        break;
-      }
+      n_records = s->sched.windows[w].n_ct;
+      rc = permute_plan_window(s, w, seg_records, 0);
+      if (rc != GSV_OK) break;
     } else {
       // ring slots are (replay % ct_cap): a segment starts at a multiple of ct_cap, so its replays sit in slots 0..n_rep-1
       rc = launch(s, gate_id_base, false, r0, r1 - r0);
@@ -1305,7 +1453,13 @@ int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const ch
 int gsv_session_garble_streaming_calls(gsv_session* s, uint64_t gate_id_base, uint64_t first_call, uint64_t n_calls, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes) {
   if (!s || !s->plan) return fail(GSV_ERR_INVALID, "null session / not a plan session");
   if (first_call > s->plan->calls.size() || n_calls > s->plan->calls.size() - first_call) return fail(GSV_ERR_INVALID, "call range outside the plan");
-  return garble_streaming_range(s, gate_id_base, size_t(first_call), size_t(first_call + n_calls), dir, first_index, n_threads, hashes);
+  // wires, gate ids and the MAC states continue from slice to slice: a slice either starts a new pass or continues the previous one
+  if (first_call != 0 && first_call != s->next_call && !s->unchecked_slices)
+    return fail(GSV_ERR_INVALID, "slice starts at call " + std::to_string(first_call) + " but the previous slice ended at call " + std::to_string(s->next_call) +
+                                     " (gsv_session_set_unchecked_slices for timing runs)");
+  int rc = garble_streaming_range(s, gate_id_base, size_t(first_call), size_t(first_call + n_calls), dir, first_index, n_threads, hashes);
+  if (rc == GSV_OK) { s->next_call = first_call + n_calls; s->garbled = s->plan_retain && s->next_call == s->plan->calls.size(); }
+  return rc;
 }
 int gsv_plan_call_info(const gsv_plan* p, uint64_t call, uint64_t* gate_offset, uint64_t* n_gates, uint64_t* ct_offset, uint64_t* n_ciphertexts, uint64_t* n_steps) {
   if (!p || call >= p->calls.size()) return fail(GSV_ERR_INVALID, "null plan / call index out of range");
@@ -1336,7 +1490,8 @@ int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base) {
 int gsv_session_evaluate_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, uint8_t* hashes) {
   if (!s || !dir) return fail(GSV_ERR_INVALID, "null argument");
   const Program& g = s->prog();
-  const uint64_t n_ct = s->plan ? s->plan_max_block : g.n_ct, total = s->plan ? s->plan->calls.size() : s->replays, seg = s->plan ? 1 : s->ct_cap;
+  // plan sessions: one window of the schedule per segment (its calls' blocks are consecutive in the file)
+  const uint64_t n_ct = s->plan ? s->plan_max_block : g.n_ct, total = s->plan ? s->sched.windows.size() : s->replays, seg = s->plan ? 1 : s->ct_cap;
   const size_t n_inst = s->n_inst;
   HIPCHK(hipSetDevice(s->e->device));
   const uint64_t seg_records = seg * n_ct;
@@ -1354,7 +1509,7 @@ int gsv_session_evaluate_streaming(gsv_session* s, uint64_t gate_id_base, const 
   if (hipEventRecord(s->ev0, s->e->stream) != hipSuccess) { close_files(); return fail(GSV_ERR_DEVICE, "hipEventRecord failed"); }
   for (uint64_t r0 = 0; r0 < total && rc == GSV_OK; r0 += seg) {
     const uint64_t r1 = std::min(total, r0 + seg);
-    const uint64_t n_records = s->plan ? s->call_prog(size_t(r0)).n_ct : (r1 - r0) * n_ct;  // per instance
+    const uint64_t n_records = s->plan ? s->sched.windows[size_t(r0)].n_ct : (r1 - r0) * n_ct;  // per instance
     host.resize(size_t(n_records) * 16);
     for (size_t i = 0; i < n_inst && rc == GSV_OK; ++i) {
       if (n_records && std::fread(host.data(), 16, n_records, files[i]) != n_records) {
@@ -1368,11 +1523,8 @@ int gsv_session_evaluate_streaming(gsv_session* s, uint64_t gate_id_base, const 
     }
     if (rc != GSV_OK) break;
     if (s->plan) {
-      const size_t k = size_t(r0);
-      const Program& cp = s->call_prog(k);
-      uint8_t* block = static_cast<uint8_t*>(s->CT) + (s->plan_retain ? s->plan->calls[k].ct_off : 0) * 16;
-      if (gsvk_gather_segment(block, s->ct_stride(), s->call_dev[k].dp.ct_pos, cp.n_ct, 1, uint32_t(n_inst), s->ct_gate, seg_records, 1, s->e->stream) != 0) { rc = fail(GSV_ERR_DEVICE, "ciphertext scatter launch failed"); break; }
-      rc = launch_plan_call(s, k, gate_id_base, true);
+      rc = permute_plan_window(s, size_t(r0), seg_records, 1);
+      if (rc == GSV_OK) rc = launch_plan_window(s, size_t(r0), gate_id_base, true);
     } else {
       if (gsvk_gather_segment(s->CT, s->ct_stride(), s->dp.ct_pos, n_ct, uint32_t(r1 - r0), uint32_t(n_inst), s->ct_gate, seg_records, 1, s->e->stream) != 0) { rc = fail(GSV_ERR_DEVICE, "ciphertext scatter launch failed"); break; }
       rc = launch(s, gate_id_base, true, r0, r1 - r0);

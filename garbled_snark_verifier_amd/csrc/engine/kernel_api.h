@@ -10,6 +10,20 @@
 namespace gsv {
 namespace dev {
 
+// One call of a plan inside a BATCH launch (engine.cpp: independent calls of a plan run side by side, blockIdx.y = call): the
+// call's program image, its gate-id / ciphertext offsets and the base of its own scratch region inside every instance's wire file.
+struct CallDesc {
+  const void* steps;
+  const void* ands;
+  const void* xors;
+  uint64_t gid_off;   // added to KernelArgs::gid_base
+  uint64_t ct_off;    // record offset of the call's ciphertext block inside every instance's device stream
+  uint32_t w_base;    // first slot of the call's scratch region inside the instance's wire file
+  uint32_t n_steps;
+  uint64_t pad_[2];
+};
+static_assert(sizeof(CallDesc) == 64, "CallDesc layout");
+
 struct KernelArgs {
   const void* steps;   // StepDesc[n_steps]   {and_off, and_cnt, xor_off, xor_cnt}
   const void* ands;    // AndRec[]            32 B
@@ -37,6 +51,7 @@ struct KernelArgs {
   uint32_t instances_per_wg;  // 1, 2 or 4 (n needs a program compiled for 1/n of the LDS window)
   uint32_t hasher;            // 0 = AesNiHasher, 1 = Blake3Hasher
   unsigned long long* step_clock;  // diagnostics: workgroup 0 stamps the 100 MHz wall clock at the start of every step of the last replay (null = off)
+  const CallDesc* calls;  // non-null: batch launch, grid.y = calls; steps / ands / xors / n_steps / ct_offset come from calls[blockIdx.y]
   uint32_t diag;  // timing experiments only (GSV_DIAG env; honoured by a library built with -DGSV_DIAG_BUILD = `build.py --diag`, ignored by
                   // the production build): 1 = skip AES, 4 = skip label loads, 8 = skip stores, 16 = no multi-lane narrow form
 };
@@ -47,6 +62,8 @@ struct KernelArgs {
 extern "C" {
 int gsvk_upload_round_keys(const uint32_t rk[44]);
 int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, int evaluate, hipStream_t stream);
+// grid = (instance groups, n_calls): ka->calls[0 .. n_calls) run side by side (n_calls <= 65535)
+int gsvk_launch_batch(const gsv::dev::KernelArgs* ka, uint32_t n_instances, uint32_t n_calls, int evaluate, hipStream_t stream);
 int gsvk_gather_outputs(const void* W, const void* VB, uint32_t n_slots, const uint32_t* slots, uint32_t n_out, uint32_t n_instances,
                         void* out, void* out_bits, hipStream_t stream);
 // stage[i] <-> stream[(idx / n_ct) * n_ct + ct_pos[idx % n_ct]] for idx = first + i, i < n  (scatter != 0: stage -> stream)

@@ -177,6 +177,16 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   if (threadIdx.x < 4u * NI) *reinterpret_cast<lds_u32*>(uintptr_t(GSV_LDS_TABLE_BYTES + (threadIdx.x / 4u) * (GSV_LDS_SLOTS / NI) * 16u + (threadIdx.x % 4u) * 4u)) = 0u;
   if (threadIdx.x < uint32_t(NI)) *reinterpret_cast<lds_u8*>(uintptr_t(GSV_LDS_TABLE_BYTES + GSV_LDS_SLOTS * 16u + threadIdx.x * (GSV_LDS_SLOTS / NI))) = uint8_t(0);
   __syncthreads();
+  // Batch launch (plans): blockIdx.y selects one of several independent calls that run side by side; everything that differs
+  // between them comes from a 64-byte descriptor behind a wave-uniform address (scalar loads).
+  uint32_t w_base = 0;
+  if (ka.calls) {
+    typedef const CallDesc GSV_CST cst_call;
+    cst_call* cd = (cst_call*)ka.calls + blockIdx.y;
+    ka.steps = cd->steps; ka.ands = cd->ands; ka.xors = cd->xors;
+    ka.gid_base += cd->gid_off; ka.ct_offset = cd->ct_off; ka.n_steps = cd->n_steps;
+    w_base = cd->w_base;
+  }
   constexpr uint32_t BT = GSV_BLOCK_THREADS / NI;  // threads per instance
   // which instance of this workgroup: wave-uniform (BT is a multiple of 64), so say so — every per-instance base
   // address below then lives in SGPRs instead of costing a VGPR each
@@ -196,8 +206,8 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   WireFile wf;
   wf.win_base = GSV_LDS_TABLE_BYTES + sub * (GSV_LDS_SLOTS / NI) * 16u;
   wf.bit_base = GSV_LDS_TABLE_BYTES + GSV_LDS_SLOTS * 16u + sub * (GSV_LDS_SLOTS / NI);
-  wf.hbm = (glb_u128*)(ka.W + size_t(inst) * ka.n_slots);      // C-style cast: generic -> global address space
-  wf.hbm_bits = (glb_u8*)(ka.VB + size_t(inst) * ka.n_slots);
+  wf.hbm = (glb_u128*)(ka.W + size_t(inst) * ka.n_slots + w_base);      // C-style cast: generic -> global address space
+  wf.hbm_bits = (glb_u8*)(ka.VB + size_t(inst) * ka.n_slots + w_base);
   glb_u128* __restrict__ CT = (glb_u128*)(ka.CT + size_t(inst) * ka.ct_stride + ka.ct_offset);
   glb_u32* __restrict__ CTw = (glb_u32*)CT;
   Label delta{{0, 0, 0, 0}};
@@ -556,7 +566,9 @@ int gsvk_upload_round_keys(const uint32_t rk[44]) {
   for (int i = 0; i < 44; ++i) dev_rk[i] = (i >= 4 && i < 40) ? ((rk[i] >> 8) | (rk[i] << 24)) : rk[i];
   return int(hipMemcpyToSymbol(HIP_SYMBOL(gsv::dev::c_rk), dev_rk, 44 * sizeof(uint32_t)));
 }
-int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, int evaluate, hipStream_t stream) {
+int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, int evaluate, hipStream_t stream) { return gsvk_launch_batch(ka, n_instances, 1, evaluate, stream); }
+int gsvk_launch_batch(const gsv::dev::KernelArgs* ka, uint32_t n_instances, uint32_t n_calls, int evaluate, hipStream_t stream) {
+  if (n_calls == 0 || n_calls > 65535u || (n_calls > 1 && !ka->calls)) return int(hipErrorInvalidValue);
   const size_t lds = GSV_LDS_BYTES;
   // The opt-in to 160 KiB of dynamic LDS is a per-device function attribute: done once per device (an engine per GPU may live
   // in one process, and sessions may be driven from several host threads).
@@ -583,7 +595,7 @@ int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, in
   }
   const bool blake3 = ka->hasher == 1;
   const uint32_t ni = blake3 ? 1u : (ka->instances_per_wg == 4 ? 4u : ka->instances_per_wg == 2 ? 2u : 1u);
-  const dim3 grid((n_instances + ni - 1) / ni);
+  const dim3 grid((n_instances + ni - 1) / ni, n_calls);
   if (blake3) {
     if (evaluate) hipLaunchKernelGGL((gsv::dev::run_program_kernel<true, 1, 1>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
     else hipLaunchKernelGGL((gsv::dev::run_program_kernel<false, 1, 1>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);

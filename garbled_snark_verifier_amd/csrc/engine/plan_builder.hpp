@@ -426,8 +426,14 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
   uint32_t next_global = 0;
   for (uint32_t w : inputs) global_of[w] = next_global++;
   bp.n_inputs = next_global;
-  std::vector<uint32_t> free_ids;
-  auto alloc_global = [&]() -> uint32_t { if (!free_ids.empty()) { uint32_t g = free_ids.back(); free_ids.pop_back(); return g; } return next_global++; };
+  // Recycling is FIFO with slack: a freed id is handed out again only once `slack` younger ids wait behind it.  A session runs
+  // independent calls side by side (schedule.hpp) and sees global ids as memory locations: an id reused right away would chain its
+  // new writer behind every reader of the old value (WAR) although the two calls have nothing to do with each other; with the
+  // queue the reuse distance is slack / (outputs per call) calls, beyond any scheduling window.  Cost: slack x 16 bytes per instance
+  // (GSV_PLAN_ID_SLACK, default 262 144 ids = 4 MB).
+  std::deque<uint32_t> free_ids;
+  const size_t id_slack = getenv("GSV_PLAN_ID_SLACK") ? size_t(std::max(0, atoi(getenv("GSV_PLAN_ID_SLACK")))) : size_t(262144);
+  auto alloc_global = [&]() -> uint32_t { if (free_ids.size() > id_slack) { uint32_t g = free_ids.front(); free_ids.pop_front(); return g; } return next_global++; };
   // released after segment si has read its inputs; each wire once even when a call names it several times
   auto release_dead_inputs = [&](size_t si) {
     for (uint32_t w : m.segments[si].in_ssa)

@@ -185,16 +185,25 @@ inline Fq2 double_(CircuitContext& c, const Fq2& a) { return {{fq::double_(c, a.
 inline Fq2 half(CircuitContext& c, const Fq2& a) { return {{fq::half(c, a.c[0]), fq::half(c, a.c[1])}}; }                                 // fq2.rs:211-219
 inline Fq2 triple(CircuitContext& c, const Fq2& a) { Fq2 a2 = double_(c, a); return add(c, a, a2); }                                      // fq2.rs:221-228
 inline Fq2 div6(CircuitContext& c, const Fq2& a) { return {{fq::div6(c, a.c[0]), fq::div6(c, a.c[1])}}; }                                 // fq2.rs:386-394
-inline Fq2 mul_montgomery(CircuitContext& c, const Fq2& a, const Fq2& b) {  // fq2.rs:230-255
-  Wires a_sum = fq::add(c, a.c[0], a.c[1]);
-  Wires b_sum = fq::add(c, b.c[0], b.c[1]);
-  Wires a0_b0 = fq::mul_montgomery(c, a.c[0], b.c[0]);
-  Wires a1_b1 = fq::mul_montgomery(c, a.c[1], b.c[1]);
-  Wires sum_prod = fq::mul_montgomery(c, a_sum, b_sum);
-  Wires c0 = fq::sub(c, a0_b0, a1_b1);
-  Wires sum_a0b0_a1b1 = fq::add(c, a0_b0, a1_b1);
-  Wires c1 = fq::sub(c, sum_prod, sum_a0b0_a1b1);
-  return {{c0, c1}};
+// fq2.rs:230-255.  The reference does not make the Fq2 multiplication / squaring components; here they are wrapped in one (as the
+// cyclotomic squaring below): a component boundary changes nothing in the gate stream — a wire is dead iff nothing reads it, wherever
+// the boundary is; the oracle's fixtures, generated before the wrappers existed, did not move — and it gives a plan a unit of the
+// granularity at which an instance has width: an Fq12 multiplication is 15 independent Fq2 multiplications (fq12.rs:199-221,
+// fq6.rs:194-260), which a session runs side by side on 15 CUs (schedule.hpp).
+inline Fq2 mul_montgomery(CircuitContext& c0, const Fq2& a_, const Fq2& b_) {
+  Wires out = component(c0, KeyBuilder("fq2::mul_montgomery"), concat(a_.to_wires(), b_.to_wires()), 508, [](CircuitContext& c, const Wires& in) {
+    const Fq2 a = Fq2::from_wires(slice(in, 0, 508)), b = Fq2::from_wires(slice(in, 508, 1016));
+    Wires a_sum = fq::add(c, a.c[0], a.c[1]);
+    Wires b_sum = fq::add(c, b.c[0], b.c[1]);
+    Wires a0_b0 = fq::mul_montgomery(c, a.c[0], b.c[0]);
+    Wires a1_b1 = fq::mul_montgomery(c, a.c[1], b.c[1]);
+    Wires sum_prod = fq::mul_montgomery(c, a_sum, b_sum);
+    Wires c0 = fq::sub(c, a0_b0, a1_b1);
+    Wires sum_a0b0_a1b1 = fq::add(c, a0_b0, a1_b1);
+    Wires c1 = fq::sub(c, sum_prod, sum_a0b0_a1b1);
+    return Fq2{{c0, c1}}.to_wires();
+  });
+  return Fq2::from_wires(out);
 }
 inline Fq2 mul_by_nonresidue(CircuitContext& c, const Fq2& a) {  // fq2.rs:324-339
   Wires a0_3 = fq::triple(c, a.c[0]);
@@ -205,13 +214,17 @@ inline Fq2 mul_by_nonresidue(CircuitContext& c, const Fq2& a) {  // fq2.rs:324-3
   Wires c1 = fq::add(c, a1_9, a.c[0]);
   return {{c0, c1}};
 }
-inline Fq2 square_montgomery(CircuitContext& c, const Fq2& a) {  // fq2.rs:341-354
-  Wires a0_plus_a1 = fq::add(c, a.c[0], a.c[1]);
-  Wires a0_minus_a1 = fq::sub(c, a.c[0], a.c[1]);
-  Wires a0_a1 = fq::mul_montgomery(c, a.c[0], a.c[1]);
-  Wires c0 = fq::mul_montgomery(c, a0_plus_a1, a0_minus_a1);
-  Wires c1 = fq::double_(c, a0_a1);
-  return {{c0, c1}};
+inline Fq2 square_montgomery(CircuitContext& c0, const Fq2& a_) {  // fq2.rs:341-354 (wrapped like mul_montgomery above)
+  Wires out = component(c0, KeyBuilder("fq2::square_montgomery"), a_.to_wires(), 508, [](CircuitContext& c, const Wires& in) {
+    const Fq2 a = Fq2::from_wires(in);
+    Wires a0_plus_a1 = fq::add(c, a.c[0], a.c[1]);
+    Wires a0_minus_a1 = fq::sub(c, a.c[0], a.c[1]);
+    Wires a0_a1 = fq::mul_montgomery(c, a.c[0], a.c[1]);
+    Wires c0 = fq::mul_montgomery(c, a0_plus_a1, a0_minus_a1);
+    Wires c1 = fq::double_(c, a0_a1);
+    return Fq2{{c0, c1}}.to_wires();
+  });
+  return Fq2::from_wires(out);
 }
 }  // namespace fq2
 

@@ -175,6 +175,37 @@ int gsv_session_create_plan(gsv_engine* e, const gsv_plan* plan, size_t n_instan
 /* retain_stream = 0: the device keeps ONE call block of ciphertexts (plans of any length); such a session is driven by
  * gsv_session_garble_streaming only (each call's block is drained while the next call runs). */
 int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_instances, int retain_stream, gsv_session** out);
+/* Call-level concurrency.  The reference gets its width from `total` instances garbled side by side, one per core
+ * (cut_and_choose/garbler.rs:206-234); with 1-16 instances on a 256-CU GPU the width has to come from INSIDE an instance.  A plan
+ * session therefore executes a SCHEDULE of the plan: the calls are taken in windows of consecutive stream order, inside a window
+ * they are levelled by their data flow through the global wires (RAW / WAW / WAR on the global ids) and independent calls run
+ * side by side in one launch (grid = instance groups x calls), each in a scratch region of its own inside the instance's wire
+ * file.  Gate ids and ciphertext positions are those of the stream order, so the result is bit-identical to the sequential run.
+ *   retain_stream         as gsv_session_create_plan_ex
+ *   max_concurrent_calls  0 = as many as give every CU a workgroup (GSV_PLAN_CONCURRENCY overrides); 1 = sequential
+ *   window_ct_records     ciphertext records per instance of one window (the device block of a session that does not retain the
+ *                         stream; the drain's gate-order copy is as large again); 0 = chosen from the free device memory
+ *   max_scratch_slots     16-byte slots per instance for the scratch regions of one batch; 0 = chosen from the free device memory
+ *   max_window_calls      0 = 4096 */
+typedef struct gsv_plan_session_opts {
+  int retain_stream;
+  uint32_t max_concurrent_calls;
+  uint64_t window_ct_records;
+  uint64_t max_scratch_slots;
+  uint32_t max_window_calls;
+  uint32_t reserved;
+} gsv_plan_session_opts;
+int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_instances, const gsv_plan_session_opts* opts, gsv_session** out);
+typedef struct gsv_plan_schedule_info {
+  uint64_t n_calls, n_windows, n_batches, max_batch_calls;
+  uint64_t scratch_slots, wire_file_slots;  /* per instance: scratch area / whole wire file (scratch + global wires) */
+  uint64_t window_ct_records;               /* largest window, ciphertext records per instance */
+  uint64_t critical_steps, total_steps;     /* device steps: sum over batches of the longest call / sum over all calls */
+} gsv_plan_schedule_info;
+int gsv_session_plan_schedule_info(const gsv_session* s, gsv_plan_schedule_info* info);
+/* Window `window` of the session's schedule: calls [first_call, first_call + n_calls) of the plan.  Slices handed to
+ * gsv_session_garble_streaming_calls start and end on window boundaries. */
+int gsv_session_plan_window(const gsv_session* s, uint64_t window, uint64_t* first_call, uint64_t* n_calls, uint64_t* n_batches);
 
 /* Garble (GarbleMode): per instance i: delta[16i..], const_label0 = {false.label0, true.label0}
  * (32 B per instance), input_label0 (n_inputs*16 B per instance).  Asynchronous on the engine stream. */
@@ -205,6 +236,10 @@ int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const ch
  * new pass (MACs from zero, gc files truncated; later slices append).  `hashes` receives the MAC states after this slice — the
  * commitments once the last slice has run.  Output labels are gathered by the slice that ends with the plan's last call. */
 int gsv_session_garble_streaming_calls(gsv_session* s, uint64_t gate_id_base, uint64_t first_call, uint64_t n_calls, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes);
+/* A slice must start a new pass (first_call == 0) or continue where the previous slice ended, and start / end on window boundaries
+ * of the session's schedule; anything else is GSV_ERR_INVALID.  Timing harnesses that garble slices out of order (stale wires,
+ * meaningless MACs) say so explicitly: */
+int gsv_session_set_unchecked_slices(gsv_session* s, int on);
 
 /* Evaluate with the ciphertexts streamed from <dir>/gc_<first_index + instance>.bin (EvaluateMode over a FileSource:
  * evaluate_mode.rs:59-196, ciphertext_source.rs:36-107), one ring / one plan call at a time, for streams of any length.  Like

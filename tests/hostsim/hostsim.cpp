@@ -15,6 +15,7 @@
 #include "../../garbled_snark_verifier_amd/csrc/engine/host_crypto.hpp"
 #include "../../garbled_snark_verifier_amd/csrc/engine/plan_builder.hpp"
 #include "../../garbled_snark_verifier_amd/csrc/engine/program.hpp"
+#include "../../garbled_snark_verifier_amd/csrc/engine/schedule.hpp"
 #include "../../garbled_snark_verifier_amd/csrc/gadgets/circuits.hpp"
 
 using namespace gsv;
@@ -157,6 +158,8 @@ int hostsim_run(SimProgram* sp, int evaluate, uint32_t replays, uint64_t gid_bas
 struct SimPlan {
   BuiltPlan bp;
   uint64_t n_ct = 0;
+  Schedule sched;        // hostsim_plan_schedule: the engine's call-level schedule (schedule.hpp); empty = stream order
+  bool scheduled = false;
 };
 int hostsim_plan_build(const char* spec, const char* units_csv, SimPlan** out, uint64_t* info /* 8: n_inputs n_outputs n_gates n_ct n_calls n_programs n_globals n_unit_programs */) {
   try {
@@ -193,15 +196,111 @@ int hostsim_plan_build(const char* spec, const char* units_csv, SimPlan** out, u
   } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 void hostsim_plan_free(SimPlan* p) { delete p; }
+static uint32_t plan_n_globals(const BuiltPlan& bp) {
+  uint32_t n_globals = bp.n_inputs;
+  for (auto& c : bp.calls) {
+    for (uint32_t w : c.in_globals) if (w < PLAN_WIRE_FALSE) n_globals = std::max(n_globals, w + 1);
+    for (uint32_t w : c.out_globals) n_globals = std::max(n_globals, w + 1);
+  }
+  return n_globals;
+}
+// The engine's scheduler (schedule.hpp, the very code engine.cpp runs at session creation) over this plan; the schedule is checked
+// against the hazard rules and kept: hostsim_plan_run then executes it with the device's batch semantics (all pre-copies of a
+// batch, then its calls — visited in REVERSE order —, then all post-copies).  info: n_windows n_batches max_batch_calls scratch_slots
+// critical_steps total_steps max_window_ct.
+int hostsim_plan_schedule(SimPlan* sp, uint32_t max_calls, uint64_t max_slots, uint64_t window_ct, uint32_t window_calls, uint64_t* info /* 7 */) {
+  try {
+    const BuiltPlan& bp = sp->bp;
+    std::vector<SchedCall> calls(bp.calls.size());
+    for (size_t k = 0; k < bp.calls.size(); ++k) {
+      const BuiltPlan::Call& c = bp.calls[k];
+      const Program& g = bp.programs[size_t(c.program)];
+      calls[k].in = c.in_globals.data(); calls[k].n_in = c.in_globals.size();
+      calls[k].out = c.out_globals.data(); calls[k].n_out = c.out_globals.size();
+      calls[k].n_slots = g.n_slots; calls[k].n_ct = g.n_ct; calls[k].n_steps = g.n_steps;
+    }
+    SchedParams p;
+    p.max_calls_per_batch = max_calls; p.max_batch_slots = max_slots ? max_slots : ~0ull; p.max_window_ct = window_ct ? window_ct : ~0ull;
+    p.max_window_calls = window_calls ? window_calls : 4096;
+    const uint32_t n_ids = plan_n_globals(bp);
+    sp->sched = schedule_calls(calls, n_ids, bp.outputs, p);
+    const std::string err = verify_schedule(calls, n_ids, bp.outputs, sp->sched);
+    if (!err.empty()) gsv_panic("schedule violates a hazard: " + err);
+    sp->scheduled = true;
+    if (info) {
+      info[0] = sp->sched.windows.size(); info[1] = sp->sched.batches.size(); info[2] = 0;
+      for (auto& b : sp->sched.batches) info[2] = std::max<uint64_t>(info[2], b.count);
+      info[3] = sp->sched.scratch_slots; info[4] = sp->sched.critical_steps; info[5] = sp->sched.total_steps; info[6] = sp->sched.max_window_ct;
+    }
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+static int plan_run_scheduled(SimPlan* sp, int evaluate, uint64_t gid_base, const uint8_t delta[16], const uint8_t consts[32], const uint8_t* inputs,
+                              const uint8_t* input_bits, uint8_t* cts, uint8_t* out_labels, uint8_t* out_bits) {
+  const BuiltPlan& bp = sp->bp;
+  const Schedule& sc = sp->sched;
+  const uint32_t n_globals = plan_n_globals(bp);
+  std::vector<uint8_t> G(size_t(n_globals) * 16, 0xC3), GB(n_globals, 0);
+  for (uint32_t i = 0; i < bp.n_inputs; ++i) { std::memcpy(&G[size_t(i) * 16], inputs + 16 * i, 16); if (evaluate) GB[i] = input_bits[i] ? 1 : 0; }
+  const Label d = evaluate ? Label{{0, 0, 0, 0}} : load(delta);
+  std::vector<uint64_t> gid_off(bp.calls.size()), ct_off(bp.calls.size());
+  { uint64_t g = 0, c = 0; for (size_t k = 0; k < bp.calls.size(); ++k) { gid_off[k] = g; ct_off[k] = c; const Program& pr = bp.programs[size_t(bp.calls[k].program)]; g += pr.n_gates; c += pr.n_ct; } }
+  // ONE scratch area shared by the calls of a batch, at the offsets the schedule assigned (overlaps would corrupt results)
+  std::vector<uint8_t> W(size_t(std::max<uint64_t>(sc.scratch_slots, 8)) * 16, 0xA5), VB(std::max<uint64_t>(sc.scratch_slots, 8), 0);
+  for (const Schedule::Batch& b : sc.batches) {
+    for (uint32_t j = 0; j < b.count; ++j) {  // pre-copies
+      const uint32_t k = sc.order[b.first + j];
+      const BuiltPlan::Call& c = bp.calls[k];
+      const Program& g = bp.programs[size_t(c.program)];
+      const size_t base = sc.scratch_base[k];
+      std::memset(&W[base * 16], 0xA5, size_t(g.n_slots) * 16);
+      std::memcpy(&W[base * 16], consts, 32);
+      std::memset(&W[(base + SLOT_ZERO) * 16], 0, 16);
+      VB[base + 0] = 0; VB[base + 1] = 1; VB[base + SLOT_ZERO] = 0;
+      for (size_t i = 0; i < c.in_globals.size(); ++i) {
+        const uint32_t w = c.in_globals[i];
+        const size_t dst = base + g.input_slots[i];
+        if (w == PLAN_WIRE_FALSE) { std::memcpy(&W[dst * 16], consts, 16); VB[dst] = 0; }
+        else if (w == PLAN_WIRE_TRUE) { std::memcpy(&W[dst * 16], consts + 16, 16); VB[dst] = 1; }
+        else { std::memcpy(&W[dst * 16], &G[size_t(w) * 16], 16); VB[dst] = GB[w]; }
+      }
+    }
+    for (uint32_t j = b.count; j-- > 0;) {  // the calls, last first
+      const uint32_t k = sc.order[b.first + j];
+      const Program& g = bp.programs[size_t(bp.calls[k].program)];
+      const size_t base = sc.scratch_base[k];
+      std::vector<uint8_t> w(W.begin() + base * 16, W.begin() + (base + g.n_slots) * 16), vb(VB.begin() + base, VB.begin() + base + g.n_slots);
+      interpret(g, evaluate != 0, gid_base + gid_off[k], d, w, vb, cts + ct_off[k] * 16);
+      std::memcpy(&W[base * 16], w.data(), w.size());
+      std::memcpy(&VB[base], vb.data(), vb.size());
+    }
+    for (uint32_t j = 0; j < b.count; ++j) {  // post-copies
+      const uint32_t k = sc.order[b.first + j];
+      const BuiltPlan::Call& c = bp.calls[k];
+      const Program& g = bp.programs[size_t(c.program)];
+      const size_t base = sc.scratch_base[k];
+      for (size_t i = 0; i < c.out_globals.size(); ++i) {
+        const uint32_t src = g.output_slots[i];
+        if (src & SLOT_LDS_FLAG) gsv_panic("program output in the LDS window");
+        std::memcpy(&G[size_t(c.out_globals[i]) * 16], &W[(base + src) * 16], 16);
+        GB[c.out_globals[i]] = VB[base + src];
+      }
+    }
+  }
+  for (size_t i = 0; i < bp.outputs.size(); ++i) {
+    const uint32_t w = bp.outputs[i];
+    if (w == PLAN_WIRE_FALSE) { std::memcpy(out_labels + 16 * i, consts, 16); if (out_bits) out_bits[i] = 0; }
+    else if (w == PLAN_WIRE_TRUE) { std::memcpy(out_labels + 16 * i, consts + 16, 16); if (out_bits) out_bits[i] = 1; }
+    else { std::memcpy(out_labels + 16 * i, &G[size_t(w) * 16], 16); if (out_bits) out_bits[i] = GB[w]; }
+  }
+  return 0;
+}
 int hostsim_plan_run(SimPlan* sp, int evaluate, uint64_t gid_base, const uint8_t delta[16], const uint8_t consts[32], const uint8_t* inputs,
                      const uint8_t* input_bits, uint8_t* cts, uint8_t* out_labels, uint8_t* out_bits) {
   try {
+    if (sp->scheduled) return plan_run_scheduled(sp, evaluate, gid_base, delta, consts, inputs, input_bits, cts, out_labels, out_bits);
     const BuiltPlan& bp = sp->bp;
-    uint32_t n_globals = bp.n_inputs;
-    for (auto& c : bp.calls) {
-      for (uint32_t w : c.in_globals) if (w < PLAN_WIRE_FALSE) n_globals = std::max(n_globals, w + 1);
-      for (uint32_t w : c.out_globals) n_globals = std::max(n_globals, w + 1);
-    }
+    const uint32_t n_globals = plan_n_globals(bp);
     std::vector<uint8_t> G(size_t(n_globals) * 16, 0xC3), GB(n_globals, 0);
     for (uint32_t i = 0; i < bp.n_inputs; ++i) { std::memcpy(&G[size_t(i) * 16], inputs + 16 * i, 16); if (evaluate) GB[i] = input_bits[i] ? 1 : 0; }
     const Label d = evaluate ? Label{{0, 0, 0, 0}} : load(delta);

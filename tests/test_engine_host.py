@@ -220,6 +220,50 @@ def test_plan_builder_matches_flat_stream(spec, units, seed):
     assert (ob == eo).all() and (oa == np.where(ob[:, None] == 1, out ^ delta[None, :], out)).all()
 
 
+@pytest.mark.parametrize("spec,units,seed,sched", [
+    ("random_circuit:3", ["test::random_block"], 1, dict(max_calls=64)),                       # 145 calls side by side where the data flow allows
+    ("random_circuit:8", ["test::random_block"], 2, dict(max_calls=4, window_calls=16)),       # small batches, windows of 16 calls
+    ("fq_complex", ["fp254::montgomery_reduce", "bigint::mul_karatsuba"], 2, dict(max_calls=8)),
+    ("g1_mux_add", ["bigint::multiplexer", "g1::add_montgomery"], 3, dict(max_calls=16)),      # three independent multiplexers, then the addition
+    ("g1_mux_add", ["bigint::multiplexer", "g1::add_montgomery"], 3, dict(max_calls=16, max_slots=1)),  # scratch budget forces one call per batch
+    ("driver_mix", ["test::inner", "bigint::add"], 6, dict(max_calls=32, window_ct=300)),      # ciphertext windows
+])
+def test_scheduled_plan_matches_flat_stream(spec, units, seed, sched):
+    """schedule.hpp — the code engine.cpp runs at session creation — over a plan: windows of consecutive calls, levelled by the RAW /
+    WAW / WAR hazards on the (recycled) global ids, independent calls in one batch with scratch regions of their own.  The host
+    interpreter executes the schedule with the device's batch semantics (all pre-copies, the calls in REVERSE order in one shared
+    scratch area, all post-copies): the stream, its CBC-MAC, the output labels and the evaluation must still be the oracle's."""
+    sp = h.SimPlan(spec, units)
+    info = sp.schedule(**sched)
+    assert info["n_batches"] <= sp.info["n_calls"] and info["critical_steps"] <= info["total_steps"]
+    if sched.get("max_slots") == 1:
+        assert info["max_batch_calls"] == 1
+    ref = o.garble(spec, seed)
+    n_in = ref.n_in
+    labs = h.labels_from_seed(seed, 3 + n_in)
+    delta, consts, inputs = labs[0], labs[1:3], labs[3:]
+    out, cts = sp.garble(delta, consts, inputs)
+    assert ref.n_ciphertexts == cts.shape[0] and (ref.ciphertexts == cts).all() and (ref.output_label0 == out).all()
+    bits = np.random.default_rng(seed).integers(0, 2, n_in).astype(np.uint8)
+    act = np.where(bits[:, None] == 1, inputs ^ delta[None, :], inputs)
+    oa, ob = sp.evaluate(np.stack([consts[0], consts[1] ^ delta]), act, bits, cts)
+    eo, _, _ = o.execute(spec, bits)
+    assert (ob == eo).all() and (oa == np.where(ob[:, None] == 1, out ^ delta[None, :], out)).all()
+
+
+def test_schedule_finds_the_independent_calls():
+    """Width is found where the circuit has it: the three coordinate multiplexers of g1::multiplexer are independent (one batch of
+    three), and the chain-like random_circuit:3 still packs its 145 calls into fewer batches."""
+    sp = h.SimPlan("g1_mux_add", ["bigint::multiplexer", "g1::add_montgomery"])
+    info = sp.schedule(max_calls=16)
+    assert info["max_batch_calls"] >= 3 and info["n_batches"] < sp.info["n_calls"]
+    seq = sp.schedule(max_calls=1)
+    assert seq["n_batches"] == sp.info["n_calls"] and seq["critical_steps"] == seq["total_steps"] and info["critical_steps"] < seq["critical_steps"]
+    sp = h.SimPlan("random_circuit:3", ["test::random_block"])
+    info = sp.schedule(max_calls=64)
+    assert info["n_batches"] < sp.info["n_calls"] and info["max_batch_calls"] >= 2
+
+
 def test_plan_from_circuit_builds_without_a_device_and_in_both_modes():
     """gsv_plan_from_circuit is host-only work: units are compiled on a worker pool while the driver records (plan_builder.hpp
     CompilePool), with GSV_PLAN_WINDOW_DIV once for half / a quarter of the LDS window.  Every mode gives the reference's counts; the
