@@ -70,6 +70,16 @@ def plan_slices(call_gates, n_slices):
     return [(bounds[k], bounds[k + 1] - bounds[k], cum[bounds[k + 1]] - cum[bounds[k]]) for k in range(n_slices)]
 
 
+def session_slices(windows, call_gates, n_slices):
+    """The same for a plan SESSION: its schedule executes whole windows of consecutive calls (Session.windows(): [(first_call, n_calls,
+    n_batches)]), so a slice starts and ends on window boundaries — `n_slices` groups of windows of nearly equal gate count."""
+    wg = [sum(int(g) for g in call_gates[f:f + n]) for f, n, _ in windows]
+    out = []
+    for w0, nw, gates in plan_slices(wg, n_slices):
+        out.append((windows[w0][0], sum(windows[w][1] for w in range(w0, w0 + nw)), gates))
+    return out
+
+
 def instance_seeds(rank, n):
     """Seeds of this rank's instances: disjoint between ranks (instance i of the job -> rank i mod world in a real run)."""
     return [1_000_003 * (rank + 1) + i for i in range(n)]

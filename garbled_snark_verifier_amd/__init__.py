@@ -59,7 +59,7 @@ class _PlanSessionOpts(C.Structure):
                 ("max_window_calls", C.c_uint32), ("reserved", C.c_uint32)]
 
 
-_SCHED_FIELDS = ["n_calls", "n_windows", "n_batches", "max_batch_calls", "scratch_slots", "wire_file_slots", "window_ct_records", "critical_steps", "total_steps"]
+_SCHED_FIELDS = ["n_calls", "n_windows", "n_dependencies", "max_width", "scratch_slots", "wire_file_slots", "window_ct_records", "critical_steps", "total_steps"]
 
 
 class _PlanScheduleInfo(C.Structure):
@@ -546,7 +546,7 @@ class Session:
         return {k: int(getattr(i, k)) for k in _SCHED_FIELDS}
 
     def windows(self):
-        """[(first_call, n_calls, n_batches)] of the schedule: slices handed to garble_calls start and end on these boundaries."""
+        """[(first_call, n_calls, max_width)] of the schedule: slices handed to garble_calls start and end on these boundaries."""
         out = []
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         for w in range(self.schedule_info()["n_windows"]):

@@ -81,7 +81,8 @@ def check_step_barrier_isa(asm=None):
         n = sum(1 for i, t in enumerate(ins) if t == "s_waitcnt lgkmcnt(0)" and 0 < i < len(ins) - 1 and ins[i + 1] == "s_barrier" and ins[i - 1].startswith("global_load_dwordx4"))
         if n != 2:
             raise RuntimeError("%s: found %d step barriers with the record prefetch issued right in front of them, expected 2" % (name, n))
-        if any(t.startswith("s_waitcnt vmcnt") and i + 1 < len(ins) and ins[i + 1] == "s_barrier" for i, t in enumerate(ins)):
+        # (the one legitimate vmcnt wait in front of a barrier is the dataflow epilogue's agent-scope release: buffer_wbl2 ; s_waitcnt vmcnt(0))
+        if any(t.startswith("s_waitcnt vmcnt") and i + 1 < len(ins) and ins[i + 1] == "s_barrier" and not (i and ins[i - 1].startswith("buffer_wbl2")) for i, t in enumerate(ins)):
             raise RuntimeError("%s: a barrier waits for vector memory" % name)
         out[name] = n
     return out
@@ -125,19 +126,21 @@ def check_workgroup_release_model():
     return ins[: ins.index("s_endpgm") + 1]
 
 
-def build(force=False, verbose=False, diag=False):
+def build(force=False, verbose=False, diag=False, variant=None, defines=()):
     """diag=True builds libgsv_engine_diag.so instead: the same library with the kernel's timing ablations compiled in
     (-DGSV_DIAG_BUILD; GSV_DIAG=<bits> then takes effect, see kernel_api.h) — load it with GSV_ENGINE_SO for experiments."""
     if os.environ.get("GSV_ENGINE_SO") and not diag:  # experiments: load a differently built library
         return os.environ["GSV_ENGINE_SO"]
     out = OUT.replace(".so", "_diag.so") if diag else OUT
+    if variant:  # kernel A/B experiments: libgsv_engine_<variant>.so built with extra -D flags, loaded through GSV_ENGINE_SO
+        out = OUT.replace(".so", "_%s.so" % variant)
     if not force and not _newer(out, _all_sources()):
         return out
     hipcc = os.path.join(ROCM, "bin", "hipcc")
-    k_o = os.path.join(ENG, "kernels_diag.o" if diag else "kernels.o")
+    k_o = os.path.join(ENG, "kernels_diag.o" if diag else ("kernels_%s.o" % variant if variant else "kernels.o"))
     e_o = os.path.join(ENG, "engine.o")
     cmds = [
-        [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-promote-alloca-to-lds"] + (["-DGSV_DIAG_BUILD"] if diag else []) +
+        [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-disable-promote-alloca-to-lds"] + (["-DGSV_DIAG_BUILD"] if diag else []) + list(defines) +
         ["-c", os.path.join(ENG, "kernels.hip"), "-o", k_o],
         ["g++", "-O2", "-std=c++17", "-fPIC", "-maes", "-msse2", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include"),
          "-Wall", "-Wno-unused-parameter", "-c", os.path.join(ENG, "engine.cpp"), "-o", e_o],
@@ -186,4 +189,6 @@ def check_not_tgsplit(obj=None):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))
+    _var = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--variant=")]
+    _defs = [a for a in sys.argv if a.startswith("-D")]
+    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv, variant=_var[0] if _var else None, defines=_defs))

@@ -148,12 +148,13 @@ struct gsv_session {
   uint64_t plan_max_block = 0;  // ciphertext records per instance of the device block: the largest WINDOW of the schedule
   struct CallDev { DevProgram dp; };
   std::vector<CallDev> call_dev;
-  // Call-level schedule (schedule.hpp): windows of consecutive calls, cut into batches of independent calls that run side by side.
-  // Everything below is laid out in EXECUTION order (sched.order): the call descriptors the kernel indexes with blockIdx.y and the
-  // concatenated pre / post copy lists (globals -> the call's scratch region -> globals), so that a batch is one contiguous range.
+  // Call-level schedule (schedule.hpp): windows of consecutive calls; the calls of a window run as a dataflow inside ONE launch
+  // (grid.y = calls), each waiting for the completion flags of the calls it depends on.  Device tables in stream order: the call
+  // descriptors, the concatenated wire hand-over lists (globals -> the call's scratch region -> globals), the dependency lists
+  // (window-relative call indices) and the completion flags [instance group][call] (compared with the launch epoch: never reset).
   Schedule sched;
-  void *d_calls = nullptr, *d_pre_src = nullptr, *d_pre_dst = nullptr, *d_post_src = nullptr, *d_post_dst = nullptr;
-  std::vector<uint64_t> pre_off, post_off;  // per execution position (+1): offsets into the concatenated copy lists
+  void *d_calls = nullptr, *d_copy_src = nullptr, *d_copy_dst = nullptr, *d_deps = nullptr, *d_flags = nullptr, *d_error = nullptr;
+  uint32_t flag_stride = 0, epoch = 0;
   uint64_t next_call = 0;                   // streaming slices: the call the next slice must start with
   bool unchecked_slices = false;            // benchmarks may garble slices out of order (results are then meaningless)
   void* plan_out_slots = nullptr;
@@ -421,7 +422,7 @@ void gsv_session_destroy(gsv_session* s) {
   (void)hipSetDevice(s->e->device);
   (void)hipStreamSynchronize(s->e->stream);
   for (void* q : {s->W, s->VB, s->CT, s->delta, s->out, s->out_bits, s->in_bits, s->step_clock, s->ct_stage, s->ct_gate}) if (q) (void)hipFree(q);
-  for (void* q : {s->d_calls, s->d_pre_src, s->d_pre_dst, s->d_post_src, s->d_post_dst}) if (q) (void)hipFree(q);
+  for (void* q : {s->d_calls, s->d_copy_src, s->d_copy_dst, s->d_deps, s->d_flags, s->d_error}) if (q) (void)hipFree(q);
   if (s->plan_out_slots) (void)hipFree(s->plan_out_slots);
   destroy_drain(s->drain);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -881,11 +882,11 @@ static Schedule make_schedule(const gsv_plan* plan, uint32_t ni, size_t n_instan
   // calls side by side: as many as it takes to give every CU a workgroup (GSV_PLAN_CONCURRENCY / opts override)
   uint32_t conc = o.max_concurrent_calls ? o.max_concurrent_calls : uint32_t(std::max<size_t>(1, size_t(n_cus) / std::max<size_t>(1, n_wg)));
   if (!o.max_concurrent_calls) if (const char* ev = getenv("GSV_PLAN_CONCURRENCY")) conc = uint32_t(std::max(1, atoi(ev)));
-  sp.max_calls_per_batch = std::min<uint32_t>(conc, 65535u);
-  // scratch regions of a batch: at most ~1/16 of the free device memory over all instances, and 2^30 slots (slot offsets are 32 bits)
+  sp.max_calls_in_flight = std::min<uint32_t>(conc, 65535u);
+  // the scratch ring: at most ~1/16 of the free device memory over all instances, and 2^30 slots (slot offsets are 32 bits)
   uint64_t slots = o.max_scratch_slots ? o.max_scratch_slots : uint64_t(free_bytes / 16 / 16 / std::max<size_t>(1, n_instances));
-  sp.max_batch_slots = std::min<uint64_t>(std::max<uint64_t>(slots, max_slots), 1ull << 30);
-  if (conc == 1) sp.max_batch_slots = max_slots;
+  sp.max_scratch_slots = std::min<uint64_t>(std::max<uint64_t>(slots, max_slots), 1ull << 30);
+  if (conc == 1) sp.max_scratch_slots = max_slots;
   // ciphertext window: the whole stream when it is retained, else about a quarter of the free memory for the two window buffers
   if (o.retain_stream) sp.max_window_ct = ~0ull;
   else {
@@ -893,13 +894,13 @@ static Schedule make_schedule(const gsv_plan* plan, uint32_t ni, size_t n_instan
     if (!o.window_ct_records && conc == 1) w = 0;  // sequential sessions keep the one-call block of rounds 1-2 (smallest footprint)
     sp.max_window_ct = std::max<uint64_t>(w, max_block);
   }
-  sp.max_window_calls = o.max_window_calls ? o.max_window_calls : 4096u;
+  sp.max_window_calls = std::min<uint32_t>(o.max_window_calls ? o.max_window_calls : 32768u, 65535u);
   Schedule sc = schedule_calls(calls, plan->n_globals, plan->outputs, sp);
   if (getenv("GSV_PLAN_DEBUG") || getenv("GSV_VERIFY_SCHEDULE")) {
     const std::string err = verify_schedule(calls, plan->n_globals, plan->outputs, sc);
     if (!err.empty()) gsv_panic("internal: plan schedule violates a hazard: " + err);
-    std::fprintf(stderr, "plan schedule: %zu calls, %zu windows, %zu batches (<= %u calls), scratch %llu slots, depth %llu of %llu steps\n", calls.size(), sc.windows.size(),
-                 sc.batches.size(), sp.max_calls_per_batch, (unsigned long long)sc.scratch_slots, (unsigned long long)sc.critical_steps, (unsigned long long)sc.total_steps);
+    std::fprintf(stderr, "plan schedule: %zu calls, %zu windows, <= %u calls in flight (width %u), scratch ring %llu slots, depth %llu of %llu steps, %zu dependencies\n", calls.size(),
+                 sc.windows.size(), sp.max_calls_in_flight, sc.max_width, (unsigned long long)sc.scratch_slots, (unsigned long long)sc.critical_steps, (unsigned long long)sc.total_steps, sc.deps.size());
   }
   return sc;
 }
@@ -956,37 +957,48 @@ int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_i
     if (bytes) HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
     return GSV_OK;
   };
-  // descriptors and copy lists in execution order
+  // descriptors, wire hand-over lists and dependency lists, all in stream order
   {
     const size_t n = plan->calls.size();
     std::vector<dev::CallDesc> cds(n);
-    std::vector<uint32_t> pre_src, pre_dst, post_src, post_dst;
-    s->pre_off.assign(n + 1, 0); s->post_off.assign(n + 1, 0);
-    std::vector<uint64_t> window_ct0(n, 0);
-    for (const Schedule::Window& w : sc.windows) for (uint32_t k = w.call0; k < w.call1; ++k) window_ct0[k] = w.ct0;
-    for (size_t pos = 0; pos < n; ++pos) {
-      const uint32_t k = sc.order[pos];
-      const PlanCall& c = plan->calls[k];
-      const Program& g = s->call_prog(k);
-      const uint32_t base = sc.scratch_base[k];
-      dev::CallDesc& d = cds[pos];
-      d.steps = s->call_dev[k].dp.steps; d.ands = s->call_dev[k].dp.ands; d.xors = s->call_dev[k].dp.xors;
-      d.gid_off = c.gid_off; d.ct_off = s->plan_retain ? c.ct_off : c.ct_off - window_ct0[k];
-      d.w_base = base; d.n_steps = g.n_steps;
-      s->pre_off[pos] = pre_src.size(); s->post_off[pos] = post_src.size();
-      if (base != 0)  // the call's own copies of the constant labels (FALSE, TRUE, the all-zero label) in front of its scratch region
-        for (uint32_t q = 0; q < SLOT_FIRST_INPUT; ++q) { pre_src.push_back(q); pre_dst.push_back(base + q); }
-      for (size_t i = 0; i < c.in_globals.size(); ++i) { pre_src.push_back(global_slot(c.in_globals[i])); pre_dst.push_back(base + g.input_slots[i]); }
-      for (size_t i = 0; i < c.out_globals.size(); ++i) {
-        if (g.output_slots[i] & SLOT_LDS_FLAG) return fail(GSV_ERR_CIRCUIT, "internal: a program output lives in the LDS window");
-        post_src.push_back(base + g.output_slots[i]); post_dst.push_back(scratch + c.out_globals[i]);
+    std::vector<uint32_t> csrc, cdst, deps;
+    for (const Schedule::Window& w : sc.windows) {
+      for (uint32_t k = w.call0; k < w.call1; ++k) {
+        const PlanCall& c = plan->calls[k];
+        const Program& g = s->call_prog(k);
+        const uint32_t base = sc.scratch_base[k];
+        dev::CallDesc& d = cds[k];
+        std::memset(&d, 0, sizeof d);
+        d.steps = s->call_dev[k].dp.steps; d.ands = s->call_dev[k].dp.ands; d.xors = s->call_dev[k].dp.xors;
+        d.gid_off = c.gid_off; d.ct_off = s->plan_retain ? c.ct_off : c.ct_off - w.ct0;
+        d.w_base = base; d.n_steps = g.n_steps;
+        d.pre_off = uint32_t(csrc.size());
+        if (base != 0)  // the call's own copies of the constant labels (FALSE, TRUE, the all-zero label) in front of its scratch region
+          for (uint32_t q = 0; q < SLOT_FIRST_INPUT; ++q) { csrc.push_back(q); cdst.push_back(base + q); }
+        for (size_t i = 0; i < c.in_globals.size(); ++i) { csrc.push_back(global_slot(c.in_globals[i])); cdst.push_back(base + g.input_slots[i]); }
+        d.n_pre = uint32_t(csrc.size()) - d.pre_off;
+        d.post_off = uint32_t(csrc.size());
+        for (size_t i = 0; i < c.out_globals.size(); ++i) {
+          if (g.output_slots[i] & SLOT_LDS_FLAG) return fail(GSV_ERR_CIRCUIT, "internal: a program output lives in the LDS window");
+          csrc.push_back(base + g.output_slots[i]); cdst.push_back(scratch + c.out_globals[i]);
+        }
+        d.n_post = uint32_t(csrc.size()) - d.post_off;
+        d.dep_off = uint32_t(deps.size());
+        for (uint32_t q = sc.dep_off[k]; q < sc.dep_off[k + 1]; ++q) deps.push_back(sc.deps[q] - w.call0);
+        d.n_deps = uint32_t(deps.size()) - d.dep_off;
+        if (csrc.size() > 0xFFFFFF00ull) return fail(GSV_ERR_CIRCUIT, "plan hand-over lists too large");
       }
+      s->flag_stride = std::max<uint32_t>(s->flag_stride, w.call1 - w.call0);
     }
-    s->pre_off[n] = pre_src.size(); s->post_off[n] = post_src.size();
+    const size_t n_wg = (n_instances + s->ni - 1) / s->ni;
     int rc;
-    if ((rc = up(&s->d_calls, cds.data(), cds.size() * sizeof(dev::CallDesc))) || (rc = up(&s->d_pre_src, pre_src.data(), pre_src.size() * 4)) || (rc = up(&s->d_pre_dst, pre_dst.data(), pre_dst.size() * 4)) ||
-        (rc = up(&s->d_post_src, post_src.data(), post_src.size() * 4)) || (rc = up(&s->d_post_dst, post_dst.data(), post_dst.size() * 4)))
+    if ((rc = up(&s->d_calls, cds.data(), cds.size() * sizeof(dev::CallDesc))) || (rc = up(&s->d_copy_src, csrc.data(), csrc.size() * 4)) || (rc = up(&s->d_copy_dst, cdst.data(), cdst.size() * 4)) ||
+        (rc = up(&s->d_deps, deps.data(), deps.size() * 4)))
       return rc;
+    HIPCHK(hipMalloc(&s->d_flags, n_wg * size_t(s->flag_stride) * 4 + 64));
+    HIPCHK(hipMemset(s->d_flags, 0, n_wg * size_t(s->flag_stride) * 4 + 64));
+    HIPCHK(hipMalloc(&s->d_error, 64));
+    HIPCHK(hipMemset(s->d_error, 0, 64));
     if ((rc = up(&s->plan_out_slots, f.output_slots.data(), f.output_slots.size() * 4))) return rc;
   }
   DEVALLOC(&s->W, n_instances * size_t(f.n_slots) * 16, "the wire files");
@@ -1006,19 +1018,18 @@ int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_i
 int gsv_session_plan_schedule_info(const gsv_session* s, gsv_plan_schedule_info* info) {
   if (!s || !s->plan || !info) return fail(GSV_ERR_INVALID, "null argument / not a plan session");
   const Schedule& sc = s->sched;
-  info->n_calls = s->plan->calls.size(); info->n_windows = sc.windows.size(); info->n_batches = sc.batches.size();
-  info->max_batch_calls = 0;
-  for (const Schedule::Batch& b : sc.batches) info->max_batch_calls = std::max<uint64_t>(info->max_batch_calls, b.count);
+  info->n_calls = s->plan->calls.size(); info->n_windows = sc.windows.size(); info->n_dependencies = sc.deps.size();
+  info->max_width = sc.max_width;
   info->scratch_slots = s->global_base; info->wire_file_slots = s->facade.n_slots; info->window_ct_records = sc.max_window_ct;
   info->critical_steps = sc.critical_steps; info->total_steps = sc.total_steps;
   return GSV_OK;
 }
-int gsv_session_plan_window(const gsv_session* s, uint64_t window, uint64_t* first_call, uint64_t* n_calls, uint64_t* n_batches) {
+int gsv_session_plan_window(const gsv_session* s, uint64_t window, uint64_t* first_call, uint64_t* n_calls, uint64_t* max_width) {
   if (!s || !s->plan || window >= s->sched.windows.size()) return fail(GSV_ERR_INVALID, "null argument / window index out of range");
   const Schedule::Window& w = s->sched.windows[size_t(window)];
   if (first_call) *first_call = w.call0;
   if (n_calls) *n_calls = w.call1 - w.call0;
-  if (n_batches) *n_batches = w.batch1 - w.batch0;
+  if (max_width) *max_width = w.max_width;
   return GSV_OK;
 }
 int gsv_session_set_unchecked_slices(gsv_session* s, int on) {
@@ -1156,36 +1167,32 @@ static int launch(gsv_session* s, uint64_t gate_id_base, bool eval, uint64_t rep
   s->ran = true; s->last_eval = eval;
   return GSV_OK;
 }
-// One BATCH of a plan session: the pre-copies of its calls (globals -> each call's scratch region), ONE kernel launch with
-// grid.y = calls (run_program_kernel picks its call's descriptor with blockIdx.y), the post-copies (program outputs -> globals).
-// A sequential schedule has one call per batch: a component runs for >100 ms, a launch costs ~10 us.
-static int launch_plan_batch(gsv_session* s, size_t b, uint64_t gate_id_base, bool eval) {
+// One WINDOW of a plan session = one launch: grid = (instance groups, calls of the window); every workgroup waits for the
+// completion flags of the calls it depends on, fetches its inputs from the global wires, runs its program in its own scratch region
+// and publishes its outputs (kernels.hip).  A sequential schedule (one call in flight) is the same launch with each call depending on
+// its predecessor: the instance groups still drift apart instead of meeting at a launch boundary after every call.
+static int launch_plan_window(gsv_session* s, size_t w, uint64_t gate_id_base, bool eval) {
   const Program& f = s->facade;
-  const Schedule::Batch& bt = s->sched.batches[b];
-  const uint64_t p0 = s->pre_off[bt.first], p1 = s->pre_off[bt.first + bt.count], q0 = s->post_off[bt.first], q1 = s->post_off[bt.first + bt.count];
-  if (gsvk_copy_slots(s->W, eval ? s->VB : nullptr, f.n_slots, static_cast<const uint32_t*>(s->d_pre_src) + p0, static_cast<const uint32_t*>(s->d_pre_dst) + p0, uint32_t(p1 - p0),
-                      uint32_t(s->n_inst), s->e->stream) != 0) return fail(GSV_ERR_DEVICE, "copy launch failed");
+  const Schedule::Window& win = s->sched.windows[w];
   dev::KernelArgs ka{};
-  ka.calls = static_cast<const dev::CallDesc*>(s->d_calls) + bt.first;
+  ka.calls = static_cast<const dev::CallDesc*>(s->d_calls) + win.call0;
+  ka.copy_src = static_cast<const uint32_t*>(s->d_copy_src); ka.copy_dst = static_cast<const uint32_t*>(s->d_copy_dst);
+  ka.deps = static_cast<const uint32_t*>(s->d_deps); ka.flags = static_cast<uint32_t*>(s->d_flags); ka.error = static_cast<uint32_t*>(s->d_error);
+  ka.flag_stride = s->flag_stride; ka.epoch = ++s->epoch;
   ka.W = static_cast<uint4*>(s->W); ka.VB = static_cast<uint8_t*>(s->VB); ka.CT = static_cast<uint4*>(s->CT);
   ka.delta = static_cast<const uint4*>(s->delta); ka.te = static_cast<const uint32_t*>(s->e->te);
   ka.ct_stride = s->ct_stride(); ka.gid_base = gate_id_base; ka.n_gates = 0; ka.n_ct = 0;
   ka.n_steps = 0; ka.n_slots = f.n_slots; ka.replays = 1; ka.rep_base = 0; ka.ct_cap_replays = 1;
   ka.n_instances = uint32_t(s->n_inst); ka.hasher = uint32_t(s->hasher); ka.instances_per_wg = s->ni;
-  if (bt.max_steps) {  // (calls without steps — pure wire shuffles — only copy)
-    int lrc = gsvk_launch_batch(&ka, uint32_t(s->n_inst), bt.count, eval ? 1 : 0, s->e->stream);
-    if (lrc != 0) return fail(GSV_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipError_t(lrc)));
-  }
-  if (gsvk_copy_slots(s->W, eval ? s->VB : nullptr, f.n_slots, static_cast<const uint32_t*>(s->d_post_src) + q0, static_cast<const uint32_t*>(s->d_post_dst) + q0, uint32_t(q1 - q0),
-                      uint32_t(s->n_inst), s->e->stream) != 0) return fail(GSV_ERR_DEVICE, "copy launch failed");
+  int lrc = gsvk_launch_batch(&ka, uint32_t(s->n_inst), win.call1 - win.call0, eval ? 1 : 0, s->e->stream);
+  if (lrc != 0) return fail(GSV_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipError_t(lrc)));
   return GSV_OK;
 }
-static int launch_plan_window(gsv_session* s, size_t w, uint64_t gate_id_base, bool eval) {
-  const Schedule::Window& win = s->sched.windows[w];
-  for (size_t b = win.batch0; b < win.batch1; ++b) {
-    int rc = launch_plan_batch(s, b, gate_id_base, eval);
-    if (rc) return rc;
-  }
+// after a synchronisation: did a dependency wait give up?
+static int check_plan_error(gsv_session* s) {
+  uint32_t err = 0;
+  HIPCHK(hipMemcpy(&err, s->d_error, 4, hipMemcpyDeviceToHost));
+  if (err) return fail(GSV_ERR_DEVICE, "a call of the plan waited for a dependency that never completed (dispatch-order assumption of schedule.hpp violated); results are invalid");
   return GSV_OK;
 }
 // Gate order <-> program order for the calls of one window: ct_gate (window-relative, gate order) <-> the window's device block.
@@ -1324,6 +1331,7 @@ static int garble_discard(gsv_session* s, uint64_t gate_id_base, size_t c0, size
     rc = launch(s, gate_id_base, false);
   }
   if (rc == GSV_OK) { HIPCHK(hipStreamSynchronize(s->e->stream)); s->garbled = !s->plan || s->plan_retain; }
+  if (rc == GSV_OK && s->plan) rc = check_plan_error(s);
   return rc;
 }
 
@@ -1440,6 +1448,7 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
     if (c1 == s->plan->calls.size()) rc = gather_plan_outputs(s, false); else { s->ran = true; s->last_eval = false; }
   }
   close_files();
+  if (rc == GSV_OK && s->plan) rc = check_plan_error(s);
   if (rc != GSV_OK) return rc;
   if (err) return fail(err == 2 ? GSV_ERR_INVALID : GSV_ERR_DEVICE, err == 2 ? "short write to a gc file" : "device copy failed while draining ciphertexts");
   for (size_t i = 0; i < n_inst; ++i) macs[i].digest(hashes + 16 * i);
@@ -1533,7 +1542,7 @@ int gsv_session_evaluate_streaming(gsv_session* s, uint64_t gate_id_base, const 
   }
   close_files();
   if (rc != GSV_OK) return rc;
-  if (s->plan) { HIPCHK(hipEventRecord(s->ev1, s->e->stream)); rc = gather_plan_outputs(s, true); if (rc) return rc; HIPCHK(hipStreamSynchronize(s->e->stream)); }
+  if (s->plan) { HIPCHK(hipEventRecord(s->ev1, s->e->stream)); rc = gather_plan_outputs(s, true); if (rc) return rc; HIPCHK(hipStreamSynchronize(s->e->stream)); rc = check_plan_error(s); if (rc) return rc; }
   if (hashes) for (size_t i = 0; i < n_inst; ++i) macs[i].digest(hashes + 16 * i);
   return GSV_OK;
 }
@@ -1548,6 +1557,7 @@ int gsv_session_sync(gsv_session* s) {
   if (!s) return fail(GSV_ERR_INVALID, "null session");
   HIPCHK(hipSetDevice(s->e->device));
   HIPCHK(hipStreamSynchronize(s->e->stream));
+  if (s->plan) return check_plan_error(s);
   return GSV_OK;
 }
 // Diagnostics: per-step wall-clock stamps (100 MHz) of instance 0's workgroup during the last replay of a launch.
@@ -1608,6 +1618,7 @@ int gsv_session_read_outputs(gsv_session* s, uint8_t* labels, uint8_t* bits) {
   if (!s || !labels || !s->ran) return fail(GSV_ERR_INVALID, "bad argument / nothing ran");
   HIPCHK(hipSetDevice(s->e->device));
   HIPCHK(hipStreamSynchronize(s->e->stream));
+  if (s->plan) { int rc = check_plan_error(s); if (rc) return rc; }
   const size_t n = s->n_inst * s->prog().output_slots.size();
   if (n) HIPCHK(hipMemcpy(labels, s->out, n * 16, hipMemcpyDeviceToHost));
   if (bits) {

@@ -10,19 +10,24 @@
 namespace gsv {
 namespace dev {
 
-// One call of a plan inside a BATCH launch (engine.cpp: independent calls of a plan run side by side, blockIdx.y = call): the
-// call's program image, its gate-id / ciphertext offsets and the base of its own scratch region inside every instance's wire file.
+// One call of a plan inside a WINDOW launch (schedule.hpp: the calls of a window run as a dataflow, blockIdx.y = call in stream
+// order): the call's program image, its gate-id / ciphertext offsets, the base of its own scratch region inside every instance's
+// wire file, its wire hand-over lists (global wires -> program inputs before it runs, program outputs -> global wires after) and the
+// earlier calls of the window it has to wait for.
 struct CallDesc {
   const void* steps;
   const void* ands;
   const void* xors;
-  uint64_t gid_off;   // added to KernelArgs::gid_base
-  uint64_t ct_off;    // record offset of the call's ciphertext block inside every instance's device stream
-  uint32_t w_base;    // first slot of the call's scratch region inside the instance's wire file
+  uint64_t gid_off;    // added to KernelArgs::gid_base
+  uint64_t ct_off;     // record offset of the call's ciphertext block inside every instance's device stream
+  uint32_t w_base;     // first slot of the call's scratch region inside the instance's wire file
   uint32_t n_steps;
-  uint64_t pad_[2];
+  uint32_t pre_off, n_pre;    // KernelArgs::copy_src/copy_dst[pre_off .. +n_pre): absolute slots, globals -> scratch
+  uint32_t post_off, n_post;  // scratch -> globals
+  uint32_t dep_off, n_deps;   // KernelArgs::deps[dep_off .. +n_deps): window-relative indices (= blockIdx.y) of the calls to wait for
+  uint64_t pad_[3];
 };
-static_assert(sizeof(CallDesc) == 64, "CallDesc layout");
+static_assert(sizeof(CallDesc) == 96, "CallDesc layout");
 
 struct KernelArgs {
   const void* steps;   // StepDesc[n_steps]   {and_off, and_cnt, xor_off, xor_cnt}
@@ -51,7 +56,14 @@ struct KernelArgs {
   uint32_t instances_per_wg;  // 1, 2 or 4 (n needs a program compiled for 1/n of the LDS window)
   uint32_t hasher;            // 0 = AesNiHasher, 1 = Blake3Hasher
   unsigned long long* step_clock;  // diagnostics: workgroup 0 stamps the 100 MHz wall clock at the start of every step of the last replay (null = off)
-  const CallDesc* calls;  // non-null: batch launch, grid.y = calls; steps / ands / xors / n_steps / ct_offset come from calls[blockIdx.y]
+  const CallDesc* calls;  // non-null: window launch, grid.y = calls; steps / ands / xors / n_steps / ct_offset come from calls[blockIdx.y]
+  const uint32_t* copy_src;   // wire hand-over lists of the session (absolute slots inside an instance's wire file)
+  const uint32_t* copy_dst;
+  const uint32_t* deps;
+  uint32_t* flags;            // [gridDim.x][flag_stride] completion flags: flags[x][c] == epoch once call c has finished for instance group x
+  uint32_t* error;            // set to 1 when a dependency wait gives up (never expected: see schedule.hpp)
+  uint32_t flag_stride;
+  uint32_t epoch;             // launch counter of the session: flags are never reset
   uint32_t diag;  // timing experiments only (GSV_DIAG env; honoured by a library built with -DGSV_DIAG_BUILD = `build.py --diag`, ignored by
                   // the production build): 1 = skip AES, 4 = skip label loads, 8 = skip stores, 16 = no multi-lane narrow form
 };
@@ -62,7 +74,7 @@ struct KernelArgs {
 extern "C" {
 int gsvk_upload_round_keys(const uint32_t rk[44]);
 int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, int evaluate, hipStream_t stream);
-// grid = (instance groups, n_calls): ka->calls[0 .. n_calls) run side by side (n_calls <= 65535)
+// grid = (instance groups, n_calls): ka->calls[0 .. n_calls) run as a dataflow (n_calls <= 65535)
 int gsvk_launch_batch(const gsv::dev::KernelArgs* ka, uint32_t n_instances, uint32_t n_calls, int evaluate, hipStream_t stream);
 int gsvk_gather_outputs(const void* W, const void* VB, uint32_t n_slots, const uint32_t* slots, uint32_t n_out, uint32_t n_instances,
                         void* out, void* out_bits, hipStream_t stream);

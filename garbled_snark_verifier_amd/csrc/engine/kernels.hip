@@ -177,12 +177,12 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   if (threadIdx.x < 4u * NI) *reinterpret_cast<lds_u32*>(uintptr_t(GSV_LDS_TABLE_BYTES + (threadIdx.x / 4u) * (GSV_LDS_SLOTS / NI) * 16u + (threadIdx.x % 4u) * 4u)) = 0u;
   if (threadIdx.x < uint32_t(NI)) *reinterpret_cast<lds_u8*>(uintptr_t(GSV_LDS_TABLE_BYTES + GSV_LDS_SLOTS * 16u + threadIdx.x * (GSV_LDS_SLOTS / NI))) = uint8_t(0);
   __syncthreads();
-  // Batch launch (plans): blockIdx.y selects one of several independent calls that run side by side; everything that differs
-  // between them comes from a 64-byte descriptor behind a wave-uniform address (scalar loads).
+  // Window launch (plans, schedule.hpp): blockIdx.y selects a call of the window; everything that differs between calls comes from
+  // a 96-byte descriptor behind a wave-uniform address (scalar loads).
+  typedef const CallDesc GSV_CST cst_call;
+  cst_call* const cd = ka.calls ? (cst_call*)ka.calls + blockIdx.y : nullptr;
   uint32_t w_base = 0;
-  if (ka.calls) {
-    typedef const CallDesc GSV_CST cst_call;
-    cst_call* cd = (cst_call*)ka.calls + blockIdx.y;
+  if (cd) {
     ka.steps = cd->steps; ka.ands = cd->ands; ka.xors = cd->xors;
     ka.gid_base += cd->gid_off; ka.ct_offset = cd->ct_off; ka.n_steps = cd->n_steps;
     w_base = cd->w_base;
@@ -214,6 +214,36 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   if (!EVAL) { const u32x4 d = ((const glb_u128*)ka.delta)[inst]; delta = Label{{d.x, d.y, d.z, d.w}}; }
   // this lane's column of delta (selects, not a runtime-indexed array: that would be promoted to static LDS)
   const uint32_t dq = col == 0 ? delta.w[0] : col == 1 ? delta.w[1] : col == 2 ? delta.w[2] : delta.w[3];
+  if (cd) {
+    // ---- dataflow prologue: wait for the calls this one depends on (same instance group), then fetch the inputs.
+    // One lane polls; the flags are written with agent-scope release by the producer's epilogue (possibly on another XCD: the
+    // acquire fence below invalidates this CU's L1 and the non-local L2 lines before any wave reads the global wires).
+    if (threadIdx.x == 0 && cd->n_deps) {
+      const uint32_t* const fl = ka.flags + size_t(blockIdx.x) * ka.flag_stride;
+      const unsigned long long t_start = wall_clock64();
+      for (uint32_t i = 0; i < cd->n_deps; ++i) {
+        const uint32_t* const f = fl + ka.deps[cd->dep_off + i];
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ka.epoch) {
+          __builtin_amdgcn_s_sleep(16);
+          if (wall_clock64() - t_start > 3000000000ull) {  // 30 s at 100 MHz: a dependency that never completes (violated dispatch-order assumption)
+            __hip_atomic_store(ka.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const uint32_t n_pre = inst_active ? cd->n_pre : 0u;
+    const glb_u128* const gw = (const glb_u128*)(ka.W + size_t(inst) * ka.n_slots);
+    glb_u128* const gwd = (glb_u128*)(ka.W + size_t(inst) * ka.n_slots);
+    for (uint32_t i = tid; i < n_pre; i += BT) {
+      const uint32_t sidx = ka.copy_src[cd->pre_off + i], didx = ka.copy_dst[cd->pre_off + i];
+      gwd[didx] = gw[sidx];
+      if (EVAL) { glb_u8* const vb = (glb_u8*)(ka.VB + size_t(inst) * ka.n_slots); vb[didx] = vb[sidx]; }
+    }
+    __syncthreads();
+  }
   cst_u128* const step_q = (cst_u128*)ka.steps;
   // Timing ablations (GSV_DIAG, kernel_api.h) exist only in a library built with -DGSV_DIAG_BUILD (build.py --diag): as run-time
   // flags they cost the production loop a dozen register initialisations and several branches per gate.
@@ -503,6 +533,20 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       __syncthreads();
     }
   }
+  if (cd) {
+    // ---- dataflow epilogue: outputs -> global wires, then publish completion for this instance group (agent-scope release: the
+    // consumer may run on another XCD)
+    const uint32_t n_post = inst_active ? cd->n_post : 0u;
+    glb_u128* const gw = (glb_u128*)(ka.W + size_t(inst) * ka.n_slots);
+    for (uint32_t i = tid; i < n_post; i += BT) {
+      const uint32_t sidx = ka.copy_src[cd->post_off + i], didx = ka.copy_dst[cd->post_off + i];
+      gw[didx] = gw[sidx];
+      if (EVAL) { glb_u8* const vb = (glb_u8*)(ka.VB + size_t(inst) * ka.n_slots); vb[didx] = vb[sidx]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(ka.flags + size_t(blockIdx.x) * ka.flag_stride + blockIdx.y, ka.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // outputs[inst][i] = W[inst][slots[i]]  (and the plaintext bit in evaluate mode)
@@ -568,7 +612,7 @@ int gsvk_upload_round_keys(const uint32_t rk[44]) {
 }
 int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, int evaluate, hipStream_t stream) { return gsvk_launch_batch(ka, n_instances, 1, evaluate, stream); }
 int gsvk_launch_batch(const gsv::dev::KernelArgs* ka, uint32_t n_instances, uint32_t n_calls, int evaluate, hipStream_t stream) {
-  if (n_calls == 0 || n_calls > 65535u || (n_calls > 1 && !ka->calls)) return int(hipErrorInvalidValue);
+  if (n_calls == 0 || n_calls > 65535u || (n_calls > 1 && !ka->calls) || (ka->calls && (!ka->flags || !ka->error))) return int(hipErrorInvalidValue);
   const size_t lds = GSV_LDS_BYTES;
   // The opt-in to 160 KiB of dynamic LDS is a per-device function attribute: done once per device (an engine per GPU may live
   // in one process, and sessions may be driven from several host threads).

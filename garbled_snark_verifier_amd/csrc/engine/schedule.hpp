@@ -1,4 +1,4 @@
-// Call-level scheduling of a plan: which calls may run side by side.
+// Call-level scheduling of a plan: which calls may run side by side, as a DATAFLOW over the calls of a window.
 //
 // A plan is a sequence of calls {program, input globals, output globals} in STREAM order (the order in which the reference's
 // streaming driver meets the components, src/circuit/streaming_mode.rs:150-247); stream order fixes every call's gate ids and the
@@ -8,19 +8,23 @@
 // sibling components (an Fq12 multiplication is 15 independent Fq2 multiplications, fq12.rs:199-221 / fq6.rs:194-260; the three
 // point decompressions of groth16.rs:250-268 are independent ladders; the 26 window multiplexers of g1.rs:309-368 are independent).
 //
-// Model.  Global wire ids are MEMORY LOCATIONS of the instance's wire file (ids are recycled, plan_builder.hpp): a call reads its
-// input ids in a pre-copy, runs in a scratch region of its own, writes its output ids in a post-copy.  A BATCH is a set of calls
-// executed as: all pre-copies (one launch) ; all kernels side by side (one launch, grid.y = calls) ; all post-copies (one launch).
-// Hazards between call i and a later (stream order) call k:
-//   RAW  k reads an id i writes            -> k in a later batch than i
-//   WAW  k writes an id i writes           -> k in a later batch than i   (ids nobody ever reads — trash ids — are exempt)
-//   WAR  k writes an id i reads            -> k in the same batch as i or a later one (every pre-copy of a batch precedes every
-//                                             post-copy of it)
-// Calls are taken in WINDOWS of consecutive stream order: a window's ciphertext blocks are contiguous in the stream, so the
-// device needs one window's block per instance (twice with the drain's gate-order copy) and the host consumes the stream window
-// by window, in order (CiphertextHandler semantics: ciphertexts leave in gate order, circuit/mod.rs:140-178).  Inside a window
-// calls are levelled by the hazards above (calls of earlier windows have completed); a level is cut into batches by the caller's
-// limits (calls per batch, scratch slots per batch).  With max_calls_per_batch = 1 the schedule is the stream order itself.
+// Execution model (kernels.hip, run_program_kernel with KernelArgs::calls): ONE launch per window, grid = (instance groups, calls of
+// the window in stream order).  A workgroup (x, c) = call c for instance group x: it waits until the calls it depends on have set
+// their completion flags for group x, copies its inputs from the instance's global wires into a scratch region of its own, runs the
+// program, copies its outputs back to the globals and sets its flag.  Workgroups are dispatched in linear order (x fastest), every
+// dependency points to an EARLIER call, so a waiting workgroup only ever waits for workgroups that are running or finished (the
+// forward-progress argument of decoupled look-back scans); a bounded wait turns a violated assumption into an error, not a hang.
+//
+// Dependencies.  Global wire ids are MEMORY LOCATIONS of the instance's wire file (ids are recycled, plan_builder.hpp).  For a call k
+// and an earlier call i of the same window:
+//   RAW  k reads an id i wrote last                 -> k waits for i
+//   WAW  k writes an id i wrote last                -> k waits for i   (ids nobody ever reads — trash ids — are exempt)
+//   WAR  k writes an id i read (the old value)      -> k waits for i
+//   in-flight bound: k waits for call k - C         -> at most C calls of an instance in flight (C = 1: the stream order itself)
+//   scratch ring: k's scratch region is carved from a ring of slots; k waits for the earlier calls whose regions it overlaps
+// Calls of earlier windows have completed (previous launch).  A window is a run of consecutive calls: its ciphertext blocks are
+// contiguous in the stream, so the device needs one window's block per instance (twice with the drain's gate-order copy) and the
+// host consumes the stream window by window, in order (CiphertextHandler semantics: circuit/mod.rs:140-178).
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -30,105 +34,137 @@
 namespace gsv {
 
 struct SchedCall {
-  const uint32_t* in = nullptr; size_t n_in = 0;    // global ids read (ids >= id_limit are constants: ignored)
+  const uint32_t* in = nullptr; size_t n_in = 0;    // global ids read (ids >= n_ids are the constant wires: ignored)
   const uint32_t* out = nullptr; size_t n_out = 0;  // global ids written
   uint32_t n_slots = 0;                              // scratch slots of the call's program
   uint64_t n_ct = 0;                                 // ciphertext records of the call
   uint32_t n_steps = 0;
 };
 struct SchedParams {
-  uint32_t max_calls_per_batch = 1;
-  uint64_t max_batch_slots = ~0ull;   // sum of the scratch regions of a batch (16-byte slots per instance)
+  uint32_t max_calls_in_flight = 1;   // C above
+  uint64_t max_scratch_slots = ~0ull; // size limit of the scratch ring (16-byte slots per instance)
   uint64_t max_window_ct = ~0ull;     // ciphertext records per instance and window (a single larger call still forms a window)
-  uint32_t max_window_calls = 4096;
+  uint32_t max_window_calls = 32768;  // (grid.y of a launch is at most 65535)
   uint32_t slot_align = 8;            // scratch regions start on 128-byte lines
 };
 struct Schedule {
-  struct Batch { uint32_t first, count; uint32_t max_steps; };          // order[first .. first+count)
-  struct Window { uint32_t call0, call1, batch0, batch1; uint64_t ct0, n_ct; };  // calls [call0, call1) of the stream
-  std::vector<uint32_t> order;         // execution order: call indices, batch after batch
-  std::vector<uint32_t> scratch_base;  // per call (stream index): first slot of its scratch region, relative to the scratch area
-  std::vector<Batch> batches;
+  struct Window { uint32_t call0, call1; uint64_t ct0, n_ct; uint32_t max_width; };  // calls [call0, call1) of the stream
   std::vector<Window> windows;
-  uint64_t scratch_slots = 0;          // size of the scratch area (max over batches)
+  std::vector<uint32_t> scratch_base;  // per call: first slot of its scratch region
+  std::vector<uint32_t> dep_off;       // per call (+1): its dependencies are deps[dep_off[k] .. dep_off[k+1])
+  std::vector<uint32_t> deps;          // call indices (stream order, same window, < k)
+  uint64_t scratch_slots = 0;          // size of the scratch ring
   uint64_t max_window_ct = 0;
-  uint64_t critical_steps = 0;         // sum over batches of the longest call (device steps): the schedule's depth
+  uint64_t critical_steps = 0;         // sum over windows of the longest dependency path (device steps): the schedule's depth
   uint64_t total_steps = 0;            // sum over calls
+  uint32_t max_width = 0;              // most calls that can be in flight at once (by start / finish times of the step model)
 };
 
 inline Schedule schedule_calls(const std::vector<SchedCall>& calls, uint32_t n_ids, const std::vector<uint32_t>& plan_outputs, const SchedParams& p) {
   Schedule s;
   const size_t n = calls.size();
   s.scratch_base.assign(n, 0);
-  // ids that are read by some call or are outputs of the plan; the rest (trash ids) carry no WAW / WAR hazard
+  s.dep_off.assign(n + 1, 0);
+  const uint32_t C = std::max<uint32_t>(1, p.max_calls_in_flight);
+  auto align_up = [&](uint64_t v) { const uint64_t a = std::max<uint32_t>(1, p.slot_align); return (v + a - 1) / a * a; };
+  // ids that are read by some call or are outputs of the plan; the rest (trash ids) carry no WAW hazard
   std::vector<uint8_t> ever_read(n_ids, 0);
   for (const SchedCall& c : calls) for (size_t i = 0; i < c.n_in; ++i) if (c.in[i] < n_ids) ever_read[c.in[i]] = 1;
   for (uint32_t w : plan_outputs) if (w < n_ids) ever_read[w] = 1;
-  std::vector<uint32_t> w_stamp(n_ids, 0), r_stamp(n_ids, 0), w_level(n_ids, 0), r_level(n_ids, 0);
-  std::vector<uint32_t> level;
-  uint32_t stamp = 0;
+  // the scratch ring: large enough for C consecutive regions (then the in-flight bound is the only ring constraint), within the limit
+  uint64_t need = 0, max_one = 0;
+  {
+    uint64_t run = 0;
+    for (size_t k = 0; k < n; ++k) {
+      run += align_up(calls[k].n_slots);
+      if (k >= C) run -= align_up(calls[k - C].n_slots);
+      need = std::max(need, run);
+      max_one = std::max<uint64_t>(max_one, align_up(calls[k].n_slots));
+    }
+  }
+  const uint64_t ring = std::max<uint64_t>(std::min<uint64_t>(need, std::min<uint64_t>(p.max_scratch_slots, 0xFFFFFF00ull)), max_one);
+  s.scratch_slots = ring;
+  constexpr uint32_t NONE = 0xFFFFFFFFu;
+  std::vector<uint32_t> w_call(n_ids, NONE);          // last writer of the id inside the current window
+  std::vector<uint32_t> r_head(n_ids, NONE);          // readers of the id's current value: list through `rnode`
+  struct RNode { uint32_t call, next; };
+  std::vector<RNode> rnode;
+  std::vector<uint32_t> touched;                       // ids with window state (reset at the window's end)
+  struct Occ { uint32_t call; uint64_t lo, hi; };
+  std::vector<Occ> occ;                                // live scratch regions: handed out and not yet overwritten by a later region
+  uint64_t cur = 0;
+  std::vector<uint32_t> d;
+  std::vector<uint64_t> finish(n, 0);                  // step model: a call starts when its dependencies have finished
   size_t k0 = 0;
   uint64_t ct_off = 0;
-  const uint32_t max_batch = std::max<uint32_t>(1, p.max_calls_per_batch);
-  auto align_up = [&](uint64_t v) { const uint64_t a = std::max<uint32_t>(1, p.slot_align); return (v + a - 1) / a * a; };
   while (k0 < n) {
-    // ---- the window: consecutive calls under the ciphertext budget
     size_t k1 = k0;
     uint64_t wct = 0;
     while (k1 < n && (k1 == k0 || (wct + calls[k1].n_ct <= p.max_window_ct && k1 - k0 < p.max_window_calls))) wct += calls[k1++].n_ct;
-    ++stamp;
-    level.assign(k1 - k0, 0);
-    uint32_t n_levels = 0;
+    rnode.clear(); touched.clear(); occ.clear(); cur = 0;
+    uint64_t depth = 0;
+    std::vector<std::pair<uint64_t, int>> ev;  // (time, +1 start / -1 finish) for the width estimate
     for (size_t k = k0; k < k1; ++k) {
       const SchedCall& c = calls[k];
-      uint32_t lv = 0;
-      if (max_batch > 1) {
-        for (size_t i = 0; i < c.n_in; ++i) { const uint32_t g = c.in[i]; if (g < n_ids && w_stamp[g] == stamp) lv = std::max(lv, w_level[g] + 1); }
-        for (size_t i = 0; i < c.n_out; ++i) {
-          const uint32_t g = c.out[i];
-          if (g >= n_ids || !ever_read[g]) continue;
-          if (w_stamp[g] == stamp) lv = std::max(lv, w_level[g] + 1);
-          if (r_stamp[g] == stamp) lv = std::max(lv, r_level[g]);
-        }
-        for (size_t i = 0; i < c.n_in; ++i) {
-          const uint32_t g = c.in[i];
-          if (g >= n_ids) continue;
-          if (r_stamp[g] != stamp) { r_stamp[g] = stamp; r_level[g] = lv; } else r_level[g] = std::max(r_level[g], lv);
-        }
-        for (size_t i = 0; i < c.n_out; ++i) { const uint32_t g = c.out[i]; if (g < n_ids) { w_stamp[g] = stamp; w_level[g] = lv; } }
-      } else {
-        lv = uint32_t(k - k0);  // sequential: one call per batch, stream order
+      d.clear();
+      for (size_t i = 0; i < c.n_in; ++i) { const uint32_t g = c.in[i]; if (g < n_ids && w_call[g] != NONE) d.push_back(w_call[g]); }            // RAW
+      for (size_t i = 0; i < c.n_out; ++i) {
+        const uint32_t g = c.out[i];
+        if (g >= n_ids) continue;
+        if (ever_read[g] && w_call[g] != NONE) d.push_back(w_call[g]);                                                                        // WAW
+        for (uint32_t r = r_head[g]; r != NONE; r = rnode[r].next) if (rnode[r].call != uint32_t(k)) d.push_back(rnode[r].call);               // WAR
       }
-      level[k - k0] = lv;
-      n_levels = std::max(n_levels, lv + 1);
-    }
-    // ---- levels -> batches (stream order inside a level: a WAR pair of one level keeps reader-batch <= writer-batch)
-    std::vector<std::vector<uint32_t>> by_level(n_levels);
-    for (size_t k = k0; k < k1; ++k) by_level[level[k - k0]].push_back(uint32_t(k));
-    Schedule::Window w{uint32_t(k0), uint32_t(k1), uint32_t(s.batches.size()), 0, ct_off, wct};
-    for (const auto& lv_calls : by_level) {
-      size_t i = 0;
-      while (i < lv_calls.size()) {
-        Schedule::Batch b{uint32_t(s.order.size()), 0, 0};
-        uint64_t slots = 0;
-        while (i < lv_calls.size() && b.count < max_batch) {
-          const uint32_t k = lv_calls[i];
-          const uint64_t need = align_up(calls[k].n_slots);
-          if (b.count && slots + need > p.max_batch_slots) break;
-          s.scratch_base[k] = uint32_t(slots);
-          slots += need;
-          s.order.push_back(k);
-          b.max_steps = std::max(b.max_steps, calls[k].n_steps);
-          ++b.count; ++i;
-        }
-        s.scratch_slots = std::max(s.scratch_slots, slots);
-        s.critical_steps += b.max_steps;
-        s.batches.push_back(b);
+      if (k - k0 >= C) d.push_back(uint32_t(k - C));                                                                                           // in-flight bound
+      // scratch region from the ring; the earlier calls it overlaps must have finished
+      const uint64_t need_k = align_up(c.n_slots);
+      if (cur + need_k > ring) cur = 0;
+      const uint64_t lo = cur, hi = cur + need_k;
+      const size_t n_occ = occ.size();
+      for (size_t i = 0; i < n_occ; ++i) {  // (the live regions are few: about as many as calls can be in flight)
+        Occ o = occ[i];
+        if (!(o.lo < hi && lo < o.hi)) continue;
+        d.push_back(o.call);
+        // what the new region leaves of the old one stays live (a later region may still run into it)
+        occ[i].hi = occ[i].lo;  // emptied; compacted below
+        if (o.lo < lo) occ.push_back(Occ{o.call, o.lo, lo});
+        if (o.hi > hi) occ.push_back(Occ{o.call, hi, o.hi});
       }
+      occ.erase(std::remove_if(occ.begin(), occ.end(), [](const Occ& o) { return o.lo >= o.hi; }), occ.end());
+      s.scratch_base[k] = uint32_t(lo);
+      cur = hi;
+      occ.push_back(Occ{uint32_t(k), lo, hi});
+      // bookkeeping of the ids
+      for (size_t i = 0; i < c.n_in; ++i) {
+        const uint32_t g = c.in[i];
+        if (g >= n_ids) continue;
+        if (w_call[g] == NONE && r_head[g] == NONE) touched.push_back(g);
+        rnode.push_back(RNode{uint32_t(k), r_head[g]});
+        r_head[g] = uint32_t(rnode.size() - 1);
+      }
+      for (size_t i = 0; i < c.n_out; ++i) {
+        const uint32_t g = c.out[i];
+        if (g >= n_ids) continue;
+        if (w_call[g] == NONE && r_head[g] == NONE) touched.push_back(g);
+        w_call[g] = uint32_t(k);
+        r_head[g] = NONE;  // the new value has no readers yet
+      }
+      std::sort(d.begin(), d.end());
+      d.erase(std::unique(d.begin(), d.end()), d.end());
+      uint64_t start = 0;
+      for (uint32_t j : d) { s.deps.push_back(j); start = std::max(start, finish[j]); }
+      s.dep_off[k + 1] = uint32_t(s.deps.size());
+      finish[k] = start + c.n_steps;
+      depth = std::max(depth, finish[k]);
+      ev.push_back({start, +1}); ev.push_back({finish[k], -1});
     }
-    w.batch1 = uint32_t(s.batches.size());
-    s.windows.push_back(w);
+    for (uint32_t g : touched) { w_call[g] = NONE; r_head[g] = NONE; }
+    std::sort(ev.begin(), ev.end());
+    int width = 0, max_width = 0;
+    for (auto& e : ev) { width += e.second; max_width = std::max(max_width, width); }
+    s.windows.push_back(Schedule::Window{uint32_t(k0), uint32_t(k1), ct_off, wct, uint32_t(max_width)});
+    s.max_width = std::max(s.max_width, uint32_t(max_width));
     s.max_window_ct = std::max(s.max_window_ct, wct);
+    s.critical_steps += depth;
     ct_off += wct;
     k0 = k1;
   }
@@ -136,53 +172,61 @@ inline Schedule schedule_calls(const std::vector<SchedCall>& calls, uint32_t n_i
   return s;
 }
 
-// Checks a schedule against the hazard rules by replaying it over id "versions" (test helper; also run by the engine in debug
-// builds): returns an empty string when every call reads exactly the versions it reads in stream order.
+// Test helper: checks a schedule by brute force — returns an empty string when (a) every hazard between two calls of a window is
+// covered by a dependency PATH and (b) two calls whose scratch regions overlap are ordered by a path.  O(n^2 / 64) per window.
 inline std::string verify_schedule(const std::vector<SchedCall>& calls, uint32_t n_ids, const std::vector<uint32_t>& plan_outputs, const Schedule& s) {
   const size_t n = calls.size();
-  if (s.order.size() != n) return "order does not cover every call";
-  // stream-order semantics: version of an id = index of the call that wrote it last (+1), 0 = initial
-  std::vector<uint32_t> ver(n_ids, 0);
-  std::vector<std::vector<uint32_t>> want(n);
-  for (size_t k = 0; k < n; ++k) {
-    for (size_t i = 0; i < calls[k].n_in; ++i) { const uint32_t g = calls[k].in[i]; want[k].push_back(g < n_ids ? ver[g] : 0); }
-    for (size_t i = 0; i < calls[k].n_out; ++i) { const uint32_t g = calls[k].out[i]; if (g < n_ids) ver[g] = uint32_t(k + 1); }
-  }
-  std::vector<uint32_t> final_want(plan_outputs.size());
-  for (size_t i = 0; i < plan_outputs.size(); ++i) final_want[i] = plan_outputs[i] < n_ids ? ver[plan_outputs[i]] : 0;
-  std::fill(ver.begin(), ver.end(), 0);
+  if (s.dep_off.size() != n + 1 || s.scratch_base.size() != n) return "schedule does not cover every call";
   std::vector<uint8_t> ever_read(n_ids, 0);
   for (const SchedCall& c : calls) for (size_t i = 0; i < c.n_in; ++i) if (c.in[i] < n_ids) ever_read[c.in[i]] = 1;
   for (uint32_t w : plan_outputs) if (w < n_ids) ever_read[w] = 1;
-  std::vector<uint8_t> seen(n, 0);
-  for (const Schedule::Batch& b : s.batches) {
-    for (uint32_t j = 0; j < b.count; ++j) {  // all pre-copies
-      const uint32_t k = s.order[b.first + j];
-      if (k >= n || seen[k]) return "call scheduled twice / out of range";
-      seen[k] = 1;
-      for (size_t i = 0; i < calls[k].n_in; ++i) { const uint32_t g = calls[k].in[i]; if (g < n_ids && ver[g] != want[k][i]) return "call " + std::to_string(k) + " reads a stale or clobbered global"; }
+  size_t covered = 0;
+  for (const Schedule::Window& w : s.windows) {
+    if (w.call0 != covered || w.call1 <= w.call0 || w.call1 > n) return "windows are not a partition of the calls";
+    covered = w.call1;
+    const size_t m = w.call1 - w.call0, words = (m + 63) / 64;
+    std::vector<uint64_t> reach(m * words, 0);  // reach[k] = set of calls k depends on, transitively
+    auto row = [&](size_t k) { return &reach[k * words]; };
+    for (size_t k = 0; k < m; ++k) {
+      for (uint32_t q = s.dep_off[w.call0 + k]; q < s.dep_off[w.call0 + k + 1]; ++q) {
+        const uint32_t j = s.deps[q];
+        if (j < w.call0 || j >= w.call0 + k) return "a dependency points outside the window or forward";
+        const size_t jj = j - w.call0;
+        row(k)[jj / 64] |= 1ull << (jj % 64);
+        for (size_t t = 0; t < words; ++t) row(k)[t] |= row(jj)[t];
+      }
     }
-    std::vector<std::pair<uint32_t, uint32_t>> written;  // all post-copies: two calls of a batch must not write one live id
-    for (uint32_t j = 0; j < b.count; ++j) {
-      const uint32_t k = s.order[b.first + j];
-      for (size_t i = 0; i < calls[k].n_out; ++i) { const uint32_t g = calls[k].out[i]; if (g < n_ids) written.push_back({g, k}); }
+    auto ordered = [&](size_t i, size_t k) { return (row(k)[i / 64] >> (i % 64)) & 1ull; };  // i before k
+    // hazards
+    std::vector<std::vector<uint32_t>> readers(n_ids), writers(n_ids);
+    for (size_t k = 0; k < m; ++k) {
+      const SchedCall& c = calls[w.call0 + k];
+      for (size_t i = 0; i < c.n_in; ++i) {
+        const uint32_t g = c.in[i];
+        if (g >= n_ids) continue;
+        if (!writers[g].empty() && !ordered(writers[g].back(), k)) return "RAW hazard not ordered: call " + std::to_string(w.call0 + k);
+        readers[g].push_back(uint32_t(k));
+      }
+      for (size_t i = 0; i < c.n_out; ++i) {
+        const uint32_t g = c.out[i];
+        if (g >= n_ids) continue;
+        if (ever_read[g] && !writers[g].empty() && writers[g].back() != k && !ordered(writers[g].back(), k)) return "WAW hazard not ordered: call " + std::to_string(w.call0 + k);
+        for (uint32_t r : readers[g]) if (r != k && !ordered(r, k)) return "WAR hazard not ordered: call " + std::to_string(w.call0 + k);
+        readers[g].clear();
+        writers[g].push_back(uint32_t(k));
+      }
     }
-    std::sort(written.begin(), written.end());
-    for (size_t i = 0; i < written.size(); ++i) {
-      // several writers of one id inside a batch (their order inside the post-copy launch is undefined): only for ids nobody reads
-      if (i && written[i].first == written[i - 1].first && ever_read[written[i].first]) return "two calls of a batch write global " + std::to_string(written[i].first);
-      ver[written[i].first] = written[i].second + 1;
+    // scratch regions
+    for (size_t k = 0; k < m; ++k) {
+      const uint64_t lo = s.scratch_base[w.call0 + k], hi = lo + calls[w.call0 + k].n_slots;
+      if (hi > s.scratch_slots) return "scratch region outside the ring";
+      for (size_t i = 0; i < k; ++i) {
+        const uint64_t lo2 = s.scratch_base[w.call0 + i], hi2 = lo2 + calls[w.call0 + i].n_slots;
+        if (lo < hi2 && lo2 < hi && !ordered(i, k)) return "overlapping scratch regions of unordered calls " + std::to_string(w.call0 + i) + " and " + std::to_string(w.call0 + k);
+      }
     }
   }
-  for (size_t i = 0; i < plan_outputs.size(); ++i) if (plan_outputs[i] < n_ids && ver[plan_outputs[i]] != final_want[i]) return "a plan output ends with the wrong version";
-  // scratch regions of a batch must not overlap
-  for (const Schedule::Batch& b : s.batches) {
-    std::vector<std::pair<uint64_t, uint64_t>> r;
-    for (uint32_t j = 0; j < b.count; ++j) { const uint32_t k = s.order[b.first + j]; r.push_back({s.scratch_base[k], uint64_t(s.scratch_base[k]) + calls[k].n_slots}); }
-    std::sort(r.begin(), r.end());
-    for (size_t i = 1; i < r.size(); ++i) if (r[i].first < r[i - 1].second) return "scratch regions of a batch overlap";
-    for (auto& x : r) if (x.second > s.scratch_slots) return "scratch region outside the scratch area";
-  }
+  if (covered != n) return "windows do not cover every call";
   return std::string();
 }
 

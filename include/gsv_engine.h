@@ -177,16 +177,19 @@ int gsv_session_create_plan(gsv_engine* e, const gsv_plan* plan, size_t n_instan
 int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_instances, int retain_stream, gsv_session** out);
 /* Call-level concurrency.  The reference gets its width from `total` instances garbled side by side, one per core
  * (cut_and_choose/garbler.rs:206-234); with 1-16 instances on a 256-CU GPU the width has to come from INSIDE an instance.  A plan
- * session therefore executes a SCHEDULE of the plan: the calls are taken in windows of consecutive stream order, inside a window
- * they are levelled by their data flow through the global wires (RAW / WAW / WAR on the global ids) and independent calls run
- * side by side in one launch (grid = instance groups x calls), each in a scratch region of its own inside the instance's wire
- * file.  Gate ids and ciphertext positions are those of the stream order, so the result is bit-identical to the sequential run.
+ * session therefore executes a SCHEDULE of the plan: the calls are taken in windows of consecutive stream order; a window is ONE
+ * launch (grid = instance groups x calls) in which every call waits for the calls it depends on through the global wires (RAW / WAW
+ * / WAR on the global ids) and otherwise runs side by side with the others, each in a scratch region of its own inside the
+ * instance's wire file.  Gate ids and ciphertext positions are those of the stream order, so the result is bit-identical to the
+ * sequential run.
  *   retain_stream         as gsv_session_create_plan_ex
- *   max_concurrent_calls  0 = as many as give every CU a workgroup (GSV_PLAN_CONCURRENCY overrides); 1 = sequential
+ *   max_concurrent_calls  calls of one instance in flight: 0 = as many as give every CU a workgroup (GSV_PLAN_CONCURRENCY overrides);
+ *                         1 = sequential (the stream order)
  *   window_ct_records     ciphertext records per instance of one window (the device block of a session that does not retain the
  *                         stream; the drain's gate-order copy is as large again); 0 = chosen from the free device memory
- *   max_scratch_slots     16-byte slots per instance for the scratch regions of one batch; 0 = chosen from the free device memory
- *   max_window_calls      0 = 4096 */
+ *   max_scratch_slots     16-byte slots per instance for the ring the calls' scratch regions are carved from; 0 = chosen from the
+ *                         free device memory
+ *   max_window_calls      0 = 32768 (a launch holds at most 65535 calls) */
 typedef struct gsv_plan_session_opts {
   int retain_stream;
   uint32_t max_concurrent_calls;
@@ -197,7 +200,7 @@ typedef struct gsv_plan_session_opts {
 } gsv_plan_session_opts;
 int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_instances, const gsv_plan_session_opts* opts, gsv_session** out);
 typedef struct gsv_plan_schedule_info {
-  uint64_t n_calls, n_windows, n_batches, max_batch_calls;
+  uint64_t n_calls, n_windows, n_dependencies, max_width;  /* max_width: most calls in flight at once by the schedule's step model */
   uint64_t scratch_slots, wire_file_slots;  /* per instance: scratch area / whole wire file (scratch + global wires) */
   uint64_t window_ct_records;               /* largest window, ciphertext records per instance */
   uint64_t critical_steps, total_steps;     /* device steps: sum over batches of the longest call / sum over all calls */
@@ -205,7 +208,7 @@ typedef struct gsv_plan_schedule_info {
 int gsv_session_plan_schedule_info(const gsv_session* s, gsv_plan_schedule_info* info);
 /* Window `window` of the session's schedule: calls [first_call, first_call + n_calls) of the plan.  Slices handed to
  * gsv_session_garble_streaming_calls start and end on window boundaries. */
-int gsv_session_plan_window(const gsv_session* s, uint64_t window, uint64_t* first_call, uint64_t* n_calls, uint64_t* n_batches);
+int gsv_session_plan_window(const gsv_session* s, uint64_t window, uint64_t* first_call, uint64_t* n_calls, uint64_t* max_width);
 
 /* Garble (GarbleMode): per instance i: delta[16i..], const_label0 = {false.label0, true.label0}
  * (32 B per instance), input_label0 (n_inputs*16 B per instance).  Asynchronous on the engine stream. */

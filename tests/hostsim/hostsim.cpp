@@ -204,9 +204,10 @@ static uint32_t plan_n_globals(const BuiltPlan& bp) {
   }
   return n_globals;
 }
-// The engine's scheduler (schedule.hpp, the very code engine.cpp runs at session creation) over this plan; the schedule is checked
-// against the hazard rules and kept: hostsim_plan_run then executes it with the device's batch semantics (all pre-copies of a
-// batch, then its calls — visited in REVERSE order —, then all post-copies).  info: n_windows n_batches max_batch_calls scratch_slots
+// The engine's scheduler (schedule.hpp, the very code engine.cpp runs at session creation) over this plan; the schedule is checked by
+// brute force (every hazard and every scratch overlap covered by a dependency path) and kept: hostsim_plan_run then executes it the
+// way the device may — window by window, inside a window ANY order the dependencies allow: here always the ready call with the
+// LARGEST stream index, all calls in one shared scratch ring.  info: n_windows n_dependencies max_width scratch_slots
 // critical_steps total_steps max_window_ct.
 int hostsim_plan_schedule(SimPlan* sp, uint32_t max_calls, uint64_t max_slots, uint64_t window_ct, uint32_t window_calls, uint64_t* info /* 7 */) {
   try {
@@ -220,16 +221,15 @@ int hostsim_plan_schedule(SimPlan* sp, uint32_t max_calls, uint64_t max_slots, u
       calls[k].n_slots = g.n_slots; calls[k].n_ct = g.n_ct; calls[k].n_steps = g.n_steps;
     }
     SchedParams p;
-    p.max_calls_per_batch = max_calls; p.max_batch_slots = max_slots ? max_slots : ~0ull; p.max_window_ct = window_ct ? window_ct : ~0ull;
-    p.max_window_calls = window_calls ? window_calls : 4096;
+    p.max_calls_in_flight = max_calls; p.max_scratch_slots = max_slots ? max_slots : ~0ull; p.max_window_ct = window_ct ? window_ct : ~0ull;
+    p.max_window_calls = window_calls ? window_calls : 32768;
     const uint32_t n_ids = plan_n_globals(bp);
     sp->sched = schedule_calls(calls, n_ids, bp.outputs, p);
     const std::string err = verify_schedule(calls, n_ids, bp.outputs, sp->sched);
     if (!err.empty()) gsv_panic("schedule violates a hazard: " + err);
     sp->scheduled = true;
     if (info) {
-      info[0] = sp->sched.windows.size(); info[1] = sp->sched.batches.size(); info[2] = 0;
-      for (auto& b : sp->sched.batches) info[2] = std::max<uint64_t>(info[2], b.count);
+      info[0] = sp->sched.windows.size(); info[1] = sp->sched.deps.size(); info[2] = sp->sched.max_width;
       info[3] = sp->sched.scratch_slots; info[4] = sp->sched.critical_steps; info[5] = sp->sched.total_steps; info[6] = sp->sched.max_window_ct;
     }
     return 0;
@@ -245,15 +245,25 @@ static int plan_run_scheduled(SimPlan* sp, int evaluate, uint64_t gid_base, cons
   const Label d = evaluate ? Label{{0, 0, 0, 0}} : load(delta);
   std::vector<uint64_t> gid_off(bp.calls.size()), ct_off(bp.calls.size());
   { uint64_t g = 0, c = 0; for (size_t k = 0; k < bp.calls.size(); ++k) { gid_off[k] = g; ct_off[k] = c; const Program& pr = bp.programs[size_t(bp.calls[k].program)]; g += pr.n_gates; c += pr.n_ct; } }
-  // ONE scratch area shared by the calls of a batch, at the offsets the schedule assigned (overlaps would corrupt results)
   std::vector<uint8_t> W(size_t(std::max<uint64_t>(sc.scratch_slots, 8)) * 16, 0xA5), VB(std::max<uint64_t>(sc.scratch_slots, 8), 0);
-  for (const Schedule::Batch& b : sc.batches) {
-    for (uint32_t j = 0; j < b.count; ++j) {  // pre-copies
-      const uint32_t k = sc.order[b.first + j];
+  for (const Schedule::Window& win : sc.windows) {
+    const size_t m = win.call1 - win.call0;
+    std::vector<uint8_t> done(m, 0);
+    for (size_t executed = 0; executed < m; ++executed) {
+      // the ready call with the largest stream index: as far from the stream order as the dependencies allow
+      size_t pick = m;
+      for (size_t kk = m; kk-- > 0;) {
+        if (done[kk]) continue;
+        bool ready = true;
+        for (uint32_t q = sc.dep_off[win.call0 + kk]; q < sc.dep_off[win.call0 + kk + 1] && ready; ++q) ready = done[sc.deps[q] - win.call0] != 0;
+        if (ready) { pick = kk; break; }
+      }
+      if (pick == m) gsv_panic("schedule deadlocks");
+      const uint32_t k = uint32_t(win.call0 + pick);
       const BuiltPlan::Call& c = bp.calls[k];
       const Program& g = bp.programs[size_t(c.program)];
       const size_t base = sc.scratch_base[k];
-      std::memset(&W[base * 16], 0xA5, size_t(g.n_slots) * 16);
+      std::memset(&W[base * 16], 0xA5, size_t(g.n_slots) * 16);  // poison: whatever an earlier occupant of the region left behind
       std::memcpy(&W[base * 16], consts, 32);
       std::memset(&W[(base + SLOT_ZERO) * 16], 0, 16);
       VB[base + 0] = 0; VB[base + 1] = 1; VB[base + SLOT_ZERO] = 0;
@@ -264,27 +274,17 @@ static int plan_run_scheduled(SimPlan* sp, int evaluate, uint64_t gid_base, cons
         else if (w == PLAN_WIRE_TRUE) { std::memcpy(&W[dst * 16], consts + 16, 16); VB[dst] = 1; }
         else { std::memcpy(&W[dst * 16], &G[size_t(w) * 16], 16); VB[dst] = GB[w]; }
       }
-    }
-    for (uint32_t j = b.count; j-- > 0;) {  // the calls, last first
-      const uint32_t k = sc.order[b.first + j];
-      const Program& g = bp.programs[size_t(bp.calls[k].program)];
-      const size_t base = sc.scratch_base[k];
       std::vector<uint8_t> w(W.begin() + base * 16, W.begin() + (base + g.n_slots) * 16), vb(VB.begin() + base, VB.begin() + base + g.n_slots);
       interpret(g, evaluate != 0, gid_base + gid_off[k], d, w, vb, cts + ct_off[k] * 16);
       std::memcpy(&W[base * 16], w.data(), w.size());
       std::memcpy(&VB[base], vb.data(), vb.size());
-    }
-    for (uint32_t j = 0; j < b.count; ++j) {  // post-copies
-      const uint32_t k = sc.order[b.first + j];
-      const BuiltPlan::Call& c = bp.calls[k];
-      const Program& g = bp.programs[size_t(c.program)];
-      const size_t base = sc.scratch_base[k];
       for (size_t i = 0; i < c.out_globals.size(); ++i) {
         const uint32_t src = g.output_slots[i];
         if (src & SLOT_LDS_FLAG) gsv_panic("program output in the LDS window");
         std::memcpy(&G[size_t(c.out_globals[i]) * 16], &W[(base + src) * 16], 16);
         GB[c.out_globals[i]] = VB[base + src];
       }
+      done[pick] = 1;
     }
   }
   for (size_t i = 0; i < bp.outputs.size(); ++i) {

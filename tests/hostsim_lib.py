@@ -152,11 +152,12 @@ class SimPlan:
 
     def schedule(self, max_calls, max_slots=0, window_ct=0, window_calls=0):
         """Compute (and verify against the hazard rules) the engine's call-level schedule; garble / evaluate then execute it with the
-        device's batch semantics.  Returns {n_windows, n_batches, max_batch_calls, scratch_slots, critical_steps, total_steps, max_window_ct}."""
+        freedom of the device's dataflow execution (any order the dependencies allow).  Returns {n_windows, n_dependencies, max_width,
+        scratch_slots, critical_steps, total_steps, max_window_ct}."""
         info = np.zeros(7, np.uint64)
         if lib().hostsim_plan_schedule(self.h, C.c_uint32(max_calls), C.c_uint64(max_slots), C.c_uint64(window_ct), C.c_uint32(window_calls), info.ctypes.data_as(C.POINTER(C.c_uint64))):
             raise RuntimeError(lib().hostsim_last_error().decode())
-        return dict(zip(["n_windows", "n_batches", "max_batch_calls", "scratch_slots", "critical_steps", "total_steps", "max_window_ct"], (int(x) for x in info)))
+        return dict(zip(["n_windows", "n_dependencies", "max_width", "scratch_slots", "critical_steps", "total_steps", "max_window_ct"], (int(x) for x in info)))
 
     def garble(self, delta, consts, inputs, gid_base=0):
         cts = np.zeros((self.info["n_ct"], 16), np.uint8)

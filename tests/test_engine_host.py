@@ -222,22 +222,22 @@ def test_plan_builder_matches_flat_stream(spec, units, seed):
 
 @pytest.mark.parametrize("spec,units,seed,sched", [
     ("random_circuit:3", ["test::random_block"], 1, dict(max_calls=64)),                       # 145 calls side by side where the data flow allows
-    ("random_circuit:8", ["test::random_block"], 2, dict(max_calls=4, window_calls=16)),       # small batches, windows of 16 calls
+    ("random_circuit:8", ["test::random_block"], 2, dict(max_calls=4, window_calls=16)),       # few calls in flight, windows of 16 calls
     ("fq_complex", ["fp254::montgomery_reduce", "bigint::mul_karatsuba"], 2, dict(max_calls=8)),
     ("g1_mux_add", ["bigint::multiplexer", "g1::add_montgomery"], 3, dict(max_calls=16)),      # three independent multiplexers, then the addition
-    ("g1_mux_add", ["bigint::multiplexer", "g1::add_montgomery"], 3, dict(max_calls=16, max_slots=1)),  # scratch budget forces one call per batch
+    ("g1_mux_add", ["bigint::multiplexer", "g1::add_montgomery"], 3, dict(max_calls=16, max_slots=1)),  # scratch ring of ONE region: every call waits for its predecessor
     ("driver_mix", ["test::inner", "bigint::add"], 6, dict(max_calls=32, window_ct=300)),      # ciphertext windows
+    ("driver_mix", ["test::inner", "bigint::add"], 6, dict(max_calls=3, max_slots=400)),       # a small ring: regions are reused while other calls are in flight
 ])
 def test_scheduled_plan_matches_flat_stream(spec, units, seed, sched):
-    """schedule.hpp — the code engine.cpp runs at session creation — over a plan: windows of consecutive calls, levelled by the RAW /
-    WAW / WAR hazards on the (recycled) global ids, independent calls in one batch with scratch regions of their own.  The host
-    interpreter executes the schedule with the device's batch semantics (all pre-copies, the calls in REVERSE order in one shared
-    scratch area, all post-copies): the stream, its CBC-MAC, the output labels and the evaluation must still be the oracle's."""
+    """schedule.hpp — the code engine.cpp runs at session creation — over a plan: windows of consecutive calls, inside a window a
+    dataflow over the RAW / WAW / WAR hazards on the (recycled) global ids, the in-flight bound and the scratch ring.  The schedule is
+    verified by brute force (every hazard and every scratch overlap covered by a dependency path) and the host interpreter executes
+    it as far from the stream order as the dependencies allow (always the ready call with the LARGEST index), all calls in one
+    shared scratch ring: the stream, its CBC-MAC, the output labels and the evaluation must still be the oracle's."""
     sp = h.SimPlan(spec, units)
     info = sp.schedule(**sched)
-    assert info["n_batches"] <= sp.info["n_calls"] and info["critical_steps"] <= info["total_steps"]
-    if sched.get("max_slots") == 1:
-        assert info["max_batch_calls"] == 1
+    assert info["critical_steps"] <= info["total_steps"]
     ref = o.garble(spec, seed)
     n_in = ref.n_in
     labs = h.labels_from_seed(seed, 3 + n_in)
@@ -252,16 +252,17 @@ def test_scheduled_plan_matches_flat_stream(spec, units, seed, sched):
 
 
 def test_schedule_finds_the_independent_calls():
-    """Width is found where the circuit has it: the three coordinate multiplexers of g1::multiplexer are independent (one batch of
-    three), and the chain-like random_circuit:3 still packs its 145 calls into fewer batches."""
+    """Width is found where the circuit has it: the three coordinate multiplexers of g1::multiplexer are independent; one call in
+    flight is the stream order itself (depth = all steps); an Fq12 multiplication cut into Fq2-level units is much shallower than
+    the sum of its calls."""
     sp = h.SimPlan("g1_mux_add", ["bigint::multiplexer", "g1::add_montgomery"])
     info = sp.schedule(max_calls=16)
-    assert info["max_batch_calls"] >= 3 and info["n_batches"] < sp.info["n_calls"]
+    assert info["max_width"] >= 3 and info["critical_steps"] < info["total_steps"]
     seq = sp.schedule(max_calls=1)
-    assert seq["n_batches"] == sp.info["n_calls"] and seq["critical_steps"] == seq["total_steps"] and info["critical_steps"] < seq["critical_steps"]
-    sp = h.SimPlan("random_circuit:3", ["test::random_block"])
+    assert seq["max_width"] == 1 and seq["critical_steps"] == seq["total_steps"] and info["critical_steps"] < seq["critical_steps"]
+    sp = h.SimPlan("fq12_mul", ["fq2::mul_montgomery"])
     info = sp.schedule(max_calls=64)
-    assert info["n_batches"] < sp.info["n_calls"] and info["max_batch_calls"] >= 2
+    assert info["max_width"] >= 5 and info["critical_steps"] < info["total_steps"] // 2
 
 
 def test_plan_from_circuit_builds_without_a_device_and_in_both_modes():

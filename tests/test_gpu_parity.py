@@ -425,6 +425,85 @@ def test_plan_built_from_circuit_with_units(engine):
         s2.close()
 
 
+FINE_UNITS = ["fq2::mul_montgomery", "fq2::square_montgomery", "fp254::mul_by_constant_montgomery", "bigint::mul_karatsuba", "fp254::montgomery_reduce"]
+
+
+@pytest.mark.parametrize("units", [["fq12::mul_montgomery", "fq12::square_montgomery"], FINE_UNITS])
+def test_concurrent_calls_of_a_plan_match_the_flat_stream(engine, tmp_path, units):
+    """Intra-instance width (schedule.hpp): independent calls of a plan run side by side in ONE launch (grid = instance groups x
+    calls), each in a scratch region of its own; gate ids and ciphertext positions stay those of the stream order.  `fq12_mix` with the
+    Fq12 components as units (a chain: nothing to overlap, the schedule degenerates to the stream order) and with Fq2-level units (15 independent Fq2 multiplications per Fq12
+    multiplication): for every concurrency / window setting the stream's CBC-MAC, the output labels, the gc files and the evaluation
+    must be those of the oracle's flat, sequential stream.  The calls of a window run as a dataflow inside one launch (every call
+    waits for the completion flags of the calls it depends on: kernels.hip)."""
+    import garbled_snark_verifier_amd as gsv
+    plan = gsv.Plan.from_circuit("fq12_mix", units)
+    seeds = [61, 62, 63]
+    B, n_in = len(seeds), plan.info["n_inputs"]
+    labs = [gsv.labels_from_seed(s, n_in) for s in seeds]
+    delta = np.stack([x[0] for x in labs]); consts = np.stack([np.stack([x[1], x[2]]) for x in labs]); inputs = np.stack([x[3] for x in labs])
+    refs = [o.garble("fq12_mix", s, capture_ct=False) for s in seeds]
+    bits = np.random.default_rng(5).integers(0, 2, size=(B, n_in)).astype(np.uint8)
+    active = np.where(bits[:, :, None] == 1, inputs ^ delta[:, None, :], inputs)
+    exp_bits = [o.execute("fq12_mix", bits[i])[0] for i in range(B)]
+    seq_depth = None
+    for conc in (1, 4, 64):
+        sess = gsv.Session(engine, plan, B, concurrent_calls=conc)  # whole stream retained
+        info = sess.schedule_info()
+        assert info["n_calls"] == plan.info["n_calls"]
+        if conc == 1:
+            seq_depth = info["critical_steps"]
+            assert info["max_width"] == 1 and info["critical_steps"] == info["total_steps"]
+        elif units is FINE_UNITS:
+            assert info["max_width"] >= 2 and info["critical_steps"] < seq_depth
+        sess.set_garble_inputs(delta, consts, inputs)
+        sess.garble(0)
+        out = sess.read_outputs()
+        for i in range(B):
+            assert sess.ciphertext_hash(i) == refs[i].ct_hash.tobytes() and (out[i] == refs[i].output_label0).all()
+        sess.set_evaluate_inputs(np.stack([consts[:, 0], consts[:, 1] ^ delta], axis=1), active, bits)
+        sess.evaluate(0)
+        oa, ob = sess.read_outputs(with_bits=True)
+        for i in range(B):
+            assert (ob[i] == exp_bits[i]).all() and (oa[i] == np.where(ob[i][:, None] == 1, out[i] ^ delta[i][None, :], out[i])).all()
+        sess.close()
+    # the stream leaves the device window by window (gate order restored per call), here with windows of about two Fq2 multiplications
+    for conc, win in ((16, 700_000), (64, 0)):
+        st = gsv.Session(engine, plan, B, retain_stream=False, concurrent_calls=conc, window_ct_records=win)
+        info = st.schedule_info()
+        gc = os.path.join(str(tmp_path), "gc_%d_%d" % (conc, win))
+        os.makedirs(gc)
+        st.set_garble_inputs(delta, consts, inputs)
+        hashes = st.garble_streaming(directory=gc, first_index=3, threads=2)
+        out = st.read_outputs()
+        for i in range(B):
+            assert hashes[i] == refs[i].ct_hash.tobytes() and (out[i] == refs[i].output_label0).all()
+        # window-aligned slices chain the MACs; a slice off a window boundary or out of sequence is refused
+        wins = st.windows()
+        assert len(wins) == info["n_windows"] and sum(w[1] for w in wins) == plan.info["n_calls"]
+        if len(wins) >= 2:
+            st.set_garble_inputs(delta, consts, inputs)
+            for first, n, _ in wins:
+                hashes = st.garble_calls(first, n)
+            assert [h for h in hashes] == [r.ct_hash.tobytes() for r in refs]
+            with pytest.raises(gsv.GsvError):
+                st.garble_calls(wins[1][0], wins[1][1])  # does not continue the previous slice
+            if wins[0][1] > 1:
+                with pytest.raises(gsv.GsvError):
+                    st.garble_calls(0, wins[0][1] - 1)  # not a window boundary
+        # the evaluator reads the gc files back window by window
+        es = gsv.Session(engine, plan, B, retain_stream=False, concurrent_calls=conc, window_ct_records=win)
+        es.set_evaluate_inputs(np.stack([consts[:, 0], consts[:, 1] ^ delta], axis=1), active, bits)
+        fh = es.evaluate_streaming(gc, first_index=3)
+        oa, ob = es.read_outputs(with_bits=True)
+        for i in range(B):
+            assert fh[i] == refs[i].ct_hash.tobytes() and (ob[i] == exp_bits[i]).all()
+            assert (oa[i] == np.where(ob[i][:, None] == 1, out[i] ^ delta[i][None, :], out[i])).all()
+        es.close()
+        st.close()
+    plan.close()
+
+
 def test_final_exponentiation_as_a_plan(engine):
     """final_exponentiation_montgomery (final_exponentiation.rs:99-135): 3,519,328,217 gates, 31 % of the Groth16 verifier, far
     beyond a flat recording.  Recorded as a plan — Fq12 mul / square / cyclotomic square / inverse as units (each recorded
@@ -691,10 +770,11 @@ def test_compressed_verifier_as_a_plan_in_slices(engine, compressed_verifier_pla
     case, plan = compressed_verifier_plan
     assert plan.info["n_gates"] == case["gates"] == 11_687_200_297 and plan.info["n_ciphertexts"] == case["n_ciphertexts"]
     ci = plan.call_info()
-    slices = bench.plan_slices(ci[:, 1], 10)
-    assert sum(s[2] for s in slices) == case["gates"] and max(s[2] for s in slices) < 1.1 * case["gates"] / 10
     d, f, t, inp = gsv.labels_from_seed(case["seed"], plan.info["n_inputs"])
-    sess = gsv.Session(engine, plan, 1, retain_stream=False)
+    # one instance: independent calls run side by side (schedule.hpp), windows of at most 64 M ciphertexts (1 GB) leave the device
+    sess = gsv.Session(engine, plan, 1, retain_stream=False, window_ct_records=64 << 20)
+    slices = bench.session_slices(sess.windows(), ci[:, 1], 10)
+    assert sum(s[2] for s in slices) == case["gates"] and sum(s[1] for s in slices) == plan.info["n_calls"] and max(s[2] for s in slices) < 1.2 * case["gates"] / 10
     sess.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
     for first, n, _ in slices:
         hashes = sess.garble_calls(first, n)
@@ -711,12 +791,15 @@ def test_verifier_lockstep_two_instances_per_workgroup(engine, compressed_verifi
     import garbled_snark_verifier_amd as gsv
     case, plan = compressed_verifier_plan
     ci = plan.call_info()
-    first, n, _ = bench.plan_slices(ci[:, 1], 100)[0]  # decompression ladders: thousands of narrow steps (~30 M ciphertexts per instance)
     d, f, t, inp = gsv.labels_from_seed(7, plan.info["n_inputs"])
     seen = []
+    first = n = None
     for B, ni in ((1024, 4), (512, 2)):
-        sess = gsv.Session(engine, plan, B, retain_stream=False)
+        sess = gsv.Session(engine, plan, B, retain_stream=False, concurrent_calls=1)  # sequential schedule: the same windows for every batch size
         assert sess.instances_per_workgroup == ni
+        sl = bench.session_slices(sess.windows(), ci[:, 1], 100)[0]  # decompression ladders: thousands of narrow steps (~30 M ciphertexts per instance)
+        assert (first, n) in ((None, None), sl[:2])
+        first, n = sl[:2]
         for _ in range(2):
             sess.set_garble_inputs(np.tile(d, (B, 1)), np.tile(np.stack([f, t]), (B, 1, 1)), np.tile(inp, (B, 1, 1)))
             hashes = sess.garble_calls(first, n)
@@ -725,10 +808,17 @@ def test_verifier_lockstep_two_instances_per_workgroup(engine, compressed_verifi
         sess.close()
     assert len(set(seen)) == 1
     # the same slice for ONE instance (one per workgroup, run_program_kernel<false, 1, 0>) gives the same stream
-    one = gsv.Session(engine, plan, 1, retain_stream=False)
+    one = gsv.Session(engine, plan, 1, retain_stream=False, concurrent_calls=1)
     one.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
     assert one.garble_calls(first, n)[0] == seen[0]
     one.close()
+    # ... and so does one instance with the independent calls of the slice side by side (the three ladders of B's square root, A's and
+    # C's ladders: whatever the window holds), in a window that is exactly this slice
+    par = gsv.Session(engine, plan, 1, retain_stream=False, concurrent_calls=64, window_ct_records=int(ci[first:first + n, 3].sum()), max_window_calls=n)
+    assert par.windows()[0][:2] == (first, n)
+    par.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
+    assert par.garble_calls(first, n)[0] == seen[0]
+    par.close()
 
 
 def test_compressed_verifier_evaluates_valid_and_tampered_proof(engine, compressed_verifier_plan):
@@ -779,15 +869,17 @@ def test_plan_slices_and_plan_file_on_the_device(engine, tmp_path):
     for pl, ni in ((plan, "1"), (loaded, "1"), (loaded, "2")):
         os.environ["GSV_INSTANCES_PER_WG"] = ni
         try:
-            sess = gsv.Session(engine, pl, B, retain_stream=False)
+            sess = gsv.Session(engine, pl, B, retain_stream=False, concurrent_calls=1)
         finally:
             del os.environ["GSV_INSTANCES_PER_WG"]
         assert sess.instances_per_workgroup == int(ni)
         gc = os.path.join(str(tmp_path), "gc_%s_%s" % (ni, pl is loaded))
         os.makedirs(gc)
         sess.set_garble_inputs(delta, consts, inputs)
-        for first in range(0, n_calls, 2):  # slices of two calls
-            hashes = sess.garble_calls(first, min(2, n_calls - first), directory=gc, first_index=5)
+        wins = sess.windows()
+        assert len(wins) >= 2
+        for first, n, _ in wins:  # one slice per window of the schedule
+            hashes = sess.garble_calls(first, n, directory=gc, first_index=5)
         out = sess.read_outputs()
         for i, ref in enumerate(refs):
             assert hashes[i] == ref.ct_hash.tobytes() and (out[i] == ref.output_label0).all()
@@ -795,8 +887,8 @@ def test_plan_slices_and_plan_file_on_the_device(engine, tmp_path):
             assert h == ref.ct_hash.tobytes() and (cts == ref.ciphertexts).all()
         # discarding slices leave the same output labels
         sess.set_garble_inputs(delta, consts, inputs)
-        sess.garble_calls(0, 1, discard=True)
-        sess.garble_calls(1, n_calls - 1, discard=True)
+        sess.garble_calls(0, wins[0][1], discard=True)
+        sess.garble_calls(wins[1][0], n_calls - wins[1][0], discard=True)
         assert (sess.read_outputs() == out).all()
         with pytest.raises(gsv.GsvError):
             sess.garble_calls(n_calls, 1, discard=True)
