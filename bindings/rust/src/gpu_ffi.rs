@@ -1,0 +1,79 @@
+//! `extern "C"` declarations of include/gsv_engine.h (libgsv_engine.so).  Plain pointers and sizes; every function returns 0 on
+//! success, a non-zero `gsv_status` otherwise (the C side never unwinds).  `chk` turns non-zero into `panic!`, the reference's own
+//! error behaviour on this path (garble_mode.rs:170-177,221; evaluate_mode.rs:141).
+#![allow(non_camel_case_types, dead_code)]
+use std::os::raw::{c_char, c_int};
+
+#[repr(C)]
+pub struct GsvGate {
+    pub wire_a: u64,
+    pub wire_b: u64,
+    pub wire_c: u64, // u64::MAX = WireId::UNREACHABLE (src/core/wire.rs:8): dead gate, gate id still consumed
+    pub gate_type: u8, // GateType repr(C) discriminant (src/core/gate_type.rs:3-15)
+    pub pad: [u8; 7],
+}
+macro_rules! opaque { ($($n:ident),*) => { $( #[repr(C)] pub struct $n { _p: [u8; 0] } )* } }
+opaque!(GsvRecorder, GsvProgram, GsvEngine, GsvSession, GsvPlan, GsvPlanRecorder);
+
+#[repr(C)]
+#[derive(Default)]
+pub struct GsvPlanSessionOpts {
+    pub retain_stream: c_int,
+    pub max_concurrent_calls: u32,
+    pub window_ct_records: u64,
+    pub max_scratch_slots: u64,
+    pub max_window_calls: u32,
+    pub reserved: u32,
+}
+
+pub const GSV_HASHER_AES: c_int = 0; // AesNiHasher   (src/hashers/mod.rs:54-96)
+pub const GSV_HASHER_BLAKE3: c_int = 1; // Blake3Hasher  (src/hashers/mod.rs:22-51)
+
+extern "C" {
+    pub fn gsv_last_error() -> *const c_char;
+    // recording: the CircuitMode seam
+    pub fn gsv_recorder_create(out: *mut *mut GsvRecorder) -> c_int;
+    pub fn gsv_recorder_destroy(r: *mut GsvRecorder);
+    pub fn gsv_recorder_allocate_wire(r: *mut GsvRecorder, credits: u16, wire_out: *mut u64) -> c_int;
+    pub fn gsv_recorder_declare_input(r: *mut GsvRecorder, wire: u64) -> c_int;
+    pub fn gsv_recorder_push_gates(r: *mut GsvRecorder, gates: *const GsvGate, n: usize) -> c_int;
+    pub fn gsv_recorder_declare_outputs(r: *mut GsvRecorder, wires: *const u64, n: usize) -> c_int;
+    pub fn gsv_program_compile(r: *mut GsvRecorder, fb_out: *const u32, fb_in: *const u32, n_fb: usize, out: *mut *mut GsvProgram) -> c_int;
+    pub fn gsv_program_destroy(p: *mut GsvProgram);
+    // plans: component-level programs (the verifier)
+    pub fn gsv_plan_recorder_create(out: *mut *mut GsvPlanRecorder) -> c_int;
+    pub fn gsv_plan_recorder_destroy(r: *mut GsvPlanRecorder);
+    pub fn gsv_plan_recorder_allocate_wire(r: *mut GsvPlanRecorder, credits: u16, wire_out: *mut u64) -> c_int;
+    pub fn gsv_plan_recorder_declare_input(r: *mut GsvPlanRecorder, wire: u64) -> c_int;
+    pub fn gsv_plan_recorder_push_gates(r: *mut GsvPlanRecorder, gates: *const GsvGate, n: usize) -> c_int;
+    pub fn gsv_plan_recorder_call(r: *mut GsvPlanRecorder, program: *const GsvProgram, in_wires: *const u64, out_wires: *mut u64) -> c_int;
+    pub fn gsv_plan_recorder_finish(r: *mut GsvPlanRecorder, output_wires: *const u64, n_outputs: usize, out: *mut *mut GsvPlan) -> c_int;
+    pub fn gsv_plan_destroy(p: *mut GsvPlan);
+    pub fn gsv_plan_io(p: *const GsvPlan, n_inputs: *mut u64, n_outputs: *mut u64) -> c_int;
+    // engine + sessions
+    pub fn gsv_engine_create(device: c_int, out: *mut *mut GsvEngine) -> c_int;
+    pub fn gsv_engine_destroy(e: *mut GsvEngine);
+    pub fn gsv_session_create(e: *mut GsvEngine, p: *const GsvProgram, n_instances: usize, replays: u64, ct_cap: u64, out: *mut *mut GsvSession) -> c_int;
+    pub fn gsv_session_create_plan_opts(e: *mut GsvEngine, plan: *const GsvPlan, n_instances: usize, opts: *const GsvPlanSessionOpts, out: *mut *mut GsvSession) -> c_int;
+    pub fn gsv_session_destroy(s: *mut GsvSession);
+    pub fn gsv_session_set_hasher(s: *mut GsvSession, kind: c_int) -> c_int;
+    pub fn gsv_session_set_garble_inputs(s: *mut GsvSession, delta: *const u8, const_label0: *const u8, input_label0: *const u8) -> c_int;
+    pub fn gsv_session_garble(s: *mut GsvSession, gate_id_base: u64) -> c_int;
+    pub fn gsv_session_garble_streaming(s: *mut GsvSession, gate_id_base: u64, dir: *const c_char, first_index: u64, n_threads: c_int, hashes: *mut u8) -> c_int;
+    pub fn gsv_session_set_evaluate_inputs(s: *mut GsvSession, const_active: *const u8, input_active: *const u8, input_bits: *const u8) -> c_int;
+    pub fn gsv_session_upload_ciphertexts(s: *mut GsvSession, instance: usize, cts: *const u8, n: u64) -> c_int;
+    pub fn gsv_session_evaluate(s: *mut GsvSession, gate_id_base: u64) -> c_int;
+    pub fn gsv_session_evaluate_streaming(s: *mut GsvSession, gate_id_base: u64, dir: *const c_char, first_index: u64, hashes: *mut u8) -> c_int;
+    pub fn gsv_session_sync(s: *mut GsvSession) -> c_int;
+    pub fn gsv_session_read_outputs(s: *mut GsvSession, labels: *mut u8, bits: *mut u8) -> c_int;
+    pub fn gsv_session_read_ciphertexts(s: *mut GsvSession, instance: usize, first: u64, n: u64, out: *mut u8) -> c_int;
+    pub fn gsv_session_ciphertext_hash(s: *mut GsvSession, instance: usize, hash: *mut u8) -> c_int;
+    pub fn gsv_commit_labels(labels: *const u8, n: u64, out: *mut u8) -> c_int;
+}
+
+pub fn chk(rc: c_int) {
+    if rc != 0 {
+        let msg = unsafe { std::ffi::CStr::from_ptr(gsv_last_error()) }.to_string_lossy().into_owned();
+        panic!("gsv engine: status {rc}: {msg}");
+    }
+}

@@ -459,6 +459,7 @@ class GarbleMode final : public CircuitMode {
     S a0 = read_label0(g.a, "wire_a");
     S b0 = read_label0(g.b, "wire_b");
     uint64_t gate_id = gate_index++;           // :192 — before the UNREACHABLE test
+    if (gate_id >= gate_limit) throw StopAtGateLimit();  // (bench only: time a PREFIX of a long stream; never set by the parity paths)
     if (g.c == UNREACHABLE) return;            // :195-197
     S c0, ct;
     if (garble_gate(g.t, a0, b0, delta, gate_id, c0, ct)) {  // :201-210
@@ -469,6 +470,8 @@ class GarbleMode final : public CircuitMode {
     if (g.c == FALSE_WIRE || g.c == TRUE_WIRE) gsv_panic("gate output is a constant wire");
     if (!storage_.set(g.c, [&](std::optional<S>& d) { d = c0; })) gsv_panic("evaluate_gate: output wire NotFound");
   }
+  struct StopAtGateLimit {};
+  uint64_t gate_limit = ~0ull;
   S delta;
   GarbledWire false_wire, true_wire;
   uint64_t gate_index = 0, n_ciphertexts = 0;
@@ -683,7 +686,28 @@ int gsvo_evaluate(const char* circuit, uint64_t capacity, const uint8_t true_act
   } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 
-// ---- cpu_baseline leg of bench.py: time one garbling instance (single thread), inline CBC-MAC.
+// ---- cpu_baseline leg of bench.py: time the first `max_gates` gates of one garbling instance (single thread, inline CBC-MAC): the
+// reference's per-gate loop on a PREFIX of the real stream (the whole verifier takes ~8 minutes on one core).  ct_hash = MAC state
+// after the prefix (deterministic in seed and max_gates).
+int gsvo_bench_garble_prefix(const char* circuit, uint64_t capacity, uint64_t seed, uint64_t max_gates, double* seconds, uint64_t* gates, uint8_t ct_hash[16]) {
+  try {
+    NamedCircuit nc = make_circuit(circuit);
+    auto t0 = std::chrono::steady_clock::now();
+    GarbleMode mode(capacity, seed);
+    mode.gate_limit = max_gates;
+    StreamingRunner run(mode, nc.n_inputs, nc.fn);
+    const Wires& in = run.prepare();
+    for (size_t i = 0; i < in.size(); ++i) mode.feed(in[i], mode.issue_garbled_wire());
+    for (WireId w : in) { GarbledWire gw; mode.lookup(w, gw); }
+    try { run.execute(); } catch (const GarbleMode::StopAtGateLimit&) {}
+    auto t1 = std::chrono::steady_clock::now();
+    *seconds = std::chrono::duration<double>(t1 - t0).count();
+    *gates = std::min<uint64_t>(mode.gate_index, max_gates);
+    std::memcpy(ct_hash, mode.hash.h.b, 16);
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+// ---- the same for a whole (small) circuit
 int gsvo_bench_garble(const char* circuit, uint64_t capacity, uint64_t seed, double* seconds, uint64_t* gates, uint8_t ct_hash[16]) {
   try {
     NamedCircuit nc = make_circuit(circuit);

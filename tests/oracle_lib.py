@@ -214,6 +214,14 @@ def bench_garble(circuit, seed=0, capacity=200_000):
     return sec.value, gates.value, h.tobytes()
 
 
+def bench_garble_prefix(circuit, max_gates, seed=0, capacity=200_000):
+    """Time the first `max_gates` gates of a (long) circuit's garbling on one core: (seconds, gates, MAC state after the prefix)."""
+    sec, gates = C.c_double(), C.c_uint64()
+    h = np.zeros(16, np.uint8)
+    _check(lib().gsvo_bench_garble_prefix(circuit.encode(), capacity, seed, C.c_uint64(int(max_gates)), C.byref(sec), C.byref(gates), _p(h)))
+    return sec.value, gates.value, h.tobytes()
+
+
 # ---- helpers shared by the tests -------------------------------------------------------------
 FQ_P = 21888242871839275222246405745257275088696311157297823662689037894645226208583
 FQ_R = 1 << 254

@@ -55,3 +55,29 @@ def test_one_public_input_compressed_verifier_table(counter):
     assert second["pairing::ell_by_constant_montgomery"][0] == 182 and second["fq12::mul_by_034_montgomery"] == (91, 1_530_187_022)
     assert second["pairing::double_in_place_circuit_montgomery"] == (64, 64 * 10_124_254) and second["pairing::add_in_place_montgomery"] == (27, 27 * 15_683_482)
     assert second["fq12::cyclotomic_square_montgomery"] == (186, 186 * 8_032_850) and second["fq12::inverse_montgomery"] == (4, 4 * 61_993_136)
+
+
+def test_json_output_in_the_reference_examples_schema(tmp_path):
+    """tools/gate_counts --json prints the schema of the reference's own counter (examples/groth16_gc_gate_count.rs:126-141), so that
+    first contact with cargo is `cargo run --example groth16_gc_gate_count -- --json --compressed` diffed key by key.  Pinned here:
+    the keys, and the per-GateType breakdown == the counts of the CPU oracle's flat garbling of the SAME circuit (committed fixture
+    tests/golden/groth16_verify_compressed_1pub_golden.json: one public input, the configuration the reference quotes 11,174,708,821
+    gates for) — two different walks of the restated gadgets (memoising counter / real two-pass driver) agree gate type by gate type."""
+    import json
+    exe = str(tmp_path / "gate_counts")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "garbled_snark_verifier_amd", "csrc"), os.path.join(ROOT, "tools", "gate_counts.cpp"), "-o", exe])
+    case = json.load(open(os.path.join(ROOT, "tests", "golden", "groth16_verify_compressed_1pub_golden.json")))
+    d = json.loads(subprocess.check_output([exe, case["circuit"], "2", "--json", "--verified", "true" if case["expected_output"] else "false"], text=True))
+    assert set(d) >= {"circuit_size", "gate_count", "verification_result", "compressed"} and set(d["circuit_size"]) == {"k", "constraints"}
+    gc = d["gate_count"]
+    assert set(gc) == {"nonfree", "nonfree_formatted", "free", "free_formatted", "total", "total_formatted", "breakdown"}
+    assert gc["breakdown"] == case["gate_counts"] and gc["total"] == case["gates"] == 11_456_865_898 and gc["free"] + gc["nonfree"] == gc["total"]
+    assert gc["nonfree"] == sum(gc["breakdown"][:8]) == 2_980_378_785 and gc["total_formatted"] == "11.5B" and gc["nonfree_formatted"] == "3.0B"
+    assert d["compressed"] is True and d["verification_result"] is True and d["inputs"] == case["n_inputs"] == 254 + 255 + 509 + 255
+    # the difference to the reference's published figure, as this tree stands: machine-checkable, and attributed per component
+    assert gc["total"] - 11_174_708_821 == 282_157_077
+    comp = {c["name"]: c for c in d["components"]}
+    assert sum(c["gates_self"] for c in d["components"]) + d["root_level_gates"] == gc["total"]
+    assert comp["bigint::add"]["gates_self"] == 10_092_937_600 and comp["fp254::mul_by_constant_montgomery"]["keys"] == 1305
+    top = {c["name"]: (c["calls"], c["gates"]) for c in d["tree"]["children"]}
+    assert top["pairing::multi_miller_loop_groth16_evaluate_montgomery_fast"] == (1, 6_907_999_657) and top["final_exponentiation_montgomery"] == (1, 3_519_328_217)
