@@ -2,25 +2,35 @@
 """Headline benchmark: gates/s (garble) on the Groth16/BN254 verifier circuit, one rank per GPU.
 
 Workload (BASELINE.json configs[3]): the restated `groth16_verify_compressed` circuit (reference: src/gadgets/groth16.rs:250-268,
-the circuit src/garbled_groth16.rs garbles and examples/groth16_garble.rs:116-129 times): point decompression, window-10 MSM,
-Miller loop, final exponentiation, comparison — 11,687,200,297 gates per instance for the synthetic 2-public-input verifying
-key of tests/groth16_ref.py (the reference quotes 11,174,708,821 for its 1-public-input key; DESIGN.md §2 has the
-component-by-component reconciliation), recorded as a plan of component programs and garbled exactly as the reference streams
-it.  Every GPU garbles `--instances` (default 1024 = four per workgroup on 256 CUs) independent cut-and-choose instances (own seed => own
-delta / labels / ciphertext stream).
+the circuit src/garbled_groth16.rs garbles and examples/groth16_garble.rs:116-129 times) for a verifying key with ONE public input
+— the reference's own benchmark configuration (`GarblerInput { public_params_len: 1, .. }`, examples/groth16_garble.rs:107-110,
+groth16_cut_and_choose.rs:116-119): point decompression, window-10 MSM, Miller loop, final exponentiation, comparison —
+11,456,865,898 gates per instance as this tree's gadgets emit them (the reference's README quotes 11,174,708,821; DESIGN.md §2:
+component-by-component reconciliation, tools/gate_counts --json for a key-by-key diff against the reference's own counter),
+recorded as a plan of component programs and garbled exactly as the reference streams it.  Every GPU garbles `--instances`
+(default 1024 = four per workgroup on 256 CUs) independent cut-and-choose instances (own seed => own delta / labels / ciphertext
+stream).
 
-A "step" is one SLICE of that pass: the plan's calls are cut into `--slices` consecutive groups of (nearly) equal gate count and
-step i garbles slice i mod slices for all instances of the rank — wires, gate ids and the ciphertext stream continue from step
-to step, so `--slices` consecutive steps are exactly one full verifier pass per instance (a whole pass is ~130 s at 1024
-instances, which no driver budget fits 25 times).  `value` = gates garbled by all ranks in the timed steps / elapsed, with the
-ciphertexts produced into HBM (one call block per instance, overwritten by the next call: inputs and outputs resident in HBM).
-The PCIe-inclusive rate — every ciphertext copied out and folded into the per-instance CBC-MAC commitment
-(src/ciphertext_hasher.rs:23-29), as the reference's timed garble does — is measured in the same run and reported beside it as
-`e2e_with_commitment`; it is never `value`.
+A "step" is one SLICE of that pass: the windows of the session's schedule are cut into `--slices` consecutive groups of (nearly)
+equal gate count and step i garbles slice i mod slices for all instances of the rank — wires, gate ids and the ciphertext stream
+continue from step to step, so `--slices` consecutive steps are exactly one full verifier pass per instance (a whole pass is ~125 s
+at 1024 instances, which no driver budget fits 25 times).  `value` = gates garbled by all ranks in the timed steps / elapsed, with
+the ciphertexts produced into HBM (one window's block per instance, overwritten by the next window: inputs and outputs resident in
+HBM).  Instance 0 of rank 0 carries the fixture's seed: once a whole pass has run its output label is compared with the fixture
+(`headline_output_label_match`: the very kernel instantiation that is timed).
 
-Before the timed loop rank 0 garbles ONE instance of the whole circuit through the streaming path and checks the CBC-MAC of
-the full ciphertext stream and the output label against the fixture the CPU oracle produced from the flat stream
-(`ciphertext_hash_match`).
+Beside it, measured in the same run on rank 0 (N = 1):
+  e2e_with_commitment   ONE WHOLE PASS of `--e2e-instances` instances with every ciphertext copied out over PCIe and folded into its
+                        instance's CBC-MAC (src/ciphertext_hasher.rs:23-29) — what the reference's timed garble does
+                        (examples/groth16_garble.rs:111-129).  Instance 0 carries the fixture's seed: its final MAC and output label
+                        are the `ciphertext_hash_match` against the fixture the CPU oracle produced from the flat stream.  Never `value`.
+  rate_by_instances     HBM-resident rate of whole passes at 1 and 16 instances (BASELINE configs 4 / 5 at their stated sizes) and
+                        of a sample at 256, next to the headline's 1024.
+  cpu_baseline          the C++ restatement of the reference's per-gate loop on a PREFIX of the same stream, one core and all cores.
+  mode_rates            evaluate-mode and Blake3Hasher garble rates on a component chain (rows a9 / f4 of SURVEY.md §8).
+
+`--workload cc16` is BASELINE config 5: 16 cut-and-choose instances from one master seed, instance i -> rank i mod N, garbled with
+the ciphertext commitments, one all-gather of the GarbledInstanceCommit records.
 
 `--gpus N` without a launcher spawns the N ranks itself (python -m torch.distributed.run) before anything touches a GPU.
 """
@@ -39,6 +49,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 VERIFIER_GATES = 11_174_708_821  # README.md:12 of the reference (its own 1-public-input key)
+FIXTURE = {"verifier_compressed": "groth16_verify_compressed_1pub_golden.json",  # ONE public input: the reference's benchmark configuration
+           "verifier_compressed_2pub": "groth16_verify_compressed_golden.json", "verifier": "groth16_verify_golden.json"}
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s
 AES_CEILING_AND_PER_S = 4.82e10  # tools/ubench/aes_forms.hip on MI355X (profiles/r02_final/aes_forms.txt): 9.65e10 T-table AES blocks/s with every CU full, two blocks per garbled AND
 
@@ -184,17 +196,22 @@ def timed_steps(work, slices, warmup, steps, dist, sync, time_budget_s=None, t_s
 
 # ---------------------------------------------------------------------------------------------------------- GPU workload
 class VerifierWork:
-    """`B` instances of the verifier plan on one GPU (the object timed_steps drives)."""
+    """`B` instances of the verifier plan on one GPU (the object timed_steps drives).  seeds[i] seeds instance i."""
 
-    def __init__(self, gsv, engine, plan, B, seeds):
+    def __init__(self, gsv, engine, plan, B, seeds, **session_kw):
         import numpy as np
         self.np, self.gsv, self.plan, self.B = np, gsv, plan, B
         n_in = plan.info["n_inputs"]
         self.delta = np.zeros((B, 16), np.uint8); self.consts = np.zeros((B, 2, 16), np.uint8); self.inputs = np.zeros((B, n_in, 16), np.uint8)
         for i, sd in enumerate(seeds):
             self.delta[i], self.consts[i, 0], self.consts[i, 1], self.inputs[i] = gsv.labels_from_seed(sd, n_in)
-        self.sess = gsv.Session(engine, plan, B, retain_stream=False)
+        self.sess = gsv.Session(engine, plan, B, retain_stream=False, **session_kw)
         self.seeds = seeds
+        self.ct_hashes = None  # set by a pass that drained and MAC'ed the stream
+
+    def slices(self, call_gates, n_slices):
+        """[(first_call, n_calls, gates)]: groups of whole windows of the session's schedule, nearly equal in gates."""
+        return session_slices(self.sess.windows(), call_gates, n_slices)
 
     def new_pass(self):
         self.sess.set_garble_inputs(self.delta, self.consts, self.inputs)  # fresh labels resident in HBM before the first slice starts
@@ -203,12 +220,23 @@ class VerifierWork:
         self.sess.garble_calls(first, n, discard=True)  # returns when the slice's last call has finished
         return self.sess.last_kernel_ms()
 
+    def run_pass(self, commit=False, threads=0):
+        """One whole pass; commit=True: every ciphertext drained over PCIe and folded into its instance's CBC-MAC.  Returns seconds."""
+        self.new_pass()
+        t0 = time.perf_counter()
+        if commit:
+            self.ct_hashes = self.sess.garble_streaming(threads=threads)
+        else:
+            self.sess.garble_streaming(discard=True)
+        return time.perf_counter() - t0
+
     def commit_records(self):
-        """GarbledInstanceCommit per instance (cut_and_choose/garbler.rs:61-99): label commits of inputs, outputs and constants.  The
-        ciphertext-commit field is zero here: the timed step keeps the ciphertexts in HBM (the streamed + hashed path fills it)."""
+        """GarbledInstanceCommit per instance (cut_and_choose/garbler.rs:61-99): label commits of inputs, outputs and constants, and
+        the ciphertext commitment when the pass drained the stream (zero when the ciphertexts stayed in HBM: the timed headline)."""
         from garbled_snark_verifier_amd import sharding
         out = self.sess.read_outputs()
-        return self.np.stack([sharding.commit_record(self.seeds[i], bytes(16), out[i], self.delta[i], self.consts[i, 0], self.consts[i, 1], self.inputs[i]) for i in range(self.B)])
+        ch = self.ct_hashes or [bytes(16)] * self.B
+        return self.np.stack([sharding.commit_record(self.seeds[i], ch[i], out[i], self.delta[i], self.consts[i, 0], self.consts[i, 1], self.inputs[i]) for i in range(self.B)])
 
     def close(self):
         self.sess.close()
@@ -230,13 +258,16 @@ def _plan_cache_path(args, circuit, units):
         if not d or not os.path.isdir(d):
             continue
         sub = os.path.join(d, "gsv_plan_cache_%d" % os.getuid()) if d in ("/dev/shm", "/tmp") else d
-        if os.path.exists(os.path.join(sub, name)):
+        if os.path.exists(os.path.join(sub, name)) and os.stat(sub).st_uid == os.getuid() and not (os.stat(sub).st_mode & 0o022):
             return os.path.join(sub, name)
         try:
             st = os.statvfs(d)
             if st.f_bavail * st.f_frsize < 60e9:  # the verifier plan's images are ~40 GB
                 continue
-            os.makedirs(sub, exist_ok=True)
+            os.makedirs(sub, mode=0o700, exist_ok=True)
+            ds = os.stat(sub)
+            if ds.st_uid != os.getuid() or (ds.st_mode & 0o022):  # a plan file is trusted input of the loader: only our own directory
+                continue
             return os.path.join(sub, name)
         except OSError:
             continue
@@ -245,35 +276,46 @@ def _plan_cache_path(args, circuit, units):
 
 def get_plan(gsv, engine, args, circuit, units, rank, local_rank, local_world, dist, log):
     """Local rank 0 loads the node's plan file or builds the plan (and saves it when other ranks need it); the other ranks of the
-    node load the file straight into their GPU's memory.  Returns (plan, {how, seconds, ...}, save_later)."""
+    node load the file straight into their GPU's memory.  Returns (plan, {how, seconds, ...}, save_later).  A failure on any rank is
+    agreed on by all (min over ranks) before anyone waits in a barrier: every rank exits non-zero together."""
     path = _plan_cache_path(args, circuit, units)
     t0 = time.time()
     info = {"cache_file": path}
-    plan, save_later = None, None
+    plan, save_later, err = None, None, None
     if local_rank == 0:
-        if path and os.path.exists(path):
-            plan = gsv.Plan.load(path, engine)
-            info["how"] = "loaded"
-        else:
-            try:  # ~50 GB of host memory while the plan is built
-                avail_gb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1e6
-                if avail_gb < 60:
-                    log("bench.py: %.0f GB of host memory available, the plan build needs ~50 GB" % avail_gb)
-            except (OSError, IndexError, ValueError):
-                pass
-            plan = gsv.Plan.from_circuit(circuit, units, window_div=4)  # one image per program, good for 1, 2 and 4 instances per workgroup
-            info["how"] = "built"
-            if local_world > 1:
-                if not path:
-                    raise RuntimeError("no directory with room for the plan file the other ranks load (set --plan-cache)")
-                plan.save(path)
-                info["saved_s"] = time.time() - t0
-            elif path:
-                save_later = path  # single rank: written after the result line, for the next process on this machine
+        try:
+            if path and os.path.exists(path):
+                plan = gsv.Plan.load(path, engine)
+                info["how"] = "loaded"
+            else:
+                try:  # ~50 GB of host memory while the plan is built
+                    avail_gb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1e6
+                    if avail_gb < 60:
+                        log("bench.py: %.0f GB of host memory available, the plan build needs ~50 GB" % avail_gb)
+                except (OSError, IndexError, ValueError):
+                    pass
+                plan = gsv.Plan.from_circuit(circuit, units, window_div=4)  # one image per program, good for 1, 2 and 4 instances per workgroup
+                info["how"] = "built"
+                if local_world > 1:
+                    if not path:
+                        raise RuntimeError("no directory with room for the plan file the other ranks load (set --plan-cache)")
+                    plan.save(path)
+                    info["saved_s"] = time.time() - t0
+                elif path:
+                    save_later = path  # single rank: written after the result line, for the next process on this machine
+        except Exception as e:  # noqa: BLE001
+            err = e
+    if dist.min_int(0 if err else 1) == 0:
+        raise RuntimeError("plan build / load failed on a rank: %r" % (err,))
     dist.barrier()
     if local_rank != 0:
-        plan = gsv.Plan.load(path, engine)
-        info["how"] = "loaded"
+        try:
+            plan = gsv.Plan.load(path, engine)
+            info["how"] = "loaded"
+        except Exception as e:  # noqa: BLE001
+            err = e
+    if dist.min_int(0 if err else 1) == 0:
+        raise RuntimeError("plan load failed on a rank: %r" % (err,))
     info["seconds"] = time.time() - t0
     return plan, info, save_later
 
@@ -321,29 +363,28 @@ try:
 except (AttributeError, OSError):
     pass
 import oracle_lib as o
-res = [o.bench_garble(s, seed=0) for s in %r]
-print(json.dumps({"seconds": sum(r[0] for r in res), "gates": sum(r[1] for r in res), "hashes": [r[2].hex() for r in res]}))
+sec, gates, h = o.bench_garble_prefix(%r, %d, seed=%d)
+print(json.dumps({"seconds": sec, "gates": gates, "hash": h.hex()}))
 """
 
 
-def cpu_baseline(np, o, log, budget_s=75.0):
-    """The restated CPU path (C++ oracle: AES-NI gate hash + inline CBC-MAC, the reference's per-gate loop) on this host: one core,
-    then one instance per physical core, each in its own process pinned to its core (reference: one garbling task per physical
-    core, cut_and_choose/mod.rs:131-186).  Sample per core: verifier components, ~0.36 B gates (~15 s)."""
-    specs = ["g1_scalar_mul:10", "fq12_sqmul_chain:4"]  # the MSM's window scalar multiplication + 4 square-and-multiply links of the pairing core
+def cpu_baseline(o, circuit, seed, log, prefix_gates=400_000_000, budget_s=75.0):
+    """The restated CPU path (C++ oracle: AES-NI gate hash + inline CBC-MAC, the reference's per-gate loop, garble_mode.rs:160-222) on
+    this host, timed on a PREFIX of the very stream the GPU garbles (the first `prefix_gates` gates of the verifier: decompression
+    ladders, i.e. Fq multiplications like the rest of the circuit): one core, then one instance per physical core, each in its own
+    process pinned to its core (reference: one garbling task per physical core, cut_and_choose/mod.rs:131-186)."""
     t0 = time.time()
-    ref = [o.bench_garble(s, seed=0) for s in specs]
-    one_s, one_g = sum(r[0] for r in ref), sum(r[1] for r in ref)
+    one_s, one_g, one_h = o.bench_garble_prefix(circuit, prefix_gates, seed=seed)
     out = {"value": one_g / one_s, "unit": "gates/s", "cores": 1, "kind": "port",
-           "sample": "%s garbled back to back by the C++ restatement of the reference's loop (AES-NI hash, inline CBC-MAC): %d gates per core" % (" + ".join(specs), one_g),
+           "sample": "the first %d gates of the benchmarked circuit's own stream (seed %d) garbled by the C++ restatement of the reference's loop (AES-NI hash, inline CBC-MAC)" % (one_g, seed),
            "cpu_1core": {"value": one_g / one_s, "unit": "gates/s", "cores": 1, "seconds": one_s, "gates": one_g},
-           "reference_published": {"cpu_1core": 32e6, "cpu_8cores": 249e6, "source": "README.md:12-13 of the reference (developer laptop)"}}
+           "reference_published": {"cpu_1core": 32e6, "cpu_8cores": 249e6, "source": "README.md:12-13 of the reference (developer laptop, whole circuit incl. gadget code); this port: same loop, this host's core"}}
     cpus = physical_cores()
     quota = cpu_quota_cores()
     out["host"] = {"physical_cores_in_affinity_mask": len(cpus), "cgroup_cpu_quota_cores": quota}
     if quota is not None and quota < len(cpus):  # more processes than the container may run at once would only time-slice
         cpus = cpus[: max(1, int(quota))]
-    code = _CPU_WORKER % (os.path.join(ROOT, "tests"), specs)
+    code = _CPU_WORKER % (os.path.join(ROOT, "tests"), circuit, prefix_gates, seed)
     t1 = time.perf_counter()
     procs = [subprocess.Popen([sys.executable, "-c", code, str(c)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for c in cpus]
     done, ok = [], True
@@ -351,7 +392,7 @@ def cpu_baseline(np, o, log, budget_s=75.0):
         try:
             so, _ = p.communicate(timeout=max(1.0, budget_s - (time.perf_counter() - t1)))
             r = json.loads(so.strip().splitlines()[-1])
-            ok = ok and r["hashes"] == [x[2].hex() for x in ref]  # same seed -> same ciphertext hashes on every core
+            ok = ok and r["hash"] == one_h.hex()  # same seed -> same MAC state after the prefix on every core
             done.append(r)
         except (subprocess.TimeoutExpired, ValueError, IndexError):
             p.kill()
@@ -364,6 +405,34 @@ def cpu_baseline(np, o, log, budget_s=75.0):
         out.update({"value": g / wall, "cores": len(done)})
         out["sample"] += "; all-cores leg: one process per physical core on %d cores, %.1f s wall (process start included)" % (len(done), wall)
     out["seconds_total"] = time.time() - t0
+    return out
+
+
+def mode_rates(gsv, engine, np, instances=256, replays=4):
+    """Rows a9 / f4 of SURVEY.md §8 on a component chain (fq12_sqmul replayed): device rates of EvaluateMode (one AES per AND, the
+    ciphertexts read back where the garbler left them: evaluate_mode.rs:123-158) and of the Blake3Hasher PRF (hashers/mod.rs:22-51)
+    beside the AES garble rate of the same session shape.  The evaluated output labels must be select(label0, bit)."""
+    prog = gsv.Program.from_circuit("fq12_sqmul", chain_feedback=True)
+    n_in, gates = prog.info["n_inputs"], prog.info["n_gates"] * replays
+    labs = [gsv.labels_from_seed(7000 + i, n_in) for i in range(instances)]
+    delta = np.stack([x[0] for x in labs]); consts = np.stack([np.stack([x[1], x[2]]) for x in labs]); inputs = np.stack([x[3] for x in labs])
+    out = {"circuit": "fq12_sqmul chain x%d (%d gates per instance), %d instances" % (replays, gates, instances)}
+    for name in ("aes", "blake3"):
+        sess = gsv.Session(engine, prog, instances, replays, replays)
+        sess.set_hasher(name)
+        sess.set_garble_inputs(delta, consts, inputs)
+        sess.garble(0); sess.sync()
+        out["garble_%s" % name] = instances * gates / (sess.last_kernel_ms() / 1e3)
+        label0 = sess.read_outputs()
+        bits = np.random.default_rng(1).integers(0, 2, size=(instances, n_in)).astype(np.uint8)
+        active = np.where(bits[:, :, None] == 1, inputs ^ delta[:, None, :], inputs)
+        sess.set_evaluate_inputs(np.stack([consts[:, 0], consts[:, 1] ^ delta], axis=1), active, bits)
+        sess.evaluate(0); sess.sync()
+        out["evaluate_%s" % name] = instances * gates / (sess.last_kernel_ms() / 1e3)
+        oa, ob = sess.read_outputs(with_bits=True)
+        out["evaluate_%s_consistent" % name] = bool((oa == np.where(ob[:, :, None] == 1, label0 ^ delta[:, None, :], label0)).all())
+        sess.close()
+    out["unit"] = "gates/s"
     return out
 
 
@@ -380,83 +449,137 @@ def run_verifier(args):
     def log(msg):
         print(msg, file=sys.stderr, flush=True)
 
-    compressed = args.workload == "verifier_compressed"
-    case = json.load(open(os.path.join(ROOT, "tests", "golden", "groth16_verify_compressed_golden.json" if compressed else "groth16_verify_golden.json")))
+    compressed = args.workload.startswith("verifier_compressed")
+    case = json.load(open(os.path.join(ROOT, "tests", "golden", FIXTURE[args.workload])))
     units = VERIFIER_UNITS + (["fp254::exp_chunk"] if compressed else [])
     engine = gsv.Engine(local_rank)  # raises without a HIP device: no CPU fallback
     plan, plan_info, save_later = get_plan(gsv, engine, args, case["circuit"], units, rank, local_rank, local_world, dist, log)
     t_first_launch = time.time() - T_START
     B, n_in, gates = args.instances, plan.info["n_inputs"], plan.info["n_gates"]
     n_calls = plan.info["n_calls"]
-    f_nf = plan.info["n_ciphertexts"] / gates
+    n_ct = plan.info["n_ciphertexts"]
+    f_nf = n_ct / gates
     bytes_per_gate = 64.0 + 16.0 * f_nf  # 16 B record + 2x16 B label reads + 16 B write + 16 B*f_nf ciphertext
     ci = plan.call_info()
-    slices = plan_slices(ci[:, 1], args.slices)
     image_bytes, n_programs = plan.image_bytes()
-    n_glob, n_prog_slots = plan.wire_file()
-    max_block = int(ci[:, 3].max())
+    n_pub = (n_in - 254 - 255 - 509 - 255) // 254 + 1 if compressed else None
     if rank == 0:
-        log("bench.py: plan %s in %.1f s (%d calls of %d programs, %.1f GB of program records), %d slices; per instance: wire file %.1f MB (%d + %d slots), ciphertext block %.1f MB"
-            % (plan_info["how"], plan_info["seconds"], n_calls, n_programs, image_bytes / 1e9, len(slices), (n_glob + n_prog_slots) * 16 / 1e6, n_prog_slots, n_glob, max_block * 16 / 1e6))
+        log("bench.py: plan %s in %.1f s (%d calls of %d programs, %.1f GB of program records)" % (plan_info["how"], plan_info["seconds"], n_calls, n_programs, image_bytes / 1e9))
+
+    def fixture_ok(hash_bytes, out_labels):
+        return bool(hash_bytes.hex() == case["ct_hash"] and hashlib.sha256(out_labels.tobytes()).hexdigest() == case["output_label0_sha256"])
 
     result = {}
-    # ---- whole-stream check on the fixture's seed, BEFORE the timed loop: one instance, stream drained and hashed on the host
-    if rank == 0 and not args.no_check:
-        t0 = time.time()
-        d, f, t, inp = gsv.labels_from_seed(case["seed"], n_in)
-        chk = gsv.Session(engine, plan, 1, retain_stream=False)
-        chk.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
-        h = chk.garble_streaming()[0].hex()
-        ok = h == case["ct_hash"] and hashlib.sha256(chk.read_outputs()[0].tobytes()).hexdigest() == case["output_label0_sha256"]
-        chk.close()
-        result["ciphertext_hash_match"] = bool(ok)
-        result["hash_check"] = {"circuit": "the whole circuit (%d gates, %d ciphertexts), seed %d, one instance through gsv_session_garble_streaming" % (gates, plan.info["n_ciphertexts"], case["seed"]),
-                                "gpu": h, "oracle": case["ct_hash"], "seconds": time.time() - t0}
-        log("bench.py: whole-stream hash check %s in %.1f s" % ("ok" if ok else "MISMATCH", time.time() - t0))
-    # ---- CPU baseline (rank 0 at N = 1 only), also before the timed loop so that the result line follows the timing directly
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    extras = rank == 0 and world == 1
+    # ---- CPU baseline: the restated per-gate loop on a prefix of the very stream the GPU garbles (rank 0 at N = 1 only)
+    if extras and not args.no_cpu_baseline:
         try:
             import oracle_lib as o
-            result["cpu_baseline"] = cpu_baseline(np, o, log)
+            result["cpu_baseline"] = cpu_baseline(o, case["circuit"], case["seed"], log)
             log("bench.py: cpu baseline %.3g gates/s on 1 core, %.3g on %d cores" % (result["cpu_baseline"]["cpu_1core"]["value"], result["cpu_baseline"]["value"], result["cpu_baseline"]["cores"]))
         except Exception as e:  # the baseline must not cost the run its result line
             result["cpu_baseline"] = {"error": repr(e)}
 
-    # ---- PCIe-inclusive rate with the commitment: calls from the middle of the plan, every ciphertext copied out and folded into its
-    # instance's CBC-MAC while the next call is garbled (correctness of this path: the check above).  In a session of its own, closed
-    # before the timed one is created: the drain keeps a gate-order copy of the ciphertext blocks (twice their HBM).
-    if rank == 0 and world == 1 and not args.no_e2e:
+    # ---- ONE WHOLE PASS with the commitment: every ciphertext of every instance drained over PCIe and folded into its CBC-MAC while the
+    # GPU garbles the next window (the like-for-like of the reference's timed garble, examples/groth16_garble.rs:111-129).  Instance 0
+    # carries the fixture's seed: its MAC over the whole stream and its output label are this run's ciphertext-hash check.
+    if extras and not args.no_e2e:
         try:
-            Be = max(1, min(B, args.e2e_instances))
-            e2e = VerifierWork(gsv, engine, plan, Be, instance_seeds(rank, Be))
+            Be = max(1, args.e2e_instances)
+            seeds = [case["seed"]] + instance_seeds(rank, Be)[1:]
+            e2e = VerifierWork(gsv, engine, plan, Be, seeds)
             try:
-                first = slices[len(slices) // 2][0]
-                n, g_acc = 0, 0
-                while first + n < n_calls and g_acc * Be < args.e2e_gates:
-                    g_acc += int(ci[first + n, 1]); n += 1
-                e2e.new_pass()
-                t0 = time.perf_counter()
-                e2e.sess.garble_calls(first, n, discard=False)
-                dt = time.perf_counter() - t0
-                ct = int(ci[first:first + n, 3].sum())
-                result["e2e_with_commitment"] = {"value": g_acc * Be / dt, "unit": "gates/s", "instances": Be, "instances_per_workgroup": e2e.sess.instances_per_workgroup, "seconds": dt,
-                                                 "ciphertext_gb_per_s": ct * Be * 16 / dt / 1e9,
-                                                 "sample": "calls %d..%d of the plan (%d gates, %d ciphertexts per instance) for %d instances: garbled, drained over PCIe and CBC-MAC'ed per instance on the host (gsv_session_garble_streaming_calls)"
-                                                           % (first, first + n - 1, g_acc, ct, Be)}
-                log("bench.py: e2e with commitment %.3g gates/s (%.1f GB/s of ciphertexts)" % (g_acc * Be / dt, ct * Be * 16 / dt / 1e9))
+                si = e2e.sess.schedule_info()
+                quota = cpu_quota_cores()
+                dt = e2e.run_pass(commit=True, threads=args.mac_threads)
+                out = e2e.sess.read_outputs()
+                ok = fixture_ok(e2e.ct_hashes[0], out[0])
+                result["ciphertext_hash_match"] = ok
+                gbs = n_ct * Be * 16 / dt / 1e9
+                groups = (Be + 3) // 4
+                workers = args.mac_threads or max(1, min(groups, 32, os.cpu_count() or 1))
+                result["e2e_with_commitment"] = {
+                    "value": gates * Be / dt, "unit": "gates/s", "instances": Be, "instances_per_workgroup": e2e.sess.instances_per_workgroup, "seconds": dt, "passes": 1,
+                    "ciphertext_gb_per_s": gbs, "ciphertext_gb_total": n_ct * Be * 16 / 1e9, "mac_workers": workers, "mac_chains_per_worker": 4, "host_cores_quota": quota,
+                    "windows": si["n_windows"], "window_ct_records": si["window_ct_records"], "distinct_macs": len(set(e2e.ct_hashes)),
+                    "instance0": {"seed": case["seed"], "ct_hash": e2e.ct_hashes[0].hex(), "fixture_ct_hash": case["ct_hash"], "match": ok},
+                    "per_node_ceiling_8gpus": {"gates_per_s": min(8 * gates * Be / dt, (quota or float(os.cpu_count() or 16)) * 0.75e8 / f_nf), "pcie_bound_gates_per_s": 8 * gates * Be / dt,
+                                               "mac_bound_gates_per_s": (quota or float(os.cpu_count() or 16)) * 0.75e8 / f_nf,
+                                               "note": "8 x this GPU's PCIe-bound rate, capped by the host's MAC capacity: one core advances ~0.75e8 CBC-MAC blocks/s with four chains interleaved and "
+                                                       "the stream holds f_nf = %.4f blocks per gate; cores = this container's cpu.max quota (%s) or the visible CPUs" % (f_nf, quota)},
+                    "sample": "one WHOLE pass of the circuit (%d gates, %d ciphertexts per instance) for %d instances: garbled, every ciphertext drained over PCIe and CBC-MAC'ed per instance "
+                              "on the host (gsv_session_garble_streaming); instance 0 = the fixture's seed, hash + output label compared with the oracle's flat-stream fixture" % (gates, n_ct, Be)}
+                log("bench.py: e2e with commitment %.3g gates/s (%.1f GB/s of ciphertexts, %.1f s), fixture hash %s" % (gates * Be / dt, gbs, dt, "ok" if ok else "MISMATCH"))
             finally:
                 e2e.close()
-        except Exception as e:
+        except Exception as e:  # noqa: BLE001
             result["e2e_with_commitment"] = {"error": repr(e)}
 
-    work = VerifierWork(gsv, engine, plan, B, instance_seeds(rank, B))
+    # ---- the configurations BASELINE names at their stated sizes: ONE instance (config 4) and 16 (config 5's total), whole passes with
+    # the ciphertexts produced into HBM; independent calls of the plan run side by side (schedule.hpp).  A sample of the pass at 256.
+    if extras and not args.no_rate_by_instances:
+        rbi = {}
+        try:
+            for Bi, whole in ((1, True), (16, True), (256, False)):
+                if time.time() - T_START > args.time_budget * 0.55:
+                    rbi[str(Bi)] = {"skipped": "time budget"}
+                    continue
+                w = VerifierWork(gsv, engine, plan, Bi, [case["seed"]] + instance_seeds(rank, Bi)[1:])
+                try:
+                    si = w.sess.schedule_info()
+                    if whole:
+                        dt = w.run_pass()
+                        g = gates
+                        okl = hashlib.sha256(w.sess.read_outputs()[0].tobytes()).hexdigest() == case["output_label0_sha256"]
+                    else:
+                        sl = w.slices(ci[:, 1], 10)
+                        w.sess.set_unchecked_slices(True)  # a sample from the middle of the pass: timing only
+                        w.new_pass()
+                        pick = [sl[0], sl[len(sl) // 2], sl[-1]]
+                        t0 = time.perf_counter()
+                        for first, n, _ in pick:
+                            w.run_slice(first, n)
+                        dt = time.perf_counter() - t0
+                        g = sum(x[2] for x in pick)
+                        okl = None
+                    rbi[str(Bi)] = {"gates_per_s": g * Bi / dt, "seconds": dt, "gates_per_instance": g, "whole_pass": whole, "output_label_match": okl, "instances_per_workgroup": w.sess.instances_per_workgroup,
+                                    "max_width": si["max_width"], "windows": si["n_windows"], "depth_steps": si["critical_steps"], "total_steps": si["total_steps"]}
+                    log("bench.py: %d instance(s): %.3g gates/s" % (Bi, g * Bi / dt))
+                finally:
+                    w.close()
+        except Exception as e:  # noqa: BLE001
+            rbi["error"] = repr(e)
+        result["rate_by_instances"] = rbi
+    if extras and not args.no_mode_rates:
+        try:
+            result["mode_rates"] = mode_rates(gsv, engine, np)
+        except Exception as e:  # noqa: BLE001
+            result["mode_rates"] = {"error": repr(e)}
+
+    seeds = instance_seeds(rank, B)
+    if rank == 0:
+        seeds[0] = case["seed"]  # the fixture's seed: the timed kernel's output label is checked once a whole pass has run
+    work = VerifierWork(gsv, engine, plan, B, seeds)
     ni = work.sess.instances_per_workgroup
+    slices = work.slices(ci[:, 1], args.slices)
+    sched = work.sess.schedule_info()
+    if rank == 0:
+        log("bench.py: %d instances, %d per workgroup; %d windows in %d slices; per instance: wire file %.1f MB, ciphertext window %.1f MB"
+            % (B, ni, sched["n_windows"], len(slices), sched["wire_file_slots"] * 16 / 1e6, sched["window_ct_records"] * 16 / 1e6))
 
     def sync():
         torch.cuda.synchronize()
         work.sess.sync()
 
     r = timed_steps(work, slices, args.warmup, args.steps, dist, sync, args.time_budget, T_START)
+    label_match = None
+    if rank == 0 and (args.warmup + r["steps_run"]) >= len(slices) and r["commit_table"] is not None:
+        # the last completed pass's output label of instance 0 (fixture seed), as gathered in its commit record: commit(label0) of output 0
+        from garbled_snark_verifier_amd import sharding
+        rec = r["commit_table"][0].numpy() if hasattr(r["commit_table"][0], "numpy") else np.asarray(r["commit_table"][0])
+        _, _, _, outc, _, _ = sharding.record_fields(rec, plan.info["n_outputs"], n_in)
+        exp = sharding.commit_labels(np.frombuffer(bytes.fromhex(case["first_output_label0"]), np.uint8)[None, :])[0]
+        label_match = bool((outc[0, 1] == exp).all())
     work.close()
     if rank == 0:
         el, K = r["elapsed"], r["steps_run"]
@@ -464,31 +587,39 @@ def run_verifier(args):
         n_launch = r["calls"]
         g_rank = r["gates_per_instance"] * B
         achieved = g_rank * bytes_per_gate / stream_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_final", "traffic.json")
-        if os.path.exists(tpath) and compressed:
-            try:
-                tj = json.load(open(tpath))
-                if int(tj.get("instances_per_gpu", 512)) == B:  # PMC passes of this very configuration (tools/profile_r02.sh)
-                    traffic = float(tj["hbm_bytes_per_launch"])
-            except (KeyError, ValueError):
-                pass
+        traffic, traffic_source = None, None
+        for cand in ("r03_final", "r02_final"):
+            tpath = os.path.join(ROOT, "profiles", cand, "traffic.json")
+            if os.path.exists(tpath) and compressed:
+                try:
+                    tj = json.load(open(tpath))
+                    if int(tj.get("instances_per_gpu", 512)) == B and tj.get("circuit_gates", gates) == gates:  # PMC passes of this very configuration
+                        traffic = float(tj["hbm_bytes_per_call"] if "hbm_bytes_per_call" in tj else tj["hbm_bytes_per_launch"])
+                        traffic_source = "profiles/%s/traffic.json (separate rocprofv3 --pmc passes of this workload; NOT measured in this run)" % cand
+                        break
+                except (KeyError, ValueError):
+                    pass
         result.update({
             "metric": "gates/sec (garble) on Groth16/BN254 verifier at 1/2/4/8 GPUs; ciphertext-hash match", "value": g_rank * world / el, "unit": "gates/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "restated %s circuit (synthetic 2-public-input verifying key / proof of tests/groth16_ref.py; %d gates per instance, the reference quotes 11,174,708,821 "
-                                   "for its 1-public-input key: DESIGN.md §2), %d cut-and-choose instances per GPU; one step = one of %d slices of the plan's %d calls, %d consecutive steps = one "
-                                   "full verifier pass per instance" % ("groth16_verify_compressed" if compressed else "groth16_verify", gates, B, len(slices), n_calls, len(slices)),
-                       "instances_per_gpu": B, "instances_per_workgroup": ni, "gates_per_instance": gates, "nonfree_fraction": f_nf, "plan_calls": n_calls, "plan_programs": n_programs,
+            "headline_output_label_match": label_match,
+            "config": {"workload": "restated %s circuit, %s public input(s) (synthetic verifying key / proof of tests/groth16_ref.py; %d gates per instance as this tree's gadgets emit them, the reference "
+                                   "quotes 11,174,708,821 for the same configuration: DESIGN.md §2, tools/gate_counts --json), %d cut-and-choose instances per GPU, ciphertexts produced into HBM; one step = "
+                                   "one of %d slices of the plan's %d calls, %d consecutive steps = one full verifier pass per instance"
+                                   % ("groth16_verify_compressed" if compressed else "groth16_verify", n_pub if compressed else "2", gates, B, len(slices), n_calls, len(slices)),
+                       "public_inputs": n_pub, "instances_per_gpu": B, "instances_per_workgroup": ni, "gates_per_instance": gates, "reference_published_gates": VERIFIER_GATES, "nonfree_fraction": f_nf,
+                       "plan_calls": n_calls, "plan_programs": n_programs, "plan_windows": sched["n_windows"],
                        "slices_per_pass": len(slices), "gates_per_step_per_instance": [s[2] for s in slices], "steps_requested": args.steps,
                        "passes_timed": r["gates_per_instance"] / gates, "step_device_ms": [round(x, 1) for x in r["step_ms"]], "plan": plan_info, "plan_image_gb": image_bytes / 1e9, "seconds_to_first_launch": t_first_launch,
+                       "wire_file_mb_per_instance": sched["wire_file_slots"] * 16 / 1e6, "ciphertext_window_mb_per_instance": sched["window_ct_records"] * 16 / 1e6,
                        "host_peak_rss_gb": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1e6},
             "commit_records_gathered": None if r["commit_table"] is None else list(r["commit_table"].shape),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         # one step = the launches of one slice, all of the same kernel over different component programs: averages per launch
-                         "kernel": "run_program_kernel<false, %d, 0>" % ni, "launches_timed": n_launch, "kernel_ms_avg": stream_s * 1e3 / max(1, n_launch),
-                         "algorithmic_bytes_per_launch": g_rank * bytes_per_gate / max(1, n_launch), "bytes_per_gate": bytes_per_gate,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         # one step = the window launches of one slice, all of the same kernel over different component programs; a window launch runs its calls back to back per
+                         # instance group (grid.y = calls), so the unit of the per-launch figures is one CALL of the plan for all instances of the GPU
+                         "kernel": "run_program_kernel<false, %d, 0>" % ni, "calls_timed": n_launch, "kernel_ms_avg_per_call": stream_s * 1e3 / max(1, n_launch),
+                         "algorithmic_bytes_per_call": g_rank * bytes_per_gate / max(1, n_launch), "bytes_per_gate": bytes_per_gate,
                          "note": "algorithmic-bytes accounting of SURVEY.md §8(d); fusion and the LDS label window keep most of those bytes off HBM, the limit that binds is T-table AES issue (DESIGN.md §3)",
                          "binding_limit": "aes-issue", "aes_ceiling_gates_per_s": AES_CEILING_AND_PER_S / f_nf, "aes_ceiling_frac": (g_rank / stream_s) / (AES_CEILING_AND_PER_S / f_nf)},
         })
@@ -499,6 +630,71 @@ def run_verifier(args):
                 plan.save(save_later)
                 log("bench.py: plan saved to %s in %.1f s" % (save_later, time.time() - t0))
             except Exception as e:
+                log("bench.py: plan not saved: %r" % (e,))
+    dist.barrier()
+    dist.close()
+    plan.close()
+    engine.close()
+
+
+def run_cc16(args):
+    """BASELINE config 5: 16 cut-and-choose instances of the verifier from ONE master seed, instance i -> rank i mod N, each garbled
+    with its ciphertext commitment (stream drained over PCIe and CBC-MAC'ed), ONE all-gather of the GarbledInstanceCommit records
+    (cut_and_choose/garbler.rs:191-257).  The same path runs first on a shortened circuit (Fq12 multiplication) whose gathered table
+    must equal the committed fixture built from the CPU oracle's garblings (tests/golden/cc16_golden.json).  A step = the whole job."""
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+    dist = Dist(world, "nccl", "cuda")
+    import garbled_snark_verifier_amd as gsv
+    from garbled_snark_verifier_amd import sharding
+
+    def log(msg):
+        print(msg, file=sys.stderr, flush=True)
+
+    engine = gsv.Engine(local_rank)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "cc16_golden.json")))
+    total = gold["total"]
+    # shortened circuit: every record against the fixture
+    prog = gsv.Program.from_circuit(gold["circuit"])
+    table, seeds = sharding.cut_and_choose_commit(gold["circuit"], gold["master_seed"], total, rank, world, engine=engine, program=prog, device="cuda" if world > 1 else None)
+    short_ok = bool(hashlib.sha256(table.tobytes()).hexdigest() == gold["table_sha256"] and [int(x) for x in seeds] == gold["seeds"])
+    prog.close()
+    case = json.load(open(os.path.join(ROOT, "tests", "golden", FIXTURE["verifier_compressed"])))
+    units = VERIFIER_UNITS + ["fp254::exp_chunk"]
+    plan, plan_info, save_later = get_plan(gsv, engine, args, case["circuit"], units, rank, local_rank, local_world, dist, log)
+    gates = plan.info["n_gates"]
+    times = []
+    tab = None
+    for it in range(args.warmup + args.steps):
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        tab, _ = sharding.cut_and_choose_commit(case["circuit"], gold["master_seed"], total, rank, world, engine=engine, program=plan, device="cuda" if world > 1 else None)
+        torch.cuda.synchronize(); dist.barrier()
+        dt = dist.max_float(time.perf_counter() - t0)
+        if it >= args.warmup:
+            times.append(dt)
+    if rank == 0:
+        el = sum(times)
+        ct = [bytes(tab[i][8:24]).hex() for i in range(total)]
+        result = {"metric": "gates/sec (garble) on Groth16/BN254 verifier at 1/2/4/8 GPUs; ciphertext-hash match", "value": gates * total * len(times) / el, "unit": "gates/s", "n_gpus": world,
+                  "steps": len(times), "warmup": args.warmup, "ms_per_step": el / len(times) * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                  "ciphertext_hash_match": short_ok,
+                  "config": {"workload": "cc16: %d cut-and-choose instances of the restated groth16_verify_compressed circuit (1 public input, %d gates each) from master seed %d, instance i -> rank i mod %d, "
+                                         "every ciphertext drained over PCIe and CBC-MAC'ed (the commitment the reference's Garbler::create computes, garbler.rs:219-222), one all-gather of the "
+                                         "GarbledInstanceCommit records; a step = the whole job" % (total, gates, gold["master_seed"], world),
+                             "instances_total": total, "instances_per_gpu": len(sharding.shard_instances(total, rank, world)), "gates_per_instance": gates, "plan": plan_info,
+                             "reference_published": "16 instances on 8 physical cores: ~11 m 58 s, ~249 M gates/s (README.md:13)"},
+                  "commit_records_gathered": list(tab.shape), "distinct_ciphertext_commitments": len(set(ct)),
+                  "shortened_circuit_check": {"circuit": gold["circuit"], "table_sha256": hashlib.sha256(table.tobytes()).hexdigest(), "fixture": gold["table_sha256"], "match": short_ok}}
+        print(json.dumps(result), flush=True)
+        if save_later:
+            try:
+                plan.save(save_later)
+            except Exception as e:  # noqa: BLE001
                 log("bench.py: plan not saved: %r" % (e,))
     dist.barrier()
     dist.close()
@@ -569,7 +765,7 @@ def run_synthetic(args):
             result["ciphertext_hash_match"] = bool(chk.ciphertext_hash[1] == ref.ct_hash.tobytes() and (chk.output_label0[1] == ref.output_label0).all())
         if world == 1 and not args.no_cpu_baseline:
             import oracle_lib as o
-            result["cpu_baseline"] = cpu_baseline(np, o, lambda m: None)
+            result["cpu_baseline"] = cpu_baseline(o, args.component + "_chain:16", seeds[0], lambda m: None)
         print(json.dumps(result), flush=True)
     dist.barrier()
     dist.close()
@@ -581,18 +777,22 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--instances", type=int, default=1024, help="cut-and-choose instances per GPU (4 x the 256 CUs: four per workgroup; 257..512: two per workgroup)")
-    ap.add_argument("--e2e-instances", type=int, default=512, help="instances of the e2e_with_commitment measurement (its gate-order copy of the ciphertext blocks doubles their HBM)")
+    ap.add_argument("--e2e-instances", type=int, default=64, help="instances of the e2e_with_commitment measurement: ONE WHOLE PASS, every ciphertext drained over PCIe (47.7 GB per "
+                    "instance at ~50 GB/s) and CBC-MAC'ed")
+    ap.add_argument("--mac-threads", type=int, default=0, help="host threads of the drain (0 = up to 32, one per four instances)")
     ap.add_argument("--slices", type=int, default=10, help="steps per full verifier pass: the plan's calls are cut into this many slices of equal gate count")
-    ap.add_argument("--workload", default="verifier_compressed", choices=["synthetic", "verifier", "verifier_compressed"],
-                    help="verifier_compressed (default) / verifier: the restated groth16_verify_compressed / groth16_verify circuit of the committed fixture as a plan of "
-                         "component programs; synthetic: the Groth16-shaped chain")
+    ap.add_argument("--workload", default="verifier_compressed", choices=["synthetic", "verifier", "verifier_compressed", "verifier_compressed_2pub", "cc16"],
+                    help="verifier_compressed (default): the restated groth16_verify_compressed circuit with ONE public input (the reference's benchmark configuration) as a plan of component "
+                         "programs; verifier_compressed_2pub / verifier: round-2 fixtures (two public inputs, with / without point decompression); cc16: BASELINE config 5 (16 instances from one "
+                         "master seed over the ranks, commitments, one all-gather); synthetic: the Groth16-shaped chain")
     ap.add_argument("--time-budget", type=float, default=840.0, help="seconds from process start within which the timed steps must end; steps are reduced (and reported) if they would not fit")
     ap.add_argument("--plan-cache", default=None, help="directory of the plan file shared by the ranks of a node (default: $GSV_PLAN_CACHE, /dev/shm, /tmp)")
     ap.add_argument("--no-plan-cache", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--e2e-gates", type=float, default=1.5e11, help="gates (all instances) garbled by the e2e_with_commitment measurement")
+    ap.add_argument("--no-rate-by-instances", action="store_true")
+    ap.add_argument("--no-mode-rates", action="store_true")
     ap.add_argument("--replays", type=int, default=0, help="synthetic: chain links per instance (0 = enough for 11.17 B gates)")
     ap.add_argument("--ct-ring", type=int, default=2, help="synthetic: replays of ciphertexts kept per instance in HBM")
     ap.add_argument("--component", default="fq12_sqmul", choices=["fq12_sqmul", "fq12_mul"], help="synthetic: link of the chain")
@@ -609,6 +809,8 @@ def main():
         sys.exit(2)
     if args.workload == "synthetic":
         run_synthetic(args)
+    elif args.workload == "cc16":
+        run_cc16(args)
     else:
         run_verifier(args)
     # sessions, plan and engine are closed in order by now (and the package's atexit hook closes whatever is left before the

@@ -5,7 +5,9 @@
 #include <hip/hip_vector_types.h>
 #include <stdint.h>
 
+#ifndef GSV_BLOCK_THREADS
 #define GSV_BLOCK_THREADS 1024
+#endif
 
 namespace gsv {
 namespace dev {

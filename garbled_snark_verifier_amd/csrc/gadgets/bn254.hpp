@@ -246,7 +246,12 @@ inline Fq6 mul_by_nonresidue(CircuitContext& c, const Fq6& a) {  // fq6.rs:346-3
   Fq2 u = fq2::mul_by_nonresidue(c, a.c[2]);
   return {{u, a.c[0], a.c[1]}};
 }
-inline Fq6 mul_montgomery(CircuitContext& c, const Fq6& a, const Fq6& b) {  // fq6.rs:194-260
+// fq6.rs:194-260, wrapped in a component like the Fq2 multiplication above (stream-neutral): the unit at which an Fq12 multiplication /
+// squaring has its width — three / two Fq6 multiplications that a plan session runs side by side, each with its own pre- and
+// post-additions inside (cutting finer, at the Fq2 multiplications, doubles the dependency depth: schedule.hpp).
+inline Fq6 mul_montgomery(CircuitContext& c0_, const Fq6& a_, const Fq6& b_) {
+  Wires out = component(c0_, KeyBuilder("fq6::mul_montgomery"), concat(a_.to_wires(), b_.to_wires()), 1524, [](CircuitContext& c, const Wires& in) {
+  const Fq6 a = Fq6::from_wires(slice(in, 0, 1524)), b = Fq6::from_wires(slice(in, 1524, 3048));
   const Fq2 &a_c0 = a.c[0], &a_c1 = a.c[1], &a_c2 = a.c[2];
   const Fq2 &b_c0 = b.c[0], &b_c1 = b.c[1], &b_c2 = b.c[2];
   Fq2 v0 = fq2::mul_montgomery(c, a_c0, b_c0);
@@ -306,7 +311,9 @@ inline Fq6 mul_montgomery(CircuitContext& c, const Fq6& a, const Fq6& b) {  // f
   Fq2 c2 = fq2::sub(c, wires_29, v4_6);
 
   Fq6 result{{c0, c1, c2}};
-  return div6(c, result);
+  return div6(c, result).to_wires();
+  });
+  return Fq6::from_wires(out);
 }
 }  // namespace fq6
 

@@ -176,49 +176,69 @@ inline Fq2 mul_constant_by_fq_montgomery(CircuitContext& c, const HFq2& a, const
 }  // namespace fq2
 
 namespace fq6 {
-inline Fq6 mul_by_fq2_montgomery(CircuitContext& c, const Fq6& a, const Fq2& b) {  // fq6.rs:326-332
-  return {{fq2::mul_montgomery(c, a.c[0], b), fq2::mul_montgomery(c, a.c[1], b), fq2::mul_montgomery(c, a.c[2], b)}};
+// The three sparse Fq6 multiplications below are wrapped in components of their own like fq6::mul_montgomery (bn254.hpp): stream-
+// neutral, and the units at which a line evaluation (mul_by_034: two mul_by_01 + one mul_by_fq2, mutually independent up to a few
+// additions) has its width for a plan session.
+inline Fq6 mul_by_fq2_montgomery(CircuitContext& c0_, const Fq6& a_, const Fq2& b_) {  // fq6.rs:326-332
+  Wires out = component(c0_, KeyBuilder("fq6::mul_by_fq2_montgomery"), concat(a_.to_wires(), b_.to_wires()), 1524, [](CircuitContext& c, const Wires& in) {
+    const Fq6 a = Fq6::from_wires(slice(in, 0, 1524));
+    const Fq2 b = Fq2::from_wires(slice(in, 1524, 2032));
+    return Fq6{{fq2::mul_montgomery(c, a.c[0], b), fq2::mul_montgomery(c, a.c[1], b), fq2::mul_montgomery(c, a.c[2], b)}}.to_wires();
+  });
+  return Fq6::from_wires(out);
 }
-inline Fq6 mul_by_01_montgomery(CircuitContext& c, const Fq6& a, const Fq2& c0, const Fq2& c1) {  // fq6.rs:351-379
-  const Fq2 &a0 = a.c[0], &a1 = a.c[1], &a2 = a.c[2];
-  Fq2 w1 = fq2::mul_montgomery(c, a0, c0);
-  Fq2 w2 = fq2::mul_montgomery(c, a1, c1);
-  Fq2 w3 = fq2::add(c, a1, a2);
-  Fq2 w4 = fq2::mul_montgomery(c, w3, c1);
-  Fq2 w5 = fq2::sub(c, w4, w2);
-  Fq2 w6 = fq2::mul_by_nonresidue(c, w5);
-  Fq2 w7 = fq2::add(c, w6, w1);
-  Fq2 w8 = fq2::add(c, a0, a1);
-  Fq2 w9 = fq2::add(c, c0, c1);
-  Fq2 w10 = fq2::mul_montgomery(c, w8, w9);
-  Fq2 w11 = fq2::sub(c, w10, w1);
-  Fq2 w12 = fq2::sub(c, w11, w2);
-  Fq2 w13 = fq2::add(c, a0, a2);
-  Fq2 w14 = fq2::mul_montgomery(c, w13, c0);
-  Fq2 w15 = fq2::sub(c, w14, w1);
-  Fq2 w16 = fq2::add(c, w15, w2);
-  return {{w7, w12, w16}};
+inline Fq6 mul_by_01_montgomery(CircuitContext& c0_, const Fq6& a_, const Fq2& c0_in, const Fq2& c1_in) {  // fq6.rs:351-379
+  Wires out = component(c0_, KeyBuilder("fq6::mul_by_01_montgomery"), concat(concat(a_.to_wires(), c0_in.to_wires()), c1_in.to_wires()), 1524, [](CircuitContext& c, const Wires& in) {
+    const Fq6 a = Fq6::from_wires(slice(in, 0, 1524));
+    const Fq2 c0 = Fq2::from_wires(slice(in, 1524, 2032)), c1 = Fq2::from_wires(slice(in, 2032, 2540));
+    const Fq2 &a0 = a.c[0], &a1 = a.c[1], &a2 = a.c[2];
+    Fq2 w1 = fq2::mul_montgomery(c, a0, c0);
+    Fq2 w2 = fq2::mul_montgomery(c, a1, c1);
+    Fq2 w3 = fq2::add(c, a1, a2);
+    Fq2 w4 = fq2::mul_montgomery(c, w3, c1);
+    Fq2 w5 = fq2::sub(c, w4, w2);
+    Fq2 w6 = fq2::mul_by_nonresidue(c, w5);
+    Fq2 w7 = fq2::add(c, w6, w1);
+    Fq2 w8 = fq2::add(c, a0, a1);
+    Fq2 w9 = fq2::add(c, c0, c1);
+    Fq2 w10 = fq2::mul_montgomery(c, w8, w9);
+    Fq2 w11 = fq2::sub(c, w10, w1);
+    Fq2 w12 = fq2::sub(c, w11, w2);
+    Fq2 w13 = fq2::add(c, a0, a2);
+    Fq2 w14 = fq2::mul_montgomery(c, w13, c0);
+    Fq2 w15 = fq2::sub(c, w14, w1);
+    Fq2 w16 = fq2::add(c, w15, w2);
+    return Fq6{{w7, w12, w16}}.to_wires();
+  });
+  return Fq6::from_wires(out);
 }
 // fq6.rs:381-410: c1 is a constant handed over in Montgomery form
-inline Fq6 mul_by_01_constant1_montgomery(CircuitContext& c, const Fq6& a, const Fq2& c0, const Fq2Const& c1) {
-  const Fq2 &a0 = a.c[0], &a1 = a.c[1], &a2 = a.c[2];
-  Fq2 w1 = fq2::mul_montgomery(c, a0, c0);
-  Fq2 w2 = fq2::mul_by_constant_montgomery(c, a1, c1);
-  Fq2 w3 = fq2::add(c, a1, a2);
-  Fq2 w4 = fq2::mul_by_constant_montgomery(c, w3, c1);
-  Fq2 w5 = fq2::sub(c, w4, w2);
-  Fq2 w6 = fq2::mul_by_nonresidue(c, w5);
-  Fq2 w7 = fq2::add(c, w6, w1);
-  Fq2 w8 = fq2::add(c, a0, a1);
-  Fq2 w9 = fq2::add_constant(c, c0, c1);
-  Fq2 w10 = fq2::mul_montgomery(c, w8, w9);
-  Fq2 w11 = fq2::sub(c, w10, w1);
-  Fq2 w12 = fq2::sub(c, w11, w2);
-  Fq2 w13 = fq2::add(c, a0, a2);
-  Fq2 w14 = fq2::mul_montgomery(c, w13, c0);
-  Fq2 w15 = fq2::sub(c, w14, w1);
-  Fq2 w16 = fq2::add(c, w15, w2);
-  return {{w7, w12, w16}};
+inline Fq6 mul_by_01_constant1_montgomery(CircuitContext& c0_, const Fq6& a_, const Fq2& c0_in, const Fq2Const& c1) {
+  const std::string k0 = c1.c0.key_bytes(), k1 = c1.c1.key_bytes();
+  Wires out = component(c0_, KeyBuilder("fq6::mul_by_01_constant1_montgomery").param("c1_0", k0.data(), k0.size()).param("c1_1", k1.data(), k1.size()),
+                        concat(a_.to_wires(), c0_in.to_wires()), 1524, [&c1](CircuitContext& c, const Wires& in) {
+    const Fq6 a = Fq6::from_wires(slice(in, 0, 1524));
+    const Fq2 c0 = Fq2::from_wires(slice(in, 1524, 2032));
+    const Fq2 &a0 = a.c[0], &a1 = a.c[1], &a2 = a.c[2];
+    Fq2 w1 = fq2::mul_montgomery(c, a0, c0);
+    Fq2 w2 = fq2::mul_by_constant_montgomery(c, a1, c1);
+    Fq2 w3 = fq2::add(c, a1, a2);
+    Fq2 w4 = fq2::mul_by_constant_montgomery(c, w3, c1);
+    Fq2 w5 = fq2::sub(c, w4, w2);
+    Fq2 w6 = fq2::mul_by_nonresidue(c, w5);
+    Fq2 w7 = fq2::add(c, w6, w1);
+    Fq2 w8 = fq2::add(c, a0, a1);
+    Fq2 w9 = fq2::add_constant(c, c0, c1);
+    Fq2 w10 = fq2::mul_montgomery(c, w8, w9);
+    Fq2 w11 = fq2::sub(c, w10, w1);
+    Fq2 w12 = fq2::sub(c, w11, w2);
+    Fq2 w13 = fq2::add(c, a0, a2);
+    Fq2 w14 = fq2::mul_montgomery(c, w13, c0);
+    Fq2 w15 = fq2::sub(c, w14, w1);
+    Fq2 w16 = fq2::add(c, w15, w2);
+    return Fq6{{w7, w12, w16}}.to_wires();
+  });
+  return Fq6::from_wires(out);
 }
 }  // namespace fq6
 

@@ -100,11 +100,12 @@ def all_gather_records(local, total, rank, world, device=None):
     return out.cpu()[torch.from_numpy(np.argsort(idx, kind="stable"))]
 
 
-def garble_and_commit(circuit, seeds, indexes, engine=None, program=None, replays=1, gc_dir=None):
-    """Garbler::create + commit (garbler.rs:191-257) for the given (index, seed) pairs in ONE launch: returns the
+def garble_and_commit(circuit, seeds, indexes, engine=None, program=None, replays=1, gc_dir=None, session_kw=None):
+    """Garbler::create + commit (garbler.rs:191-257) for the given (index, seed) pairs in ONE session: returns the
     [len(seeds), record_len] commit records; with gc_dir the ciphertext streams go to gc_<index>.bin
-    (ciphertext_repository.rs:94-127).  Indexes must be consecutive when gc_dir is used."""
-    from . import Engine, Program, Session, labels_from_seed
+    (ciphertext_repository.rs:94-127).  Indexes must be consecutive when gc_dir is used.  `program` may be a Plan (the
+    verifier): the stream is then drained window by window of the session's schedule."""
+    from . import Engine, Plan, Program, Session, labels_from_seed
     engine = engine or Engine(0)
     program = program or Program.from_circuit(circuit, chain_feedback=replays > 1)
     n_in = program.info["n_inputs"]
@@ -112,7 +113,10 @@ def garble_and_commit(circuit, seeds, indexes, engine=None, program=None, replay
     delta = np.zeros((B, 16), np.uint8); consts = np.zeros((B, 2, 16), np.uint8); inputs = np.zeros((B, n_in, 16), np.uint8)
     for i, s in enumerate(seeds):
         delta[i], consts[i, 0], consts[i, 1], inputs[i] = labels_from_seed(int(s), n_in)
-    sess = Session(engine, program, B, replays, min(replays, 2) if replays > 1 else 1)
+    if isinstance(program, Plan):
+        sess = Session(engine, program, B, retain_stream=False, **(session_kw or {}))
+    else:
+        sess = Session(engine, program, B, replays, min(replays, 2) if replays > 1 else 1)
     sess.set_garble_inputs(delta, consts, inputs)
     if gc_dir is not None:
         assert list(indexes) == list(range(indexes[0], indexes[0] + B)), "gc files are numbered first_index + i"
@@ -121,6 +125,28 @@ def garble_and_commit(circuit, seeds, indexes, engine=None, program=None, replay
     recs = np.stack([commit_record(indexes[i], hashes[i], outs[i], delta[i], consts[i, 0], consts[i, 1], inputs[i]) for i in range(B)])
     sess.close()
     return recs
+
+
+def cut_and_choose_commit(circuit, master_seed, total, rank, world, engine=None, program=None, garble=None, device=None, session_kw=None):
+    """BASELINE config 5 / `Garbler::create` -> `commit` (garbler.rs:191-257) across ranks: `total` seeds are drawn from one master
+    seed (:201-203), instance i goes to rank i mod world (the reference: one instance per pinned core, mod.rs:131-186), every rank
+    garbles its instances WITH the ciphertext commitment (AESAccumulatingHash over the whole stream, :219-222) and builds their
+    GarbledInstanceCommit records, and ONE all-gather leaves every rank with the [total, record_len] table ordered by instance
+    index.  Nothing else is exchanged.  `garble(circuit, seeds, indexes) -> records` replaces the GPU garbler in the CPU tests.
+    Returns (table as a uint8 numpy array, seeds)."""
+    seeds = instance_seeds(master_seed, total)
+    mine = shard_instances(total, rank, world)
+    if garble is None:
+        garble = lambda c, sd, idx: garble_and_commit(c, sd, idx, engine=engine, program=program, session_kw=session_kw)  # noqa: E731
+    n_out, n_in = (program.info["n_outputs"], program.info["n_inputs"]) if program is not None else (None, None)
+    if mine:
+        local = np.ascontiguousarray(garble(circuit, [int(seeds[i]) for i in mine], mine), np.uint8)
+    else:
+        if n_out is None:
+            raise ValueError("a rank without instances needs `program` to size its (empty) share of the gather")
+        local = np.zeros((0, record_len(n_out, n_in)), np.uint8)
+    table = all_gather_records(torch.from_numpy(local), total, rank, world, device=device)
+    return table.numpy(), seeds
 
 
 def run_regarbling(commits, to_finalize, seeds, circuit, gc_dir, engine=None, program=None, replays=1):

@@ -126,6 +126,19 @@ def test_sliced_timed_loop_world2_gloo():
             assert (t0[rank * 2 + i] == exp).all()
 
 
+def test_session_slices_follow_window_boundaries():
+    """A plan session executes whole windows of its schedule: slices are groups of windows, nearly equal in gates, covering every call."""
+    sys.path.insert(0, ROOT)
+    import bench
+    gates = [100 + (7 * k) % 50 for k in range(40)]
+    windows = [(0, 3, 1), (3, 1, 1), (4, 10, 2), (14, 6, 1), (20, 20, 3)]
+    sl = bench.session_slices(windows, gates, 3)
+    assert [x[0] for x in sl] == sorted(x[0] for x in sl) and sl[0][0] == 0 and sum(x[1] for x in sl) == 40 and sum(x[2] for x in sl) == sum(gates)
+    starts = {w[0] for w in windows}
+    assert all(x[0] in starts for x in sl) and len(sl) == 3
+    assert len(bench.session_slices(windows, gates, 50)) == len(windows)  # never more slices than windows
+
+
 def test_bench_refuses_mismatched_world_size():
     """`--gpus 8` under a launcher that started a different number of ranks must fail loudly, not run on fewer GPUs."""
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")

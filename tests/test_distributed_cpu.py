@@ -71,6 +71,60 @@ def test_shard_and_gather_commits_world2():
         assert (res[0][i] == exp).all()
 
 
+def _cc16_worker(rank, world, port, total, master_seed, circuit, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from garbled_snark_verifier_amd import sharding
+    import hostsim_lib as h
+    sp = h.SimProgram(circuit)
+
+    def garble(c, seeds, indexes):  # the GPU garbler's stand-in: the host interpreter of the compiled device schedule
+        recs = []
+        for sd, idx in zip(seeds, indexes):
+            labs = h.labels_from_seed(sd, 3 + sp.info["n_inputs"])
+            delta, consts, inputs = labs[0], labs[1:3], labs[3:]
+            out, cts = sp.garble(delta, consts, inputs)
+            recs.append(sharding.commit_record(idx, h.cbcmac(cts), out, delta, consts[0], consts[1], inputs))
+        return np.stack(recs)
+
+    table, seeds = sharding.cut_and_choose_commit(circuit, master_seed, total, rank, world, garble=garble, device="cpu")
+    q.put((rank, table.copy(), [int(x) for x in seeds]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cc16_cut_and_choose_commit_world2():
+    """BASELINE config 5 as sharding.cut_and_choose_commit runs it (bench.py --workload cc16): 16 seeds from one master seed,
+    instance i -> rank i mod 2, every instance garbled WITH its ciphertext commitment, one all-gather of the GarbledInstanceCommit
+    records.  Here on gloo with the host interpreter as the garbler and a shortened circuit (Fq multiplication): both ranks end up
+    with the same table, and all 16 records equal the ones built from the CPU oracle's garbling."""
+    world, total, master, circuit = 2, 16, 2024, "fq_mul"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cc16_worker, args=(r, world, port, total, master, circuit, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, table, seeds = q.get(timeout=300)
+        res[r] = (table, seeds)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert (res[0][0] == res[1][0]).all() and res[0][1] == res[1][1] and len(set(res[0][1])) == total
+    sys.path.insert(0, ROOT)
+    from garbled_snark_verifier_amd import sharding
+    assert res[0][0].shape == (total, sharding.record_len(254, 508))
+    for i in range(total):
+        g = o.garble(circuit, res[0][1][i])
+        exp = sharding.commit_record(i, g.ct_hash.tobytes(), g.output_label0, g.delta, g.false_label0, g.true_label0, g.input_label0)
+        assert (res[0][0][i] == exp).all(), "record %d differs from the oracle's" % i
+
+
 def test_shard_instances_partition():
     sys.path.insert(0, ROOT)
     from garbled_snark_verifier_amd import sharding

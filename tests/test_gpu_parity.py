@@ -230,6 +230,28 @@ def test_cut_and_choose_fanout_and_commit_records(engine):
     assert bytes(table[0].numpy()[24:40]) == o.cbcmac(g.input_label0[0][0].tobytes())
 
 
+def test_cc16_cut_and_choose_commit_on_one_gpu(engine):
+    """BASELINE config 5 at N = 1 on a shortened circuit: sharding.cut_and_choose_commit (what bench.py --workload cc16 runs) draws 16
+    seeds from the master seed, garbles all 16 instances of the Fq12 multiplication on the GPU WITH their ciphertext commitments
+    (stream drained + CBC-MAC'ed), builds the GarbledInstanceCommit records and "gathers" them: every record must equal the one
+    the committed fixture holds (built from the CPU oracle's garblings, tests/golden/make_cc16_golden.py), and three of them are
+    rebuilt from the oracle here."""
+    import hashlib
+    import garbled_snark_verifier_amd as gsv
+    from garbled_snark_verifier_amd import sharding
+    gold = json.load(open(os.path.join(os.path.dirname(GOLDEN), "cc16_golden.json")))
+    prog = gsv.Program.from_circuit(gold["circuit"])
+    table, seeds = sharding.cut_and_choose_commit(gold["circuit"], gold["master_seed"], gold["total"], 0, 1, engine=engine, program=prog)
+    assert [int(x) for x in seeds] == gold["seeds"] and table.shape == (gold["total"], gold["record_len"])
+    assert [hashlib.sha256(r.tobytes()).hexdigest() for r in table] == gold["record_sha256"]
+    assert hashlib.sha256(table.tobytes()).hexdigest() == gold["table_sha256"]
+    for i in (0, 7, 15):
+        g = o.garble(gold["circuit"], gold["seeds"][i], capture_ct=False)
+        exp = sharding.commit_record(i, g.ct_hash.tobytes(), g.output_label0, g.delta, g.false_label0, g.true_label0, g.input_label0)
+        assert (table[i] == exp).all()
+    prog.close()
+
+
 def test_two_instances_per_workgroup(engine, monkeypatch):
     """More instances than CUs: sessions switch to two instances per workgroup (each with half of the LDS label window,
     program variant compiled on demand).  Forced here on small batches, odd batch size included (idle second half),
@@ -752,7 +774,8 @@ def compressed_verifier_plan():
     (what bench.py builds: one image per program, compiled for a quarter of the LDS window; ~100 s of host time and ~50 GB of host
     memory on the GPU box)."""
     import garbled_snark_verifier_amd as gsv
-    case = json.load(open(os.path.join(os.path.dirname(GOLDEN), "groth16_verify_compressed_golden.json")))
+    # ONE public input: the reference's own benchmark configuration (examples/groth16_garble.rs:107-110, groth16_cut_and_choose.rs:116-119)
+    case = json.load(open(os.path.join(os.path.dirname(GOLDEN), "groth16_verify_compressed_1pub_golden.json")))
     plan = gsv.Plan.from_circuit(case["circuit"], VERIFIER_UNITS + ["fp254::exp_chunk"], window_div=4)
     yield case, plan
     plan.close()
@@ -762,13 +785,13 @@ def test_compressed_verifier_as_a_plan_in_slices(engine, compressed_verifier_pla
     """BASELINE config 4.  groth16_verify_compressed (groth16.rs:250-268: decompression of A, B, C; MSM; projective-to-affine;
     Miller loop; final exponentiation; comparison) for the synthetic instance of tests/groth16_ref.py as one plan, garbled the way
     bench.py steps through it — in slices of consecutive calls, the stream drained and CBC-MAC'ed slice by slice: the final MAC
-    and the output label == the fixture the CPU oracle produced from the FLAT 11,687,200,297-gate stream
+    and the output label == the fixture the CPU oracle produced from the FLAT 11,456,865,898-gate stream (one public input)
     (tests/golden/make_big_golden.py).  tools/groth16_plan.py --compressed also evaluates a valid and a tampered proof."""
     import hashlib
     import bench
     import garbled_snark_verifier_amd as gsv
     case, plan = compressed_verifier_plan
-    assert plan.info["n_gates"] == case["gates"] == 11_687_200_297 and plan.info["n_ciphertexts"] == case["n_ciphertexts"]
+    assert plan.info["n_gates"] == case["gates"] == 11_456_865_898 and plan.info["n_ciphertexts"] == case["n_ciphertexts"] == 2_980_165_547
     ci = plan.call_info()
     d, f, t, inp = gsv.labels_from_seed(case["seed"], plan.info["n_inputs"])
     # one instance: independent calls run side by side (schedule.hpp), windows of at most 64 M ciphertexts (1 GB) leave the device
