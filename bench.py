@@ -562,6 +562,7 @@ def run_verifier(args):
     work = VerifierWork(gsv, engine, plan, B, seeds)
     ni = work.sess.instances_per_workgroup
     slices = work.slices(ci[:, 1], args.slices)
+    work_windows = work.sess.windows()
     sched = work.sess.schedule_info()
     if rank == 0:
         log("bench.py: %d instances, %d per workgroup; %d windows in %d slices; per instance: wire file %.1f MB, ciphertext window %.1f MB"
@@ -584,7 +585,11 @@ def run_verifier(args):
     if rank == 0:
         el, K = r["elapsed"], r["steps_run"]
         stream_s = sum(r["step_ms"]) / 1e3  # device time of the timed steps: HIP events on the engine's stream around every slice
-        n_launch = r["calls"]
+        n_calls_timed = r["calls"]
+        # kernel dispatches of the timed steps: ONE per window of the schedule (its calls are rows of the grid); what rocprofv3 counts
+        wins = work_windows
+        win_per_slice = [sum(1 for w in wins if sl[0] <= w[0] < sl[0] + sl[1]) for sl in slices]
+        n_launch = sum(win_per_slice[(args.warmup + j) % len(slices)] for j in range(K))
         g_rank = r["gates_per_instance"] * B
         achieved = g_rank * bytes_per_gate / stream_s / 1e9
         traffic, traffic_source = None, None
@@ -593,8 +598,8 @@ def run_verifier(args):
             if os.path.exists(tpath) and compressed:
                 try:
                     tj = json.load(open(tpath))
-                    if int(tj.get("instances_per_gpu", 512)) == B and tj.get("circuit_gates", gates) == gates:  # PMC passes of this very configuration
-                        traffic = float(tj["hbm_bytes_per_call"] if "hbm_bytes_per_call" in tj else tj["hbm_bytes_per_launch"])
+                    if int(tj.get("instances_per_gpu", 512)) == B and tj.get("circuit_gates") == gates:  # PMC passes of this very configuration (circuit and batch)
+                        traffic = float(tj["hbm_bytes_per_launch"])
                         traffic_source = "profiles/%s/traffic.json (separate rocprofv3 --pmc passes of this workload; NOT measured in this run)" % cand
                         break
                 except (KeyError, ValueError):
@@ -616,10 +621,10 @@ def run_verifier(args):
                        "host_peak_rss_gb": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1e6},
             "commit_records_gathered": None if r["commit_table"] is None else list(r["commit_table"].shape),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         # one step = the window launches of one slice, all of the same kernel over different component programs; a window launch runs its calls back to back per
-                         # instance group (grid.y = calls), so the unit of the per-launch figures is one CALL of the plan for all instances of the GPU
-                         "kernel": "run_program_kernel<false, %d, 0>" % ni, "calls_timed": n_launch, "kernel_ms_avg_per_call": stream_s * 1e3 / max(1, n_launch),
-                         "algorithmic_bytes_per_call": g_rank * bytes_per_gate / max(1, n_launch), "bytes_per_gate": bytes_per_gate,
+                         # one step = the window launches of one slice, all of the same kernel over different component programs; a launch = one WINDOW of the schedule
+                         # (grid.y = its calls) for all instances of the GPU: `launches_timed` dispatches, what rocprofv3 --kernel-trace counts
+                         "kernel": "run_program_kernel<false, %d, 0>" % ni, "launches_timed": n_launch, "kernel_ms_avg": stream_s * 1e3 / max(1, n_launch),
+                         "algorithmic_bytes_per_launch": g_rank * bytes_per_gate / max(1, n_launch), "bytes_per_gate": bytes_per_gate, "calls_timed": n_calls_timed,
                          "note": "algorithmic-bytes accounting of SURVEY.md §8(d); fusion and the LDS label window keep most of those bytes off HBM, the limit that binds is T-table AES issue (DESIGN.md §3)",
                          "binding_limit": "aes-issue", "aes_ceiling_gates_per_s": AES_CEILING_AND_PER_S / f_nf, "aes_ceiling_frac": (g_rank / stream_s) / (AES_CEILING_AND_PER_S / f_nf)},
         })

@@ -774,6 +774,13 @@ int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out) {
     g.n_slots = m.n_slots; g.n_lds_slots = m.n_lds_slots; g.lds_slots_limit = m.lds_slots_limit; g.fb_stage_base = m.fb_stage_base; g.and_depth = m.and_depth;
     g.n_and_steps = m.n_and_steps; g.max_step_width = m.max_step_width; g.peak_live = m.peak_live;
     if (m.window_div != 1 && m.window_div != 2 && m.window_div != 4) { bad = true; break; }
+    // The file is input: counts are checked against the file size BEFORE they are multiplied, slot counts against the record
+    // format's 20-bit slot space, and every step's record ranges against the record arrays (the records themselves — 40 GB for the
+    // verifier — are not re-validated: plan files live in a directory only their owner can write, bench.py / _plan_cache_path).
+    const uint64_t lim = mp.size;
+    if (m.n_steps > 0xFFFFFFFFull || m.n_steps > lim / sizeof(StepDesc) || m.n_ands > lim / sizeof(AndRec) || m.n_xors > lim / sizeof(XorRec) || m.n_ct_pos > lim / 4 || m.n_inputs > lim / 4 ||
+        m.n_outputs > lim / 4 || m.n_ct_pos != m.n_ct || m.n_ands != m.n_ct || m.n_slots < SLOT_FIRST_INPUT + m.n_inputs || m.n_slots > SLOT_LDS_FLAG || m.lds_slots_limit > LDS_WINDOW_SLOTS ||
+        m.n_lds_slots > m.lds_slots_limit) { bad = true; break; }
     q->window_div = m.window_div;
     const uint8_t* steps = take(m.n_steps * sizeof(StepDesc));
     const uint8_t* ands = take(m.n_ands * sizeof(AndRec));
@@ -782,6 +789,17 @@ int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out) {
     const uint8_t* ins = take(m.n_inputs * 4);
     const uint8_t* outs = take(m.n_outputs * 4);
     if (bad) break;
+    {
+      const StepDesc* sd = reinterpret_cast<const StepDesc*>(steps);
+      for (uint64_t i = 0; i < m.n_steps && !bad; ++i)
+        bad = uint64_t(sd[i].and_off) + sd[i].and_cnt > m.n_ands || uint64_t(sd[i].xor_off) + sd[i].xor_cnt > m.n_xors;
+      const uint32_t* cp = reinterpret_cast<const uint32_t*>(ctp);
+      for (uint64_t i = 0; i < m.n_ct_pos && !bad; ++i) bad = cp[i] >= m.n_ct;
+      const uint32_t *is = reinterpret_cast<const uint32_t*>(ins), *os = reinterpret_cast<const uint32_t*>(outs);
+      for (uint64_t i = 0; i < m.n_inputs && !bad; ++i) bad = is[i] >= m.n_slots;
+      for (uint64_t i = 0; i < m.n_outputs && !bad; ++i) bad = os[i] >= m.n_slots;  // (an LDS-window slot carries bit 20: rejected as well)
+      if (bad) break;
+    }
     g.input_slots.assign(reinterpret_cast<const uint32_t*>(ins), reinterpret_cast<const uint32_t*>(ins) + m.n_inputs);
     g.output_slots.assign(reinterpret_cast<const uint32_t*>(outs), reinterpret_cast<const uint32_t*>(outs) + m.n_outputs);
     if (!e) {  // host copy: a complete program (hostsim, saving again, uploading to any device later)

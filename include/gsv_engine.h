@@ -98,6 +98,10 @@ typedef struct gsv_program_info {
 int gsv_program_get_info(const gsv_program* p, gsv_program_info* info);
 
 /* ---- plans: component-level programs ----------------------------------------------------------------
+ * NOTE for a Rust host: the 11 B-gate verifier cannot go through the flat recorder above (13 bytes of trace per gate); it runs as a plan,
+ * and a plan is NOT a pure "one more CircuitMode": it needs a hook inside the reference's StreamingMode::with_named_child
+ * (streaming_mode.rs:189-241; bindings/rust/streaming_mode_unit_hook.patch) through which the mode receives whole component calls, and one
+ * extra #[component] around the ladder chunks of exp_by_constant_montgomery (fp254impl.rs:713-722).  Both are stream-neutral.
  * The reference instantiates a few component shapes thousands of times (with_named_child, streaming_mode.rs:150-247); the
  * 11 B-gate verifier cannot be recorded as one flat program.  A plan is a sequence of CALLS to compiled programs over one
  * wire file per instance: wires that cross calls are "global" wires (dense ids chosen by the caller; ids 0..n_inputs-1 are

@@ -3,7 +3,9 @@
 rocprofv3 --pmc passes) -> profiles/<dir>/traffic.json with HBM bytes per launch as MI355X_MICROARCH.md prescribes: both
 counters are in KiB; on gfx950 FETCH_SIZE reads half of the bytes of wide coalesced 16-byte-per-lane reads, so it is doubled
 before it is compared with a byte count (the kernel's reads are record streams and 16-byte label reads: the doubled figure is an
-upper bound, the raw one a lower bound; both are kept).  usage: traffic_from_pmc.py profiles/r02_final [algorithmic bytes per launch [instances per GPU]]"""
+upper bound, the raw one a lower bound; both are kept).  usage: traffic_from_pmc.py profiles/r03_final [algorithmic bytes per launch [instances per GPU [gates per instance of the circuit]]]
+(bench.py quotes the figure only for a run of the same batch AND the same circuit; a launch = one dispatch of run_program_kernel = one
+window of the plan session's schedule since round 3)"""
 import json
 import os
 import sys
@@ -19,6 +21,8 @@ out = {"kernel": "run_program_kernel (garble)", "launches_fetch_pass": nf, "laun
                "dispatch count; hbm_bytes_per_launch applies the guide's gfx950 correction (FETCH_SIZE x 2)"}
 if len(sys.argv) > 3:
     out["instances_per_gpu"] = int(sys.argv[3])  # bench.py quotes the figure only for a run of the same configuration
+if len(sys.argv) > 4:
+    out["circuit_gates"] = int(sys.argv[4])
 if len(sys.argv) > 2:
     out["algorithmic_bytes_per_launch"] = float(sys.argv[2])
     out["traffic_over_algorithmic"] = out["hbm_bytes_per_launch"] / float(sys.argv[2])
