@@ -176,3 +176,21 @@ class SimPlan:
                                   _p(np.ascontiguousarray(input_bits, np.uint8)), _p(cts), _p(out), _p(bits)):
             raise RuntimeError(lib().hostsim_last_error().decode())
         return out, bits
+
+
+def trace(spec, cap=40_000_000):
+    """The raw gate stream the product's recorder (RecordMode under the two-pass driver, program.hpp) sees for a named circuit:
+    (type[n], a[n], b[n], c[n]) as SSA ids — 0 / 1 the constants, c == 0xFFFFFFFF for a dead gate — plus the SSA ids of the circuit's
+    inputs and outputs.  n_inputs / n_outputs come from compiling the circuit once (SimProgram)."""
+    info = SimProgram(spec).info
+    t = np.zeros(cap, np.uint8)
+    a, b, c = (np.zeros(cap, np.uint32) for _ in range(3))
+    n, nw = C.c_uint64(), C.c_uint32()
+    ins, outs = np.zeros(info["n_inputs"], np.uint32), np.zeros(info["n_outputs"], np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    rc = lib().hostsim_trace(spec.encode(), C.c_uint64(cap), t.ctypes.data_as(C.POINTER(C.c_uint8)), a.ctypes.data_as(u32p), b.ctypes.data_as(u32p), c.ctypes.data_as(u32p), C.byref(n), C.byref(nw),
+                             ins.ctypes.data_as(u32p), outs.ctypes.data_as(u32p))
+    if rc:
+        raise RuntimeError("trace of %s: %s" % (spec, "capacity too small" if rc == 2 else lib().hostsim_last_error().decode()))
+    k = n.value
+    return t[:k], a[:k], b[:k], c[:k], ins, outs
