@@ -96,10 +96,25 @@ struct WireFile {
   __device__ __forceinline__ lds_u128* win(uint32_t slot) const { return reinterpret_cast<lds_u128*>(uintptr_t((slot << 4) + (win_base - (GSV_SLOT_LDS_FLAG << 4)))); }
   __device__ __forceinline__ lds_u32* win_word(uint32_t slot, uint32_t c) const { return reinterpret_cast<lds_u32*>(uintptr_t((slot << 4) + (win_base - (GSV_SLOT_LDS_FLAG << 4)) + c * 4u)); }
   __device__ __forceinline__ lds_u8* win_bit(uint32_t idx) const { return reinterpret_cast<lds_u8*>(uintptr_t(bit_base + idx)); }
+  // A label lives EITHER in the LDS window or in the HBM wire file, lane by lane.  Written as `if (lds) v = *win(slot); else v = hbm[slot];`
+  // both loads target the same registers, and since LDS and vector-memory results return out of order with respect to each other the
+  // compiler puts `s_waitcnt lgkmcnt(0)` between them: a wave that holds both kinds of operands waits for each operand's LDS round trip
+  // before it issues that operand's global load.  Round 3 measured the alternative (GSV_LD_SPLIT_REGS: two register sets and a select,
+  // all ten loads of a gate in flight at once): 24 fewer waits per step body, but +13 VGPRs, 60 more spilled scalars (the lane masks of
+  // the selects) and 20 v_cndmask per gate — 5 % SLOWER on wide programs (9.77 against 10.27 x 10^10 gates/s at 1 024 instances), 6 % on the
+  // ladders, 4 % on the inversions, +-0 for a single instance (tools/kernel_ab3.py): the other waves of the CU already hide those waits.
   __device__ __forceinline__ Label ld(uint32_t slot) const {
+#ifndef GSV_LD_SPLIT_REGS
     u32x4 v;
     if (slot & GSV_SLOT_LDS_FLAG) v = *win(slot); else v = hbm[slot];
     return Label{{v.x, v.y, v.z, v.w}};
+#else
+    const bool in_lds = (slot & GSV_SLOT_LDS_FLAG) != 0;
+    u32x4 vl, vg;
+    if (in_lds) vl = *win(slot);
+    if (!in_lds) vg = hbm[slot];
+    return Label{{in_lds ? vl.x : vg.x, in_lds ? vl.y : vg.y, in_lds ? vl.z : vg.z, in_lds ? vl.w : vg.w}};
+#endif
   }
   __device__ __forceinline__ void st(uint32_t slot, const Label& l) const {
     const u32x4 v = {l.w[0], l.w[1], l.w[2], l.w[3]};
@@ -107,17 +122,33 @@ struct WireFile {
   }
   // one 32-bit column of a label (narrow-step mode: a label is spread over the 4 lanes of a quad)
   __device__ __forceinline__ uint32_t ld_word(uint32_t slot, uint32_t c) const {
+#ifndef GSV_LD_SPLIT_REGS
     uint32_t v;
     if (slot & GSV_SLOT_LDS_FLAG) v = *win_word(slot, c); else v = ((const glb_u32*)hbm)[slot * 4u + c];
     return v;
+#else
+    const bool in_lds = (slot & GSV_SLOT_LDS_FLAG) != 0;
+    uint32_t vl, vg;
+    if (in_lds) vl = *win_word(slot, c);
+    if (!in_lds) vg = ((const glb_u32*)hbm)[slot * 4u + c];
+    return in_lds ? vl : vg;
+#endif
   }
   __device__ __forceinline__ void st_word(uint32_t slot, uint32_t c, uint32_t v) const {
     if (slot & GSV_SLOT_LDS_FLAG) *win_word(slot, c) = v; else ((glb_u32*)hbm)[slot * 4u + c] = v;
   }
   __device__ __forceinline__ uint32_t ld_bit(uint32_t slot) const {
+#ifndef GSV_LD_SPLIT_REGS
     uint32_t b;
     if (slot & GSV_SLOT_LDS_FLAG) b = *win_bit(slot & GSV_SLOT_INDEX_MASK); else b = hbm_bits[slot];
     return b;
+#else
+    const bool in_lds = (slot & GSV_SLOT_LDS_FLAG) != 0;
+    uint32_t bl, bg;
+    if (in_lds) bl = *win_bit(slot & GSV_SLOT_INDEX_MASK);
+    if (!in_lds) bg = hbm_bits[slot];
+    return in_lds ? bl : bg;
+#endif
   }
   __device__ __forceinline__ void st_bit(uint32_t slot, uint32_t b) const {
     if (slot & GSV_SLOT_LDS_FLAG) *win_bit(slot & GSV_SLOT_INDEX_MASK) = uint8_t(b); else hbm_bits[slot] = uint8_t(b);
