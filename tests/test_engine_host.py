@@ -306,6 +306,14 @@ def test_step_barrier_isa_check():
     probe = build.check_workgroup_release_model()
     st, ba, ld = (next(i for i, t in enumerate(probe) if t.startswith(x)) for x in ("global_store", "s_barrier", "global_load"))
     assert st < ba < ld and not any("vmcnt" in t or t.startswith("buffer_") for t in probe[st:ld])
+    # the correctness precondition itself — the kernels object is NOT built for threadgroup-split mode — is what build() enforces
+    # (the instruction-adjacency properties above are performance properties: build() only warns about them)
+    assert build.check_not_tgsplit() is True
+    # the dataflow epilogue's agent-scope release (buffer_wbl2 ; s_waitcnt vmcnt(0) ; s_barrier) is the one vmcnt wait in front of a barrier
+    funcs = build._functions(asm)
+    for name, ins in funcs.items():
+        if "run_program_kernel" in name:
+            assert sum(1 for i, t in enumerate(ins) if t.startswith("buffer_wbl2") and ins[i + 1].startswith("s_waitcnt vmcnt(0)")) >= 1, name
 
 
 def test_interleaved_cbcmac_equals_single_chains():

@@ -526,6 +526,31 @@ def test_concurrent_calls_of_a_plan_match_the_flat_stream(engine, tmp_path, unit
     plan.close()
 
 
+def test_dataflow_between_calls_with_several_instances_per_workgroup(engine, monkeypatch):
+    """The completion flags of the dataflow are per INSTANCE GROUP (workgroup): with two and four instances per workgroup (lockstep groups
+    sharing the step barrier) and several calls in flight per group the plan must still give the oracle's stream for every instance —
+    including a batch that does not fill its last workgroup."""
+    import garbled_snark_verifier_amd as gsv
+    plan = gsv.Plan.from_circuit("fq12_mix", FINE_UNITS, window_div=4)
+    seeds = [71, 72, 73, 74, 75, 76, 77]
+    B, n_in = len(seeds), plan.info["n_inputs"]
+    labs = [gsv.labels_from_seed(s, n_in) for s in seeds]
+    delta = np.stack([x[0] for x in labs]); consts = np.stack([np.stack([x[1], x[2]]) for x in labs]); inputs = np.stack([x[3] for x in labs])
+    refs = [o.garble("fq12_mix", s, capture_ct=False) for s in seeds]
+    for ni in ("2", "4"):
+        monkeypatch.setenv("GSV_INSTANCES_PER_WG", ni)
+        sess = gsv.Session(engine, plan, B, retain_stream=False, concurrent_calls=8, window_ct_records=3_000_000)
+        monkeypatch.delenv("GSV_INSTANCES_PER_WG")
+        assert sess.instances_per_workgroup == int(ni) and sess.schedule_info()["max_width"] >= 2 and sess.schedule_info()["n_windows"] >= 2
+        sess.set_garble_inputs(delta, consts, inputs)
+        hashes = sess.garble_streaming(threads=2)
+        out = sess.read_outputs()
+        for i in range(B):
+            assert hashes[i] == refs[i].ct_hash.tobytes() and (out[i] == refs[i].output_label0).all()
+        sess.close()
+    plan.close()
+
+
 def test_final_exponentiation_as_a_plan(engine):
     """final_exponentiation_montgomery (final_exponentiation.rs:99-135): 3,519,328,217 gates, 31 % of the Groth16 verifier, far
     beyond a flat recording.  Recorded as a plan — Fq12 mul / square / cyclotomic square / inverse as units (each recorded
