@@ -511,6 +511,444 @@ def fq12_square(c, a):  # fq12.rs:311-324 (#[component])
     return [c0, c1]
 
 
+# ------------------------------------------------------------------------------------------------ more of bigint / fp254impl: the Fq inversion
+def double_without_overflow(c, a):  # add.rs:134-141 (#[bn_component]: no gates, but the call reads all of `a`)
+    c._call(a)
+    return [FALSE] + a[:-1]
+
+
+def self_or_zero_inv(c, a, s):  # cmp.rs:24-40 (#[bn_component])
+    c._call(a, s)
+    out = []
+    for a_i in a:
+        w = c.issue()
+        c.gate(and_variant_type([0, 1, 0]), a_i, s, w)
+        out.append(w)
+    return out
+
+
+def equal_zero(c, a):  # cmp.rs:87-107 (#[component])
+    c._call(a)
+    if len(a) == 1:
+        z = c.issue()
+        c.gate(XOR, a[0], TRUE, z)
+        return z
+    res = c.issue()
+    c.gate(XNOR, a[0], a[1], res)
+    for a_i in a[1:]:
+        nxt = c.issue()
+        c.gate(and_variant_type([1, 0, 0]), a_i, res, nxt)
+        res = nxt
+    return res
+
+
+def equal_constant(c, a, b):  # cmp.rs:60-85 (#[component], b off-circuit)
+    c._call(a)
+    if b == 0:
+        return equal_zero(c, a)
+    bb = bits_with_len(b, len(a))
+    one_ind = bb.index(1)
+    res = a[one_ind]
+    for i, a_i in enumerate(a):
+        if i == one_ind:
+            continue
+        nr = c.issue()
+        c.gate(and_variant_type([not bb[i], 0, 0]), a_i, res, nr)
+        res = nr
+    return res
+
+
+def odd_part(c, a):  # add.rs:155-195 (not a component)
+    n = len(a)
+    select_bn = [a[0]] + [c.issue() for _ in range(n - 1)]  # from_ctx(n-1) then insert(0, a[0])
+    for i in range(1, n):
+        c.gate(OR, select_bn[i - 1], a[i], select_bn[i])
+    k = [a[0]] + [c.issue() for _ in range(n - 1)]
+    for i in range(1, n):
+        c.gate(and_variant_type([1, 0, 0]), select_bn[i - 1], a[i], k[i])
+    odd_acc = list(a)
+    for i in range(n):
+        half_res = half(odd_acc)
+        odd_acc = select(c, odd_acc, half_res, select_bn[i])
+    return odd_acc, k
+
+
+def fq_equal_constant(c, a, b):  # fp254impl.rs:87-93 (not a component)
+    return equal_constant(c, a, b)
+
+
+def const_wires(v, n=N_BITS):  # BigIntWires::new_constant
+    return [TRUE if b else FALSE for b in bits_with_len(v, n)]
+
+
+def fq_inverse(c, a):  # fp254impl.rs:333-663 (#[bn_component]); binary extended Euclid, 4 iterations per child component
+    c._call(a)
+    odd, even_part = odd_part(c, a)
+    neg_odd = fq_neg(c, odd)
+    u, v = half(neg_odd), odd
+    k, r, s = const_wires(1), const_wires(1), const_wires(2)
+    for it0 in range(0, 2 * N_BITS, 4):
+        c._call(u, v, r, s, k)  # with_named_child("inverse_iteration", IterationContext)
+        for _ in range(min(4, 2 * N_BITS - it0)):
+            not_x1, not_x2 = u[0], v[0]
+            x3 = greater_than(c, u, v)
+            p2 = c.issue()
+            c.gate(and_variant_type([0, 1, 0]), not_x1, not_x2, p2)
+            p3 = c.issue()
+            wires_2 = c.issue()
+            c.gate(AND, not_x1, not_x2, wires_2)
+            c.gate(AND, wires_2, x3, p3)
+            p4 = c.issue()
+            c.gate(NIMP, wires_2, x3, p4)
+            u1, v1, r1 = half(u), v, r
+            s1 = double_without_overflow(c, s)
+            k1 = add_constant_without_carry(c, k, 1)
+            u2, v2 = u, half(v)
+            r2 = double_without_overflow(c, r)
+            s2 = s
+            k2 = add_constant_without_carry(c, k, 1)
+            u3 = sub_without_borrow(c, u1, v2)
+            v3 = v
+            r3 = add_without_carry(c, r, s)
+            s3 = double_without_overflow(c, s)
+            k3 = add_constant_without_carry(c, k, 1)
+            u4 = u
+            v4 = sub_without_borrow(c, v2, u1)
+            r4 = double_without_overflow(c, r)
+            s4 = add_without_carry(c, r, s)
+            k4 = add_constant_without_carry(c, k, 1)
+
+            def mix(w1, w2, w3, w4):
+                t1 = self_or_zero_inv(c, w1, not_x1)
+                t2 = self_or_zero(c, w2, p2)
+                t3 = self_or_zero(c, w3, p3)
+                t4 = self_or_zero(c, w4, p4)
+                a1 = add_without_carry(c, t1, t2)
+                a2 = add_without_carry(c, a1, t3)
+                return add_without_carry(c, a2, t4)
+            new_u = mix(u1, u2, u3, u4)
+            new_v = mix(v1, v2, v3, v4)
+            new_r = mix(r1, r2, r3, r4)
+            new_s = mix(s1, s2, s3, s4)
+            new_k = mix(k1, k2, k3, k4)
+            v_eq_1 = equal_constant(c, v, 1)
+            u = select(c, u, new_u, v_eq_1)
+            v = select(c, v, new_v, v_eq_1)
+            r = select(c, r, new_r, v_eq_1)
+            s = select(c, s, new_s, v_eq_1)
+            k = select(c, k, new_k, v_eq_1)
+    # divide the result by the even part of the input
+    c._call(s, even_part)  # "inverse::divide_result_by_even_part"
+    for it0 in range(0, N_BITS, 4):
+        c._call(s, even_part)  # "...::chunk"
+        for _ in range(min(4, N_BITS - it0)):
+            upd_s = fq_half(c, s)
+            upd_e = fq_half(c, even_part)
+            sel = equal_constant(c, even_part, 1)
+            s = select(c, s, upd_s, sel)
+            even_part = select(c, even_part, upd_e, sel)
+    # divide the result by 2^k
+    c._call(s, k)  # "inverse::divide_result_by_2^k"
+    for it0 in range(0, 2 * N_BITS, 4):
+        c._call(s, k)  # "...::chunk"
+        for _ in range(min(4, 2 * N_BITS - it0)):
+            upd_s = fq_half(c, s)
+            upd_k = fq_add_constant(c, k, P - 1)
+            sel = fq_equal_constant(c, k, 0)
+            s = select(c, s, upd_s, sel)
+            k = select(c, k, upd_k, sel)
+    return s
+
+
+R_MOD_P = (1 << N_BITS) % P
+
+
+def fq_mul_by_constant(c, a, b):  # fp254impl.rs:252-275 (#[bn_component], b off-circuit: its integer value)
+    c._call(a)
+    if b == 0:
+        return const_wires(0)
+    if b == R_MOD_P:
+        return list(a)
+    return montgomery_reduce(c, mul_by_constant(c, a, b))
+
+
+def fq_inverse_montgomery(c, a):  # fp254impl.rs:665-678
+    return fq_mul_by_constant(c, fq_inverse(c, a), pow(R_MOD_P, 3, P))
+
+
+# ------------------------------------------------------------------------------------------------ fq2 / fq12 / g1 / pairing steps
+def fq2_square(c, a):  # fq2.rs:341-354
+    p_ = fq_add(c, a[0], a[1])
+    m_ = fq_sub(c, a[0], a[1])
+    a0a1 = fq_mul(c, a[0], a[1])
+    c0 = fq_mul(c, p_, m_)
+    c1 = fq_double(c, a0a1)
+    return [c0, c1]
+
+
+def fq2_neg(c, a): return [fq_neg(c, a[0]), fq_neg(c, a[1])]    # fq2.rs:179-186
+def fq2_half(c, a): return [fq_half(c, a[0]), fq_half(c, a[1])]  # fq2.rs:211-219
+def fq2_mul_by_fq(c, a, b): return [fq_mul(c, a[0], b), fq_mul(c, a[1], b)]  # fq2.rs:282-291
+
+
+def fq2_mul_by_constant(c, a, b):  # fq2.rs:257-280; b = (b0, b1) exactly as handed over
+    if b == (1, 0):
+        return [list(a[0]), list(a[1])]
+    a_sum = fq_add(c, a[0], a[1])
+    a0b0 = fq_mul_by_constant(c, a[0], b[0])
+    a1b1 = fq_mul_by_constant(c, a[1], b[1])
+    sm = fq_mul_by_constant(c, a_sum, (b[0] + b[1]) % P)
+    c0 = fq_sub(c, a0b0, a1b1)
+    s_ = fq_add(c, a0b0, a1b1)
+    c1 = fq_sub(c, sm, s_)
+    return [c0, c1]
+
+
+def fq12_cyclotomic_square(c, a):  # fq12.rs:326-392 (not a component in the reference)
+    c0, c1, c2 = a[0]
+    c3, c4, c5 = a[1]
+
+    def fp4(x, y, beta_of, added_to):
+        xy = fq2_mul(c, x, y)
+        x_plus_y = fq2_add(c, x, y)
+        y_beta = fq2_mul_by_nonresidue(c, beta_of)
+        x_plus_y_beta = fq2_add(c, added_to, y_beta)
+        xy_beta = fq2_mul_by_nonresidue(c, xy)
+        w1 = fq2_mul(c, x_plus_y, x_plus_y_beta)
+        w2 = fq2_add(c, xy, xy_beta)
+        return fq2_sub(c, w1, w2), fq2_double(c, xy)
+    t0, t1 = fp4(c0, c4, c4, c0)
+    t2, t3 = fp4(c2, c3, c2, c3)
+    t4, t5 = fp4(c1, c5, c5, c1)
+
+    def three_minus(t, cc):
+        w1 = fq2_sub(c, t, cc)
+        w2 = fq2_double(c, w1)
+        return fq2_add(c, w2, t)
+
+    def three_plus(t, cc):
+        w1 = fq2_add(c, t, cc)
+        w2 = fq2_double(c, w1)
+        return fq2_add(c, w2, t)
+    z0 = three_minus(t0, c0)
+    z4 = three_minus(t2, c1)
+    z3 = three_minus(t4, c2)
+    t5_beta = fq2_mul_by_nonresidue(c, t5)
+    z2 = three_plus(t5_beta, c3)
+    z1 = three_plus(t1, c4)
+    z5 = three_plus(t3, c5)
+    return [[z0, z4, z3], [z2, z1, z5]]
+
+
+def multiplexer_bit(c, a, s):  # basic.rs:74-105 (#[component]): in-place pairwise reduction by selector bits, LSB first
+    c._call(a, s)
+    cur = list(a)
+    for sel in s:
+        cur = [selector(c, cur[i + 1], cur[i], sel) for i in range(0, len(cur), 2)]
+    return cur[0]
+
+
+def bigint_multiplexer(c, a, s):  # cmp.rs:173-197 (#[bn_component]); a = list of 2^w bigints
+    c._call(*a, s)
+    return [multiplexer_bit(c, [a_i[bit] for a_i in a], s) for bit in range(len(a[0]))]
+
+
+def g1_add(c, p, q):  # g1.rs:159-235 (#[component])
+    c._call(*p, *q)
+    x1, y1, z1 = p
+    x2, y2, z2 = q
+    z1s = fq_square(c, z1); z2s = fq_square(c, z2)
+    z1c = fq_mul(c, z1s, z1); z2c = fq_mul(c, z2s, z2)
+    u1 = fq_mul(c, x1, z2s); u2 = fq_mul(c, x2, z1s)
+    s1 = fq_mul(c, y1, z2c); s2 = fq_mul(c, y2, z1c)
+    r = fq_sub(c, s1, s2); h = fq_sub(c, u1, u2)
+    h2 = fq_square(c, h)
+    g = fq_mul(c, h, h2); v = fq_mul(c, u1, h2)
+    r2 = fq_square(c, r)
+    r2g = fq_add(c, r2, g)
+    vd = fq_double(c, v)
+    x3 = fq_sub(c, r2g, vd)
+    vx3 = fq_sub(c, v, x3)
+    w = fq_mul(c, r, vx3)
+    s1g = fq_mul(c, s1, g)
+    y3 = fq_sub(c, w, s1g)
+    z1z2 = fq_mul(c, z1, z2)
+    z3 = fq_mul(c, z1z2, h)
+    z1_0 = fq_equal_constant(c, z1, 0)
+    z2_0 = fq_equal_constant(c, z2, 0)
+    zero = const_wires(0)
+    sel = [z1_0, z2_0]
+    x = bigint_multiplexer(c, [x3, x2, x1, zero], sel)
+    y = bigint_multiplexer(c, [y3, y2, y1, zero], sel)
+    z = bigint_multiplexer(c, [z3, z2, z1, zero], sel)
+    return [x, y, z]
+
+
+G2_COEFF_B = (19485874751759354771024239261021720505790618469301721065564631296452457478373, 266929791119991161246907387137283842545076965332900288569378510910307636690)  # ark_bn254::g2::Config::COEFF_B
+
+
+def _mont2(b): return (b[0] * R_MOD_P % P, b[1] * R_MOD_P % P)
+
+
+def g2_double_in_place(c, r):  # pairing.rs:359-407 (#[component]); returns (new r, line coefficients)
+    c._call(*[w for f2 in r for w in f2])
+    rx, ry, rz = r
+    a = fq2_mul(c, rx, ry)
+    a = fq2_half(c, a)
+    b = fq2_square(c, ry)
+    cc = fq2_square(c, rz)
+    c_triple = fq2_triple(c, cc)
+    e = fq2_mul_by_constant(c, c_triple, _mont2(G2_COEFF_B))
+    f = fq2_triple(c, e)
+    g = fq2_add(c, b, f)
+    g = fq2_half(c, g)
+    ryrz = fq2_add(c, ry, rz)
+    ryrzs = fq2_square(c, ryrz)
+    bc = fq2_add(c, b, cc)
+    h = fq2_sub(c, ryrzs, bc)
+    i = fq2_sub(c, e, b)
+    j = fq2_square(c, rx)
+    es = fq2_square(c, e)
+    j_triple = fq2_triple(c, j)
+    bf = fq2_sub(c, b, f)
+    new_x = fq2_mul(c, a, bf)
+    es_triple = fq2_triple(c, es)
+    gs = fq2_square(c, g)
+    new_y = fq2_sub(c, gs, es_triple)
+    new_z = fq2_mul(c, b, h)
+    hn = fq2_neg(c, h)
+    return [new_x, new_y, new_z], [hn, j_triple, i]
+
+
+def g2_add_in_place(c, r, q):  # pairing.rs:409-464 (#[component])
+    c._call(*[w for f2 in r for w in f2], *[w for f2 in q for w in f2])
+    rx, ry, rz = r
+    qx, qy = q[0], q[1]
+    w1 = fq2_mul(c, qy, rz)
+    theta = fq2_sub(c, ry, w1)
+    w2 = fq2_mul(c, qx, rz)
+    lam = fq2_sub(c, rx, w2)
+    cc = fq2_square(c, theta)
+    d = fq2_square(c, lam)
+    e = fq2_mul(c, lam, d)
+    f = fq2_mul(c, rz, cc)
+    g = fq2_mul(c, rx, d)
+    w3 = fq2_add(c, e, f)
+    w4 = fq2_double(c, g)
+    h = fq2_sub(c, w3, w4)
+    neg_theta = fq2_neg(c, theta)
+    w5 = fq2_mul(c, theta, qx)
+    w6 = fq2_mul(c, lam, qy)
+    j = fq2_sub(c, w5, w6)
+    new_x = fq2_mul(c, lam, h)
+    w7 = fq2_sub(c, g, h)
+    w8 = fq2_mul(c, theta, w7)
+    w9 = fq2_mul(c, e, ry)
+    new_y = fq2_sub(c, w8, w9)
+    new_z = fq2_mul(c, rz, e)
+    return [new_x, new_y, new_z], [lam, neg_theta, j]
+
+
+def fq6_mul_by_fq2(c, a, b): return [fq2_mul(c, a[k], b) for k in range(3)]  # fq6.rs:326-332
+
+
+def fq6_mul_by_01(c, a, c0, c1):  # fq6.rs:351-379
+    w1 = fq2_mul(c, a[0], c0)
+    w2 = fq2_mul(c, a[1], c1)
+    w3 = fq2_add(c, a[1], a[2])
+    w4 = fq2_mul(c, w3, c1)
+    w5 = fq2_sub(c, w4, w2)
+    w6 = fq2_mul_by_nonresidue(c, w5)
+    w7 = fq2_add(c, w6, w1)
+    w8 = fq2_add(c, a[0], a[1])
+    w9 = fq2_add(c, c0, c1)
+    w10 = fq2_mul(c, w8, w9)
+    w11 = fq2_sub(c, w10, w1)
+    w12 = fq2_sub(c, w11, w2)
+    w13 = fq2_add(c, a[0], a[2])
+    w14 = fq2_mul(c, w13, c0)
+    w15 = fq2_sub(c, w14, w1)
+    w16 = fq2_add(c, w15, w2)
+    return [w7, w12, w16]
+
+
+def fq12_mul_by_034(c, a, c0, c3, c4):  # fq12.rs:266-285 (#[component])
+    c._call(_flat12(a), c0[0], c0[1], c3[0], c3[1], c4[0], c4[1])
+    w1 = fq6_mul_by_01(c, a[1], c3, c4)
+    w2 = fq6_mul_by_nonresidue(c, w1)
+    w3 = fq6_mul_by_fq2(c, a[0], c0)
+    new_c0 = fq6_add(c, w2, w3)
+    w4 = fq6_add(c, a[0], a[1])
+    w5 = fq2_add(c, c3, c0)
+    w6 = fq6_mul_by_01(c, w4, w5, c4)
+    w7 = fq6_add(c, w1, w3)
+    new_c1 = fq6_sub(c, w6, w7)
+    return [new_c0, new_c1]
+
+
+def ell(c, f, coeffs, px, py):  # pairing.rs:160-171 (not a component)
+    c0 = fq2_mul_by_fq(c, coeffs[0], py)
+    c3 = fq2_mul_by_fq(c, coeffs[1], px)
+    return fq12_mul_by_034(c, f, c0, c3, coeffs[2])
+
+
+def fq2_add_constant(c, a, b): return [fq_add_constant(c, a[0], b[0]), fq_add_constant(c, a[1], b[1])]  # fq2.rs:170-177
+
+
+def fq2_mul_constant_by_fq(c, a_std, b):  # fq2.rs:307-322 (#[component(offcircuit_args = "a")]): a a STANDARD-form constant, b a wire
+    c._call(b)
+    return [fq_mul_by_constant(c, b, a_std[0] * R_MOD_P % P), fq_mul_by_constant(c, b, a_std[1] * R_MOD_P % P)]
+
+
+def fq6_mul_by_01_constant1(c, a, c0, c1):  # fq6.rs:381-410; c1 a constant in Montgomery form
+    w1 = fq2_mul(c, a[0], c0)
+    w2 = fq2_mul_by_constant(c, a[1], c1)
+    w3 = fq2_add(c, a[1], a[2])
+    w4 = fq2_mul_by_constant(c, w3, c1)
+    w5 = fq2_sub(c, w4, w2)
+    w6 = fq2_mul_by_nonresidue(c, w5)
+    w7 = fq2_add(c, w6, w1)
+    w8 = fq2_add(c, a[0], a[1])
+    w9 = fq2_add_constant(c, c0, c1)
+    w10 = fq2_mul(c, w8, w9)
+    w11 = fq2_sub(c, w10, w1)
+    w12 = fq2_sub(c, w11, w2)
+    w13 = fq2_add(c, a[0], a[2])
+    w14 = fq2_mul(c, w13, c0)
+    w15 = fq2_sub(c, w14, w1)
+    w16 = fq2_add(c, w15, w2)
+    return [w7, w12, w16]
+
+
+def fq12_mul_by_034_constant4(c, a, c0, c3, c4):  # fq12.rs:287-310 (#[component(offcircuit_args = "c4")])
+    c._call(_flat12(a), c0[0], c0[1], c3[0], c3[1])
+    w1 = fq6_mul_by_01_constant1(c, a[1], c3, c4)
+    w2 = fq6_mul_by_nonresidue(c, w1)
+    w3 = fq6_mul_by_fq2(c, a[0], c0)
+    new_c0 = fq6_add(c, w2, w3)
+    w4 = fq6_add(c, a[0], a[1])
+    w5 = fq2_add(c, c3, c0)
+    w6 = fq6_mul_by_01_constant1(c, w4, w5, c4)
+    w7 = fq6_add(c, w1, w3)
+    new_c1 = fq6_sub(c, w6, w7)
+    return [new_c0, new_c1]
+
+
+def ell_by_constant(c, f, coeffs_std, p):  # pairing.rs:923-942 (#[component(offcircuit_args = "coeffs")]); p = (x, y, z) wires
+    c._call(_flat12(f), p[0], p[1], p[2])
+    new_c0 = fq2_mul_constant_by_fq(c, coeffs_std[0], p[1])
+    new_c1 = fq2_mul_constant_by_fq(c, coeffs_std[1], p[0])
+    return fq12_mul_by_034_constant4(c, f, new_c0, new_c1, _mont2(coeffs_std[2]))
+
+
+def _ell_const_circuit(k):
+    import bn254_ref as T
+    coeffs = T.ell_coeffs(T.G2_GEN)[k]  # the reference's native ell_coeffs(q) (pairing.rs:88-126) for the G2 generator: host constants
+    return lambda c, i: _flat12(ell_by_constant(c, _fq12(i, 0), coeffs, [_fq(i, 12), _fq(i, 13), _fq(i, 14)]))
+
+
+def _g2(i, base): return [[_fq(i, base + 2 * k), _fq(i, base + 2 * k + 1)] for k in range(3)]
+def _g2_step_out(rc): return [w for part in rc for f2 in part for fq in f2 for w in fq]
 def _flat12(x): return [w for f6 in x for f2 in f6 for fq in f2 for w in fq]
 def _fq12(i, base): return [[[_fq(i, base + 6 * h + 2 * k), _fq(i, base + 6 * h + 2 * k + 1)] for k in range(3)] for h in range(2)]
 
@@ -534,6 +972,14 @@ CIRCUITS = {
     "fq2_mul": (1016, lambda c, i: sum(fq2_mul(c, [_fq(i, 0), _fq(i, 1)], [_fq(i, 2), _fq(i, 3)]), [])),
     "fq12_mul": (6096, lambda c, i: _flat12(fq12_mul(c, _fq12(i, 0), _fq12(i, 12)))),       # BASELINE config 3 (tests/fq12_mul_e2e.rs)
     "fq12_square": (3048, lambda c, i: _flat12(fq12_square(c, _fq12(i, 0)))),
+    "fq12_cyclotomic_square": (3048, lambda c, i: _flat12(fq12_cyclotomic_square(c, _fq12(i, 0)))),
+    "fq_inverse": (254, lambda c, i: fq_inverse_montgomery(c, i)),
+    "g1_add": (1524, lambda c, i: sum(g1_add(c, [_fq(i, 0), _fq(i, 1), _fq(i, 2)], [_fq(i, 3), _fq(i, 4), _fq(i, 5)]), [])),
+    "g2_double": (1524, lambda c, i: _g2_step_out(g2_double_in_place(c, _g2(i, 0)))),
+    "g2_add": (3048, lambda c, i: _g2_step_out(g2_add_in_place(c, _g2(i, 0), _g2(i, 6)))),
+    "ell_eval": (3048 + 1524 + 508, lambda c, i: _flat12(ell(c, _fq12(i, 0), [[_fq(i, 12 + 2 * k), _fq(i, 13 + 2 * k)] for k in range(3)], _fq(i, 18), _fq(i, 19)))),
+    "ell_const:0": (3048 + 762, _ell_const_circuit(0)),   # a doubling step's line ...
+    "ell_const:3": (3048 + 762, _ell_const_circuit(3)),   # ... and the first addition step's (ATE_LOOP_COUNT: 64th digit 0, 63rd 1)
     "fq6_mul": (3048, lambda c, i: sum(sum(fq6_mul(c, [[_fq(i, 2 * k), _fq(i, 2 * k + 1)] for k in range(3)], [[_fq(i, 6 + 2 * k), _fq(i, 6 + 2 * k + 1)] for k in range(3)]), []), [])),
 }
 

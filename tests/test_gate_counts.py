@@ -81,3 +81,23 @@ def test_json_output_in_the_reference_examples_schema(tmp_path):
     assert comp["bigint::add"]["gates_self"] == 10_092_937_600 and comp["fp254::mul_by_constant_montgomery"]["keys"] == 1305
     top = {c["name"]: (c["calls"], c["gates"]) for c in d["tree"]["children"]}
     assert top["pairing::multi_miller_loop_groth16_evaluate_montgomery_fast"] == (1, 6_907_999_657) and top["final_exponentiation_montgomery"] == (1, 3_519_328_217)
+
+
+def test_independent_python_count_of_the_whole_verifier(counter):
+    """tests/ref_verifier_count.py composes the WHOLE groth16_verify_compressed circuit a second time, in Python, from the independent
+    restatement of the gadgets (tests/ref_gadgets.py, written from the Rust source; its building blocks are compared gate by gate with
+    the product's recorder in tests/test_ref_gadgets.py) and counts it in counting mode — no C++ involved.  It must agree with the C++
+    gadgets under tools/gate_counts and with the CPU oracle's flat garbling (the fixture) per GateType and per top-level component:
+    11,456,865,898 gates is what this reference tree's gadgets emit for one public input, whichever way they are walked."""
+    import json
+    import ref_verifier_count as V
+    case = json.load(open(os.path.join(ROOT, "tests", "golden", "groth16_verify_compressed_1pub_golden.json")))
+    r = V.count(n_pub=1, seed=6)
+    assert r["breakdown"] == case["gate_counts"] and r["total"] == case["gates"] == 11_456_865_898 and r["nonfree"] == 2_980_378_785
+    inst = G.make_instance(n_pub=1, seed=6)
+    total, nonfree, tree = counter(G.compressed_circuit_name(inst), 2)
+    assert (total, nonfree) == (r["total"], r["nonfree"])
+    top = {name: v[1] for (depth, name), v in tree.items() if depth == 1}
+    for name, gates in r["top"].items():
+        assert top[name] == gates, name
+    assert sum(r["top"].values()) + 3_047 == total  # + Fq12::equal_constant: twelve 254-bit comparisons (253 gates each) and the 11 ANDs of the tree above them

@@ -3,8 +3,13 @@ the same reference gadgets (tests/ref_gadgets.py, written from the Rust source):
 by their DEFINITION (constant / circuit input k / output of gate j), and whether the gate is dead.  A mistake in gate order, operand
 order, gate type or a dead-gate decision inside the shared C++ producers would be common-mode for every GPU-vs-oracle test; it is
 not common-mode here.  Covered: ripple adders / subtracters, constant adders, comparators, selectors, naive + Karatsuba
-multiplication, constant multiplication (mod 2^k), Montgomery reduction, every Fq operation, Fq2 / Fq6 / Fq12 multiplication, Fq12 squaring — the
-primitives that make up > 99 % of the verifier's gates."""
+multiplication, constant multiplication (mod 2^k), Montgomery reduction, every Fq operation, Fq2 / Fq6 / Fq12 multiplication, G1 addition —
+the primitives that make up > 99 % of the verifier's gates — and (slow set) the verifier's building blocks above them: Fq12 squaring and
+cyclotomic squaring, the sparse Fq12 multiplications inside the wire and the CONSTANT line evaluations (`ell_montgomery`,
+`ell_by_constant_montgomery`: 43 % of the verifier's gates), the G2 doubling / addition steps with their line coefficients, and the Fq
+inversion (binary extended Euclid, 508 iterations in chunked components)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -18,7 +23,13 @@ def _product_stream(spec):
     return R.canonical(gates, ins.tolist(), outs.tolist(), dead_marker=0xFFFFFFFF)
 
 
-@pytest.mark.parametrize("spec", ["u254_add", "bigint_mul:22", "bigint_mul:40", "fq_add", "fq_sub", "fq_neg", "fq_double", "fq_half", "fq_triple", "fq_div6", "fq_mul", "fq2_mul", "fq6_mul", "fq12_mul"])  # ("fq12_square" is in ref_gadgets.CIRCUITS too: 13.6 M gates, left out of the default run for time)
+FAST = ["u254_add", "bigint_mul:22", "bigint_mul:40", "fq_add", "fq_sub", "fq_neg", "fq_double", "fq_half", "fq_triple", "fq_div6", "fq_mul", "fq2_mul", "fq6_mul", "g1_add", "fq12_mul"]
+# The verifier's larger building blocks (8-23 M gates each; 6 minutes of Python in total): run with GSV_SLOW_TESTS=1; the log of this
+# round's run is committed as profiles/r03_parity/ref_gadgets_slow.log.
+SLOW = ["fq12_square", "fq12_cyclotomic_square", "g2_double", "g2_add", "ell_eval", "ell_const:0", "ell_const:3", "fq_inverse"]
+
+
+@pytest.mark.parametrize("spec", FAST + [pytest.param(x, marks=pytest.mark.skipif(os.environ.get("GSV_SLOW_TESTS") != "1", reason="slow: set GSV_SLOW_TESTS=1")) for x in SLOW])
 def test_product_gate_stream_equals_independent_restatement(spec):
     got, got_out = _product_stream(spec)
     exp, exp_out = R.emit(spec)
