@@ -11,6 +11,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -507,9 +508,17 @@ int gsv_plan_from_circuit(const char* spec, const char* units_csv, gsv_plan** ou
   mode.compile_in_background(opt, single_image);  // units are compiled while the driver records the rest of the circuit
   StreamingRunner run(mode, nc.n_inputs, nc.fn);
   std::vector<uint32_t> in_ssa, out_ssa;
+  const bool dbg = getenv("GSV_PLAN_DEBUG") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
   for (WireId w : run.prepare()) in_ssa.push_back(mode.define_input(w));
+  if (dbg) std::fprintf(stderr, "plan: metadata pass done at %.1f s\n", since());
   for (WireId w : run.execute()) out_ssa.push_back(mode.current(w));
+  if (dbg) std::fprintf(stderr, "plan: recorded at %.1f s (%zu units, %zu glue classes)\n", since(), mode.units.size(), mode.glue_classes.size());
+  mode.wait_for_compilations();
+  if (dbg) std::fprintf(stderr, "plan: background compilations finished at %.1f s\n", since());
   BuiltPlan bp = finish_plan(mode, in_ssa, out_ssa, opt);
+  if (dbg) std::fprintf(stderr, "plan: all programs compiled at %.1f s\n", since());
   std::unique_ptr<gsv_plan> plan(new gsv_plan());
   for (size_t k = 0; k < bp.programs.size(); ++k) {
     gsv_program* q = new gsv_program();
@@ -1316,7 +1325,9 @@ static int ensure_drain(gsv_session* s, size_t T, uint64_t seg_records) {
   gsv_drain& d = *s->drain;
   d.macs = keep;
   d.chunk = chunk;
-  const int n_copy_streams = getenv("GSV_DRAIN_COPIES") ? std::max(1, atoi(getenv("GSV_DRAIN_COPIES"))) : 6;
+  // Copy sets in flight at once.  Round 3, whole Miller-loop pass at 64 instances (tools/e2e_plan_drain.py, profiles/r03_e2e/): 1 set
+  // 48 GB/s, 2-4 sets 50 GB/s, 6 sets 40 GB/s, 12 sets 41 GB/s — the link is full with two or three 16 MiB copies queued.
+  const int n_copy_streams = getenv("GSV_DRAIN_COPIES") ? std::max(1, atoi(getenv("GSV_DRAIN_COPIES"))) : 3;
   bool ok = true;
   for (int k = 0; k < n_copy_streams && ok; ++k) {
     hipStream_t st;
@@ -1432,7 +1443,14 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   // Pipeline: kernel k+1 runs beside drain k.  Drains are serialised (an instance's MAC must see its replays in order);
   // the gather of segment k+1 needs the gate-order buffer back, i.e. drain k joined.
   std::vector<std::thread> cur;
-  auto join = [](std::vector<std::thread>& p) { for (auto& th : p) th.join(); p.clear(); };
+  // GSV_DRAIN_STATS=1: where the host thread of the pipeline waits (for the previous drain = the host side is the slower stage; for
+  // the kernel + gather = the device is), printed once per call
+  const bool stats = getenv("GSV_DRAIN_STATS") != nullptr;
+  double t_wait_drain = 0, t_wait_device = 0;
+  uint64_t drained_records = 0;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto secs = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
+  auto join = [&](std::vector<std::thread>& p) { const auto t0 = std::chrono::steady_clock::now(); for (auto& th : p) th.join(); p.clear(); t_wait_drain += secs(t0); };
   int rc = GSV_OK;
   if (hipEventRecord(s->ev0, s->e->stream) != hipSuccess) { close_files(); return fail(GSV_ERR_DEVICE, "hipEventRecord failed"); }
   for (uint64_t r0 = first; r0 < total && rc == GSV_OK; r0 += seg) {
@@ -1457,10 +1475,20 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
         break;
       }
     }
-    if (hipStreamSynchronize(s->e->stream) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "kernel failed"); break; }
+    {
+      const auto t0 = std::chrono::steady_clock::now();
+      if (hipStreamSynchronize(s->e->stream) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "kernel failed"); break; }
+      t_wait_device += secs(t0);
+    }
+    drained_records += n_records;
     drain(n_records, cur);
   }
   join(cur);
+  if (stats) {
+    const double tot = secs(t_begin);
+    std::fprintf(stderr, "drain: %.2f s for %zu instances x %llu records (%.1f GB/s), %zu MAC workers; host thread waited %.2f s for drains and %.2f s for the device\n", tot, n_inst,
+                 (unsigned long long)drained_records, double(drained_records) * double(n_inst) * 16e-9 / tot, T, t_wait_drain, t_wait_device);
+  }
   if (rc == GSV_OK && s->plan) {
     (void)hipEventRecord(s->ev1, s->e->stream);
     if (c1 == s->plan->calls.size()) rc = gather_plan_outputs(s, false); else { s->ran = true; s->last_eval = false; }

@@ -146,7 +146,11 @@ struct Program {
 
 struct CompileOptions {
   uint32_t lds_slots = LDS_WINDOW_SLOTS;  // 0 = keep every wire in HBM
-  uint32_t lds_max_lifetime = 8;          // a wire goes to the LDS window only if it dies within this many steps
+  // A wire goes to the LDS window only if it dies within this many steps; among the eligible outputs of a step the shortest-lived get
+  // the free slots.  8 and 1024 are equal on wide programs (the window is always contended: 1.030 vs 1.032e11 gates/s on fq12_mix at
+  // 1024 instances); on narrow ones, whose window is mostly empty, long-lived wires stop going through the HBM wire file:
+  // +5 % on the decompression ladders and the inversions (profiles/r03_kernel/lds_lifetime_ab.log).
+  uint32_t lds_max_lifetime = 1024;
   bool order_by_reader = true;            // order the gates of a step by the position of their output's first reader
   uint32_t hbm_arena_factor = 4;          // HBM wire file = factor x peak live wires (next-fit then sweeps mostly free space)
   bool fuse = true;                       // fold free gates into their readers / into the AND that feeds them

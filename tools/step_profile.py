@@ -18,11 +18,11 @@ n_in = prog.info["n_inputs"]
 and_cnt, xor_cnt, rl, rh, wl, wh = (st[:, i] for i in range(6))
 names = ["narrow (multi-lane AES)", "wide <=1024 gates", "wide <=4096 gates", "wide >4096 gates"]
 for B in batches:
-    BT = 1024 // (2 if B > 256 else 1)  # threads per instance (two instances per workgroup above 256 instances; HBM columns are the 1-per-WG variant's)
-    narrow = (and_cnt > 0) & (and_cnt * 8 + xor_cnt <= BT)
-    cls = np.where(narrow, 0, np.where(and_cnt + xor_cnt <= 1024, 1, np.where(and_cnt + xor_cnt <= 4096, 2, 3)))
     d, f, t, inp = gsv.labels_from_seed(1, n_in)
     sess = gsv.Session(eng, prog, B, 3, 1)
+    BT = 1024 // sess.instances_per_workgroup  # threads per instance (the HBM columns are the one-instance-per-workgroup image's)
+    narrow = (and_cnt > 0) & (and_cnt * 8 + xor_cnt <= BT)
+    cls = np.where(narrow, 0, np.where(and_cnt + xor_cnt <= 1024, 1, np.where(and_cnt + xor_cnt <= 4096, 2, 3)))
     sess.enable_step_clock()
     sess.set_garble_inputs(np.tile(d, (B, 1)), np.tile(np.stack([f, t]), (B, 1, 1)), np.tile(inp, (B, 1, 1)))
     for _ in range(2):
@@ -31,7 +31,7 @@ for B in batches:
     ms = sess.last_kernel_ms() / 3
     clk = sess.read_step_clock().astype(np.int64)
     us = np.diff(clk) / 100.0
-    print("== %s B=%d: %.2f ms/replay (events), %.2f ms (step clocks), %d steps" % (spec, B, ms, us.sum() / 1e3, len(us)))
+    print("== %s B=%d (%d per workgroup): %.2f ms/replay (events), %.2f ms (step clocks), %d steps" % (spec, B, sess.instances_per_workgroup, ms, us.sum() / 1e3, len(us)))
     print("%-26s %7s %10s %9s %9s %10s %10s" % ("class", "steps", "gates", "time ms", "us/step", "hbm rd/st", "hbm wr/st"))
     for k, nm in enumerate(names):
         for hb, tag in ((0, "no HBM labels"), (1, "HBM labels")):
