@@ -506,15 +506,13 @@ int gsv_plan_from_circuit(const char* spec, const char* units_csv, gsv_plan** ou
   const bool single_image = window_div > 1;
   if (single_image) opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / window_div);
   mode.compile_in_background(opt, single_image);  // units are compiled while the driver records the rest of the circuit
-  StreamingRunner run(mode, nc.n_inputs, nc.fn);
   std::vector<uint32_t> in_ssa, out_ssa;
   const bool dbg = getenv("GSV_PLAN_DEBUG") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-  for (WireId w : run.prepare()) in_ssa.push_back(mode.define_input(w));
-  if (dbg) std::fprintf(stderr, "plan: metadata pass done at %.1f s\n", since());
-  for (WireId w : run.execute()) out_ssa.push_back(mode.current(w));
-  if (dbg) std::fprintf(stderr, "plan: recorded at %.1f s (%zu units, %zu glue classes)\n", since(), mode.units.size(), mode.glue_classes.size());
+  size_t n_recorders = 0;
+  record_plan(mode, nc.n_inputs, nc.fn, nc.warmups, in_ssa, out_ssa, &n_recorders);
+  if (dbg) std::fprintf(stderr, "plan: recorded at %.1f s (%zu units, %zu glue classes, %zu warm-ups on %zu threads)\n", since(), mode.units.size(), mode.glue_classes.size(), nc.warmups.size(), n_recorders);
   mode.wait_for_compilations();
   if (dbg) std::fprintf(stderr, "plan: background compilations finished at %.1f s\n", since());
   BuiltPlan bp = finish_plan(mode, in_ssa, out_ssa, opt);

@@ -67,7 +67,8 @@ struct KernelArgs {
   uint32_t flag_stride;
   uint32_t epoch;             // launch counter of the session: flags are never reset
   uint32_t diag;  // timing experiments only (GSV_DIAG env; honoured by a library built with -DGSV_DIAG_BUILD = `build.py --diag`, ignored by
-                  // the production build): 1 = skip AES, 4 = skip label loads, 8 = skip stores, 16 = no multi-lane narrow form
+                  // the production build): 1 = skip AES, 4 = skip label loads, 8 = skip stores, 16 = no multi-lane narrow form,
+                  // 32 = no step barrier, 64 = no record prefetch, 128 = no load of an AND record's second half
 };
 
 }  // namespace dev

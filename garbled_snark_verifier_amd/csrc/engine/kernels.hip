@@ -280,8 +280,9 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   // flags they cost the production loop a dozen register initialisations and several branches per gate.
 #ifdef GSV_DIAG_BUILD
   const bool no_store = (ka.diag & 8u) != 0, no_load = (ka.diag & 4u) != 0, no_aes = (ka.diag & 1u) != 0, no_narrow = (ka.diag & 16u) != 0;
+  const bool no_barrier = (ka.diag & 32u) != 0, no_refill = (ka.diag & 64u) != 0, no_hi = (ka.diag & 128u) != 0;  // step skeleton: what is the floor made of?
 #else
-  constexpr bool no_store = false, no_load = false, no_aes = false, no_narrow = false;
+  constexpr bool no_store = false, no_load = false, no_aes = false, no_narrow = false, no_barrier = false, no_refill = false, no_hi = false;
 #endif
 
   for (uint32_t rep = 0; rep < ka.replays; ++rep) {
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       return *(const glb_u128*)p;
     };
     auto load_and_rec = [&](uint32_t k) -> Rec { return *(const glb_u128*)(and_bytes + size_t(k) * 32u); };      // record k of the AND array, first half
-    auto load_and_hi = [&](uint32_t k) -> u32x2 { return *(const glb_u64*)(and_bytes + size_t(k) * 32u + 16u); };  // second half
+    auto load_and_hi = [&](uint32_t k) -> u32x2 { if (no_hi) return u32x2{k, 0u}; return *(const glb_u64*)(and_bytes + size_t(k) * 32u + 16u); };  // second half
     // Two record registers in ping-pong: step s consumes one (loaded at the end of step s-2) and, once it is done with it,
     // refills the SAME registers with the record of step s+2.  No in-flight load is ever copied to another register: a copy
     // would make the compiler wait for the load it has just issued at the top of every step (which is what a rotating
@@ -533,8 +534,9 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       // keep r0's registers reserved through the step: were they handed to a store's data in between, the refill below would
       // have to wait for that store (vmcnt(0) in front of the prefetch) before it could overwrite them
       asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w)::"memory");
-      r0 = load_rec(n2sd);  // stays in flight across the barrier and the whole next step
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (!no_refill) r0 = load_rec(n2sd);  // stays in flight across the barrier and the whole next step
+      if (no_barrier) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     for (uint32_t s = 0; s < ka.n_steps; s += 2) {
       const u32x4 sdA2 = load_desc(s + 2);  // lands during the step; the record load that needs it is issued at the step's end

@@ -101,6 +101,20 @@ class CompilePool {
   std::exception_ptr err_;
 };
 
+// The units of a plan under construction, shared by every recorder working on it: the driver's own PlanRecordMode and the warm-up
+// recorders (gsv_plan_from_circuit runs a circuit's warm-up mini-circuits on other threads so that the constant-specialised units —
+// the verifier has 178 line functions of 18 M gates each — are recorded side by side instead of one after the other by the driver).
+// index: cache key -> unit, or -1 while some thread is recording it (the others wait instead of recording it again).
+struct PlanUnitCache {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::unordered_map<std::string, int> index;
+  std::vector<std::unique_ptr<PlanUnit>> units;
+  std::unique_ptr<CompilePool> pool;  // set by compile_in_background
+  CompileOptions bg_opt;
+  bool bg_drop = false;
+};
+
 // A glue segment in canonical form: operands are either a wire defined earlier in the same segment (its definition index:
 // the SSA ids defined inside a segment are consecutive) or the k-th distinct outside wire in first-use order.  Segments
 // with the same canonical form (a gadget that is not a component, repeated) share one compiled program.
@@ -125,15 +139,20 @@ struct PlanSegment {
 
 class PlanRecordMode final : public CircuitMode, public UnitHook {
  public:
-  explicit PlanRecordMode(std::vector<std::string> unit_names) : unit_names_(std::move(unit_names)) { ver_.assign(2, 0); ver_[1] = 1; written_.assign(2, 1); }
+  explicit PlanRecordMode(std::vector<std::string> unit_names, std::shared_ptr<PlanUnitCache> cache = nullptr)
+      : cache_(cache ? std::move(cache) : std::make_shared<PlanUnitCache>()), units(cache_->units), unit_names_(std::move(unit_names)) {
+    ver_.assign(2, 0); ver_[1] = 1; written_.assign(2, 1);
+  }
+  const std::shared_ptr<PlanUnitCache>& cache() const { return cache_; }
+  const std::vector<std::string>& unit_names() const { return unit_names_; }
 
   // Compile every unit as soon as it has been recorded, on a worker pool, with the options finish_plan will be given.
   // drop_traces: free a unit's trace once its program exists (no other variant of the program will be compiled).
   void compile_in_background(const CompileOptions& opt, bool drop_traces) {
-    bg_opt_ = opt; bg_drop_ = drop_traces;
-    pool_.reset(new CompilePool(plan_compile_threads()));
+    cache_->bg_opt = opt; cache_->bg_drop = drop_traces;
+    cache_->pool.reset(new CompilePool(plan_compile_threads()));
   }
-  void wait_for_compilations() { if (pool_) pool_->wait(); }
+  void wait_for_compilations() { if (cache_->pool) cache_->pool->wait(); }
 
   // ---- CircuitMode (same rules as RecordMode, program.hpp)
   WireId allocate_wire(Credits credits) override {
@@ -177,8 +196,18 @@ class PlanRecordMode final : public CircuitMode, public UnitHook {
       live[i] = out_credits[i] != 0;
       cache_key.push_back(live[i] ? '1' : '0');
     }
-    auto it = unit_index_.find(cache_key);
-    if (it == unit_index_.end()) {
+    PlanUnitCache& uc = *cache_;
+    int unit_id = -1;
+    {
+      std::unique_lock<std::mutex> lk(uc.mu);
+      for (;;) {
+        auto it = uc.index.find(cache_key);
+        if (it == uc.index.end()) { uc.index.emplace(cache_key, -1); break; }  // ours to record
+        if (it->second >= 0) { unit_id = it->second; break; }
+        uc.cv.wait(lk);  // another recorder is at it
+      }
+    }
+    if (unit_id < 0) try {
       // record the component on its own (nested components are flattened into it)
       RecordMode rec;
       StreamingRunner run(rec, inputs.size(), body);
@@ -201,22 +230,33 @@ class PlanRecordMode final : public CircuitMode, public UnitHook {
       }
       u->trace = std::move(rec.trace());
       u->n_gates = u->trace.size();
-      it = unit_index_.emplace(cache_key, int(units.size())).first;
-      units.push_back(std::move(u));
-      if (pool_) {
-        PlanUnit* pu = units.back().get();  // stable: the vector holds pointers; nothing else touches the trace before finish_plan
-        const CompileOptions opt = bg_opt_;
-        const bool drop = bg_drop_;
-        pool_->submit([pu, opt, drop] {
+      PlanUnit* pu = u.get();  // stable: the vector holds pointers; nothing else touches the trace before finish_plan
+      {
+        std::lock_guard<std::mutex> lk(uc.mu);
+        unit_id = int(uc.units.size());
+        uc.units.push_back(std::move(u));
+        uc.index[cache_key] = unit_id;
+      }
+      uc.cv.notify_all();
+      if (uc.pool) {
+        const CompileOptions opt = uc.bg_opt;
+        const bool drop = uc.bg_drop;
+        uc.pool->submit([pu, opt, drop] {
           pu->compiled.reset(new Program(compile_program(pu->trace, pu->inputs, pu->outputs, {}, opt)));
           if (drop) pu->trace = Trace();
         });
       }
+    } catch (...) {
+      { std::lock_guard<std::mutex> lk(uc.mu); auto it = uc.index.find(cache_key); if (it != uc.index.end() && it->second < 0) uc.index.erase(it); }
+      uc.cv.notify_all();
+      throw;
     }
-    const PlanUnit& u = *units[size_t(it->second)];
+    const PlanUnit* up;
+    { std::lock_guard<std::mutex> lk(uc.mu); up = uc.units[size_t(unit_id)].get(); }  // the vector may grow under another recorder
+    const PlanUnit& u = *up;
     (void)tpl; (void)Out::Internal;
     PlanSegment seg;
-    seg.unit = it->second;
+    seg.unit = unit_id;
     for (WireId w : inputs) seg.in_ssa.push_back(w == FALSE_WIRE ? PLAN_WIRE_FALSE : w == TRUE_WIRE ? PLAN_WIRE_TRUE : read(w));
     seg.out_ssa.assign(u.outputs.size(), DEAD_WIRE);
     out.assign(arity, UNREACHABLE);
@@ -307,7 +347,10 @@ class PlanRecordMode final : public CircuitMode, public UnitHook {
 
   uint64_t n_gates() const { return n_gates_; }
   uint32_t n_ssa() const { return next_ssa_; }
-  std::vector<std::unique_ptr<PlanUnit>> units;
+ private:
+  std::shared_ptr<PlanUnitCache> cache_;
+ public:
+  std::vector<std::unique_ptr<PlanUnit>>& units;  // the cache's (single-threaded use only: after the warm-up recorders have been joined)
   std::vector<PlanSegment> segments;
   std::vector<std::unique_ptr<GlueClass>> glue_classes;
 
@@ -337,16 +380,58 @@ class PlanRecordMode final : public CircuitMode, public UnitHook {
     return id;
   }
   std::vector<std::string> unit_names_;
-  std::unordered_map<std::string, int> unit_index_;
   std::unordered_multimap<uint64_t, int> class_index_;
   std::vector<uint32_t> ver_;
   std::vector<uint8_t> written_;
   uint32_t next_ssa_ = 2;  // 0 / 1 are the constants
   uint64_t n_gates_ = 0;
-  std::unique_ptr<CompilePool> pool_;
-  CompileOptions bg_opt_;
-  bool bg_drop_ = false;
 };
+
+// The recording itself: the two-pass driver walks (n_inputs, fn) on this thread while up to a quarter of the compile threads
+// (GSV_PLAN_WARMUP_THREADS, 0 = none) run the circuit's warm-up mini-circuits, each under a recorder of its own that shares `mode`'s
+// unit cache: a unit the warm-ups reach first is recorded (and sent to the compile pool) by them, the driver waits for one that is
+// still being recorded and records what the warm-ups do not cover.  The plan is the same with or without them.
+// Warmup: anything with .n_inputs and .fn (NamedCircuit::Warmup).  in_ssa / out_ssa: the circuit's inputs / outputs for finish_plan.
+template <class Warmup>
+inline void record_plan(PlanRecordMode& mode, size_t n_inputs, const CircuitFn& fn, const std::vector<Warmup>& warmups, std::vector<uint32_t>& in_ssa,
+                        std::vector<uint32_t>& out_ssa, size_t* n_recorders_out = nullptr) {
+  std::atomic<size_t> next{0};
+  const size_t n = warmups.size();
+  struct Crew {
+    std::vector<std::thread> th;
+    std::atomic<size_t>& next; size_t n;
+    ~Crew() { next.store(n); for (auto& t : th) if (t.joinable()) t.join(); }  // (the driver threw: stop handing out warm-ups)
+  } crew{{}, next, n};
+  std::mutex err_mu;
+  std::exception_ptr err;
+  size_t nrec = std::max<size_t>(1, plan_compile_threads() / 4);
+  if (const char* e = getenv("GSV_PLAN_WARMUP_THREADS")) nrec = size_t(std::max(0, atoi(e)));
+  nrec = std::min(nrec, n);
+  if (n_recorders_out) *n_recorders_out = nrec;
+  for (size_t t = 0; t < nrec; ++t)
+    crew.th.emplace_back([&] {
+      for (;;) {
+        const size_t i = next.fetch_add(1);
+        if (i >= n) return;
+        try {
+          PlanRecordMode wm(mode.unit_names(), mode.cache());
+          StreamingRunner wrun(wm, warmups[i].n_inputs, warmups[i].fn);
+          for (WireId w : wrun.prepare()) wm.define_input(w);
+          (void)wrun.execute();
+        } catch (...) {
+          std::lock_guard<std::mutex> lk(err_mu);
+          if (!err) err = std::current_exception();
+          next.store(n);
+          return;
+        }
+      }
+    });
+  StreamingRunner run(mode, n_inputs, fn);
+  for (WireId w : run.prepare()) in_ssa.push_back(mode.define_input(w));
+  for (WireId w : run.execute()) out_ssa.push_back(mode.current(w));
+  for (auto& t : crew.th) t.join();
+  if (err) std::rethrow_exception(err);
+}
 
 // The finished plan in host form: programs (units first, then one per glue segment) and calls over global wire ids.
 // Runs fn(0 .. n-1) on up to GSV_COMPILE_THREADS (default: the hardware's, at most 16) threads; the first exception is rethrown.

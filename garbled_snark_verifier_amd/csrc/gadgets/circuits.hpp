@@ -26,6 +26,11 @@ struct NamedCircuit {
   size_t n_inputs = 0;
   size_t n_outputs = 0;
   CircuitFn fn;
+  // Mini-circuits that call, once each, components the circuit will instantiate with constants of its own (the 178 line functions
+  // of a verifying key's gamma and delta).  A plan builder may run them on other threads to record those units side by side ahead of
+  // the driver; they change nothing in the circuit's gate stream (a unit missing from the warm-up is simply recorded by the driver).
+  struct Warmup { size_t n_inputs; CircuitFn fn; };
+  std::vector<Warmup> warmups;
 };
 
 // G2 generator of BN254 (affine, standard form): the constant Q of the pairing test circuits
@@ -121,6 +126,22 @@ inline Wires random_block(CircuitContext& c, const Wires& in, uint64_t seed, uin
     if (rng.below(10) != 0) pool.push_back(o);  // ~10 % of the gates are never read: dead unless chosen as output
   }
   return pool;
+}
+}  // namespace detail
+
+namespace detail {
+// One warm-up per constant line function of the Miller loop's two fixed G2 points (pairing.rs:923-942 as called from 944-1007):
+// inputs f (Fq12) and p (G1), every output live — the shape multi_miller_loop_groth16_evaluate_montgomery_fast calls them in.
+inline void add_ell_warmups(NamedCircuit& nc, const gadgets::HFq2& q1x, const gadgets::HFq2& q1y, const gadgets::HFq2& q2x, const gadgets::HFq2& q2y) {
+  using namespace gadgets;
+  for (int which = 0; which < 2; ++which) {
+    auto ell = std::make_shared<std::vector<HEllCoeff>>(which == 0 ? h_ell_coeffs(q1x, q1y) : h_ell_coeffs(q2x, q2y));
+    for (size_t k = 0; k < ell->size(); ++k)
+      nc.warmups.push_back({3048 + 762, [ell, k](CircuitContext& c, const Wires& in) {
+        G1Wires p{slice(in, 3048, 3302), slice(in, 3302, 3556), slice(in, 3556, 3810)};
+        return pairing::ell_by_constant_montgomery(c, Fq12::from_wires(slice(in, 0, 3048)), (*ell)[k], p).to_wires();
+      }});
+  }
 }
 }  // namespace detail
 
@@ -267,6 +288,7 @@ inline NamedCircuit make_circuit(const std::string& spec) {
       const HFq2 gx = test_g2_generator_x(), gy = test_g2_generator_y();
       return pairing::multi_miller_loop_groth16_evaluate_montgomery_fast(c, g1(0), g1(762), g1(1524), gx, gy, gx, HFq2::neg(gy), pairing::g2_from_wires(slice(in, 2286, 3810))).to_wires();
     };
+    detail::add_ell_warmups(nc, test_g2_generator_x(), test_g2_generator_y(), test_g2_generator_x(), HFq2::neg(test_g2_generator_y()));
   } else if (name == "g1_add") {  // g1.rs:159-235
     nc.n_inputs = 1524; nc.n_outputs = 762;
     nc.fn = [](CircuitContext& c, const Wires& in) { return g1_to_wires(g1::add_montgomery(c, g1_from_wires(slice(in, 0, 762)), g1_from_wires(slice(in, 762, 1524)))); };
@@ -303,6 +325,7 @@ inline NamedCircuit make_circuit(const std::string& spec) {
       const size_t o = n_pub * 254;
       return Wires{groth16::verify(c, pub, g1_from_wires(slice(in, o, o + 762)), pairing::g2_from_wires(slice(in, o + 762, o + 2286)), g1_from_wires(slice(in, o + 2286, o + 3048)), *vk)};
     };
+    detail::add_ell_warmups(nc, vk->gamma_x, HFq2::neg(vk->gamma_y), vk->delta_x, HFq2::neg(vk->delta_y));  // groth16.rs:58-110 hands -gamma, -delta to the Miller loop
   } else if (name == "groth16_verify_compressed") {  // groth16.rs:250-268; inputs: public scalars, (A.x, flag), (B.x, flag), (C.x, flag) (groth16.rs:410-421)
     if (colon == std::string::npos) gsv_panic("groth16_verify_compressed needs a verifying key: groth16_verify_compressed:<hex>");
     size_t n_pub = 0;
@@ -315,6 +338,7 @@ inline NamedCircuit make_circuit(const std::string& spec) {
       return Wires{groth16::verify_compressed(c, pub, slice(in, o, o + 254), in[o + 254], Fq2::from_wires(slice(in, o + 255, o + 763)), in[o + 763],
                                               slice(in, o + 764, o + 1018), in[o + 1018], *vk)};
     };
+    detail::add_ell_warmups(nc, vk->gamma_x, HFq2::neg(vk->gamma_y), vk->delta_x, HFq2::neg(vk->delta_y));
   } else if (name == "fq_sqrt") {  // fq.rs:290-299
     one_fq([](CircuitContext& c, const Wires& a) { return fq::sqrt_montgomery(c, a); });
   } else if (name == "fq2_sqrt") {  // fq2.rs:425-446
@@ -336,6 +360,11 @@ inline NamedCircuit make_circuit(const std::string& spec) {
       Fq12 w = fq12::mul_montgomery(c, v, t);
       return w.c[0].to_wires();
     };
+    // warm-ups for the plan builder's tests: the square and the fully live multiplication (the half-dead one is left to the driver)
+    nc.warmups.push_back({3048, [](CircuitContext& c, const Wires& in) { return fq12::square_montgomery(c, Fq12::from_wires(in)).to_wires(); }});
+    nc.warmups.push_back({6096, [](CircuitContext& c, const Wires& in) {
+      return fq12::mul_montgomery(c, Fq12::from_wires(slice(in, 0, 3048)), Fq12::from_wires(slice(in, 3048, 6096))).to_wires();
+    }});
   } else if (name == "gate") {
     if (!has_param || param > 10) gsv_panic("gate:T needs T in 0..10");
     GateType t = static_cast<GateType>(param);

@@ -171,12 +171,12 @@ int hostsim_plan_build(const char* spec, const char* units_csv, SimPlan** out, u
     }
     NamedCircuit nc = make_circuit(spec);
     PlanRecordMode mode(names);
-    StreamingRunner run(mode, nc.n_inputs, nc.fn);
-    std::vector<uint32_t> in_ssa, out_ssa;
-    for (WireId w : run.prepare()) in_ssa.push_back(mode.define_input(w));
-    for (WireId w : run.execute()) out_ssa.push_back(mode.current(w));
     CompileOptions opt;
     if (const char* e = getenv("GSV_FUSE")) opt.fuse = atoi(e) != 0;
+    if (getenv("HOSTSIM_PLAN_BACKGROUND")) mode.compile_in_background(opt, false);  // the engine's way: units compiled on the pool while recording goes on
+    std::vector<uint32_t> in_ssa, out_ssa;
+    record_plan(mode, nc.n_inputs, nc.fn, nc.warmups, in_ssa, out_ssa);  // as gsv_plan_from_circuit: warm-up recorders beside the driver
+    mode.wait_for_compilations();
     auto sp = std::make_unique<SimPlan>();
     const size_t n_units = mode.units.size();
     sp->bp = finish_plan(mode, in_ssa, out_ssa, opt);

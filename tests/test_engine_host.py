@@ -265,6 +265,28 @@ def test_schedule_finds_the_independent_calls():
     assert info["max_width"] >= 5 and info["critical_steps"] < info["total_steps"] // 2
 
 
+def test_warmup_recorders_give_the_same_plan(monkeypatch):
+    """plan_builder.hpp record_plan: a circuit's warm-up mini-circuits (circuits.hpp NamedCircuit::warmups; the verifier's 178 constant
+    line functions, here fq12_mix's square and multiplication) are recorded by other threads while the driver walks the circuit, with
+    the units compiled on the pool as in the engine.  The plan must be the same with and without them — same calls, same programs —
+    and must interpret to the oracle's stream; the half-dead multiplication the warm-ups do not cover is recorded by the driver."""
+    import garbled_snark_verifier_amd as gsv
+    units = ["fq12::mul_montgomery", "fq12::square_montgomery"]
+    infos = []
+    for threads in ("0", "2"):
+        monkeypatch.setenv("GSV_PLAN_WARMUP_THREADS", threads)
+        plan = gsv.Plan.from_circuit("fq12_mix", units, window_div=4)
+        infos.append((dict(plan.info), plan.image_bytes(), plan.call_info().tobytes()))
+        plan.close()
+    assert infos[0] == infos[1] and infos[0][0]["n_calls"] >= 4
+    monkeypatch.setenv("HOSTSIM_PLAN_BACKGROUND", "1")
+    sp = h.SimPlan("fq12_mix", units)
+    ref = o.garble("fq12_mix", 4)
+    labs = h.labels_from_seed(4, 3 + ref.n_in)
+    out, cts = sp.garble(labs[0], labs[1:3], labs[3:])
+    assert (ref.ciphertexts == cts).all() and (ref.output_label0 == out).all() and h.cbcmac(cts) == ref.ct_hash.tobytes()
+
+
 def test_plan_from_circuit_builds_without_a_device_and_in_both_modes():
     """gsv_plan_from_circuit is host-only work: units are compiled on a worker pool while the driver records (plan_builder.hpp
     CompilePool), with GSV_PLAN_WINDOW_DIV once for half / a quarter of the LDS window.  Every mode gives the reference's counts; the
