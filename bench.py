@@ -275,8 +275,8 @@ def _plan_cache_path(args, circuit, units):
 
 
 def get_plan(gsv, engine, args, circuit, units, rank, local_rank, local_world, dist, log):
-    """Local rank 0 loads the node's plan file or builds the plan (and saves it when other ranks need it); the other ranks of the
-    node load the file straight into their GPU's memory.  Returns (plan, {how, seconds, ...}, save_later).  A failure on any rank is
+    """Local rank 0 loads the node's plan file or builds the plan straight into that file; every rank of the node then streams the
+    file into its GPU's memory (without a cache directory a single rank builds the plan in memory).  Returns (plan, {how, seconds, ...}, save_later).  A failure on any rank is
     agreed on by all (min over ranks) before anyone waits in a barrier: every rank exits non-zero together."""
     path = _plan_cache_path(args, circuit, units)
     t0 = time.time()
@@ -288,21 +288,20 @@ def get_plan(gsv, engine, args, circuit, units, rank, local_rank, local_world, d
                 plan = gsv.Plan.load(path, engine)
                 info["how"] = "loaded"
             else:
-                try:  # ~50 GB of host memory while the plan is built
-                    avail_gb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 1e6
-                    if avail_gb < 60:
-                        log("bench.py: %.0f GB of host memory available, the plan build needs ~50 GB" % avail_gb)
-                except (OSError, IndexError, ValueError):
-                    pass
-                plan = gsv.Plan.from_circuit(circuit, units, window_div=4)  # one image per program, good for 1, 2 and 4 instances per workgroup
-                info["how"] = "built"
-                if local_world > 1:
-                    if not path:
+                if path:
+                    # straight into the node's plan file: each program is written by the worker that compiled it and dropped, so the
+                    # host never holds the 41 GB of records (gsv_plan_build_file: ~25 GB peak instead of ~54 GB); then every rank —
+                    # this one too — streams the file into its GPU's memory
+                    t1 = time.time()
+                    gsv.Plan.build_file(circuit, units, path, window_div=4)  # one image per program, good for 1, 2 and 4 instances per workgroup
+                    info["build_s"] = time.time() - t1
+                    plan = gsv.Plan.load(path, engine)
+                    info["how"] = "built to file, loaded"
+                else:
+                    if local_world > 1:
                         raise RuntimeError("no directory with room for the plan file the other ranks load (set --plan-cache)")
-                    plan.save(path)
-                    info["saved_s"] = time.time() - t0
-                elif path:
-                    save_later = path  # single rank: written after the result line, for the next process on this machine
+                    plan = gsv.Plan.from_circuit(circuit, units, window_div=4)  # no directory for a plan file: ~54 GB of host memory
+                    info["how"] = "built"
         except Exception as e:  # noqa: BLE001
             err = e
     if dist.min_int(0 if err else 1) == 0:

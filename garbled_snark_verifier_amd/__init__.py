@@ -79,7 +79,7 @@ EXPORTS = [
     "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_cbcmac_update_many", "gsv_commit_labels",
     "gsv_plan_from_circuit", "gsv_plan_io", "gsv_plan_recorder_create", "gsv_plan_recorder_destroy", "gsv_plan_recorder_allocate_wire",
     "gsv_plan_recorder_declare_input", "gsv_plan_recorder_push_gates", "gsv_plan_recorder_call", "gsv_plan_recorder_finish", "gsv_plan_create", "gsv_plan_destroy", "gsv_plan_add_call", "gsv_plan_finish", "gsv_plan_counts", "gsv_session_create_plan", "gsv_session_create_plan_ex",
-    "gsv_session_garble_streaming", "gsv_session_garble_streaming_calls", "gsv_plan_call_info", "gsv_plan_image_bytes", "gsv_plan_wire_file", "gsv_plan_save", "gsv_plan_load", "gsv_session_evaluate_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
+    "gsv_session_garble_streaming", "gsv_session_garble_streaming_calls", "gsv_plan_call_info", "gsv_plan_image_bytes", "gsv_plan_wire_file", "gsv_plan_save", "gsv_plan_load", "gsv_plan_build_file", "gsv_session_evaluate_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
     "gsv_session_create_plan_opts", "gsv_session_plan_schedule_info", "gsv_session_plan_window", "gsv_session_set_unchecked_slices",
 ]
 
@@ -152,6 +152,7 @@ def lib():
         L.gsv_plan_wire_file.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.gsv_plan_save.argtypes = [vp, C.c_char_p]
         L.gsv_plan_load.argtypes = [C.c_char_p, vp, C.POINTER(vp)]
+        L.gsv_plan_build_file.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
         L.gsv_session_instances_per_workgroup.argtypes = [vp, C.POINTER(C.c_int)]
         L.gsv_session_enable_step_clock.argtypes = [vp]
         L.gsv_session_read_step_clock.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -349,6 +350,24 @@ class Plan:
         self.n_inputs, self.n_outputs = n_in.value, n_out.value
         self.info = {"n_inputs": n_in.value, "n_outputs": n_out.value, "n_gates": g.value, "n_ciphertexts": c.value, "n_calls": k.value, "n_steps": 0}
         return self
+
+    @staticmethod
+    def build_file(spec, units, path, window_div=4):
+        """Build the plan of a built-in circuit straight into the plan file `path` (gsv_plan_build_file): every program is written
+        by the worker that compiled it and dropped from memory.  Load it with Plan.load(path, engine)."""
+        if int(window_div) not in (2, 4):
+            raise ValueError("window_div must be 2 or 4 (one image per program)")
+        saved = {k: os.environ.get(k) for k in ("GSV_PLAN_WINDOW_DIV", "GSV_PLAN_HALF_WINDOW")}
+        os.environ["GSV_PLAN_WINDOW_DIV"] = str(int(window_div))
+        os.environ.pop("GSV_PLAN_HALF_WINDOW", None)
+        try:
+            _chk(lib().gsv_plan_build_file(spec.encode(), ",".join(units).encode(), os.fsencode(path)))
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
 
     def _read_info(self):
         g, c, k = C.c_uint64(), C.c_uint64(), C.c_uint64()

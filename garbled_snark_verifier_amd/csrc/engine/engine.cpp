@@ -481,7 +481,14 @@ int gsv_plan_finish(gsv_plan* p, uint32_t n_inputs, const uint32_t* output_globa
 // Record one of the built-in restated circuits under the two-pass driver with the named components (comma separated,
 // e.g. "fq12::mul_montgomery,fq12::square_montgomery") turned into calls of separately compiled programs; everything
 // between them is compiled as glue programs (plan_builder.hpp).
-int gsv_plan_from_circuit(const char* spec, const char* units_csv, gsv_plan** out) {
+static int plan_window_div(uint32_t* window_div) {
+  *window_div = 1;
+  if (getenv("GSV_PLAN_HALF_WINDOW") && atoi(getenv("GSV_PLAN_HALF_WINDOW")) != 0) *window_div = 2;
+  if (const char* e = getenv("GSV_PLAN_WINDOW_DIV")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) *window_div = uint32_t(v); else return fail(GSV_ERR_INVALID, "GSV_PLAN_WINDOW_DIV must be 1, 2 or 4"); }
+  return GSV_OK;
+}
+// sink: see PlanUnitCache::sink (gsv_plan_build_file); empty = the programs stay in memory
+static int plan_from_circuit_impl(const char* spec, const char* units_csv, const std::function<void(Program&)>& sink, gsv_plan** out) {
   if (!spec || !units_csv || !out) return fail(GSV_ERR_INVALID, "null argument");
   GSV_TRY
   std::vector<std::string> names;
@@ -501,9 +508,10 @@ int gsv_plan_from_circuit(const char* spec, const char* units_csv, gsv_plan** ou
   // compilation for plans with hundreds of programs, at a smaller window when sessions have few instances).
   // GSV_PLAN_HALF_WINDOW=1 is the older spelling of GSV_PLAN_WINDOW_DIV=2.
   uint32_t window_div = 1;
-  if (getenv("GSV_PLAN_HALF_WINDOW") && atoi(getenv("GSV_PLAN_HALF_WINDOW")) != 0) window_div = 2;
-  if (const char* e = getenv("GSV_PLAN_WINDOW_DIV")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) window_div = uint32_t(v); else return fail(GSV_ERR_INVALID, "GSV_PLAN_WINDOW_DIV must be 1, 2 or 4"); }
+  { int rc = plan_window_div(&window_div); if (rc) return rc; }
   const bool single_image = window_div > 1;
+  if (sink && !single_image) return fail(GSV_ERR_INVALID, "a plan is built straight to a file only with one image per program (GSV_PLAN_WINDOW_DIV=2|4)");
+  mode.cache()->sink = sink;
   if (single_image) opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / window_div);
   mode.compile_in_background(opt, single_image);  // units are compiled while the driver records the rest of the circuit
   std::vector<uint32_t> in_ssa, out_ssa;
@@ -539,6 +547,7 @@ int gsv_plan_from_circuit(const char* spec, const char* units_csv, gsv_plan** ou
   return GSV_OK;
   GSV_CATCH
 }
+int gsv_plan_from_circuit(const char* spec, const char* units_csv, gsv_plan** out) { return plan_from_circuit_impl(spec, units_csv, nullptr, out); }
 // ---- plan recorder: the plan builder behind the C ABI, for a host that runs its own two-pass driver
 struct gsv_plan_recorder {
   PlanRecordMode mode{std::vector<std::string>()};
@@ -638,14 +647,16 @@ int gsv_plan_counts(const gsv_plan* p, uint64_t* n_gates, uint64_t* n_ciphertext
 // machine: rank 0 of a node builds and saves, every other rank (and every later process) loads.  gsv_plan_load with an engine
 // streams each program's records from the (memory-mapped, page-cache shared) file straight into that GPU's memory; the host
 // keeps only the metadata a session needs, so a loading rank's private memory stays small.  Layout (little endian, every array
-// padded to 16 bytes):  PlanFileHeader | per program: PlanFileProgram, steps, ands, xors, ct_pos, input_slots, output_slots |
-// per call: {program, n_in, n_out}, in_globals, out_globals | outputs.
+// padded to 16 bytes):  PlanFileHeader | program blocks in any order, each: PlanFileProgram, steps, ands, xors, ct_pos, input_slots,
+// output_slots | at calls_off, per call: {program, n_in, n_out}, in_globals, out_globals | outputs | at table_off: one uint64 file
+// offset per program.  The table is what lets gsv_plan_build_file append a program the moment a worker has compiled it.
 namespace {
-constexpr char PLAN_MAGIC[8] = {'G', 'S', 'V', 'P', 'L', 'A', 'N', '3'};
+constexpr char PLAN_MAGIC[8] = {'G', 'S', 'V', 'P', 'L', 'A', 'N', '4'};
 struct PlanFileHeader {
   char magic[8];
   uint32_t n_programs, n_calls, n_globals, n_inputs, n_outputs, lds_window_slots;
   uint64_t n_gates, n_ct, rec_sizes;  // rec_sizes: sizeof(StepDesc) | sizeof(AndRec) << 16 | sizeof(XorRec) << 32 (format guard)
+  uint64_t calls_off, table_off;
 };
 struct PlanFileProgram {
   uint64_t n_steps, n_ands, n_xors, n_ct_pos, n_inputs, n_outputs;
@@ -659,6 +670,78 @@ struct FileCloser { FILE* f; ~FileCloser() { if (f) std::fclose(f); } };
 struct Mapping {
   const uint8_t* base = nullptr; size_t size = 0; int fd = -1;
   ~Mapping() { if (base) munmap(const_cast<uint8_t*>(base), size); if (fd >= 0) close(fd); }
+};
+// Writes a plan file: program blocks may be appended from several threads (each reserves its range, then pwrite()s it), the calls,
+// the offset table and the header follow when the plan is complete; the file appears under its name only then (temp file + rename).
+class PlanFileWriter {
+ public:
+  ~PlanFileWriter() { if (fd_ >= 0) { close(fd_); std::remove(tmp_.c_str()); } }
+  int open_file(const std::string& path) {
+    path_ = path;
+    tmp_ = path + ".tmp." + std::to_string(long(getpid()));
+    fd_ = ::open(tmp_.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0600);
+    if (fd_ < 0) return fail(GSV_ERR_INVALID, "cannot create " + tmp_);
+    next_.store(pad16(sizeof(PlanFileHeader)));
+    return GSV_OK;
+  }
+  bool ok() const { return !bad_.load(); }
+  // -> file offset of the block
+  uint64_t append_program(const Program& g, uint32_t window_div) {
+    PlanFileProgram m{};
+    m.n_steps = g.steps.size(); m.n_ands = g.ands.size(); m.n_xors = g.xors.size(); m.n_ct_pos = g.ct_pos.size(); m.n_inputs = g.input_slots.size(); m.n_outputs = g.output_slots.size();
+    m.n_gates = g.n_gates; m.n_ct = g.n_ct; m.n_dead = g.n_dead; m.n_fused_free = g.n_fused_free;
+    m.reads_lds = g.reads_lds; m.reads_hbm = g.reads_hbm; m.writes_lds = g.writes_lds; m.writes_hbm = g.writes_hbm;
+    for (int i = 0; i < GATE_TYPE_COUNT; ++i) m.gate_count[i] = g.gate_count[i];
+    m.n_slots = g.n_slots; m.n_lds_slots = g.n_lds_slots; m.lds_slots_limit = g.lds_slots_limit; m.fb_stage_base = g.fb_stage_base; m.and_depth = g.and_depth;
+    m.n_and_steps = g.n_and_steps; m.max_step_width = g.max_step_width; m.peak_live = g.peak_live; m.window_div = window_div;
+    const void* parts[7] = {&m, g.steps.data(), g.ands.data(), g.xors.data(), g.ct_pos.data(), g.input_slots.data(), g.output_slots.data()};
+    const size_t lens[7] = {sizeof m, g.steps.size() * sizeof(StepDesc), g.ands.size() * sizeof(AndRec), g.xors.size() * sizeof(XorRec), g.ct_pos.size() * 4, g.input_slots.size() * 4, g.output_slots.size() * 4};
+    size_t total = 0;
+    for (size_t l : lens) total += pad16(l);
+    const uint64_t off = next_.fetch_add(total);
+    uint64_t pos = off;
+    for (int i = 0; i < 7; ++i) { put_at(pos, parts[i], lens[i]); pos += pad16(lens[i]); }
+    return off;
+  }
+  // single-threaded tail: calls, outputs, table, header; then the rename
+  int finish(const gsv_plan* p, const std::vector<uint64_t>& program_off, const std::map<const gsv_program*, uint32_t>& index) {
+    PlanFileHeader h{};
+    std::memcpy(h.magic, PLAN_MAGIC, 8);
+    h.n_programs = uint32_t(program_off.size()); h.n_calls = uint32_t(p->calls.size()); h.n_globals = p->n_globals; h.n_inputs = p->n_inputs; h.n_outputs = uint32_t(p->outputs.size());
+    h.lds_window_slots = LDS_WINDOW_SLOTS; h.n_gates = p->n_gates; h.n_ct = p->n_ct; h.rec_sizes = plan_rec_sizes();
+    std::vector<uint8_t> tail;
+    auto put = [&](const void* d, size_t n) { const uint8_t* b = static_cast<const uint8_t*>(d); tail.insert(tail.end(), b, b + n); tail.resize(pad16(tail.size()), 0); };
+    for (const PlanCall& c : p->calls) {
+      const uint32_t hdr[4] = {index.at(c.prog), uint32_t(c.in_globals.size()), uint32_t(c.out_globals.size()), 0};
+      put(hdr, sizeof hdr);
+      put(c.in_globals.data(), c.in_globals.size() * 4);
+      put(c.out_globals.data(), c.out_globals.size() * 4);
+    }
+    put(p->outputs.data(), p->outputs.size() * 4);
+    h.calls_off = next_.load();
+    h.table_off = h.calls_off + tail.size();
+    put(program_off.data(), program_off.size() * 8);
+    put_at(h.calls_off, tail.data(), tail.size());
+    put_at(0, &h, sizeof h);
+    const bool closed = close(fd_) == 0;
+    fd_ = -1;
+    if (!ok() || !closed || std::rename(tmp_.c_str(), path_.c_str()) != 0) { std::remove(tmp_.c_str()); return fail(GSV_ERR_INVALID, "cannot write " + path_); }
+    return GSV_OK;
+  }
+
+ private:
+  void put_at(uint64_t off, const void* d, size_t n) {
+    const uint8_t* b = static_cast<const uint8_t*>(d);
+    while (n) {
+      const ssize_t w = pwrite(fd_, b, n, off_t(off));
+      if (w <= 0) { bad_.store(true); return; }
+      b += w; off += uint64_t(w); n -= size_t(w);
+    }
+  }
+  int fd_ = -1;
+  std::string path_, tmp_;
+  std::atomic<uint64_t> next_{0};
+  std::atomic<bool> bad_{false};
 };
 }  // namespace
 
@@ -686,49 +769,42 @@ int gsv_plan_save(const gsv_plan* p, const char* path) {
   std::map<const gsv_program*, uint32_t> index;
   for (const PlanCall& c : p->calls)
     if (index.emplace(c.prog, uint32_t(progs.size())).second) {
-      if (c.prog->device_only) return fail(GSV_ERR_INVALID, "a plan loaded straight to the device has no host records to save");
+      if (c.prog->device_only || c.prog->prog.spilled) return fail(GSV_ERR_INVALID, "this plan holds no program records on the host (loaded straight to a device / built straight to a file)");
       progs.push_back(c.prog);
     }
-  const std::string tmp = std::string(path) + ".tmp." + std::to_string(long(getpid()));
-  FileCloser fc{std::fopen(tmp.c_str(), "wb")};
-  if (!fc.f) return fail(GSV_ERR_INVALID, "cannot create " + tmp);
-  std::setvbuf(fc.f, nullptr, _IOFBF, 8u << 20);
-  bool ok = true;
-  static const uint8_t zeros[16] = {0};
-  auto put = [&](const void* d, size_t n) { if (n) ok = ok && std::fwrite(d, 1, n, fc.f) == n; const size_t r = pad16(n) - n; if (r) ok = ok && std::fwrite(zeros, 1, r, fc.f) == r; };
-  PlanFileHeader h{};
-  std::memcpy(h.magic, PLAN_MAGIC, 8);
-  h.n_programs = uint32_t(progs.size()); h.n_calls = uint32_t(p->calls.size()); h.n_globals = p->n_globals; h.n_inputs = p->n_inputs; h.n_outputs = uint32_t(p->outputs.size());
-  h.lds_window_slots = LDS_WINDOW_SLOTS; h.n_gates = p->n_gates; h.n_ct = p->n_ct; h.rec_sizes = plan_rec_sizes();
-  put(&h, sizeof h);
-  for (const gsv_program* q : progs) {
-    const Program& g = q->prog;
-    PlanFileProgram m{};
-    m.n_steps = g.steps.size(); m.n_ands = g.ands.size(); m.n_xors = g.xors.size(); m.n_ct_pos = g.ct_pos.size(); m.n_inputs = g.input_slots.size(); m.n_outputs = g.output_slots.size();
-    m.n_gates = g.n_gates; m.n_ct = g.n_ct; m.n_dead = g.n_dead; m.n_fused_free = g.n_fused_free;
-    m.reads_lds = g.reads_lds; m.reads_hbm = g.reads_hbm; m.writes_lds = g.writes_lds; m.writes_hbm = g.writes_hbm;
-    for (int i = 0; i < GATE_TYPE_COUNT; ++i) m.gate_count[i] = g.gate_count[i];
-    m.n_slots = g.n_slots; m.n_lds_slots = g.n_lds_slots; m.lds_slots_limit = g.lds_slots_limit; m.fb_stage_base = g.fb_stage_base; m.and_depth = g.and_depth;
-    m.n_and_steps = g.n_and_steps; m.max_step_width = g.max_step_width; m.peak_live = g.peak_live; m.window_div = q->window_div;
-    put(&m, sizeof m);
-    put(g.steps.data(), g.steps.size() * sizeof(StepDesc));
-    put(g.ands.data(), g.ands.size() * sizeof(AndRec));
-    put(g.xors.data(), g.xors.size() * sizeof(XorRec));
-    put(g.ct_pos.data(), g.ct_pos.size() * 4);
-    put(g.input_slots.data(), g.input_slots.size() * 4);
-    put(g.output_slots.data(), g.output_slots.size() * 4);
+  PlanFileWriter w;
+  { int rc = w.open_file(path); if (rc) return rc; }
+  std::vector<uint64_t> off;
+  for (const gsv_program* q : progs) off.push_back(w.append_program(q->prog, q->window_div));
+  return w.finish(p, off, index);
+}
+// Build a plan and write it to `path` without ever holding it: every program is appended to the file by the worker that compiled
+// it and its records are dropped (the verifier's plan is 41 GB of records; built in memory it peaks at ~54 GB of host RSS).
+// Load the file with gsv_plan_load (with an engine: streamed to the device).  One image per program: GSV_PLAN_WINDOW_DIV=2|4.
+int gsv_plan_build_file(const char* spec, const char* units_csv, const char* path) {
+  if (!spec || !units_csv || !path) return fail(GSV_ERR_INVALID, "null argument");
+  GSV_TRY
+  uint32_t window_div = 1;
+  { int rc = plan_window_div(&window_div); if (rc) return rc; }
+  PlanFileWriter w;
+  { int rc = w.open_file(path); if (rc) return rc; }
+  gsv_plan* plan = nullptr;
+  int rc = plan_from_circuit_impl(spec, units_csv, [&](Program& g) {
+    g.file_off = w.append_program(g, window_div);
+    g.spilled = true;
+    std::vector<StepDesc>().swap(g.steps); std::vector<AndRec>().swap(g.ands); std::vector<XorRec>().swap(g.xors); std::vector<uint32_t>().swap(g.ct_pos);
+  }, &plan);
+  if (rc) return rc;
+  struct PlanOwner { gsv_plan* p; ~PlanOwner() { gsv_plan_destroy(p); } } po{plan};
+  std::vector<uint64_t> off;
+  std::map<const gsv_program*, uint32_t> index;
+  for (const gsv_program* q : plan->owned) {
+    if (!q->prog.spilled) return fail(GSV_ERR_CIRCUIT, "internal: a program was not written to the plan file");
+    index.emplace(q, uint32_t(off.size()));
+    off.push_back(q->prog.file_off);
   }
-  for (const PlanCall& c : p->calls) {
-    const uint32_t hdr[4] = {index[c.prog], uint32_t(c.in_globals.size()), uint32_t(c.out_globals.size()), 0};
-    put(hdr, sizeof hdr);
-    put(c.in_globals.data(), c.in_globals.size() * 4);
-    put(c.out_globals.data(), c.out_globals.size() * 4);
-  }
-  put(p->outputs.data(), p->outputs.size() * 4);
-  ok = ok && std::fflush(fc.f) == 0;
-  std::fclose(fc.f); fc.f = nullptr;
-  if (!ok || std::rename(tmp.c_str(), path) != 0) { std::remove(tmp.c_str()); return fail(GSV_ERR_INVALID, std::string("cannot write ") + path); }
-  return GSV_OK;
+  return w.finish(plan, off, index);
+  GSV_CATCH
 }
 
 int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out) {
@@ -750,6 +826,9 @@ int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out) {
   std::memcpy(&h, take(sizeof h), sizeof h);
   if (bad || std::memcmp(h.magic, PLAN_MAGIC, 8) != 0 || h.rec_sizes != plan_rec_sizes() || h.lds_window_slots != LDS_WINDOW_SLOTS)
     return fail(GSV_ERR_INVALID, std::string(path) + ": not a plan file of this engine build");
+  if (h.table_off > mp.size || h.calls_off > h.table_off || (h.table_off & 15) || (h.calls_off & 15) || uint64_t(h.n_programs) > (mp.size - h.table_off) / 8)
+    return fail(GSV_ERR_INVALID, std::string(path) + ": truncated or inconsistent plan file");
+  const uint64_t* const table = reinterpret_cast<const uint64_t*>(mp.base + h.table_off);
   if (e) HIPCHK(hipSetDevice(e->device));
   const size_t bounce_bytes = 64u << 20;
   struct Bounce {
@@ -770,6 +849,8 @@ int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out) {
   GSV_TRY
   for (uint32_t k = 0; k < h.n_programs; ++k) {
     PlanFileProgram m;
+    if ((table[k] & 15) || table[k] < sizeof(PlanFileHeader) || table[k] > h.calls_off) { bad = true; break; }
+    pos = size_t(table[k]);
     std::memcpy(&m, take(sizeof m), sizeof m);
     if (bad) break;
     gsv_program* q = new gsv_program();
@@ -855,6 +936,7 @@ int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out) {
     q->loaded_image_bytes = d.bytes;
   }
   if (e) { HIPCHK(hipStreamSynchronize(e->stream)); plan->device = e->device; }
+  pos = size_t(h.calls_off);
   for (uint32_t k = 0; k < h.n_calls && !bad; ++k) {
     uint32_t hdr[4];
     std::memcpy(hdr, take(sizeof hdr), sizeof hdr);

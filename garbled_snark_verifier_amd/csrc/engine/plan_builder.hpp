@@ -51,7 +51,7 @@ inline size_t plan_compile_threads() {  // GSV_COMPILE_THREADS, default: the har
 }
 
 // A small bounded worker pool: unit programs are compiled while the driver keeps recording (the recording is serial, a
-// compilation takes about as long as recording the unit).  submit() blocks while 2 x threads jobs are pending, which bounds the
+// compilation takes about as long as recording the unit).  submit() blocks while as many jobs as threads are pending, which bounds the
 // traces and compiler temporaries in flight; the first exception is rethrown by wait().
 class CompilePool {
  public:
@@ -81,7 +81,7 @@ class CompilePool {
   }
   void submit(std::function<void()> job) {
     std::unique_lock<std::mutex> lk(mu_);
-    cv_done_.wait(lk, [this] { return q_.size() < 2 * th_.size(); });
+    cv_done_.wait(lk, [this] { return q_.size() < th_.size(); });
     q_.push_back(std::move(job));
     cv_.notify_one();
   }
@@ -113,6 +113,9 @@ struct PlanUnitCache {
   std::unique_ptr<CompilePool> pool;  // set by compile_in_background
   CompileOptions bg_opt;
   bool bg_drop = false;
+  // Called (on the compiling thread) with every program the builder compiles, right after it exists: gsv_plan_build_file writes the
+  // records to the plan file there and drops them, so that the host never holds more than the programs still being compiled.
+  std::function<void(Program&)> sink;
 };
 
 // A glue segment in canonical form: operands are either a wire defined earlier in the same segment (its definition index:
@@ -241,9 +244,11 @@ class PlanRecordMode final : public CircuitMode, public UnitHook {
       if (uc.pool) {
         const CompileOptions opt = uc.bg_opt;
         const bool drop = uc.bg_drop;
-        uc.pool->submit([pu, opt, drop] {
+        PlanUnitCache* ucp = &uc;  // outlives the pool it owns
+        uc.pool->submit([pu, opt, drop, ucp] {
           pu->compiled.reset(new Program(compile_program(pu->trace, pu->inputs, pu->outputs, {}, opt)));
           if (drop) pu->trace = Trace();
+          if (ucp->sink) ucp->sink(*pu->compiled);
         });
       }
     } catch (...) {
@@ -601,7 +606,12 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
   for (uint32_t w = 2; w < nw; ++w) if (crossing[w]) ++bp.n_crossing_wires;
   if (getenv("GSV_PLAN_DEBUG")) std::fprintf(stderr, "plan: %zu segments, %u wires cross calls, %u global ids after recycling (%u inputs pinned)\n", m.segments.size(), bp.n_crossing_wires, next_global, bp.n_inputs);
   for (uint32_t w : outputs) bp.outputs.push_back(w == 0 ? PLAN_WIRE_FALSE : w == 1 ? PLAN_WIRE_TRUE : global_of[w]);
-  parallel_for_programs(bp.programs.size(), [&](size_t i) { if (!done[i]) bp.programs[i] = compile_program(bp.traces[i], bp.prog_inputs[i], bp.prog_outputs[i], {}, opt); });
+  const std::function<void(Program&)>& sink = m.cache()->sink;
+  parallel_for_programs(bp.programs.size(), [&](size_t i) {
+    if (done[i]) return;
+    bp.programs[i] = compile_program(bp.traces[i], bp.prog_inputs[i], bp.prog_outputs[i], {}, opt);
+    if (sink) { bp.traces[i] = Trace(); sink(bp.programs[i]); }
+  });
   return bp;
 }
 

@@ -142,6 +142,10 @@ struct Program {
   uint32_t and_depth = 0, n_and_steps = 0, max_step_width = 0;
   uint32_t peak_live = 0;
   uint64_t reads_lds = 0, reads_hbm = 0, writes_lds = 0, writes_hbm = 0;  // label accesses per replay by location
+  // Set when the records (steps, ands, xors, ct_pos) were written to a plan file as soon as the program existed and dropped from
+  // memory (gsv_plan_build_file): the offset of the program's block in that file.  The metadata above stays.
+  uint64_t file_off = 0;
+  bool spilled = false;
 };
 
 struct CompileOptions {

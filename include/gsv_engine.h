@@ -146,6 +146,10 @@ int gsv_plan_image_bytes(const gsv_plan* p, uint64_t* bytes, uint64_t* n_program
  * be saved again.  With e == NULL the plan is a complete host copy.  The file is specific to the engine build that wrote it. */
 int gsv_plan_save(const gsv_plan* p, const char* path);
 int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out);
+/* gsv_plan_from_circuit + gsv_plan_save without ever holding the plan: each program is appended to the file by the worker that
+ * compiled it and its records are released at once, so the build's host memory is the programs still being compiled (the verifier:
+ * ~25 GB instead of ~54 GB).  Needs one image per program (GSV_PLAN_WINDOW_DIV=2|4).  Then gsv_plan_load(path, engine). */
+int gsv_plan_build_file(const char* circuit_spec, const char* units_csv, const char* path);
 
 /* Call operands naming the constant wires instead of a global wire. */
 #define GSV_PLAN_WIRE_FALSE 0xFFFFFFFEu

@@ -168,3 +168,30 @@ def test_plan_file_roundtrip_without_device(tmp_path):
         gsv.Plan.load(b)
     with pytest.raises(gsv.GsvError):
         gsv.Plan.load(os.path.join(str(tmp_path), "missing.gsvplan"))
+    # an offset table that points outside the file / into the header is refused
+    import struct
+    tab = struct.unpack_from("<Q", raw, 8 + 6 * 4 + 3 * 8 + 8)[0]
+    for evil in (len(raw) + 16, 0):
+        open(b, "wb").write(raw[:tab] + struct.pack("<Q", evil) + raw[tab + 8:])
+        with pytest.raises(gsv.GsvError):
+            gsv.Plan.load(b)
+
+
+def test_plan_built_straight_to_a_file(tmp_path):
+    """gsv_plan_build_file: the plan is never held — each program is appended to the file by the worker that compiled it (warm-up
+    recorders and compile pool running) and dropped.  Loaded back it is the plan gsv_plan_from_circuit builds in memory: same calls,
+    same counts, same program images; the in-memory plan saved by gsv_plan_save loads to the same thing; no temp file is left."""
+    import garbled_snark_verifier_amd as gsv
+    units = ["fq12::mul_montgomery", "fq12::square_montgomery"]
+    a, b = os.path.join(str(tmp_path), "a.gsvplan"), os.path.join(str(tmp_path), "b.gsvplan")
+    gsv.Plan.build_file("fq12_mix", units, a, window_div=4)
+    ref = gsv.Plan.from_circuit("fq12_mix", units, window_div=4)
+    ref.save(b)
+    pa, pb = gsv.Plan.load(a), gsv.Plan.load(b)
+    for q in (pa, pb):
+        assert q.info == ref.info and q.image_bytes() == ref.image_bytes() and (q.call_info() == ref.call_info()).all() and q.wire_file() == ref.wire_file()
+    assert os.path.getsize(a) == os.path.getsize(b) and not [f for f in os.listdir(str(tmp_path)) if ".tmp." in f]
+    with pytest.raises(ValueError):
+        gsv.Plan.build_file("fq12_mix", units, a, window_div=1)
+    with pytest.raises(gsv.GsvError):
+        gsv.Plan.build_file("fq12_mix", units, os.path.join(str(tmp_path), "no_such_dir", "x.gsvplan"))
