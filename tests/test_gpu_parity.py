@@ -794,14 +794,23 @@ VERIFIER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cycl
 
 
 @pytest.fixture(scope="module")
-def compressed_verifier_plan():
+def compressed_verifier_plan(engine):
     """The plan of the reference's headline circuit, groth16_verify_compressed (groth16.rs:250-268), built ONCE for the tests below
-    (what bench.py builds: one image per program, compiled for a quarter of the LDS window; ~100 s of host time and ~50 GB of host
-    memory on the GPU box)."""
+    the way bench.py gets it on a fresh machine: gsv_plan_build_file (warm-up recorders beside the driver, every program written to the
+    plan file by the worker that compiled it; one image per program, compiled for a quarter of the LDS window), then gsv_plan_load
+    streams the 41 GB of records into the GPU's memory — ~55 s and ~20 GB of host memory on the GPU box."""
+    import shutil
+    import tempfile
     import garbled_snark_verifier_amd as gsv
     # ONE public input: the reference's own benchmark configuration (examples/groth16_garble.rs:107-110, groth16_cut_and_choose.rs:116-119)
     case = json.load(open(os.path.join(os.path.dirname(GOLDEN), "groth16_verify_compressed_1pub_golden.json")))
-    plan = gsv.Plan.from_circuit(case["circuit"], VERIFIER_UNITS + ["fp254::exp_chunk"], window_div=4)
+    d = tempfile.mkdtemp(prefix="gsv_test_plan_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        path = os.path.join(d, "verifier.gsvplan")
+        gsv.Plan.build_file(case["circuit"], VERIFIER_UNITS + ["fp254::exp_chunk"], path, window_div=4)
+        plan = gsv.Plan.load(path, engine)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)  # the records are in HBM now
     yield case, plan
     plan.close()
 
