@@ -495,26 +495,32 @@ def run_verifier(args):
                 ok = fixture_ok(e2e.ct_hashes[0], out[0])
                 result["ciphertext_hash_match"] = ok
                 gbs = n_ct * Be * 16 / dt / 1e9
-                groups = (Be + 3) // 4
-                workers = args.mac_threads or max(1, min(groups, 32, os.cpu_count() or 1))
-                # what ONE host core MACs with four chains interleaved (the drain's inner loop), on buffers that sit in its cache
-                bufs = [np.full(4 << 20, 17 * k + 1, np.uint8) for k in range(4)]
-                mac_core = 0.0
-                for _ in range(5):
-                    t1 = time.perf_counter()
-                    gsv.cbcmac_many(bufs)
-                    mac_core = max(mac_core, 4 * (4 << 20) / 16 / (time.perf_counter() - t1))
+                # the drain's grouping (engine.cpp gsv_drain::group_for): sixteen chains per worker on VAES hosts from 128 instances up, else four
+                chains = 16 if gsv.cbcmac_chains_per_step() == 16 and Be >= 128 else 4
+                groups = (Be + chains - 1) // chains
+                workers = args.mac_threads or max(1, min(groups, 8 if chains == 16 else 32, os.cpu_count() or 1))
+                # what ONE host core MACs (the drain's inner loop) with four chains interleaved and with as many as this host's widest form takes
+                mac_rate = {}
+                for nch in sorted({4, gsv.cbcmac_chains_per_step()}):
+                    bufs = [np.full(1 << 20, (17 * k + 1) & 255, np.uint8) for k in range(nch)]
+                    for _ in range(5):
+                        t1 = time.perf_counter()
+                        gsv.cbcmac_many(bufs)
+                        mac_rate[nch] = max(mac_rate.get(nch, 0.0), nch * (1 << 20) / 16 / (time.perf_counter() - t1))
+                mac_core = max(mac_rate.values())
                 cores = quota or float(os.cpu_count() or 16)
                 result["e2e_with_commitment"] = {
                     "value": gates * Be / dt, "unit": "gates/s", "instances": Be, "instances_per_workgroup": e2e.sess.instances_per_workgroup, "seconds": dt, "passes": 1,
-                    "ciphertext_gb_per_s": gbs, "ciphertext_gb_total": n_ct * Be * 16 / 1e9, "mac_workers": workers, "mac_chains_per_worker": 4, "host_cores_quota": quota,
+                    "ciphertext_gb_per_s": gbs, "ciphertext_gb_total": n_ct * Be * 16 / 1e9, "mac_workers": workers, "mac_chains_per_worker": chains, "host_cores_quota": quota,
                     "windows": si["n_windows"], "window_ct_records": si["window_ct_records"], "distinct_macs": len(set(e2e.ct_hashes)),
                     "instance0": {"seed": case["seed"], "ct_hash": e2e.ct_hashes[0].hex(), "fixture_ct_hash": case["ct_hash"], "match": ok},
                     "per_node_ceiling_8gpus": {"gates_per_s": min(8 * gates * Be / dt, cores * mac_core / f_nf), "pcie_bound_gates_per_s": 8 * gates * Be / dt,
                                                "mac_bound_gates_per_s": cores * mac_core / f_nf, "mac_blocks_per_s_per_core": mac_core,
-                                               "note": "8 x this GPU's PCIe-bound rate, capped by the host's MAC capacity: one core advances mac_blocks_per_s_per_core CBC-MAC blocks/s with four "
-                                                       "chains interleaved (measured in this run on cache-resident buffers) and the stream holds f_nf = %.4f blocks per gate; cores = this "
-                                                       "container's cpu.max quota (%s) or the visible CPUs" % (f_nf, quota)},
+                                               "mac_blocks_per_s_per_core_by_chains": {str(k): v for k, v in mac_rate.items()},
+                                               "note": "8 x this GPU's PCIe-bound rate, capped by the host's MAC capacity: one core advances mac_blocks_per_s_per_core CBC-MAC blocks/s with "
+                                                       "its chains interleaved (4 per step with AES-NI, 16 with VAES + AVX-512; measured in this run on cache-resident buffers; the drain "
+                                                       "groups sixteen from 128 instances up) and the stream holds f_nf = %.4f blocks per gate; cores = this container's cpu.max quota (%s) "
+                                                       "or the visible CPUs" % (f_nf, quota)},
                     "sample": "one WHOLE pass of the circuit (%d gates, %d ciphertexts per instance) for %d instances: garbled, every ciphertext drained over PCIe and CBC-MAC'ed per instance "
                               "on the host (gsv_session_garble_streaming); instance 0 = the fixture's seed, hash + output label compared with the oracle's flat-stream fixture" % (gates, n_ct, Be)}
                 log("bench.py: e2e with commitment %.3g gates/s (%.1f GB/s of ciphertexts, %.1f s), fixture hash %s" % (gates * Be / dt, gbs, dt, "ok" if ok else "MISMATCH"))

@@ -79,7 +79,7 @@ EXPORTS = [
     "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_cbcmac_update_many", "gsv_commit_labels",
     "gsv_plan_from_circuit", "gsv_plan_io", "gsv_plan_recorder_create", "gsv_plan_recorder_destroy", "gsv_plan_recorder_allocate_wire",
     "gsv_plan_recorder_declare_input", "gsv_plan_recorder_push_gates", "gsv_plan_recorder_call", "gsv_plan_recorder_finish", "gsv_plan_create", "gsv_plan_destroy", "gsv_plan_add_call", "gsv_plan_finish", "gsv_plan_counts", "gsv_session_create_plan", "gsv_session_create_plan_ex",
-    "gsv_session_garble_streaming", "gsv_session_garble_streaming_calls", "gsv_plan_call_info", "gsv_plan_image_bytes", "gsv_plan_wire_file", "gsv_plan_save", "gsv_plan_load", "gsv_plan_build_file", "gsv_session_evaluate_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
+    "gsv_session_garble_streaming", "gsv_session_garble_streaming_calls", "gsv_plan_call_info", "gsv_plan_image_bytes", "gsv_plan_wire_file", "gsv_plan_save", "gsv_plan_load", "gsv_plan_build_file", "gsv_cbcmac_chains_per_step", "gsv_session_evaluate_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
     "gsv_session_create_plan_opts", "gsv_session_plan_schedule_info", "gsv_session_plan_window", "gsv_session_set_unchecked_slices",
 ]
 
@@ -205,6 +205,11 @@ def cbcmac_many(streams, states=None):
     ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
     _chk(lib().gsv_cbcmac_update_many(_p(st), ptrs, len(arrs), n))
     return [bytes(st[i]) for i in range(len(arrs))]
+
+
+def cbcmac_chains_per_step():
+    """How many chains one host thread advances side by side (16 with VAES + AVX-512, 4 with AES-NI)."""
+    return int(lib().gsv_cbcmac_chains_per_step())
 
 
 class Program:

@@ -1375,9 +1375,14 @@ struct gsv_drain {
     void release(hipStream_t st) { { std::lock_guard<std::mutex> lk(mu); idle.push_back(st); } cv.notify_one(); }
   } copy_gate;
   std::vector<hipStream_t> copy_streams;
-  static constexpr int GROUP = 4;  // instances whose MAC chains one worker advances side by side (CbcMacHost::update_interleaved)
+  // Instances whose MAC chains one worker advances side by side: four (AES-NI, CbcMacHost::update_interleaved) or, on hosts with
+  // VAES + AVX-512 and sessions with at least 128 instances (eight workers' worth), sixteen (update_interleaved16_vaes: one core
+  // then MACs ~3 x as many blocks per second, so a node's GPUs need a third of the host cores for their commitments).
+  static constexpr int GROUP_MAX = 16;
+  static int group_for(size_t n_inst) { return CbcMacHost::have_vaes() && n_inst >= 128 ? 16 : 4; }
+  int group = 4;
   struct Worker {
-    void* pinned[2][GROUP] = {};  // two sets of pinned chunk buffers: copy set j+1 while set j is hashed
+    void* pinned[2][GROUP_MAX] = {};  // two sets of pinned chunk buffers: copy set j+1 while set j is hashed
     hipEvent_t done = nullptr;    // blocking-sync event: a worker waiting for its copies sleeps instead of spinning on a core
   };
   std::vector<Worker> workers;
@@ -1392,12 +1397,12 @@ struct gsv_drain {
   }
 };
 static void destroy_drain(gsv_drain* d) { delete d; }
-static int ensure_drain(gsv_session* s, size_t T, uint64_t seg_records) {
+static int ensure_drain(gsv_session* s, size_t T, uint64_t seg_records, int group) {
   // records per chunk: 16 MiB by default — measured on the MI355X box (tools/d2h_bw.py) a D2H copy stream moves 39-48 GB/s in 4 MiB
   // pieces and 54-57 GB/s from 16 MiB up; the buffers are page-locked once per session, not per call as in round 1
   const uint64_t chunk_mb = getenv("GSV_DRAIN_CHUNK_MB") ? std::max(1, atoi(getenv("GSV_DRAIN_CHUNK_MB"))) : 16;
   const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(seg_records, 1), (chunk_mb << 20) / 16);
-  if (s->drain && s->drain->workers.size() >= T && s->drain->chunk == chunk) return GSV_OK;
+  if (s->drain && s->drain->workers.size() >= T && s->drain->chunk == chunk && s->drain->group == group) return GSV_OK;
   std::vector<CbcMacHost> keep;
   if (s->drain) keep = s->drain->macs;
   destroy_drain(s->drain);
@@ -1405,6 +1410,7 @@ static int ensure_drain(gsv_session* s, size_t T, uint64_t seg_records) {
   gsv_drain& d = *s->drain;
   d.macs = keep;
   d.chunk = chunk;
+  d.group = group;
   // Copy sets in flight at once.  Round 3, whole Miller-loop pass at 64 instances (tools/e2e_plan_drain.py, profiles/r03_e2e/): 1 set
   // 48 GB/s, 2-4 sets 50 GB/s, 6 sets 40 GB/s, 12 sets 41 GB/s — the link is full with two or three 16 MiB copies queued.
   const int n_copy_streams = getenv("GSV_DRAIN_COPIES") ? std::max(1, atoi(getenv("GSV_DRAIN_COPIES"))) : 3;
@@ -1416,7 +1422,7 @@ static int ensure_drain(gsv_session* s, size_t T, uint64_t seg_records) {
   }
   d.workers.resize(T);
   for (gsv_drain::Worker& w : d.workers) {
-    for (auto& set : w.pinned) for (void*& q : set) ok = ok && hipHostMalloc(&q, chunk * 16, hipHostMallocDefault) == hipSuccess;
+    for (auto& set : w.pinned) for (int g = 0; g < group; ++g) ok = ok && hipHostMalloc(&set[g], chunk * 16, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&w.done, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
   }
   if (!ok) { destroy_drain(s->drain); s->drain = nullptr; return fail(GSV_ERR_DEVICE, "cannot allocate the drain buffers"); }
@@ -1455,16 +1461,16 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   const uint64_t first = s->plan ? pw0 : 0, total = s->plan ? pw1 : s->replays;
   const bool new_pass = s->plan ? c0 == 0 : true;
   const size_t n_inst = s->n_inst;
-  constexpr size_t GROUP = size_t(gsv_drain::GROUP);
+  const size_t GROUP = size_t(gsv_drain::group_for(n_inst));
   const size_t n_groups = (n_inst + GROUP - 1) / GROUP;
-  // a worker MACs GROUP streams side by side at ~3e8 blocks/s (AES-NI): a dozen of them keep up with the PCIe link, 32 leave
-  // room for slow cores without page-locking more than 4 GB of chunk buffers
-  size_t T = n_threads > 0 ? size_t(n_threads) : std::max<size_t>(1, std::min<size_t>(std::min<size_t>(n_groups, 32), std::thread::hardware_concurrency()));
+  // a worker MACs GROUP streams side by side at ~3e8 blocks/s (four chains, AES-NI) or ~1e9 (sixteen, VAES): a dozen / four of them keep
+  // up with the PCIe link, 32 leave room for slow cores without page-locking more than 4 GB (16 GB) of chunk buffers
+  size_t T = n_threads > 0 ? size_t(n_threads) : std::max<size_t>(1, std::min<size_t>(std::min<size_t>(n_groups, GROUP == 16 ? 8 : 32), std::thread::hardware_concurrency()));
   T = std::min(T, n_groups);
   HIPCHK(hipSetDevice(s->e->device));
   const uint64_t seg_records = seg * n_ct;  // per instance
   if (!s->ct_gate && seg_records) DEVALLOC(&s->ct_gate, n_inst * seg_records * 16, "the gate-order ciphertext buffer");
-  { int rc = ensure_drain(s, T, seg_records); if (rc) return rc; }
+  { int rc = ensure_drain(s, T, seg_records, int(GROUP)); if (rc) return rc; }
   gsv_drain& dr = *s->drain;
   if (new_pass || dr.macs.size() != n_inst) dr.macs.assign(n_inst, CbcMacHost());  // a new pass starts from h = 0; later slices chain
   std::vector<CbcMacHost>& macs = dr.macs;
@@ -1503,14 +1509,10 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
           if (!copy(0, 0)) { err = 1; break; }
           for (uint64_t off = 0; off < n; off += chunk, b ^= 1) {
             const uint64_t m = std::min(chunk, n - off);
-            if (ng == GROUP) {
-              CbcMacHost* const mp[GROUP] = {&macs[i0], &macs[i0 + 1], &macs[i0 + 2], &macs[i0 + 3]};
-              const uint8_t* const cp[GROUP] = {static_cast<const uint8_t*>(w.pinned[b][0]), static_cast<const uint8_t*>(w.pinned[b][1]),
-                                                static_cast<const uint8_t*>(w.pinned[b][2]), static_cast<const uint8_t*>(w.pinned[b][3])};
-              CbcMacHost::update_interleaved<int(GROUP)>(mp, cp, m);
-            } else {
-              for (size_t g = 0; g < ng; ++g) macs[i0 + g].update(static_cast<const uint8_t*>(w.pinned[b][g]), m);
-            }
+            CbcMacHost* mp[gsv_drain::GROUP_MAX];
+            const uint8_t* cp[gsv_drain::GROUP_MAX];
+            for (size_t g = 0; g < ng; ++g) { mp[g] = &macs[i0 + g]; cp[g] = static_cast<const uint8_t*>(w.pinned[b][g]); }
+            CbcMacHost::update_many(mp, cp, ng, m);  // sixteen / four chains per step, a ragged last group chain by chain
             if (dir)
               for (size_t g = 0; g < ng; ++g)
                 if (std::fwrite(w.pinned[b][g], 16, m, files[i0 + g]) != m) { err = 2; break; }
@@ -1796,6 +1798,7 @@ int gsv_cbcmac_update(uint8_t state[16], const uint8_t* cts, uint64_t n_records)
   mac.digest(state);
   return GSV_OK;
 }
+int gsv_cbcmac_chains_per_step(void) { return CbcMacHost::have_vaes() ? 16 : GSV_HOST_AESNI ? 4 : 1; }
 int gsv_cbcmac_update_many(uint8_t* states, const uint8_t* const* cts, size_t n_chains, uint64_t n_records) {
   if ((!states || !cts) && n_chains) return fail(GSV_ERR_INVALID, "null argument");
   for (size_t i = 0; i < n_chains; ++i) if (!cts[i] && n_records) return fail(GSV_ERR_INVALID, "null stream");
@@ -1807,13 +1810,10 @@ int gsv_cbcmac_update_many(uint8_t* states, const uint8_t* const* cts, size_t n_
     for (int k = 0; k < 16; ++k) first[k] = cts[i][k] ^ states[16 * i + k];
     macs[i].update(first, 1);
   }
-  size_t i = 0;
-  for (; i + 4 <= n_chains; i += 4) {
-    CbcMacHost* const mp[4] = {&macs[i], &macs[i + 1], &macs[i + 2], &macs[i + 3]};
-    const uint8_t* const cp[4] = {cts[i] + 16, cts[i + 1] + 16, cts[i + 2] + 16, cts[i + 3] + 16};
-    CbcMacHost::update_interleaved<4>(mp, cp, n_records - 1);
-  }
-  for (; i < n_chains; ++i) macs[i].update(cts[i] + 16, n_records - 1);
+  std::vector<CbcMacHost*> mp(n_chains);
+  std::vector<const uint8_t*> cp(n_chains);
+  for (size_t i = 0; i < n_chains; ++i) { mp[i] = &macs[i]; cp[i] = cts[i] + 16; }
+  CbcMacHost::update_many(mp.data(), cp.data(), n_chains, n_records - 1);  // sixteen chains per step with VAES, else four
   for (size_t k = 0; k < n_chains; ++k) macs[k].digest(states + 16 * k);
   return GSV_OK;
 }

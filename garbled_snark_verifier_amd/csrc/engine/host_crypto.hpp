@@ -10,6 +10,7 @@
 //                      only the stand-alone harness needs it: a Rust host hands labels in directly.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #if defined(__AES__) && defined(__SSE2__)
@@ -149,6 +150,64 @@ class CbcMacHost {
 #else
     for (int g = 0; g < G; ++g) mac[g]->update(cts[g], n);
 #endif
+  }
+  // Sixteen chains per step on cores with VAES + AVX-512 (Zen 4 / Zen 5, Ice Lake and later): four ZMM registers of four 128-bit
+  // lanes each, every lane an independent chain — the same ten dependent AESENC per block, four blocks per instruction.  One core
+  // then MACs what four did (bench.py reports both rates); the drain uses it when a session has enough instances to give every
+  // worker sixteen streams (engine.cpp).  All chains advance by the same n records.  Returns false (and does nothing) without VAES.
+  static bool have_vaes() {
+#if GSV_HOST_AESNI
+    static const bool v = __builtin_cpu_supports("vaes") && __builtin_cpu_supports("avx512f") && !getenv("GSV_NO_VAES");
+    return v;
+#else
+    return false;
+#endif
+  }
+#if GSV_HOST_AESNI
+  __attribute__((target("vaes,avx512f"))) static void update_interleaved16_vaes(CbcMacHost* const* mac, const uint8_t* const* cts, uint64_t n) {
+    const AesTables& t = AesTables::fixed_key();
+    __m512i rk[11], h[4];
+    for (int r = 0; r < 11; ++r) rk[r] = _mm512_broadcast_i32x4(_mm_loadu_si128(reinterpret_cast<const __m128i*>(t.rk_bytes + 16 * r)));
+    auto gather4 = [](const uint8_t* p0, const uint8_t* p1, const uint8_t* p2, const uint8_t* p3) __attribute__((target("vaes,avx512f"))) {
+      __m512i v = _mm512_castsi128_si512(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p0)));
+      v = _mm512_inserti32x4(v, _mm_loadu_si128(reinterpret_cast<const __m128i*>(p1)), 1);
+      v = _mm512_inserti32x4(v, _mm_loadu_si128(reinterpret_cast<const __m128i*>(p2)), 2);
+      return _mm512_inserti32x4(v, _mm_loadu_si128(reinterpret_cast<const __m128i*>(p3)), 3);
+    };
+    for (int z = 0; z < 4; ++z) h[z] = gather4(mac[4 * z]->h_, mac[4 * z + 1]->h_, mac[4 * z + 2]->h_, mac[4 * z + 3]->h_);
+    for (uint64_t i = 0; i < n; ++i) {
+      __m512i s[4];
+#pragma GCC unroll 4
+      for (int z = 0; z < 4; ++z)
+        s[z] = _mm512_xor_si512(_mm512_xor_si512(h[z], gather4(cts[4 * z] + 16 * i, cts[4 * z + 1] + 16 * i, cts[4 * z + 2] + 16 * i, cts[4 * z + 3] + 16 * i)), rk[0]);
+#pragma GCC unroll 16
+      for (int r = 1; r < 10; ++r) {
+#pragma GCC unroll 4
+        for (int z = 0; z < 4; ++z) s[z] = _mm512_aesenc_epi128(s[z], rk[r]);
+      }
+#pragma GCC unroll 4
+      for (int z = 0; z < 4; ++z) h[z] = _mm512_aesenclast_epi128(s[z], rk[10]);
+    }
+    for (int z = 0; z < 4; ++z) {
+      _mm_storeu_si128(reinterpret_cast<__m128i*>(mac[4 * z]->h_), _mm512_extracti32x4_epi32(h[z], 0));
+      _mm_storeu_si128(reinterpret_cast<__m128i*>(mac[4 * z + 1]->h_), _mm512_extracti32x4_epi32(h[z], 1));
+      _mm_storeu_si128(reinterpret_cast<__m128i*>(mac[4 * z + 2]->h_), _mm512_extracti32x4_epi32(h[z], 2));
+      _mm_storeu_si128(reinterpret_cast<__m128i*>(mac[4 * z + 3]->h_), _mm512_extracti32x4_epi32(h[z], 3));
+    }
+  }
+#endif
+  // `g` chains (any number) advanced by n records each: sixteen at a time with VAES, four at a time with AES-NI, the rest one by one
+  static void update_many(CbcMacHost* const* mac, const uint8_t* const* cts, size_t g, uint64_t n) {
+    size_t i = 0;
+#if GSV_HOST_AESNI
+    if (have_vaes()) for (; i + 16 <= g; i += 16) update_interleaved16_vaes(mac + i, cts + i, n);
+#endif
+    for (; i + 4 <= g; i += 4) {
+      CbcMacHost* const mp[4] = {mac[i], mac[i + 1], mac[i + 2], mac[i + 3]};
+      const uint8_t* const cp[4] = {cts[i], cts[i + 1], cts[i + 2], cts[i + 3]};
+      update_interleaved<4>(mp, cp, n);
+    }
+    for (; i < g; ++i) mac[i]->update(cts[i], n);
   }
   void digest(uint8_t out[16]) const { std::memcpy(out, h_, 16); }
 

@@ -294,6 +294,8 @@ int gsv_cbcmac_update(uint8_t state[16], const uint8_t* cts, uint64_t n_records)
  * a time side by side — one chain is bound by the latency of its dependent AES rounds, four fill the AES unit — which is how the
  * engine's own drain hashes the instances' streams. */
 int gsv_cbcmac_update_many(uint8_t* states, const uint8_t* const* cts, size_t n_chains, uint64_t n_records);
+/* Chains gsv_cbcmac_update_many (and a session's drain) advances per step on this host: 16 with VAES + AVX-512, 4 with AES-NI, else 1. */
+int gsv_cbcmac_chains_per_step(void);
 /* AesLabelCommitHasher: AES_K(label) for n labels (cut_and_choose/mod.rs:41-48). */
 int gsv_commit_labels(const uint8_t* labels, uint64_t n, uint8_t* out);
 

@@ -5,6 +5,8 @@ the oracle.  No GPU compute here; the GPU parity tests are in test_gpu_parity.py
 import ctypes as C
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -338,13 +340,23 @@ def test_step_barrier_isa_check():
             assert sum(1 for i, t in enumerate(ins) if t.startswith("buffer_wbl2") and ins[i + 1].startswith("s_waitcnt vmcnt(0)")) >= 1, name
 
 
-def test_interleaved_cbcmac_equals_single_chains():
-    """gsv_cbcmac_update_many / CbcMacHost::update_interleaved (the drain hashes four instances' streams side by side per host
-    thread): every chain equals the single-chain CBC-MAC of the oracle, for chain counts around the group size, with and
-    without a starting state, and across two calls (chaining)."""
+@pytest.mark.parametrize("no_vaes", [False, True])
+def test_interleaved_cbcmac_equals_single_chains(no_vaes):
+    """gsv_cbcmac_update_many / CbcMacHost::update_many (the drain hashes four instances' streams side by side per host thread — sixteen
+    where the host has VAES + AVX-512, update_interleaved16_vaes): every chain equals the single-chain CBC-MAC of the oracle, for chain
+    counts around both group sizes, with and without a starting state, and across two calls (chaining).  GSV_NO_VAES=1 (read once per
+    process, hence the child) pins the AES-NI path on a VAES host."""
+    if no_vaes:
+        env = dict(os.environ, GSV_NO_VAES="1")
+        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_engine_host as t, garbled_snark_verifier_amd as gsv; "
+                "assert gsv.cbcmac_chains_per_step() <= 4; t.test_interleaved_cbcmac_equals_single_chains(False)" % (ROOT, os.path.join(ROOT, "tests")))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return
     import garbled_snark_verifier_amd as gsv
+    assert gsv.cbcmac_chains_per_step() in (1, 4, 16)
     rng = np.random.default_rng(4)
-    for n_chains in (1, 3, 4, 5, 8, 11):
+    for n_chains in (1, 3, 4, 5, 8, 11, 16, 17, 37):
         for n_rec in (1, 2, 257):
             streams = [rng.integers(0, 256, n_rec * 16, dtype=np.uint8) for _ in range(n_chains)]
             got = gsv.cbcmac_many(streams)
