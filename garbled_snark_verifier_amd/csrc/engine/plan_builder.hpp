@@ -110,12 +110,12 @@ struct PlanUnitCache {
   std::condition_variable cv;
   std::unordered_map<std::string, int> index;
   std::vector<std::unique_ptr<PlanUnit>> units;
-  std::unique_ptr<CompilePool> pool;  // set by compile_in_background
-  CompileOptions bg_opt;
-  bool bg_drop = false;
   // Called (on the compiling thread) with every program the builder compiles, right after it exists: gsv_plan_build_file writes the
   // records to the plan file there and drops them, so that the host never holds more than the programs still being compiled.
   std::function<void(Program&)> sink;
+  CompileOptions bg_opt;
+  bool bg_drop = false;
+  std::unique_ptr<CompilePool> pool;  // set by compile_in_background; declared last: destroyed (its workers joined) before what the jobs use
 };
 
 // A glue segment in canonical form: operands are either a wire defined earlier in the same segment (its definition index:

@@ -37,4 +37,4 @@ for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recurs
     os.replace(f, os.path.join(out, "kernel_stats.csv"))
 PY
 find $OUT -name "*.csv" -size +4M -delete
-tail -c 600 $OUT/bench_profiled.json; tail -3 $OUT/bench_fetch.err $OUT/bench_write.err
+tail -c 600 $OUT/bench_profiled.json; tail -n 3 $OUT/bench_fetch.err; tail -n 3 $OUT/bench_write.err
