@@ -1078,7 +1078,7 @@ int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_i
         std::memset(&d, 0, sizeof d);
         d.steps = s->call_dev[k].dp.steps; d.ands = s->call_dev[k].dp.ands; d.xors = s->call_dev[k].dp.xors;
         d.gid_off = c.gid_off; d.ct_off = s->plan_retain ? c.ct_off : c.ct_off - w.ct0;
-        d.w_base = base; d.n_steps = g.n_steps;
+        d.w_base = base; d.n_steps = g.n_steps; d.and_terms = g.and_terms;
         d.pre_off = uint32_t(csrc.size());
         if (base != 0)  // the call's own copies of the constant labels (FALSE, TRUE, the all-zero label) in front of its scratch region
           for (uint32_t q = 0; q < SLOT_FIRST_INPUT; ++q) { csrc.push_back(q); cdst.push_back(base + q); }
@@ -1257,6 +1257,7 @@ static int launch(gsv_session* s, uint64_t gate_id_base, bool eval, uint64_t rep
   ka.n_fb = uint32_t(g.fb_src_slot.size()); ka.fb_stage_base = g.fb_stage_base;
   ka.n_instances = uint32_t(s->n_inst);
   ka.hasher = uint32_t(s->hasher);
+  ka.and_terms = g.and_terms;
   ka.step_clock = static_cast<unsigned long long*>(s->step_clock);
   ka.instances_per_wg = s->ni;
   if (const char* dg = getenv("GSV_DIAG")) ka.diag = uint32_t(atoi(dg));  // timing experiments (libgsv_engine_diag.so only): outputs are wrong when set
@@ -1719,7 +1720,9 @@ int gsv_program_step_stats(const gsv_program* p, uint32_t* out6) {
     for (uint32_t k = 0; k < d.and_cnt; ++k) {
       const AndRec& r = g.ands[d.and_off + k];
       rd(uint32_t(r.w0) & SLOT_MASK); rd(uint32_t(r.w0 >> 21) & SLOT_MASK); rd(uint32_t(r.w0 >> 42) & SLOT_MASK);
-      rd(uint32_t(r.w1) & SLOT_MASK); rd(uint32_t(r.w1 >> 21) & SLOT_MASK); wr(uint32_t(r.w1 >> 42) & SLOT_MASK);
+      rd(uint32_t(r.w1) & SLOT_MASK); rd(uint32_t(r.w1 >> 21) & SLOT_MASK);
+      if (g.and_terms == 4) { rd(uint32_t(r.w1 >> 42) & SLOT_MASK); rd(uint32_t(r.w2) & SLOT_MASK); rd(uint32_t(r.w2 >> 21) & SLOT_MASK); rd(uint32_t(r.w2 >> 42) & SLOT_MASK); wr(uint32_t(r.w3) & SLOT_MASK); }
+      else wr(uint32_t(r.w1 >> 42) & SLOT_MASK);
     }
     for (uint32_t k = 0; k < d.xor_cnt; ++k) {
       const XorRec& r = g.xors[d.xor_off + k];

@@ -27,7 +27,9 @@ struct CallDesc {
   uint32_t pre_off, n_pre;    // KernelArgs::copy_src/copy_dst[pre_off .. +n_pre): absolute slots, globals -> scratch
   uint32_t post_off, n_post;  // scratch -> globals
   uint32_t dep_off, n_deps;   // KernelArgs::deps[dep_off .. +n_deps): window-relative indices (= blockIdx.y) of the calls to wait for
-  uint64_t pad_[3];
+  uint32_t and_terms;         // record form of the call's program: 2 (pack_and) or 4 (pack_and4), program.hpp
+  uint32_t pad0_;
+  uint64_t pad_[2];
 };
 static_assert(sizeof(CallDesc) == 96, "CallDesc layout");
 
@@ -57,6 +59,7 @@ struct KernelArgs {
   uint32_t n_instances;
   uint32_t instances_per_wg;  // 1, 2 or 4 (n needs a program compiled for 1/n of the LDS window)
   uint32_t hasher;            // 0 = AesNiHasher, 1 = Blake3Hasher
+  uint32_t and_terms;         // record form of the program (program launches; window launches take it from the call descriptor): 2 or 4
   unsigned long long* step_clock;  // diagnostics: workgroup 0 stamps the 100 MHz wall clock at the start of every step of the last replay (null = off)
   const CallDesc* calls;  // non-null: window launch, grid.y = calls; steps / ands / xors / n_steps / ct_offset come from calls[blockIdx.y]
   const uint32_t* copy_src;   // wire hand-over lists of the session (absolute slots inside an instance's wire file)

@@ -216,8 +216,11 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   if (cd) {
     ka.steps = cd->steps; ka.ands = cd->ands; ka.xors = cd->xors;
     ka.gid_base += cd->gid_off; ka.ct_offset = cd->ct_off; ka.n_steps = cd->n_steps;
+    ka.and_terms = cd->and_terms;
     w_base = cd->w_base;
   }
+  // record form of this program (program.hpp): up to two or up to four wires per AND input — wave-uniform, the same for every gate of the launch's call
+  const bool four_wire = __builtin_amdgcn_readfirstlane(int(ka.and_terms)) == 4;
   constexpr uint32_t BT = GSV_BLOCK_THREADS / NI;  // threads per instance
   // which instance of this workgroup: wave-uniform (BT is a multiple of 64), so say so — every per-instance base
   // address below then lives in SGPRs instead of costing a VGPR each
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       return *(const glb_u128*)p;
     };
     auto load_and_rec = [&](uint32_t k) -> Rec { return *(const glb_u128*)(and_bytes + size_t(k) * 32u); };      // record k of the AND array, first half
-    auto load_and_hi = [&](uint32_t k) -> u32x2 { if (no_hi) return u32x2{k, 0u}; return *(const glb_u64*)(and_bytes + size_t(k) * 32u + 16u); };  // second half
+    auto load_and_hi = [&](uint32_t k) -> u32x4 { if (no_hi) return u32x4{k, 0u, 0u, 0u}; return *(const glb_u128*)(and_bytes + size_t(k) * 32u + 16u); };  // second half
     // Two record registers in ping-pong: step s consumes one (loaded at the end of step s-2) and, once it is done with it,
     // refills the SAME registers with the record of step s+2.  No in-flight load is ever copied to another register: a copy
     // would make the compiler wait for the load it has just issued at the top of every step (which is what a rotating
@@ -347,17 +350,27 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     u32x4 sdA = load_desc(0), sdB = load_desc(1);
     Rec recA = load_rec(sdA), recB = load_rec(sdB);
     // decoded AND record
-    struct AndOp { uint32_t a1, a2, b1, b2, p, c, t; uint64_t gid; };
-    auto decode_and = [&](const Rec& q, const u32x2& hi) -> AndOp {
+    // two-wire form: a1 a2 b1 b2 p c | gid, type.  four-wire form: a1 a2 a3 a4 b1 b2 | b3 b4 p, c, gid (a3 a4 b3 b4 are only read when four_wire)
+    struct AndOp { uint32_t a1, a2, a3, a4, b1, b2, b3, b4, p, c, t; uint64_t gid; };
+    auto decode_and = [&](const Rec& q, const u32x4& hi) -> AndOp {
       AndOp o;
-      o.a1 = q.x & GSV_SLOT_MASK;
-      o.a2 = ((q.x >> 21) | (q.y << 11)) & GSV_SLOT_MASK;
-      o.b1 = (q.y >> 10) & GSV_SLOT_MASK;
-      o.b2 = q.z & GSV_SLOT_MASK;
-      o.p = ((q.z >> 21) | (q.w << 11)) & GSV_SLOT_MASK;
-      o.c = (q.w >> 10) & GSV_SLOT_MASK;
-      o.t = (q.y >> 31) | ((q.w >> 31) << 1) | (((hi.y >> 8) & 1u) << 2);
-      o.gid = gid_base + (uint64_t(hi.x) | (uint64_t(hi.y & 0xFFu) << 32));
+      const uint32_t s0 = q.x & GSV_SLOT_MASK, s1 = ((q.x >> 21) | (q.y << 11)) & GSV_SLOT_MASK, s2 = (q.y >> 10) & GSV_SLOT_MASK;
+      const uint32_t s3 = q.z & GSV_SLOT_MASK, s4 = ((q.z >> 21) | (q.w << 11)) & GSV_SLOT_MASK, s5 = (q.w >> 10) & GSV_SLOT_MASK;
+      o.a1 = s0; o.a2 = s1;
+      if (four_wire) {
+        o.a3 = s2; o.a4 = s3; o.b1 = s4; o.b2 = s5;
+        o.b3 = hi.x & GSV_SLOT_MASK;
+        o.b4 = ((hi.x >> 21) | (hi.y << 11)) & GSV_SLOT_MASK;
+        o.p = (hi.y >> 10) & GSV_SLOT_MASK;
+        o.c = hi.z & GSV_SLOT_MASK;
+        o.t = (q.y >> 31) | ((q.w >> 31) << 1) | ((hi.y >> 31) << 2);
+        o.gid = gid_base + uint64_t((hi.z >> 21) | (hi.w << 11));
+      } else {
+        o.a3 = o.a4 = o.b3 = o.b4 = 0u;
+        o.b1 = s2; o.b2 = s3; o.p = s4; o.c = s5;
+        o.t = (q.y >> 31) | ((q.w >> 31) << 1) | (((hi.y >> 8) & 1u) << 2);
+        o.gid = gid_base + (uint64_t(hi.x) | (uint64_t(hi.y & 0xFFu) << 32));
+      }
       return o;
     };
     // One AND-family gate spread over LPG lanes (garble: two AES blocks x 4 columns, evaluate: one block x 4 columns).
@@ -371,6 +384,10 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         a_c = wf.ld_word(o.a1, col) ^ wf.ld_word(o.a2, col);
         b_c = wf.ld_word(o.b1, col) ^ wf.ld_word(o.b2, col);
         p_c = wf.ld_word(o.p, col);
+        if (four_wire) {
+          a_c ^= wf.ld_word(o.a3, col) ^ wf.ld_word(o.a4, col);
+          b_c ^= wf.ld_word(o.b3, col) ^ wf.ld_word(o.b4, col);
+        }
       }
       const uint32_t twc = tweak_word(o.gid, col);
       if (!EVAL) {
@@ -384,7 +401,10 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         asm volatile("" ::: "memory");
         if (!blk && !no_store) __builtin_nontemporal_store(ct_c, &CTw[(ct_base + cti) * 4u + col]);
       } else {
-        const uint32_t va = (wf.ld_bit(o.a1) ^ wf.ld_bit(o.a2)) & 1u, vb = (wf.ld_bit(o.b1) ^ wf.ld_bit(o.b2)) & 1u, vp = wf.ld_bit(o.p) & 1u;
+        uint32_t va = wf.ld_bit(o.a1) ^ wf.ld_bit(o.a2), vb = wf.ld_bit(o.b1) ^ wf.ld_bit(o.b2);
+        if (four_wire) { va ^= wf.ld_bit(o.a3) ^ wf.ld_bit(o.a4); vb ^= wf.ld_bit(o.b3) ^ wf.ld_bit(o.b4); }
+        va &= 1u; vb &= 1u;
+        const uint32_t vp = wf.ld_bit(o.p) & 1u;
         const uint32_t ct_c = CTw[(ct_base + cti) * 4u + col];
         const uint32_t h = no_aes ? (a_c ^ twc) : aes128_quad(aes, rkc, a_c ^ twc);
         const uint32_t use_ct = (va ^ alpha_a(t)) & 1u;
@@ -492,6 +512,10 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
             a = lxor(wf.ld(o.a1), wf.ld(o.a2));
             b = lxor(wf.ld(o.b1), wf.ld(o.b2));
             pl = wf.ld(o.p);
+            if (four_wire) {
+              a = lxor(a, lxor(wf.ld(o.a3), wf.ld(o.a4)));
+              b = lxor(b, lxor(wf.ld(o.b3), wf.ld(o.b4)));
+            }
           }
           Label c0, ct{{0, 0, 0, 0}};
           uint32_t vc = 0;
@@ -500,7 +524,10 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
             else if (HASH == 1) garble_and_blake3(t, a, b, delta, o.gid, c0, ct);
             else garble_and(aes_pass, t, a, b, delta, o.gid, c0, ct);
           } else {
-            const uint32_t va = (wf.ld_bit(o.a1) ^ wf.ld_bit(o.a2)) & 1u, vb = (wf.ld_bit(o.b1) ^ wf.ld_bit(o.b2)) & 1u, vp = wf.ld_bit(o.p) & 1u;
+            uint32_t va = wf.ld_bit(o.a1) ^ wf.ld_bit(o.a2), vb = wf.ld_bit(o.b1) ^ wf.ld_bit(o.b2);
+            if (four_wire) { va ^= wf.ld_bit(o.a3) ^ wf.ld_bit(o.a4); vb ^= wf.ld_bit(o.b3) ^ wf.ld_bit(o.b4); }
+            va &= 1u; vb &= 1u;
+            const uint32_t vp = wf.ld_bit(o.p) & 1u;
             const u32x4 cv = CT[ct_base + cti];
             if (HASH == 1) c0 = degarble_and_blake3(t, Label{{cv.x, cv.y, cv.z, cv.w}}, a, va, b, o.gid);
             else c0 = degarble_and(aes_pass, t, Label{{cv.x, cv.y, cv.z, cv.w}}, a, va, b, o.gid);

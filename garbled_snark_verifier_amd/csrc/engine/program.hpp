@@ -120,6 +120,19 @@ inline AndRec pack_and(const uint32_t in[5], uint32_t c, uint32_t type, uint64_t
                 uint64_t(in[3]) | (uint64_t(in[4]) << 21) | (uint64_t(c) << 42) | (uint64_t((type >> 1) & 1u) << 63),
                 gid | (uint64_t((type >> 2) & 1u) << 40), 0};
 }
+// The FOUR-WIRE form (Program::and_terms == 4; latency-bound programs, compile_program 0.):
+//   out = AND_t(a1 ^ a2 ^ a3 ^ a4, b1 ^ b2 ^ b3 ^ b4) ^ p
+//   w0 = a1 | a2<<21 | a3<<42 | (t&1)<<63 ;  w1 = a4 | b1<<21 | b2<<42 | ((t>>1)&1)<<63 ;
+//   w2 = b3 | b4<<21 | p<<42 | ((t>>2)&1)<<63 ;  w3 = out | gate id (31 bits: an index into the program's stream) << 21
+// A free gate that feeds an AND through a XOR of up to four wires then needs no step of its own: the square-root ladders lose 42 % of
+// their steps, the inversions 33 %, an Fq12 multiplication 13 % (tools/depth_stats.cpp) — at the price of four more label loads per AND.
+// in[9]: a1..a4, b1..b4, p.
+inline AndRec pack_and4(const uint32_t in[9], uint32_t c, uint32_t type, uint64_t gid) {
+  return AndRec{uint64_t(in[0]) | (uint64_t(in[1]) << 21) | (uint64_t(in[2]) << 42) | (uint64_t(type & 1u) << 63),
+                uint64_t(in[3]) | (uint64_t(in[4]) << 21) | (uint64_t(in[5]) << 42) | (uint64_t((type >> 1) & 1u) << 63),
+                uint64_t(in[6]) | (uint64_t(in[7]) << 21) | (uint64_t(in[8]) << 42) | (uint64_t((type >> 2) & 1u) << 63),
+                uint64_t(c) | (gid << 21)};
+}
 struct StepDesc { uint32_t and_off, and_cnt, xor_off, xor_cnt; };  // one dependency level: AND-family + free gates
 
 struct Program {
@@ -141,6 +154,7 @@ struct Program {
   uint64_t n_fused_free = 0;   // free gates left after fusion (the device executes n_ct + n_fused_free records per replay)
   uint32_t and_depth = 0, n_and_steps = 0, max_step_width = 0;
   uint32_t peak_live = 0;
+  uint32_t and_terms = 2;      // wires per AND input in the records: 2 (pack_and) or 4 (pack_and4)
   uint64_t reads_lds = 0, reads_hbm = 0, writes_lds = 0, writes_hbm = 0;  // label accesses per replay by location
   // Set when the records (steps, ands, xors, ct_pos) were written to a plan file as soon as the program existed and dropped from
   // memory (gsv_plan_build_file): the offset of the program's block in that file.  The metadata above stays.
@@ -160,6 +174,10 @@ struct CompileOptions {
   bool fuse = true;                       // fold free gates into their readers / into the AND that feeds them
   uint32_t fuse_dup_fanout = 2;           // a free gate of <= 2 operands is also folded (recomputed) when it has up to this many readers
   uint32_t and_cap = 0, xor_cap = 0;      // most AND-family / free gates in one step (0 = no cap: ASAP levels); see compile_program 1b
+  // Wires per AND input: 2, 4, or 0 = choose — four for a program whose two-wire schedule has fewer than `narrow_width` fused gates
+  // per step on average (latency-bound: fewer steps matter), two otherwise (throughput-bound: fewer label loads matter).
+  uint32_t and_terms = 0;
+  uint32_t narrow_width = 600;
 };
 
 // next-fit slot pool over a bitmap: consecutive allocations get ascending (mostly consecutive) slots, so the
@@ -197,16 +215,18 @@ class SlotPool {
 
 // ---- gate fusion ---------------------------------------------------------------------------------
 constexpr uint32_t FUSED_AND = 0x80;
+constexpr int FUSED_IN = 9;  // operand slots of a fused op: AND a1..a4 (0-3), b1..b4 (4-7), p (8) ; free x1..x4 (0-3) ; DEAD_WIRE = absent
 struct FusedOps {
   std::vector<uint8_t> kind;   // FUSED_AND | 3-bit type   or   parity bit of a free op
-  std::vector<uint32_t> in;    // 5 per op: AND a1,a2,b1,b2,p ; free x1..x4,- ; DEAD_WIRE = absent
+  std::vector<uint32_t> in;    // FUSED_IN per op
   std::vector<uint32_t> out;
   std::vector<uint32_t> gid;   // stream index of the AND gate (its gate id inside a replay); unused for free ops
   size_t size() const { return out.size(); }
-  void push(uint8_t k, const uint32_t i5[5], uint32_t o, uint32_t g) { kind.push_back(k); in.insert(in.end(), i5, i5 + 5); out.push_back(o); gid.push_back(g); }
+  void push(uint8_t k, const uint32_t i9[FUSED_IN], uint32_t o, uint32_t g) { kind.push_back(k); in.insert(in.end(), i9, i9 + FUSED_IN); out.push_back(o); gid.push_back(g); }
 };
 
-inline FusedOps fuse_trace(const Trace& t, const std::vector<uint32_t>& inputs, const std::vector<uint32_t>& outputs, const CompileOptions& opt) {
+// ka: wires per AND input (2 or 4); an expression of up to ka wires (two when ka == 2) is also folded into TWO readers (recomputed)
+inline FusedOps fuse_trace(const Trace& t, const std::vector<uint32_t>& inputs, const std::vector<uint32_t>& outputs, const CompileOptions& opt, uint32_t ka = 2) {
   const size_t n = t.size();
   const uint32_t nw = t.n_wires;
   constexpr uint8_t NOT = uint8_t(GateType::Not), XOR = uint8_t(GateType::Xor), XNOR = uint8_t(GateType::Xnor);
@@ -215,8 +235,9 @@ inline FusedOps fuse_trace(const Trace& t, const std::vector<uint32_t>& inputs, 
     for (size_t i = 0; i < n; ++i) {
       if (t.c[i] == DEAD_WIRE) continue;
       const uint8_t ty = t.type[i];
-      if (ty < 8) { const uint32_t in[5] = {t.a[i], DEAD_WIRE, t.b[i], DEAD_WIRE, DEAD_WIRE}; f.push(uint8_t(FUSED_AND | ty), in, t.c[i], uint32_t(i)); }
-      else { const uint32_t in[5] = {t.a[i], ty == NOT ? DEAD_WIRE : t.b[i], DEAD_WIRE, DEAD_WIRE, DEAD_WIRE}; f.push(ty == XOR ? 0 : 1, in, t.c[i], 0); }
+      constexpr uint32_t D = DEAD_WIRE;
+      if (ty < 8) { const uint32_t in[FUSED_IN] = {t.a[i], D, D, D, t.b[i], D, D, D, D}; f.push(uint8_t(FUSED_AND | ty), in, t.c[i], uint32_t(i)); }
+      else { const uint32_t in[FUSED_IN] = {t.a[i], ty == NOT ? D : t.b[i], D, D, D, D, D, D, D}; f.push(ty == XOR ? 0 : 1, in, t.c[i], 0); }
     }
     return f;
   }
@@ -236,14 +257,15 @@ inline FusedOps fuse_trace(const Trace& t, const std::vector<uint32_t>& inputs, 
   for (uint32_t w : outputs) pinned[w] = 1;
   std::vector<Expr> expr(nw);
   std::vector<uint8_t> absorbed(n, 0);
-  struct AndDec { uint32_t in[5]; uint32_t out; uint8_t type; };
+  struct AndDec { uint32_t in[FUSED_IN]; uint32_t out; uint8_t type; };
+  const uint32_t dup_terms = ka > 2 ? ka : 2;
   std::vector<AndDec> decs;
   auto single = [](uint32_t x) { Expr e; e.n = 1; e.par = 0; e.w[0] = x; return e; };
   // operand list of wire x for a reader that takes at most `cap` wires from it
   auto resolve = [&](uint32_t x, uint32_t cap) -> Expr {
     if (isfree[x] && !pinned[x]) {
       const Expr& ex = expr[x];
-      if (ex.n <= cap && (fan[x] == 1 || (fan[x] <= opt.fuse_dup_fanout && ex.n <= 2))) return ex;
+      if (ex.n <= cap && (fan[x] == 1 || (fan[x] <= opt.fuse_dup_fanout && ex.n <= dup_terms))) return ex;
     }
     need[x] = 1;
     return single(x);
@@ -277,11 +299,10 @@ inline FusedOps fuse_trace(const Trace& t, const std::vector<uint32_t>& inputs, 
       for (uint32_t k = 0; k < r.n; ++k) e.w[k] = r.w[k];
       expr[c] = e;
     } else {
-      const Expr ea = resolve(a, 2), eb = resolve(b, 2);
+      const Expr ea = resolve(a, ka), eb = resolve(b, ka);
       AndDec d;
-      d.in[0] = ea.n > 0 ? ea.w[0] : DEAD_WIRE; d.in[1] = ea.n > 1 ? ea.w[1] : DEAD_WIRE;
-      d.in[2] = eb.n > 0 ? eb.w[0] : DEAD_WIRE; d.in[3] = eb.n > 1 ? eb.w[1] : DEAD_WIRE;
-      d.in[4] = DEAD_WIRE;
+      for (uint32_t k = 0; k < 4; ++k) { d.in[k] = k < ea.n ? ea.w[k] : DEAD_WIRE; d.in[4 + k] = k < eb.n ? eb.w[k] : DEAD_WIRE; }
+      d.in[8] = DEAD_WIRE;
       d.type = uint8_t(ty ^ (ea.par << 2) ^ (eb.par << 1));
       d.out = c;
       // the single reader of this AND is a XOR/XNOR with an operand that already exists: fold it into the AND's output
@@ -292,7 +313,7 @@ inline FusedOps fuse_trace(const Trace& t, const std::vector<uint32_t>& inputs, 
           const uint32_t y = t.a[j] == c ? t.b[j] : t.a[j];
           if (y != c && y < c) {  // SSA ids grow in definition order: y is defined before this gate
             const Expr ey = resolve(y, 1);
-            d.in[4] = ey.n ? ey.w[0] : DEAD_WIRE;
+            d.in[8] = ey.n ? ey.w[0] : DEAD_WIRE;
             d.type ^= uint8_t(ey.par ^ (tj == XNOR ? 1 : 0));
             d.out = t.c[j];
             absorbed[j] = 1;
@@ -310,7 +331,8 @@ inline FusedOps fuse_trace(const Trace& t, const std::vector<uint32_t>& inputs, 
     if (t.type[i] < 8) { const AndDec& d = decs[kd++]; f.push(uint8_t(FUSED_AND | d.type), d.in, d.out, uint32_t(i)); continue; }
     if (!need[c] && !pinned[c]) continue;  // folded into every reader
     const Expr& e = expr[c];
-    uint32_t in[5] = {DEAD_WIRE, DEAD_WIRE, DEAD_WIRE, DEAD_WIRE, DEAD_WIRE};
+    uint32_t in[FUSED_IN];
+    for (int k = 0; k < FUSED_IN; ++k) in[k] = DEAD_WIRE;
     for (uint32_t k = 0; k < e.n; ++k) in[k] = e.w[k];
     f.push(e.par, in, c, 0);
   }
@@ -331,17 +353,41 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
   if (t.size() >= 0x7FFFFFFFull) gsv_panic("program too large: gate index must fit 31 bits per replay");
   if (opt.lds_slots > SLOT_INDEX_MASK) gsv_panic("LDS window larger than the slot encoding");
   for (size_t i = 0; i < t.size(); ++i) { p.gate_count[t.type[i]]++; if (t.c[i] == DEAD_WIRE) p.n_dead++; }
-  const FusedOps f = fuse_trace(t, inputs, outputs, opt);
+  // 0. Fusion, and how many wires an AND input may take.  Throughput-bound programs (wide steps) keep the two-wire records: every
+  // extra operand is a label load on the LDS pipe that the AES needs.  Latency-bound programs (narrow steps: ladders, inversions,
+  // carry chains) take four: a free gate that only feeds ANDs then disappears as a step of its own.
+  if (const char* e = getenv("GSV_AND_TERMS")) { const int v = atoi(e); if (v == 0 || v == 2 || v == 4) opt.and_terms = uint32_t(v); }
+  if (!opt.fuse) opt.and_terms = 2;
+  FusedOps f = fuse_trace(t, inputs, outputs, opt, opt.and_terms == 4 ? 4u : 2u);
+  p.and_terms = opt.and_terms == 4 ? 4u : 2u;
+  auto asap_steps = [&](const FusedOps& g) {
+    std::vector<uint32_t> l(nw, 0);
+    uint32_t mx = 0;
+    for (size_t i = 0; i < g.size(); ++i) {
+      uint32_t v = 0;
+      for (int k = 0; k < FUSED_IN; ++k) { const uint32_t w = g.in[size_t(FUSED_IN) * i + k]; if (w != DEAD_WIRE) v = std::max(v, l[w]); }
+      l[g.out[i]] = v + 1;
+      mx = std::max(mx, v + 1);
+    }
+    return mx;
+  };
+  if (opt.and_terms == 0 && f.size()) {
+    const uint32_t steps2 = asap_steps(f);
+    if (double(f.size()) / steps2 < double(opt.narrow_width)) {
+      FusedOps f4 = fuse_trace(t, inputs, outputs, opt, 4u);
+      if (asap_steps(f4) < steps2) { f = std::move(f4); p.and_terms = 4; }
+    }
+  }
   const size_t n = f.size();
   auto is_and = [&](size_t i) { return (f.kind[i] & FUSED_AND) != 0; };
-  auto ins = [&](size_t i) { return &f.in[5 * i]; };
+  auto ins = [&](size_t i) { return &f.in[size_t(FUSED_IN) * i]; };
 
   // 1. ASAP dependency level per wire (inputs / constants = 0) and AND-depth (statistic).
   std::vector<uint32_t> lev(nw, 0), ad(nw, 0);
   uint32_t n_steps = 0;
   for (size_t i = 0; i < n; ++i) {
     uint32_t l = 0, d = 0;
-    for (int k = 0; k < 5; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE) { l = std::max(l, lev[w]); d = std::max(d, ad[w]); } }
+    for (int k = 0; k < FUSED_IN; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE) { l = std::max(l, lev[w]); d = std::max(d, ad[w]); } }
     const uint32_t c = f.out[i];
     lev[c] = l + 1;
     ad[c] = d + (is_and(i) ? 1 : 0);
@@ -361,16 +407,16 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
     std::vector<uint32_t> prod(nw, NONE), pending(n, 0), height(n, 0), succ_off(n + 1, 0);
     for (size_t i = 0; i < n; ++i) prod[f.out[i]] = uint32_t(i);
     for (size_t i = 0; i < n; ++i)
-      for (int k = 0; k < 5; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE && prod[w] != NONE) { succ_off[prod[w] + 1]++; pending[i]++; } }
+      for (int k = 0; k < FUSED_IN; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE && prod[w] != NONE) { succ_off[prod[w] + 1]++; pending[i]++; } }
     for (size_t i = 0; i < n; ++i) succ_off[i + 1] += succ_off[i];
     std::vector<uint32_t> succ(succ_off[n]);
     {
       std::vector<uint32_t> cur(succ_off.begin(), succ_off.end() - 1);
       for (size_t i = 0; i < n; ++i)
-        for (int k = 0; k < 5; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE && prod[w] != NONE) succ[cur[prod[w]]++] = uint32_t(i); }
+        for (int k = 0; k < FUSED_IN; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE && prod[w] != NONE) succ[cur[prod[w]]++] = uint32_t(i); }
     }
     for (size_t i = n; i-- > 0;)  // the fused list is in stream order: producers precede their readers
-      for (int k = 0; k < 5; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE && prod[w] != NONE) height[prod[w]] = std::max(height[prod[w]], height[i] + 1); }
+      for (int k = 0; k < FUSED_IN; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE && prod[w] != NONE) height[prod[w]] = std::max(height[prod[w]], height[i] + 1); }
     auto key = [&](uint32_t i) -> uint64_t { return (uint64_t(height[i]) << 32) | (0xFFFFFFFFu - i); };  // longest path first, then stream order
     std::priority_queue<uint64_t> ready[2];
     for (size_t i = 0; i < n; ++i) if (pending[i] == 0) ready[is_and(i) ? 0 : 1].push(key(uint32_t(i)));
@@ -418,7 +464,7 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
         for (uint32_t k = lo; k < hi; ++k) order[k] = keyed[k - lo].second;
       }
       for (uint32_t k = cnt[2 * size_t(s)]; k < cnt[2 * size_t(s) + 2]; ++k)
-        for (int q = 0; q < 5; ++q) { const uint32_t w = ins(order[k])[q]; if (w != DEAD_WIRE) minpos[w] = std::min(minpos[w], k); }
+        for (int q = 0; q < FUSED_IN; ++q) { const uint32_t w = ins(order[k])[q]; if (w != DEAD_WIRE) minpos[w] = std::min(minpos[w], k); }
     }
   }
   // 3. last reader step per wire.  NEVER = pinned, UNUSED = no reader.
@@ -426,7 +472,7 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
   std::vector<uint32_t> last_use(nw, UNUSED);
   for (size_t i = 0; i < n; ++i) {
     const uint32_t s = step_of(i);
-    for (int q = 0; q < 5; ++q) { const uint32_t w = ins(i)[q]; if (w != DEAD_WIRE && (last_use[w] == UNUSED || last_use[w] < s)) last_use[w] = s; }
+    for (int q = 0; q < FUSED_IN; ++q) { const uint32_t w = ins(i)[q]; if (w != DEAD_WIRE && (last_use[w] == UNUSED || last_use[w] < s)) last_use[w] = s; }
   }
   last_use[0] = last_use[1] = NEVER;
   for (uint32_t w : inputs) last_use[w] = NEVER;
@@ -516,8 +562,8 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
       }
       slot[c] = sl;
       ++live;
-      uint32_t si[5];
-      for (int q = 0; q < 5; ++q) {
+      uint32_t si[FUSED_IN];
+      for (int q = 0; q < FUSED_IN; ++q) {
         const uint32_t w = ins(i)[q];
         if (w == DEAD_WIRE) { si[q] = absent; continue; }
         si[q] = slot[w];
@@ -530,7 +576,8 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
         // kilobyte.  At the gate-order index every store was its own 128-byte line (1.1 stores per line touched,
         // -16 % throughput); readers of the stream get gate order back through ct_pos (engine.cpp).
         p.ct_pos[ct_index[i]] = uint32_t(p.ands.size());
-        p.ands.push_back(pack_and(si, sl, f.kind[i] & 7u, f.gid[i]));
+        if (p.and_terms == 4) p.ands.push_back(pack_and4(si, sl, f.kind[i] & 7u, f.gid[i]));
+        else { const uint32_t s5[5] = {si[0], si[1], si[4], si[5], si[8]}; p.ands.push_back(pack_and(s5, sl, f.kind[i] & 7u, f.gid[i])); }
       } else {
         p.xors.push_back(pack_xor(si, sl, (f.kind[i] & 1u) != 0));
       }
@@ -545,7 +592,7 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
     p.max_step_width = std::max(p.max_step_width, sd.and_cnt + sd.xor_cnt);
     if (sd.and_cnt) p.n_and_steps++;
   }
-  if (getenv("GSV_SCHED_STATS")) {
+  if (getenv("GSV_SCHED_STATS") && p.and_terms == 2) {
     // coalescing of the wire-file accesses: distinct 128-byte lines (8 slots) per wave-wide access (64 consecutive records of a step)
     uint64_t acc[2] = {0, 0}, lines[2] = {0, 0}, lanes[2] = {0, 0};
     std::vector<uint32_t> ls;

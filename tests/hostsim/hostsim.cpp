@@ -95,13 +95,30 @@ static void interpret(const Program& g, bool evaluate, uint64_t gb, const Label&
     }
     for (uint32_t k = sd.and_cnt; k-- > 0;) {
       const AndRec& r = g.ands[sd.and_off + k];
-      const uint32_t a1 = uint32_t(r.w0) & SLOT_MASK, a2 = uint32_t(r.w0 >> 21) & SLOT_MASK, b1 = uint32_t(r.w0 >> 42) & SLOT_MASK;
-      const uint32_t b2 = uint32_t(r.w1) & SLOT_MASK, sp = uint32_t(r.w1 >> 21) & SLOT_MASK, sc = uint32_t(r.w1 >> 42) & SLOT_MASK;
-      const uint32_t ty = uint32_t(r.w0 >> 63) | (uint32_t(r.w1 >> 63) << 1) | (uint32_t((r.w2 >> 40) & 1u) << 2);
-      const uint64_t gid = gb + (r.w2 & 0xFFFFFFFFFFull);
+      // two record forms (program.hpp pack_and / pack_and4): up to two or up to four wires per AND input; absent operands name a zero label
+      uint32_t sa[4], sb[4], sp, sc, ty;
+      uint64_t gid;
+      const uint32_t s3[9] = {uint32_t(r.w0) & SLOT_MASK, uint32_t(r.w0 >> 21) & SLOT_MASK, uint32_t(r.w0 >> 42) & SLOT_MASK, uint32_t(r.w1) & SLOT_MASK, uint32_t(r.w1 >> 21) & SLOT_MASK,
+                              uint32_t(r.w1 >> 42) & SLOT_MASK, uint32_t(r.w2) & SLOT_MASK, uint32_t(r.w2 >> 21) & SLOT_MASK, uint32_t(r.w2 >> 42) & SLOT_MASK};
+      const uint32_t zero = g.lds_slots_limit ? SLOT_LDS_ZERO : SLOT_ZERO;
+      if (g.and_terms == 4) {
+        for (int q = 0; q < 4; ++q) { sa[q] = s3[q]; sb[q] = s3[4 + q]; }
+        sp = s3[8]; sc = uint32_t(r.w3) & SLOT_MASK;
+        ty = uint32_t(r.w0 >> 63) | (uint32_t(r.w1 >> 63) << 1) | (uint32_t(r.w2 >> 63) << 2);
+        gid = gb + ((r.w3 >> 21) & 0x7FFFFFFFull);
+      } else {
+        sa[0] = s3[0]; sa[1] = s3[1]; sb[0] = s3[2]; sb[1] = s3[3]; sa[2] = sa[3] = sb[2] = sb[3] = zero;
+        sp = s3[4]; sc = s3[5];
+        ty = uint32_t(r.w0 >> 63) | (uint32_t(r.w1 >> 63) << 1) | (uint32_t((r.w2 >> 40) & 1u) << 2);
+        gid = gb + (r.w2 & 0xFFFFFFFFFFull);
+      }
       const uint32_t cti = gate_of[sd.and_off + k];  // the ciphertext of record k sits at position k of the device stream
-      const Label a = dev::lxor(load(lab(a1)), load(lab(a2))), b = dev::lxor(load(lab(b1)), load(lab(b2))), pl = load(lab(sp));
-      const uint32_t va = (bit(a1) ^ bit(a2)) & 1u, vb = (bit(b1) ^ bit(b2)) & 1u, vp = bit(sp) & 1u;
+      Label a{{0, 0, 0, 0}}, b{{0, 0, 0, 0}};
+      uint32_t va = 0, vb = 0;
+      for (int q = 0; q < 4; ++q) { a = dev::lxor(a, load(lab(sa[q]))); b = dev::lxor(b, load(lab(sb[q]))); va ^= bit(sa[q]); vb ^= bit(sb[q]); }
+      va &= 1u; vb &= 1u;
+      const Label pl = load(lab(sp));
+      const uint32_t vp = bit(sp) & 1u;
       if (!evaluate) {
         Label c0, c;
         if (g_hasher == 1) dev::garble_and_blake3(ty, a, b, d, gid, c0, c);

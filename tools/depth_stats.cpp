@@ -53,9 +53,17 @@ static Res analyse(const Trace& t, const std::vector<uint32_t>& inputs, const st
   };
   Res r{0, 0, 0, 0, 0};
   std::vector<uint32_t> free_n(nw, 0);
+  std::vector<uint32_t> cons(nw, DEAD_WIRE);
+  for (size_t i = 0; i < n; ++i) {
+    if (t.c[i] == DEAD_WIRE) continue;
+    cons[t.a[i]] = uint32_t(i);
+    if (t.type[i] != NOT) cons[t.b[i]] = uint32_t(i);
+  }
+  std::vector<uint8_t> absorbed(n, 0);
+  constexpr uint8_t XOR = uint8_t(GateType::Xor), XNOR = uint8_t(GateType::Xnor);
   for (size_t i = 0; i < n; ++i) {
     const uint32_t c = t.c[i];
-    if (c == DEAD_WIRE) continue;
+    if (c == DEAD_WIRE || absorbed[i]) continue;
     const uint8_t ty = t.type[i];
     if (ty >= 8) {
       Expr ea = resolve(t.a[i], KX), eb;
@@ -78,9 +86,26 @@ static Res analyse(const Trace& t, const std::vector<uint32_t>& inputs, const st
       uint32_t l = 0;
       for (uint32_t q = 0; q < ea.n; ++q) l = std::max(l, lev[ea.w[q]]);
       for (uint32_t q = 0; q < eb.n; ++q) l = std::max(l, lev[eb.w[q]]);
-      lev[c] = l + 1;
+      uint32_t out = c;
+      // the product's output fold (fuse_trace): the single reader of this AND is a XOR/XNOR with an operand that already exists
+      if (fan[c] == 1 && !pinned[c]) {
+        const size_t j = cons[c];
+        const uint8_t tj = t.type[j];
+        if ((tj == XOR || tj == XNOR) && t.c[j] != DEAD_WIRE) {
+          const uint32_t y = t.a[j] == c ? t.b[j] : t.a[j];
+          if (y != c && y < c) {
+            const Expr ey = resolve(y, 1);
+            for (uint32_t q = 0; q < ey.n; ++q) l = std::max(l, lev[ey.w[q]]);
+            out = t.c[j];
+            absorbed[j] = 1;
+            isfree[out] = 0;
+            r.and_terms += ey.n;
+          }
+        }
+      }
+      lev[out] = l + 1;
       r.ands++; r.and_terms += ea.n + eb.n;
-      r.steps = std::max(r.steps, lev[c]);
+      r.steps = std::max(r.steps, lev[out]);
     }
   }
   for (uint32_t w = 2; w < nw; ++w)
@@ -98,7 +123,7 @@ int main(int argc, char** argv) {
   for (WireId w : run.execute()) outputs.push_back(mode.current(w));
   const Trace& t = mode.trace();
   std::printf("%s: %zu gates\n", spec.c_str(), t.size());
-  const uint32_t cfg[][4] = {{4, 2, 2, 2}, {4, 2, 4, 2}, {4, 2, 255, 2}, {4, 2, 255, 4}, {4, 3, 2, 2}, {4, 3, 255, 3}, {4, 4, 255, 4}, {6, 3, 255, 3}, {8, 4, 255, 4}, {8, 8, 255, 8}, {16, 16, 255, 16}};
+  const uint32_t cfg[][4] = {{4, 2, 2, 2}, {4, 3, 2, 2}, {4, 3, 2, 3}, {4, 3, 4, 3}, {4, 3, 255, 3}, {4, 4, 2, 2}, {4, 4, 2, 4}, {4, 4, 255, 4}, {8, 8, 255, 8}, {16, 16, 255, 16}};
   for (const auto& c : cfg) {
     const Res r = analyse(t, inputs, outputs, c[0], c[1], c[2], c[3]);
     std::printf("  free op <= %2u wires, AND input <= %2u, duplicate <= %2u-wire expressions into <= %3u readers: %7u steps, %9zu AND ops (%.2f wires), %9zu free ops (%.2f wires)\n",
