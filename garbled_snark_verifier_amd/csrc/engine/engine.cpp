@@ -662,7 +662,7 @@ struct PlanFileProgram {
   uint64_t n_steps, n_ands, n_xors, n_ct_pos, n_inputs, n_outputs;
   uint64_t n_gates, n_ct, n_dead, n_fused_free, reads_lds, reads_hbm, writes_lds, writes_hbm;
   uint64_t gate_count[GATE_TYPE_COUNT];
-  uint32_t n_slots, n_lds_slots, lds_slots_limit, fb_stage_base, and_depth, n_and_steps, max_step_width, peak_live, window_div, pad;
+  uint32_t n_slots, n_lds_slots, lds_slots_limit, fb_stage_base, and_depth, n_and_steps, max_step_width, peak_live, window_div, and_terms;
 };
 constexpr uint64_t plan_rec_sizes() { return uint64_t(sizeof(StepDesc)) | (uint64_t(sizeof(AndRec)) << 16) | (uint64_t(sizeof(XorRec)) << 32); }
 inline size_t pad16(size_t n) { return (n + 15) & ~size_t(15); }
@@ -693,7 +693,7 @@ class PlanFileWriter {
     m.reads_lds = g.reads_lds; m.reads_hbm = g.reads_hbm; m.writes_lds = g.writes_lds; m.writes_hbm = g.writes_hbm;
     for (int i = 0; i < GATE_TYPE_COUNT; ++i) m.gate_count[i] = g.gate_count[i];
     m.n_slots = g.n_slots; m.n_lds_slots = g.n_lds_slots; m.lds_slots_limit = g.lds_slots_limit; m.fb_stage_base = g.fb_stage_base; m.and_depth = g.and_depth;
-    m.n_and_steps = g.n_and_steps; m.max_step_width = g.max_step_width; m.peak_live = g.peak_live; m.window_div = window_div;
+    m.n_and_steps = g.n_and_steps; m.max_step_width = g.max_step_width; m.peak_live = g.peak_live; m.window_div = window_div; m.and_terms = g.and_terms;
     const void* parts[7] = {&m, g.steps.data(), g.ands.data(), g.xors.data(), g.ct_pos.data(), g.input_slots.data(), g.output_slots.data()};
     const size_t lens[7] = {sizeof m, g.steps.size() * sizeof(StepDesc), g.ands.size() * sizeof(AndRec), g.xors.size() * sizeof(XorRec), g.ct_pos.size() * 4, g.input_slots.size() * 4, g.output_slots.size() * 4};
     size_t total = 0;
@@ -860,8 +860,8 @@ int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out) {
     g.reads_lds = m.reads_lds; g.reads_hbm = m.reads_hbm; g.writes_lds = m.writes_lds; g.writes_hbm = m.writes_hbm;
     for (int i = 0; i < GATE_TYPE_COUNT; ++i) g.gate_count[i] = m.gate_count[i];
     g.n_slots = m.n_slots; g.n_lds_slots = m.n_lds_slots; g.lds_slots_limit = m.lds_slots_limit; g.fb_stage_base = m.fb_stage_base; g.and_depth = m.and_depth;
-    g.n_and_steps = m.n_and_steps; g.max_step_width = m.max_step_width; g.peak_live = m.peak_live;
-    if (m.window_div != 1 && m.window_div != 2 && m.window_div != 4) { bad = true; break; }
+    g.n_and_steps = m.n_and_steps; g.max_step_width = m.max_step_width; g.peak_live = m.peak_live; g.and_terms = m.and_terms;
+    if ((m.window_div != 1 && m.window_div != 2 && m.window_div != 4) || (m.and_terms != 2 && m.and_terms != 4)) { bad = true; break; }
     // The file is input: counts are checked against the file size BEFORE they are multiplied, slot counts against the record
     // format's 20-bit slot space, and every step's record ranges against the record arrays (the records themselves — 40 GB for the
     // verifier — are not re-validated: plan files live in a directory only their owner can write, bench.py / _plan_cache_path).

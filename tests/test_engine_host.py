@@ -96,6 +96,27 @@ def _hostsim_check(spec, seed, replays=1, oracle_spec=None):
     return sp
 
 
+def test_four_wire_and_records(monkeypatch):
+    """program.hpp pack_and4 / compile_program 0.: an AND input may be the XOR of up to FOUR wires in the records of a latency-bound
+    program (fewer than 600 fused gates per step), so free gates that only feed ANDs stop costing a step of their own — the Fq
+    multiplication drops from 1 771 to 987 steps, the random circuits and the driver's component mix keep interpreting to the oracle's
+    ciphertexts, labels and bits in either form (forced with GSV_AND_TERMS), with chained replays too; a wide program (an Fq12
+    multiplication: 1 100 gates per step) keeps the two-wire records, whose extra label loads it cannot afford."""
+    steps = {}
+    for terms in ("2", "4", "0"):
+        monkeypatch.setenv("GSV_AND_TERMS", terms)
+        for spec, seed in (("fq_mul", 1), ("random_circuit:5", 3), ("driver_mix", 2), ("random_circuit:11", 4)):
+            steps[(spec, terms)] = _hostsim_check(spec, seed).info["n_steps"]
+    assert steps[("fq_mul", "2")] == 1771 and steps[("fq_mul", "4")] == steps[("fq_mul", "0")] == 987
+    for spec in ("random_circuit:5", "driver_mix", "random_circuit:11"):
+        assert steps[(spec, "4")] <= steps[(spec, "2")]
+    import garbled_snark_verifier_amd as gsv
+    monkeypatch.setenv("GSV_AND_TERMS", "0")
+    wide = gsv.Program.from_circuit("fq12_mul").info["n_steps"]
+    monkeypatch.setenv("GSV_AND_TERMS", "4")
+    assert wide == 8197 and gsv.Program.from_circuit("fq12_mul").info["n_steps"] == 7164
+
+
 @pytest.mark.parametrize("t", range(11))
 def test_compiled_schedule_every_gate_type(t):
     _hostsim_check("gate:%d" % t, 42)
