@@ -75,8 +75,8 @@ def check_step_barrier_isa(asm=None):
     asm = asm if asm is not None else disassemble_kernels()
     out = {}
     kernels = {k: v for k, v in _functions(asm).items() if "run_program_kernel" in k}
-    if len(kernels) != 8:
-        raise RuntimeError("expected 8 instantiations of run_program_kernel, found %d" % len(kernels))
+    if len(kernels) != 16:
+        raise RuntimeError("expected 16 instantiations of run_program_kernel, found %d" % len(kernels))
     for name, ins in kernels.items():
         n = sum(1 for i, t in enumerate(ins) if t == "s_waitcnt lgkmcnt(0)" and 0 < i < len(ins) - 1 and ins[i + 1] == "s_barrier" and ins[i - 1].startswith("global_load_dwordx4"))
         if n != 2:

@@ -1257,7 +1257,7 @@ static int launch(gsv_session* s, uint64_t gate_id_base, bool eval, uint64_t rep
   ka.n_fb = uint32_t(g.fb_src_slot.size()); ka.fb_stage_base = g.fb_stage_base;
   ka.n_instances = uint32_t(s->n_inst);
   ka.hasher = uint32_t(s->hasher);
-  ka.and_terms = g.and_terms;
+  ka.and_terms = g.and_terms; ka.any_four_wire = g.and_terms == 4;
   ka.step_clock = static_cast<unsigned long long*>(s->step_clock);
   ka.instances_per_wg = s->ni;
   if (const char* dg = getenv("GSV_DIAG")) ka.diag = uint32_t(atoi(dg));  // timing experiments (libgsv_engine_diag.so only): outputs are wrong when set
@@ -1292,6 +1292,7 @@ static int launch_plan_window(gsv_session* s, size_t w, uint64_t gate_id_base, b
   ka.ct_stride = s->ct_stride(); ka.gid_base = gate_id_base; ka.n_gates = 0; ka.n_ct = 0;
   ka.n_steps = 0; ka.n_slots = f.n_slots; ka.replays = 1; ka.rep_base = 0; ka.ct_cap_replays = 1;
   ka.n_instances = uint32_t(s->n_inst); ka.hasher = uint32_t(s->hasher); ka.instances_per_wg = s->ni;
+  for (uint32_t k = win.call0; k < win.call1 && !ka.any_four_wire; ++k) ka.any_four_wire = s->call_prog(k).and_terms == 4;
   int lrc = gsvk_launch_batch(&ka, uint32_t(s->n_inst), win.call1 - win.call0, eval ? 1 : 0, s->e->stream);
   if (lrc != 0) return fail(GSV_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipError_t(lrc)));
   return GSV_OK;

@@ -164,16 +164,16 @@ class CbcMacHost {
 #endif
   }
 #if GSV_HOST_AESNI
+  __attribute__((target("vaes,avx512f"), always_inline)) static inline __m512i gather4(const uint8_t* p0, const uint8_t* p1, const uint8_t* p2, const uint8_t* p3) {
+    __m512i v = _mm512_castsi128_si512(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p0)));
+    v = _mm512_inserti32x4(v, _mm_loadu_si128(reinterpret_cast<const __m128i*>(p1)), 1);
+    v = _mm512_inserti32x4(v, _mm_loadu_si128(reinterpret_cast<const __m128i*>(p2)), 2);
+    return _mm512_inserti32x4(v, _mm_loadu_si128(reinterpret_cast<const __m128i*>(p3)), 3);
+  }
   __attribute__((target("vaes,avx512f"))) static void update_interleaved16_vaes(CbcMacHost* const* mac, const uint8_t* const* cts, uint64_t n) {
     const AesTables& t = AesTables::fixed_key();
     __m512i rk[11], h[4];
     for (int r = 0; r < 11; ++r) rk[r] = _mm512_broadcast_i32x4(_mm_loadu_si128(reinterpret_cast<const __m128i*>(t.rk_bytes + 16 * r)));
-    auto gather4 = [](const uint8_t* p0, const uint8_t* p1, const uint8_t* p2, const uint8_t* p3) __attribute__((target("vaes,avx512f"))) {
-      __m512i v = _mm512_castsi128_si512(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p0)));
-      v = _mm512_inserti32x4(v, _mm_loadu_si128(reinterpret_cast<const __m128i*>(p1)), 1);
-      v = _mm512_inserti32x4(v, _mm_loadu_si128(reinterpret_cast<const __m128i*>(p2)), 2);
-      return _mm512_inserti32x4(v, _mm_loadu_si128(reinterpret_cast<const __m128i*>(p3)), 3);
-    };
     for (int z = 0; z < 4; ++z) h[z] = gather4(mac[4 * z]->h_, mac[4 * z + 1]->h_, mac[4 * z + 2]->h_, mac[4 * z + 3]->h_);
     for (uint64_t i = 0; i < n; ++i) {
       __m512i s[4];

@@ -60,6 +60,7 @@ struct KernelArgs {
   uint32_t instances_per_wg;  // 1, 2 or 4 (n needs a program compiled for 1/n of the LDS window)
   uint32_t hasher;            // 0 = AesNiHasher, 1 = Blake3Hasher
   uint32_t and_terms;         // record form of the program (program launches; window launches take it from the call descriptor): 2 or 4
+  uint32_t any_four_wire;     // host-side kernel choice: some program of this launch is in the four-wire form (the FW instantiations)
   unsigned long long* step_clock;  // diagnostics: workgroup 0 stamps the 100 MHz wall clock at the start of every step of the last replay (null = off)
   const CallDesc* calls;  // non-null: window launch, grid.y = calls; steps / ands / xors / n_steps / ct_offset come from calls[blockIdx.y]
   const uint32_t* copy_src;   // wire hand-over lists of the session (absolute slots inside an instance's wire file)

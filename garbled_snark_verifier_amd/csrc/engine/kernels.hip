@@ -197,7 +197,9 @@ __device__ __forceinline__ uint32_t tweak_word(uint64_t gate_id, uint32_t c) {  
 // latencies).
 // HASH = 0: AesNiHasher (fixed-key AES, the hot path); HASH = 1: Blake3Hasher (src/hashers/mod.rs:22-51; the PRF most of
 // the reference's own tests use) — pure 32-bit add/xor/rotate, one gate per lane in every step (no multi-lane form).
-template <bool EVAL, int NI, int HASH>
+// FW: the launch contains a program in the four-wire record form (program.hpp pack_and4) — the decode and the four extra operand
+// loads exist only in these instantiations, so the throughput-bound launches (all programs two-wire) run the code they always ran.
+template <bool EVAL, int NI, int HASH, bool FW>
 __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelArgs ka) {
   extern __shared__ __attribute__((aligned(16))) char s_mem[];
   (void)s_mem;  // the dynamic LDS block starts at LDS address 0 (no static __shared__ in this kernel)
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     w_base = cd->w_base;
   }
   // record form of this program (program.hpp): up to two or up to four wires per AND input — wave-uniform, the same for every gate of the launch's call
-  const bool four_wire = __builtin_amdgcn_readfirstlane(int(ka.and_terms)) == 4;
+  const bool four_wire = FW && __builtin_amdgcn_readfirstlane(int(ka.and_terms)) == 4;
   constexpr uint32_t BT = GSV_BLOCK_THREADS / NI;  // threads per instance
   // which instance of this workgroup: wave-uniform (BT is a multiple of 64), so say so — every per-instance base
   // address below then lives in SGPRs instead of costing a VGPR each
@@ -342,7 +344,12 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       return *(const glb_u128*)p;
     };
     auto load_and_rec = [&](uint32_t k) -> Rec { return *(const glb_u128*)(and_bytes + size_t(k) * 32u); };      // record k of the AND array, first half
-    auto load_and_hi = [&](uint32_t k) -> u32x4 { if (no_hi) return u32x4{k, 0u, 0u, 0u}; return *(const glb_u128*)(and_bytes + size_t(k) * 32u + 16u); };  // second half
+    auto load_and_hi = [&](uint32_t k) -> u32x4 {  // second half (two-wire form: its first 8 bytes)
+      if (no_hi) return u32x4{k, 0u, 0u, 0u};
+      if (FW) return *(const glb_u128*)(and_bytes + size_t(k) * 32u + 16u);
+      const u32x2 h = *(const glb_u64*)(and_bytes + size_t(k) * 32u + 16u);
+      return u32x4{h.x, h.y, 0u, 0u};
+    };
     // Two record registers in ping-pong: step s consumes one (loaded at the end of step s-2) and, once it is done with it,
     // refills the SAME registers with the record of step s+2.  No in-flight load is ever copied to another register: a copy
     // would make the compiler wait for the load it has just issued at the top of every step (which is what a rotating
@@ -685,10 +692,11 @@ int gsvk_launch_batch(const gsv::dev::KernelArgs* ka, uint32_t n_instances, uint
     if (!attr_done.count(dev)) {
       // the kernels address LDS from byte 0: there must be no static LDS in front of the dynamic block
       hipFuncAttributes fa;
-      const void* kernels[8] = {reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 1, 0>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 1, 0>),
-                                reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 2, 0>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 2, 0>),
-                                reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 4, 0>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 4, 0>),
-                                reinterpret_cast<const void*>(gsv::dev::run_program_kernel<false, 1, 1>), reinterpret_cast<const void*>(gsv::dev::run_program_kernel<true, 1, 1>)};
+#define GSV_K(E, N, H, F) reinterpret_cast<const void*>(gsv::dev::run_program_kernel<E, N, H, F>)
+      const void* kernels[16] = {GSV_K(false, 1, 0, false), GSV_K(true, 1, 0, false), GSV_K(false, 2, 0, false), GSV_K(true, 2, 0, false), GSV_K(false, 4, 0, false), GSV_K(true, 4, 0, false),
+                                 GSV_K(false, 1, 1, false), GSV_K(true, 1, 1, false), GSV_K(false, 1, 0, true),  GSV_K(true, 1, 0, true),  GSV_K(false, 2, 0, true),  GSV_K(true, 2, 0, true),
+                                 GSV_K(false, 4, 0, true),  GSV_K(true, 4, 0, true),  GSV_K(false, 1, 1, true),  GSV_K(true, 1, 1, true)};
+#undef GSV_K
       for (const void* k : kernels) {
         if (hipFuncGetAttributes(&fa, k) != hipSuccess || fa.sharedSizeBytes != 0) return int(hipErrorInvalidValue);
         hipError_t e0 = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
@@ -700,19 +708,16 @@ int gsvk_launch_batch(const gsv::dev::KernelArgs* ka, uint32_t n_instances, uint
   const bool blake3 = ka->hasher == 1;
   const uint32_t ni = blake3 ? 1u : (ka->instances_per_wg == 4 ? 4u : ka->instances_per_wg == 2 ? 2u : 1u);
   const dim3 grid((n_instances + ni - 1) / ni, n_calls);
-  if (blake3) {
-    if (evaluate) hipLaunchKernelGGL((gsv::dev::run_program_kernel<true, 1, 1>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
-    else hipLaunchKernelGGL((gsv::dev::run_program_kernel<false, 1, 1>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
-  } else if (ni == 4) {
-    if (evaluate) hipLaunchKernelGGL((gsv::dev::run_program_kernel<true, 4, 0>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
-    else hipLaunchKernelGGL((gsv::dev::run_program_kernel<false, 4, 0>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
-  } else if (ni == 2) {
-    if (evaluate) hipLaunchKernelGGL((gsv::dev::run_program_kernel<true, 2, 0>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
-    else hipLaunchKernelGGL((gsv::dev::run_program_kernel<false, 2, 0>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
-  } else {
-    if (evaluate) hipLaunchKernelGGL((gsv::dev::run_program_kernel<true, 1, 0>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
-    else hipLaunchKernelGGL((gsv::dev::run_program_kernel<false, 1, 0>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka);
-  }
+  const bool fw = ka->any_four_wire != 0;
+#define GSV_LAUNCH(E, N, H, F) hipLaunchKernelGGL((gsv::dev::run_program_kernel<E, N, H, F>), grid, dim3(GSV_BLOCK_THREADS), lds, stream, *ka)
+#define GSV_LAUNCH_EF(N, H) do { if (evaluate) { if (fw) GSV_LAUNCH(true, N, H, true); else GSV_LAUNCH(true, N, H, false); } \
+                                 else { if (fw) GSV_LAUNCH(false, N, H, true); else GSV_LAUNCH(false, N, H, false); } } while (0)
+  if (blake3) GSV_LAUNCH_EF(1, 1);
+  else if (ni == 4) GSV_LAUNCH_EF(4, 0);
+  else if (ni == 2) GSV_LAUNCH_EF(2, 0);
+  else GSV_LAUNCH_EF(1, 0);
+#undef GSV_LAUNCH_EF
+#undef GSV_LAUNCH
   return int(hipGetLastError());
 }
 int gsvk_gather_outputs(const void* W, const void* VB, uint32_t n_slots, const uint32_t* slots, uint32_t n_out, uint32_t n_instances,

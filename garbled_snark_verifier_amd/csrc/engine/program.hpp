@@ -380,14 +380,25 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
   }
   const size_t n = f.size();
   auto is_and = [&](size_t i) { return (f.kind[i] & FUSED_AND) != 0; };
-  auto ins = [&](size_t i) { return &f.in[size_t(FUSED_IN) * i]; };
+  // two-wire programs (most of a plan's compile work) go on with five operand slots per op: a1 a2 b1 b2 p / x1 x2 x3 x4 -
+  const int fi = p.and_terms == 4 ? FUSED_IN : 5;
+  if (fi == 5) {
+    for (size_t i = 0; i < n; ++i) {
+      const uint32_t* src = &f.in[size_t(FUSED_IN) * i];
+      const uint32_t v[5] = {src[0], src[1], is_and(i) ? src[4] : src[2], is_and(i) ? src[5] : src[3], is_and(i) ? src[8] : DEAD_WIRE};
+      std::copy(v, v + 5, &f.in[5 * i]);
+    }
+    f.in.resize(5 * n);
+    f.in.shrink_to_fit();
+  }
+  auto ins = [&](size_t i) { return &f.in[size_t(fi) * i]; };
 
   // 1. ASAP dependency level per wire (inputs / constants = 0) and AND-depth (statistic).
   std::vector<uint32_t> lev(nw, 0), ad(nw, 0);
   uint32_t n_steps = 0;
   for (size_t i = 0; i < n; ++i) {
     uint32_t l = 0, d = 0;
-    for (int k = 0; k < FUSED_IN; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE) { l = std::max(l, lev[w]); d = std::max(d, ad[w]); } }
+    for (int k = 0; k < fi; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE) { l = std::max(l, lev[w]); d = std::max(d, ad[w]); } }
     const uint32_t c = f.out[i];
     lev[c] = l + 1;
     ad[c] = d + (is_and(i) ? 1 : 0);
@@ -407,16 +418,16 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
     std::vector<uint32_t> prod(nw, NONE), pending(n, 0), height(n, 0), succ_off(n + 1, 0);
     for (size_t i = 0; i < n; ++i) prod[f.out[i]] = uint32_t(i);
     for (size_t i = 0; i < n; ++i)
-      for (int k = 0; k < FUSED_IN; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE && prod[w] != NONE) { succ_off[prod[w] + 1]++; pending[i]++; } }
+      for (int k = 0; k < fi; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE && prod[w] != NONE) { succ_off[prod[w] + 1]++; pending[i]++; } }
     for (size_t i = 0; i < n; ++i) succ_off[i + 1] += succ_off[i];
     std::vector<uint32_t> succ(succ_off[n]);
     {
       std::vector<uint32_t> cur(succ_off.begin(), succ_off.end() - 1);
       for (size_t i = 0; i < n; ++i)
-        for (int k = 0; k < FUSED_IN; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE && prod[w] != NONE) succ[cur[prod[w]]++] = uint32_t(i); }
+        for (int k = 0; k < fi; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE && prod[w] != NONE) succ[cur[prod[w]]++] = uint32_t(i); }
     }
     for (size_t i = n; i-- > 0;)  // the fused list is in stream order: producers precede their readers
-      for (int k = 0; k < FUSED_IN; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE && prod[w] != NONE) height[prod[w]] = std::max(height[prod[w]], height[i] + 1); }
+      for (int k = 0; k < fi; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE && prod[w] != NONE) height[prod[w]] = std::max(height[prod[w]], height[i] + 1); }
     auto key = [&](uint32_t i) -> uint64_t { return (uint64_t(height[i]) << 32) | (0xFFFFFFFFu - i); };  // longest path first, then stream order
     std::priority_queue<uint64_t> ready[2];
     for (size_t i = 0; i < n; ++i) if (pending[i] == 0) ready[is_and(i) ? 0 : 1].push(key(uint32_t(i)));
@@ -464,7 +475,7 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
         for (uint32_t k = lo; k < hi; ++k) order[k] = keyed[k - lo].second;
       }
       for (uint32_t k = cnt[2 * size_t(s)]; k < cnt[2 * size_t(s) + 2]; ++k)
-        for (int q = 0; q < FUSED_IN; ++q) { const uint32_t w = ins(order[k])[q]; if (w != DEAD_WIRE) minpos[w] = std::min(minpos[w], k); }
+        for (int q = 0; q < fi; ++q) { const uint32_t w = ins(order[k])[q]; if (w != DEAD_WIRE) minpos[w] = std::min(minpos[w], k); }
     }
   }
   // 3. last reader step per wire.  NEVER = pinned, UNUSED = no reader.
@@ -472,7 +483,7 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
   std::vector<uint32_t> last_use(nw, UNUSED);
   for (size_t i = 0; i < n; ++i) {
     const uint32_t s = step_of(i);
-    for (int q = 0; q < FUSED_IN; ++q) { const uint32_t w = ins(i)[q]; if (w != DEAD_WIRE && (last_use[w] == UNUSED || last_use[w] < s)) last_use[w] = s; }
+    for (int q = 0; q < fi; ++q) { const uint32_t w = ins(i)[q]; if (w != DEAD_WIRE && (last_use[w] == UNUSED || last_use[w] < s)) last_use[w] = s; }
   }
   last_use[0] = last_use[1] = NEVER;
   for (uint32_t w : inputs) last_use[w] = NEVER;
@@ -563,7 +574,7 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
       slot[c] = sl;
       ++live;
       uint32_t si[FUSED_IN];
-      for (int q = 0; q < FUSED_IN; ++q) {
+      for (int q = 0; q < fi; ++q) {
         const uint32_t w = ins(i)[q];
         if (w == DEAD_WIRE) { si[q] = absent; continue; }
         si[q] = slot[w];
@@ -577,7 +588,7 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
         // -16 % throughput); readers of the stream get gate order back through ct_pos (engine.cpp).
         p.ct_pos[ct_index[i]] = uint32_t(p.ands.size());
         if (p.and_terms == 4) p.ands.push_back(pack_and4(si, sl, f.kind[i] & 7u, f.gid[i]));
-        else { const uint32_t s5[5] = {si[0], si[1], si[4], si[5], si[8]}; p.ands.push_back(pack_and(s5, sl, f.kind[i] & 7u, f.gid[i])); }
+        else p.ands.push_back(pack_and(si, sl, f.kind[i] & 7u, f.gid[i]));
       } else {
         p.xors.push_back(pack_xor(si, sl, (f.kind[i] & 1u) != 0));
       }

@@ -337,7 +337,7 @@ def test_step_barrier_isa_check():
     from garbled_snark_verifier_amd import build
     asm = build.disassemble_kernels()
     res = build.check_step_barrier_isa(asm)
-    assert len(res) == 8 and set(res.values()) == {2}  # garble / evaluate x 1, 2, 4 instances per workgroup + the two Blake3 kernels
+    assert len(res) == 16 and set(res.values()) == {2}  # (garble / evaluate x 1, 2, 4 instances per workgroup + the two Blake3 kernels) x (two-wire only / four-wire capable)
     lines = asm.splitlines()
     k = next(i for i, l in enumerate(lines) if "s_waitcnt lgkmcnt(0)" in l and "s_barrier" in lines[i + 1] and "global_load_dwordx4" in lines[i - 1])
     # something scheduled between the prefetch and the barrier
