@@ -69,6 +69,25 @@ def test_every_gate_type_all_inputs(engine, t):
             assert (sel == e.output_active[0]).all()
 
 
+@pytest.mark.parametrize("terms", ["2", "4"])
+def test_both_and_record_forms_on_the_device(engine, terms, monkeypatch):
+    """program.hpp pack_and / pack_and4: the same circuits compiled with at most two and with up to four wires per AND input (forced
+    with GSV_AND_TERMS; left alone the compiler picks four for latency-bound programs) garble and evaluate to the oracle's stream —
+    narrow steps (multi-lane AES), wide steps (one gate per lane: random circuits, Fq12 multiplication), chained replays, and with two
+    and four instances per workgroup; the two forms run different instantiations of the kernel (FW = false / true)."""
+    import garbled_snark_verifier_amd as gsv
+    monkeypatch.setenv("GSV_AND_TERMS", terms)
+    for spec, seeds in (("fq_mul", [1, 2]), ("random_circuit:5", [3]), ("driver_mix", [4, 5, 6]), ("fq12_mul", [7])):
+        g, prog = _garble_and_check(gsv, engine, spec, seeds)
+        _evaluate_and_check(gsv, engine, spec, g, prog, seeds)
+    for ni in ("2", "4"):
+        monkeypatch.setenv("GSV_INSTANCES_PER_WG", ni)
+        seeds = list(range(20, 20 + 2 * int(ni) + 1))  # a ragged last workgroup
+        g, prog = _garble_and_check(gsv, engine, "fq_mul", seeds)
+        _evaluate_and_check(gsv, engine, "fq_mul", g, prog, seeds)
+    monkeypatch.delenv("GSV_INSTANCES_PER_WG")
+
+
 def test_driver_mix_dead_gates_constants(engine):
     import garbled_snark_verifier_amd as gsv
     g, prog = _garble_and_check(gsv, engine, "driver_mix", [5, 6, 7])
