@@ -782,7 +782,7 @@ def run_synthetic(args):
                   "config": {"workload": "Groth16-shaped SYNTHETIC: chain of %d %s links = %d gates per instance; %d cut-and-choose instances per GPU" % (replays, args.component, gpr * replays, B),
                              "instances_per_gpu": B, "instances_per_workgroup": ni, "replays": replays, "nonfree_fraction": f_nf, "program_steps": info["n_steps"]},
                   "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "kernel": "run_program_kernel<false, %d, 0>" % ni, "kernel_ms_avg": stream_s * 1e3 / K, "bytes_per_gate": bytes_per_gate,
+                               "kernel": "run_program_kernel<false, %d, 0, %s>" % (ni, "true" if prog.info.get("and_terms", 2) == 4 else "false"), "kernel_ms_avg": stream_s * 1e3 / K, "bytes_per_gate": bytes_per_gate,
                                "algorithmic_bytes_per_launch": g_rank / K * bytes_per_gate, "binding_limit": "aes-issue",
                                "aes_ceiling_gates_per_s": AES_CEILING_AND_PER_S / f_nf, "aes_ceiling_frac": (g_rank / stream_s) / (AES_CEILING_AND_PER_S / f_nf)}}
         if not args.no_check:

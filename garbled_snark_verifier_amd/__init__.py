@@ -51,7 +51,7 @@ def _close_everything():
 class _ProgramInfo(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_inputs", "n_outputs", "n_gates", "n_ciphertexts", "n_dead")] + [("gate_count", C.c_uint64 * 11)] + [
         (n, C.c_uint64) for n in ("n_steps", "and_depth", "n_and_steps", "max_step_width", "n_slots", "peak_live", "device_bytes", "n_lds_slots",
-                                 "reads_lds", "reads_hbm", "writes_lds", "writes_hbm", "n_fused_free")]
+                                 "reads_lds", "reads_hbm", "writes_lds", "writes_hbm", "n_fused_free", "and_terms")]
 
 
 class _PlanSessionOpts(C.Structure):

@@ -288,6 +288,7 @@ int gsv_program_get_info(const gsv_program* p, gsv_program_info* info) {
   info->n_slots = g.n_slots; info->peak_live = g.peak_live; info->device_bytes = p->image_bytes();
   info->n_lds_slots = g.n_lds_slots; info->reads_lds = g.reads_lds; info->reads_hbm = g.reads_hbm; info->writes_lds = g.writes_lds; info->writes_hbm = g.writes_hbm;
   info->n_fused_free = g.n_fused_free;
+  info->and_terms = g.and_terms;
   return GSV_OK;
 }
 

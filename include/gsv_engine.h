@@ -94,6 +94,7 @@ typedef struct gsv_program_info {
   uint64_t n_lds_slots;    /* entries of the per-workgroup LDS label window in use */
   uint64_t reads_lds, reads_hbm, writes_lds, writes_hbm; /* label accesses per replay, by location */
   uint64_t n_fused_free;   /* free-gate records left after gate fusion (device records per replay = n_ciphertexts + this) */
+  uint64_t and_terms;      /* wires per AND input in the device records: 2, or 4 for latency-bound programs (fewer device steps) */
 } gsv_program_info;
 int gsv_program_get_info(const gsv_program* p, gsv_program_info* info);
 

@@ -112,9 +112,11 @@ def test_four_wire_and_records(monkeypatch):
         assert steps[(spec, "4")] <= steps[(spec, "2")]
     import garbled_snark_verifier_amd as gsv
     monkeypatch.setenv("GSV_AND_TERMS", "0")
-    wide = gsv.Program.from_circuit("fq12_mul").info["n_steps"]
+    wide = gsv.Program.from_circuit("fq12_mul").info
+    assert wide["n_steps"] == 8197 and wide["and_terms"] == 2 and gsv.Program.from_circuit("fq_mul").info["and_terms"] == 4
     monkeypatch.setenv("GSV_AND_TERMS", "4")
-    assert wide == 8197 and gsv.Program.from_circuit("fq12_mul").info["n_steps"] == 7164
+    forced = gsv.Program.from_circuit("fq12_mul").info
+    assert forced["n_steps"] == 7164 and forced["and_terms"] == 4
 
 
 @pytest.mark.parametrize("t", range(11))
