@@ -214,15 +214,24 @@ class SlotPool {
 };
 
 // ---- gate fusion ---------------------------------------------------------------------------------
-constexpr uint32_t FUSED_AND = 0x80;
+constexpr uint32_t FUSED_AND = 0x80;  // (FusedOps::push tests this bit)
 constexpr int FUSED_IN = 9;  // operand slots of a fused op: AND a1..a4 (0-3), b1..b4 (4-7), p (8) ; free x1..x4 (0-3) ; DEAD_WIRE = absent
 struct FusedOps {
   std::vector<uint8_t> kind;   // FUSED_AND | 3-bit type   or   parity bit of a free op
-  std::vector<uint32_t> in;    // FUSED_IN per op
+  std::vector<uint32_t> in;    // `stride` per op: 9 in the four-wire form (layout above), 5 in the two-wire form: AND a1 a2 b1 b2 p ; free x1 x2 x3 x4 -
   std::vector<uint32_t> out;
   std::vector<uint32_t> gid;   // stream index of the AND gate (its gate id inside a replay); unused for free ops
+  int stride = FUSED_IN;
   size_t size() const { return out.size(); }
-  void push(uint8_t k, const uint32_t i9[FUSED_IN], uint32_t o, uint32_t g) { kind.push_back(k); in.insert(in.end(), i9, i9 + FUSED_IN); out.push_back(o); gid.push_back(g); }
+  void reserve(size_t n) { kind.reserve(n); in.reserve(n * size_t(stride)); out.reserve(n); gid.reserve(n); }
+  // i9: the nine-slot layout whatever the stride
+  void push(uint8_t k, const uint32_t i9[FUSED_IN], uint32_t o, uint32_t g) {
+    kind.push_back(k);
+    if (stride == FUSED_IN) in.insert(in.end(), i9, i9 + FUSED_IN);
+    else if (k & 0x80) { const uint32_t v[5] = {i9[0], i9[1], i9[4], i9[5], i9[8]}; in.insert(in.end(), v, v + 5); }
+    else { const uint32_t v[5] = {i9[0], i9[1], i9[2], i9[3], 0xFFFFFFFFu}; in.insert(in.end(), v, v + 5); }
+    out.push_back(o); gid.push_back(g);
+  }
 };
 
 // ka: wires per AND input (2 or 4); an expression of up to ka wires (two when ka == 2) is also folded into TWO readers (recomputed)
@@ -231,6 +240,7 @@ inline FusedOps fuse_trace(const Trace& t, const std::vector<uint32_t>& inputs, 
   const uint32_t nw = t.n_wires;
   constexpr uint8_t NOT = uint8_t(GateType::Not), XOR = uint8_t(GateType::Xor), XNOR = uint8_t(GateType::Xnor);
   FusedOps f;
+  f.stride = ka > 2 ? FUSED_IN : 5;
   if (!opt.fuse) {
     for (size_t i = 0; i < n; ++i) {
       if (t.c[i] == DEAD_WIRE) continue;
@@ -260,6 +270,7 @@ inline FusedOps fuse_trace(const Trace& t, const std::vector<uint32_t>& inputs, 
   struct AndDec { uint32_t in[FUSED_IN]; uint32_t out; uint8_t type; };
   const uint32_t dup_terms = ka > 2 ? ka : 2;
   std::vector<AndDec> decs;
+  { size_t n_and = 0; for (size_t i = 0; i < n; ++i) n_and += t.c[i] != DEAD_WIRE && t.type[i] < 8; decs.reserve(n_and); f.reserve(n_and + n_and / 2 + 1024); }
   auto single = [](uint32_t x) { Expr e; e.n = 1; e.par = 0; e.w[0] = x; return e; };
   // operand list of wire x for a reader that takes at most `cap` wires from it
   auto resolve = [&](uint32_t x, uint32_t cap) -> Expr {
@@ -365,7 +376,7 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
     uint32_t mx = 0;
     for (size_t i = 0; i < g.size(); ++i) {
       uint32_t v = 0;
-      for (int k = 0; k < FUSED_IN; ++k) { const uint32_t w = g.in[size_t(FUSED_IN) * i + k]; if (w != DEAD_WIRE) v = std::max(v, l[w]); }
+      for (int k = 0; k < g.stride; ++k) { const uint32_t w = g.in[size_t(g.stride) * i + k]; if (w != DEAD_WIRE) v = std::max(v, l[w]); }
       l[g.out[i]] = v + 1;
       mx = std::max(mx, v + 1);
     }
@@ -380,17 +391,7 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
   }
   const size_t n = f.size();
   auto is_and = [&](size_t i) { return (f.kind[i] & FUSED_AND) != 0; };
-  // two-wire programs (most of a plan's compile work) go on with five operand slots per op: a1 a2 b1 b2 p / x1 x2 x3 x4 -
-  const int fi = p.and_terms == 4 ? FUSED_IN : 5;
-  if (fi == 5) {
-    for (size_t i = 0; i < n; ++i) {
-      const uint32_t* src = &f.in[size_t(FUSED_IN) * i];
-      const uint32_t v[5] = {src[0], src[1], is_and(i) ? src[4] : src[2], is_and(i) ? src[5] : src[3], is_and(i) ? src[8] : DEAD_WIRE};
-      std::copy(v, v + 5, &f.in[5 * i]);
-    }
-    f.in.resize(5 * n);
-    f.in.shrink_to_fit();
-  }
+  const int fi = f.stride;  // operand slots per op: 5 (two-wire) or 9 (four-wire)
   auto ins = [&](size_t i) { return &f.in[size_t(fi) * i]; };
 
   // 1. ASAP dependency level per wire (inputs / constants = 0) and AND-depth (statistic).
@@ -465,14 +466,17 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
   // (steps processed last to first, so reader positions are final) makes producer order follow consumer order.
   if (opt.order_by_reader) {
     std::vector<uint32_t> minpos(nw, 0xFFFFFFFFu);
-    std::vector<std::pair<uint32_t, uint32_t>> keyed;
+    std::vector<uint64_t> keyed;  // (first reader's position << 32) | position inside the segment: a plain sort of these IS the stable sort by reader position
+    std::vector<uint32_t> seg;
     for (uint32_t s = n_steps; s-- > 0;) {
       for (int kind = 1; kind >= 0; --kind) {
         const uint32_t lo = cnt[2 * size_t(s) + kind], hi = cnt[2 * size_t(s) + kind + 1];
+        if (hi - lo < 2) continue;
         keyed.clear();
-        for (uint32_t k = lo; k < hi; ++k) keyed.push_back({minpos[f.out[order[k]]], order[k]});
-        std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, uint32_t>& x, const std::pair<uint32_t, uint32_t>& y) { return x.first < y.first; });
-        for (uint32_t k = lo; k < hi; ++k) order[k] = keyed[k - lo].second;
+        for (uint32_t k = lo; k < hi; ++k) keyed.push_back((uint64_t(minpos[f.out[order[k]]]) << 32) | (k - lo));
+        std::sort(keyed.begin(), keyed.end());
+        seg.assign(order.begin() + lo, order.begin() + hi);
+        for (uint32_t k = lo; k < hi; ++k) order[k] = seg[uint32_t(keyed[k - lo])];
       }
       for (uint32_t k = cnt[2 * size_t(s)]; k < cnt[2 * size_t(s) + 2]; ++k)
         for (int q = 0; q < fi; ++q) { const uint32_t w = ins(order[k])[q]; if (w != DEAD_WIRE) minpos[w] = std::min(minpos[w], k); }
