@@ -528,6 +528,8 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
     p.n_ct = k;
     p.ct_pos.assign(size_t(k), 0);
     p.n_fused_free = n - k;
+    p.ands.reserve(size_t(k));
+    p.xors.reserve(n - size_t(k));
   }
   if (opt.hbm_arena_factor > 1) {
     uint32_t lv = next_in, pk = next_in;
