@@ -191,6 +191,11 @@ def test_plan_built_straight_to_a_file(tmp_path):
     for q in (pa, pb):
         assert q.info == ref.info and q.image_bytes() == ref.image_bytes() and (q.call_info() == ref.call_info()).all() and q.wire_file() == ref.wire_file()
     assert os.path.getsize(a) == os.path.getsize(b) and not [f for f in os.listdir(str(tmp_path)) if ".tmp." in f]
+    # odd shapes: no unit at all (one glue program), a single gate, units with dead / constant / passed-through outputs, 145 calls of 72 programs
+    for spec, us in (("fq_mul", ["no::such_unit"]), ("gate:0", ["x::y"]), ("driver_mix", ["test::inner", "bigint::add"]), ("random_circuit:3", ["test::random_block"])):
+        gsv.Plan.build_file(spec, us, a, window_div=4)
+        pa, pr = gsv.Plan.load(a), gsv.Plan.from_circuit(spec, us, window_div=4)
+        assert pa.info == pr.info and pa.image_bytes() == pr.image_bytes() and (pa.call_info() == pr.call_info()).all()
     with pytest.raises(ValueError):
         gsv.Plan.build_file("fq12_mix", units, a, window_div=1)
     with pytest.raises(gsv.GsvError):
