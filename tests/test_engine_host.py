@@ -312,6 +312,24 @@ def test_warmup_recorders_give_the_same_plan(monkeypatch):
     assert (ref.ciphertexts == cts).all() and (ref.output_label0 == out).all() and h.cbcmac(cts) == ref.ct_hash.tobytes()
 
 
+@pytest.mark.skipif(os.environ.get("GSV_SLOW_TESTS") != "1", reason="slow (two Miller-loop plan builds, ~45 GB of host memory): set GSV_SLOW_TESTS=1")
+def test_warmup_recorders_give_the_same_miller_loop_plan(monkeypatch):
+    """The case the warm-ups exist for: the Miller loop's 178 constant line functions (circuits.hpp add_ell_warmups) recorded by the
+    warm-up recorders while the driver walks the loop.  Same calls, same per-call gates / ciphertexts / steps, same program images as
+    the serial build."""
+    import hashlib
+    import garbled_snark_verifier_amd as gsv
+    units = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::mul_by_034_montgomery", "pairing::ell_by_constant_montgomery",
+             "pairing::double_in_place_circuit_montgomery", "pairing::add_in_place_montgomery", "pairing::mul_by_char_montgomery"]
+    seen = []
+    for threads in ("0", "2"):
+        monkeypatch.setenv("GSV_PLAN_WARMUP_THREADS", threads)
+        plan = gsv.Plan.from_circuit("miller_loop", units, window_div=4)
+        seen.append((dict(plan.info), plan.image_bytes(), hashlib.sha256(plan.call_info().tobytes()).hexdigest()))
+        plan.close()
+    assert seen[0] == seen[1] and seen[0][0]["n_gates"] == 6_909_061_143
+
+
 def test_plan_from_circuit_builds_without_a_device_and_in_both_modes():
     """gsv_plan_from_circuit is host-only work: units are compiled on a worker pool while the driver records (plan_builder.hpp
     CompilePool), with GSV_PLAN_WINDOW_DIV once for half / a quarter of the LDS window.  Every mode gives the reference's counts; the
