@@ -381,6 +381,23 @@ def test_step_barrier_isa_check():
             assert sum(1 for i, t in enumerate(ins) if t.startswith("buffer_wbl2") and ins[i + 1].startswith("s_waitcnt vmcnt(0)")) >= 1, name
 
 
+def test_step_loop_of_the_garbling_kernels_holds_no_spill_traffic():
+    """tools/spill_audit.py on the compiler's own assembly of kernels.hip (hipcc cross-compiles without a GPU): sixteen instantiations of
+    run_program_kernel, no VGPR spill and no scratch instruction anywhere, and in the step loop — the smallest loop that holds both step
+    barriers, what a replay executes per step — of the production garbling kernels (two and four instances per workgroup, with and
+    without four-wire programs) not one v_readlane / v_writelane: their SGPR spills live in the prologue, the dataflow epilogue and the
+    replay loop.  A regression here would put spill traffic on every one of a verifier pass's 8.6 M steps."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import spill_audit
+    rows = spill_audit.audit()
+    assert len(rows) == 16 and {(r["eval"], r["ni"], r["hash"], r["fw"]) for r in rows} == {(e, n, h, f) for e in (False, True) for f in (False, True) for n, h in ((1, 0), (2, 0), (4, 0), (1, 1))}
+    for r in rows:
+        assert r["vgpr_spills"] == 0 and r["kernel"]["scratch"] == 0 and r["vgprs"] <= 128, r  # 16 waves per CU need <= 128 VGPRs
+        assert r["loop"]["ins"] > 3000, r  # the step loop was found
+        if not r["eval"] and r["hash"] == 0 and r["ni"] in (2, 4):
+            assert r["loop"]["readlane"] == 0 and r["loop"]["writelane"] == 0, r
+
+
 @pytest.mark.parametrize("no_vaes", [False, True])
 def test_interleaved_cbcmac_equals_single_chains(no_vaes):
     """gsv_cbcmac_update_many / CbcMacHost::update_many (the drain hashes four instances' streams side by side per host thread — sixteen
