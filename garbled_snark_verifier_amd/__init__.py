@@ -81,7 +81,12 @@ EXPORTS = [
     "gsv_plan_recorder_declare_input", "gsv_plan_recorder_push_gates", "gsv_plan_recorder_call", "gsv_plan_recorder_finish", "gsv_plan_create", "gsv_plan_destroy", "gsv_plan_add_call", "gsv_plan_finish", "gsv_plan_counts", "gsv_session_create_plan", "gsv_session_create_plan_ex",
     "gsv_session_garble_streaming", "gsv_session_garble_streaming_calls", "gsv_plan_call_info", "gsv_plan_image_bytes", "gsv_plan_wire_file", "gsv_plan_save", "gsv_plan_load", "gsv_plan_build_file", "gsv_cbcmac_chains_per_step", "gsv_session_evaluate_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
     "gsv_session_create_plan_opts", "gsv_session_plan_schedule_info", "gsv_session_plan_window", "gsv_session_set_unchecked_slices",
+    "gsv_session_garble_streaming_sink", "gsv_session_garble_evaluate", "gsv_session_evaluate_streaming_indexed", "gsv_session_evaluate_streaming_source",
 ]
+
+# CiphertextHandler / CiphertextSource as host callbacks (include/gsv_engine.h: gsv_ct_sink_fn, gsv_ct_source_fn)
+CT_SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint8), C.c_uint64)
+CT_SOURCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint8), C.c_uint64)
 
 
 def lib():
@@ -161,6 +166,10 @@ def lib():
         L.gsv_session_plan_schedule_info.argtypes = [vp, C.POINTER(_PlanScheduleInfo)]
         L.gsv_session_plan_window.argtypes = [vp, C.c_uint64] + [C.POINTER(C.c_uint64)] * 3
         L.gsv_session_set_unchecked_slices.argtypes = [vp, C.c_int]
+        L.gsv_session_garble_streaming_sink.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, CT_SINK_FN, vp, C.c_int, u8p]
+        L.gsv_session_garble_evaluate.argtypes = [vp, vp, C.c_uint64, C.c_int, u8p]
+        L.gsv_session_evaluate_streaming_indexed.argtypes = [vp, C.c_uint64, C.c_char_p, C.POINTER(C.c_uint64), u8p]
+        L.gsv_session_evaluate_streaming_source.argtypes = [vp, C.c_uint64, CT_SOURCE_FN, vp, u8p]
         _lib = L
     return _lib
 
@@ -560,6 +569,71 @@ class Session:
             return None
         out = np.zeros((self.n, 16), np.uint8)
         _chk(lib().gsv_session_garble_streaming_calls(self.h, gate_id_base, first_call, n_calls, directory.encode() if directory else None, first_index, threads, _p(out)))
+        return [bytes(out[i]) for i in range(self.n)]
+
+    def garble_to_sink(self, handler, gate_id_base=0, first_call=0, n_calls=0, threads=0, with_hashes=False):
+        """Garble with every ciphertext handed to `handler(instance, first_record, records)` — the generic CiphertextHandler
+        (circuit/mod.rs:140-178): `records` is an [n,16] uint8 array in gate order, valid during the call only; the runs of one
+        instance arrive in stream order.  Exceptions raised by the handler abort the pass.  Returns the CBC-MACs with
+        with_hashes=True."""
+        failure = []
+
+        def _cb(_user, inst, first, ptr, n):
+            try:
+                handler(int(inst), int(first), np.ctypeslib.as_array(ptr, shape=(int(n), 16)))
+                return 0
+            except BaseException as e:  # noqa: BLE001 - must not unwind through the C frames
+                failure.append(e)
+                return 1
+
+        cb = CT_SINK_FN(_cb)
+        out = np.zeros((self.n, 16), np.uint8) if with_hashes else None
+        rc = lib().gsv_session_garble_streaming_sink(self.h, gate_id_base, first_call, n_calls, cb, None, threads, _p(out))
+        if failure:
+            raise failure[0]
+        _chk(rc)
+        return [bytes(out[i]) for i in range(self.n)] if with_hashes else None
+
+    def garble_evaluate(self, evaluator, gate_id_base=0, threads=0, with_hashes=False):
+        """Garble this (plan, retain_stream=False) session while `evaluator` — a session of the same plan and options with its inputs
+        set — evaluates every window straight from this session's device block (gsv_session_garble_evaluate)."""
+        out = np.zeros((self.n, 16), np.uint8) if with_hashes else None
+        _chk(lib().gsv_session_garble_evaluate(self.h, evaluator.h, gate_id_base, threads, _p(out)))
+        return [bytes(out[i]) for i in range(self.n)] if with_hashes else None
+
+    def evaluate_streaming_indexed(self, directory, indexes, gate_id_base=0):
+        """Evaluate with instance i reading gc_<indexes[i]>.bin: the finalized instances of a cut-and-choose run in one session."""
+        idx = np.ascontiguousarray(indexes, np.uint64)
+        assert idx.size == self.n
+        out = np.zeros((self.n, 16), np.uint8)
+        _chk(lib().gsv_session_evaluate_streaming_indexed(self.h, gate_id_base, directory.encode(), idx.ctypes.data_as(C.POINTER(C.c_uint64)), _p(out)))
+        return [bytes(out[i]) for i in range(self.n)]
+
+    def evaluate_from_source(self, source, gate_id_base=0):
+        """Evaluate with the ciphertexts pulled from `source(instance, first_record, n) -> [n,16] uint8` (None / short = exhausted):
+        the generic CiphertextSource (ciphertext_source.rs:14-34).  Returns the CBC-MACs of what was read."""
+        failure = []
+
+        def _cb(_user, inst, first, ptr, n):
+            try:
+                a = source(int(inst), int(first), int(n))
+                if a is None:
+                    return 1
+                a = _u8(a).reshape(-1)
+                if a.size != int(n) * 16:
+                    return 1
+                C.memmove(ptr, a.ctypes.data, a.size)
+                return 0
+            except BaseException as e:  # noqa: BLE001
+                failure.append(e)
+                return 2
+
+        cb = CT_SOURCE_FN(_cb)
+        out = np.zeros((self.n, 16), np.uint8)
+        rc = lib().gsv_session_evaluate_streaming_source(self.h, gate_id_base, cb, None, _p(out))
+        if failure:
+            raise failure[0]
+        _chk(rc)
         return [bytes(out[i]) for i in range(self.n)]
 
     def schedule_info(self):

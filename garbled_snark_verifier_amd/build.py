@@ -151,15 +151,34 @@ def build(force=False, verbose=False, diag=False, variant=None, defines=()):
             print(" ".join(c), file=sys.stderr)
         subprocess.check_call(c)
         if i == 0:
-            # Correctness precondition of the vmcnt-free step barrier: the code object is NOT built for threadgroup-split mode (hard
-            # failure).  The instruction-adjacency properties of the barrier are performance properties: warn, and let
-            # tests/test_engine_host.py assert them.
-            check_not_tgsplit(k_o)
-            try:
-                check_step_barrier_isa(disassemble_kernels(k_o))
-            except Exception as e:  # noqa: BLE001 - a missing llvm-objdump or a harmless rescheduling must not break the import
-                print("garbled_snark_verifier_amd.build: warning: step-barrier ISA check: %s" % e, file=sys.stderr)
+            _check_kernels_object(k_o, production=not diag and not variant)
     return out
+
+
+def _check_kernels_object(k_o, production):
+    """ISA checks on the freshly compiled kernels object, before it is linked.
+      * threadgroup-split mode is a CORRECTNESS precondition of the vmcnt-free step barrier: a detection raises.  A missing / renamed
+        llvm tool only warns (the import must not depend on binutils being installed; tests/test_engine_host.py asserts the property).
+      * the step-barrier shape (record prefetch right in front of `s_waitcnt lgkmcnt(0); s_barrier`, no vmcnt wait) is what keeps a
+        compiler bump from silently shipping a barrier that waits for store acknowledgements: fatal for the production library
+        (GSV_ALLOW_BARRIER_ISA_DRIFT=1 turns it into a warning for experiments), a warning for --diag / --variant builds."""
+    try:
+        asm = disassemble_kernels(k_o)
+        tools_ok = True
+    except (OSError, subprocess.CalledProcessError) as e:
+        print("garbled_snark_verifier_amd.build: warning: cannot disassemble the kernels object (%s): ISA checks skipped" % e, file=sys.stderr)
+        asm, tools_ok = None, False
+    if tools_ok:
+        try:
+            check_not_tgsplit(k_o)
+        except (OSError, subprocess.CalledProcessError) as e:
+            print("garbled_snark_verifier_amd.build: warning: threadgroup-split check skipped (%s)" % e, file=sys.stderr)
+        try:
+            check_step_barrier_isa(asm)
+        except RuntimeError as e:
+            if production and os.environ.get("GSV_ALLOW_BARRIER_ISA_DRIFT") != "1":
+                raise RuntimeError("step-barrier ISA check failed, library not linked (GSV_ALLOW_BARRIER_ISA_DRIFT=1 to override): %s" % e)
+            print("garbled_snark_verifier_amd.build: warning: step-barrier ISA check: %s" % e, file=sys.stderr)
 
 
 def check_not_tgsplit(obj=None):

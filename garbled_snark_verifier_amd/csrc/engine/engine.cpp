@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <chrono>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -129,8 +130,10 @@ struct gsv_engine {
 };
 
 struct gsv_drain;
+struct PairState;
 extern "C" {
 static void destroy_drain(gsv_drain* d);
+static void destroy_pair(PairState* ps);
 }
 struct gsv_session {
   gsv_engine* e = nullptr;
@@ -166,6 +169,8 @@ struct gsv_session {
   int hasher = 0;  // 0 AesNiHasher, 1 Blake3Hasher
   std::vector<uint64_t> ct_uploaded;  // per instance: records supplied by gsv_session_upload_ciphertexts
   struct gsv_drain* drain = nullptr;   // streaming drain: copy streams, pinned buffers, per-instance MAC states (created on first use)
+  void* ct_alt = nullptr;              // garble -> evaluate on the device: the second program-order ciphertext block
+  struct PairState* pair = nullptr;    // ... and its stream / events (created on first use)
   uint64_t ct_stride() const { return plan ? (plan_retain ? plan->n_ct : plan_max_block) : ct_cap * p->prog.n_ct; }  // n_ct does not depend on the variant
 };
 
@@ -427,6 +432,8 @@ void gsv_session_destroy(gsv_session* s) {
   for (void* q : {s->d_calls, s->d_copy_src, s->d_copy_dst, s->d_deps, s->d_flags, s->d_error}) if (q) (void)hipFree(q);
   if (s->plan_out_slots) (void)hipFree(s->plan_out_slots);
   destroy_drain(s->drain);
+  destroy_pair(s->pair);
+  if (s->ct_alt) (void)hipFree(s->ct_alt);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
@@ -998,7 +1005,12 @@ static Schedule make_schedule(const gsv_plan* plan, uint32_t ni, size_t n_instan
   // ciphertext window: the whole stream when it is retained, else about a quarter of the free memory for the two window buffers
   if (o.retain_stream) sp.max_window_ct = ~0ull;
   else {
-    uint64_t w = o.window_ct_records ? o.window_ct_records : uint64_t(free_bytes / 4 / 32 / std::max<size_t>(1, n_instances));
+    // Default: about a quarter of the free memory for the two window buffers, but never more than 64 M records (1 GB) per instance: a
+    // pass must be MANY windows, because the drain of window k (D2H copies, the serial CBC-MAC chains, gc files) runs beside the
+    // garbling of window k+1.  With one instance on a 288 GB device the uncapped default was 2.2 G records = 2 windows per verifier
+    // pass, half of the 27-s CBC-MAC chain uncovered: 48.2 s against 37.0 s with 1 GB windows (profiles/r03_e2e/one_instance_commit.log);
+    // it also made gsv_session_evaluate_streaming stage tens of GB on the host.
+    uint64_t w = o.window_ct_records ? o.window_ct_records : std::min<uint64_t>(uint64_t(free_bytes / 4 / 32 / std::max<size_t>(1, n_instances)), 1ull << 26);
     if (!o.window_ct_records && conc == 1) w = 0;  // sequential sessions keep the one-call block of rounds 1-2 (smallest footprint)
     sp.max_window_ct = std::max<uint64_t>(w, max_block);
   }
@@ -1096,7 +1108,7 @@ int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_i
         d.n_deps = uint32_t(deps.size()) - d.dep_off;
         if (csrc.size() > 0xFFFFFF00ull) return fail(GSV_ERR_CIRCUIT, "plan hand-over lists too large");
       }
-      s->flag_stride = std::max<uint32_t>(s->flag_stride, w.call1 - w.call0);
+      s->flag_stride = std::max<uint32_t>(s->flag_stride, w.call1 - w.call0 + 1);  // + the group's progress counter (kernels.hip, watchdog)
     }
     const size_t n_wg = (n_instances + s->ni - 1) / s->ni;
     int rc;
@@ -1280,21 +1292,29 @@ static int launch(gsv_session* s, uint64_t gate_id_base, bool eval, uint64_t rep
 // completion flags of the calls it depends on, fetches its inputs from the global wires, runs its program in its own scratch region
 // and publishes its outputs (kernels.hip).  A sequential schedule (one call in flight) is the same launch with each call depending on
 // its predecessor: the instance groups still drift apart instead of meeting at a launch boundary after every call.
-static int launch_plan_window(gsv_session* s, size_t w, uint64_t gate_id_base, bool eval) {
+static int launch_plan_window(gsv_session* s, size_t w, uint64_t gate_id_base, bool eval, void* ct_block = nullptr, hipStream_t stream = nullptr) {
   const Program& f = s->facade;
+  if (!ct_block) ct_block = s->CT;       // (garble -> evaluate: the garbler's current block, for both sessions)
+  if (!stream) stream = s->e->stream;
   const Schedule::Window& win = s->sched.windows[w];
   dev::KernelArgs ka{};
   ka.calls = static_cast<const dev::CallDesc*>(s->d_calls) + win.call0;
   ka.copy_src = static_cast<const uint32_t*>(s->d_copy_src); ka.copy_dst = static_cast<const uint32_t*>(s->d_copy_dst);
   ka.deps = static_cast<const uint32_t*>(s->d_deps); ka.flags = static_cast<uint32_t*>(s->d_flags); ka.error = static_cast<uint32_t*>(s->d_error);
   ka.flag_stride = s->flag_stride; ka.epoch = ++s->epoch;
-  ka.W = static_cast<uint4*>(s->W); ka.VB = static_cast<uint8_t*>(s->VB); ka.CT = static_cast<uint4*>(s->CT);
+  {
+    // dependency watchdog (kernels.hip): seconds without ANY completed call of the instance group before a wait gives up
+    double secs = 60.0;
+    if (const char* ev = getenv("GSV_DEP_WAIT_SECONDS")) { char* end = nullptr; const double v = std::strtod(ev, &end); if (end != ev && v > 0) secs = v; }
+    ka.wait_ticks = (unsigned long long)(std::min(secs, 86400.0) * 1e8);
+  }
+  ka.W = static_cast<uint4*>(s->W); ka.VB = static_cast<uint8_t*>(s->VB); ka.CT = static_cast<uint4*>(ct_block);
   ka.delta = static_cast<const uint4*>(s->delta); ka.te = static_cast<const uint32_t*>(s->e->te);
   ka.ct_stride = s->ct_stride(); ka.gid_base = gate_id_base; ka.n_gates = 0; ka.n_ct = 0;
   ka.n_steps = 0; ka.n_slots = f.n_slots; ka.replays = 1; ka.rep_base = 0; ka.ct_cap_replays = 1;
   ka.n_instances = uint32_t(s->n_inst); ka.hasher = uint32_t(s->hasher); ka.instances_per_wg = s->ni;
   for (uint32_t k = win.call0; k < win.call1 && !ka.any_four_wire; ++k) ka.any_four_wire = s->call_prog(k).and_terms == 4;
-  int lrc = gsvk_launch_batch(&ka, uint32_t(s->n_inst), win.call1 - win.call0, eval ? 1 : 0, s->e->stream);
+  int lrc = gsvk_launch_batch(&ka, uint32_t(s->n_inst), win.call1 - win.call0, eval ? 1 : 0, stream);
   if (lrc != 0) return fail(GSV_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipError_t(lrc)));
   return GSV_OK;
 }
@@ -1306,13 +1326,14 @@ static int check_plan_error(gsv_session* s) {
   return GSV_OK;
 }
 // Gate order <-> program order for the calls of one window: ct_gate (window-relative, gate order) <-> the window's device block.
-static int permute_plan_window(gsv_session* s, size_t w, uint64_t gate_stride, int scatter) {
+static int permute_plan_window(gsv_session* s, size_t w, uint64_t gate_stride, int scatter, void* ct_block = nullptr) {
   const Schedule::Window& win = s->sched.windows[w];
+  if (!ct_block) ct_block = s->CT;
   for (uint32_t k = win.call0; k < win.call1; ++k) {
     const Program& cp = s->call_prog(k);
     if (!cp.n_ct) continue;
     const uint64_t rel = s->plan->calls[k].ct_off - win.ct0;
-    uint8_t* block = static_cast<uint8_t*>(s->CT) + (s->plan_retain ? s->plan->calls[k].ct_off : rel) * 16;
+    uint8_t* block = static_cast<uint8_t*>(ct_block) + (s->plan_retain ? s->plan->calls[k].ct_off : rel) * 16;
     if (gsvk_gather_segment(block, s->ct_stride(), s->call_dev[k].dp.ct_pos, cp.n_ct, 1, uint32_t(s->n_inst), static_cast<uint8_t*>(s->ct_gate) + rel * 16, gate_stride, scatter, s->e->stream) != 0)
       return fail(GSV_ERR_DEVICE, scatter ? "ciphertext scatter launch failed" : "ciphertext gather launch failed");
   }
@@ -1343,6 +1364,7 @@ static int gather_plan_outputs(gsv_session* s, bool eval) {
 static int launch_plan(gsv_session* s, uint64_t gate_id_base, bool eval) {
   if (!s->plan_retain) return fail(GSV_ERR_INVALID, "this plan session keeps one window of ciphertexts only: use gsv_session_garble_streaming");
   HIPCHK(hipSetDevice(s->e->device));
+  HIPCHK(hipMemsetAsync(s->d_error, 0, 4, s->e->stream));  // every pass starts with a clean dependency-wait flag
   HIPCHK(hipEventRecord(s->ev0, s->e->stream));
   for (size_t w = 0; w < s->sched.windows.size(); ++w) {
     int rc = launch_plan_window(s, w, gate_id_base, eval);
@@ -1439,6 +1461,7 @@ static int garble_discard(gsv_session* s, uint64_t gate_id_base, size_t c0, size
   int rc = GSV_OK;
   if (s->plan) {
     size_t w0 = 0, w1 = 0;
+    if (c0 == 0) HIPCHK(hipMemsetAsync(s->d_error, 0, 4, s->e->stream));
     rc = window_range(s, c0, c1, &w0, &w1);
     for (size_t w = w0; w < w1 && rc == GSV_OK; ++w) rc = launch_plan_window(s, w, gate_id_base, false);
     if (rc == GSV_OK) {
@@ -1453,9 +1476,45 @@ static int garble_discard(gsv_session* s, uint64_t gate_id_base, size_t c0, size
   return rc;
 }
 
-static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t c0, size_t c1, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes) {
-  if (!hashes && !dir) return garble_discard(s, gate_id_base, c0, c1);  // garble only (output labels, device-rate measurements of long plans / chains)
-  if (!hashes) return fail(GSV_ERR_INVALID, "null hash buffer");
+// Where a drained stream goes (any combination): the per-instance CBC-MAC (AESAccumulatingHash), gc_<index>.bin files, a host callback.
+struct DrainSink {
+  uint8_t* hashes = nullptr;           // n_inst x 16: the MAC states after this call
+  const char* dir = nullptr;           // gc_<index>.bin, index = indexes ? indexes[i] : first_index + i
+  uint64_t first_index = 0;
+  gsv_ct_sink_fn fn = nullptr;         // CiphertextHandler::handle over a run of records of one instance
+  void* user = nullptr;
+  bool any() const { return hashes || dir || fn; }
+};
+// Garble -> evaluate on the device (gsv_session_garble_evaluate): the evaluator session consumes window k from the garbler's
+// program-order block while the garbler writes window k+1 into the other one of two blocks.
+struct PairState {
+  hipStream_t stream = nullptr;                           // the evaluator's launches
+  hipEvent_t garbled[2] = {nullptr, nullptr}, evaluated[2] = {nullptr, nullptr};
+};
+static int ensure_pair(gsv_session* s) {
+  if (!s->ct_alt) DEVALLOC(&s->ct_alt, s->n_inst * size_t(s->ct_stride()) * 16, "the second ciphertext block (garble -> evaluate)");
+  if (!s->pair) {
+    std::unique_ptr<PairState> ps(new PairState());
+    HIPCHK(hipStreamCreateWithFlags(&ps->stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+      HIPCHK(hipEventCreateWithFlags(&ps->garbled[b], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&ps->evaluated[b], hipEventDisableTiming));
+    }
+    s->pair = ps.release();
+  }
+  return GSV_OK;
+}
+static void destroy_pair(PairState* ps) {
+  if (!ps) return;
+  for (int b = 0; b < 2; ++b) { if (ps->garbled[b]) (void)hipEventDestroy(ps->garbled[b]); if (ps->evaluated[b]) (void)hipEventDestroy(ps->evaluated[b]); }
+  if (ps->stream) (void)hipStreamDestroy(ps->stream);
+  delete ps;
+}
+
+// `ev`: an evaluator session over the same plan / schedule (plan sessions that do not retain the stream): every window is evaluated
+// straight from the garbler's device block while the next window is garbled.
+static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t c0, size_t c1, const DrainSink& sink, int n_threads, gsv_session* ev = nullptr) {
+  if (!sink.any() && !ev) return garble_discard(s, gate_id_base, c0, c1);  // garble only (output labels, device-rate measurements of long plans / chains)
   const Program& g = s->prog();
   // program sessions: segments of one ring (ct_cap replays of n_ct records); plan sessions: one WINDOW of the schedule per segment
   size_t pw0 = 0, pw1 = 0;
@@ -1464,6 +1523,8 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   const uint64_t first = s->plan ? pw0 : 0, total = s->plan ? pw1 : s->replays;
   const bool new_pass = s->plan ? c0 == 0 : true;
   const size_t n_inst = s->n_inst;
+  const bool want_drain = sink.any();
+  const bool want_mac = sink.hashes != nullptr;
   const size_t GROUP = size_t(gsv_drain::group_for(n_inst));
   const size_t n_groups = (n_inst + GROUP - 1) / GROUP;
   // a worker MACs GROUP streams side by side at ~3e8 blocks/s (four chains, AES-NI) or ~1e9 (sixteen, VAES): a dozen / four of them keep
@@ -1472,25 +1533,35 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   T = std::min(T, n_groups);
   HIPCHK(hipSetDevice(s->e->device));
   const uint64_t seg_records = seg * n_ct;  // per instance
-  if (!s->ct_gate && seg_records) DEVALLOC(&s->ct_gate, n_inst * seg_records * 16, "the gate-order ciphertext buffer");
-  { int rc = ensure_drain(s, T, seg_records, int(GROUP)); if (rc) return rc; }
-  gsv_drain& dr = *s->drain;
-  if (new_pass || dr.macs.size() != n_inst) dr.macs.assign(n_inst, CbcMacHost());  // a new pass starts from h = 0; later slices chain
-  std::vector<CbcMacHost>& macs = dr.macs;
+  if (want_drain) {
+    if (!s->ct_gate && seg_records) DEVALLOC(&s->ct_gate, n_inst * seg_records * 16, "the gate-order ciphertext buffer");
+    int rc = ensure_drain(s, T, seg_records, int(GROUP));
+    if (rc) return rc;
+  }
+  if (ev) { int rc = ensure_pair(s); if (rc) return rc; }
+  if (s->plan && new_pass) HIPCHK(hipMemsetAsync(s->d_error, 0, 4, s->e->stream));  // a new pass starts with a clean dependency-wait flag
+  if (ev && new_pass) HIPCHK(hipMemsetAsync(ev->d_error, 0, 4, s->e->stream));
+  std::vector<CbcMacHost> no_macs;
+  if (want_drain && (new_pass || s->drain->macs.size() != n_inst)) s->drain->macs.assign(n_inst, CbcMacHost());  // a new pass starts from h = 0; later slices chain
+  std::vector<CbcMacHost>& macs = want_drain ? s->drain->macs : no_macs;
   std::vector<FILE*> files(n_inst, nullptr);
+  std::vector<std::string> paths(n_inst);
   auto close_files = [&]() { for (FILE*& f : files) if (f) { std::fclose(f); f = nullptr; } };
-  if (dir)
+  // a failed pass must not leave a plausible-looking prefix of a ciphertext file behind
+  auto remove_files = [&]() { if (sink.dir) for (const std::string& q : paths) if (!q.empty()) std::remove(q.c_str()); };
+  if (sink.dir)
     for (size_t i = 0; i < n_inst; ++i) {
-      const std::string path = std::string(dir) + "/gc_" + std::to_string(first_index + i) + ".bin";
-      files[i] = std::fopen(path.c_str(), new_pass ? "wb" : "ab");
-      if (!files[i]) { close_files(); return fail(GSV_ERR_INVALID, "cannot create " + path); }
+      paths[i] = std::string(sink.dir) + "/gc_" + std::to_string(sink.first_index + i) + ".bin";
+      files[i] = std::fopen(paths[i].c_str(), new_pass ? "wb" : "ab");
+      if (!files[i]) { close_files(); return fail(GSV_ERR_INVALID, "cannot create " + paths[i]); }
     }
   std::atomic<int> err{0};
-  const uint64_t chunk = dr.chunk;
-  // one drain = all instances x the `n` records per instance sitting in the gate-order buffer
-  auto drain = [&](uint64_t n, std::vector<std::thread>& pool) {
+  const uint64_t chunk = want_drain ? s->drain->chunk : 0;
+  // one drain = all instances x the `n` records per instance sitting in the gate-order buffer; `base` = stream index of the first one
+  auto drain = [&](uint64_t n, uint64_t base, std::vector<std::thread>& pool) {
+    gsv_drain& dr = *s->drain;
     for (size_t t = 0; t < T; ++t)
-      pool.emplace_back([&, t, n]() {
+      pool.emplace_back([&, t, n, base]() {
         if (hipSetDevice(s->e->device) != hipSuccess) { err = 1; return; }
         gsv_drain::Worker& w = dr.workers[t];
         for (size_t grp = t; grp < n_groups && !err && n; grp += T) {
@@ -1512,13 +1583,18 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
           if (!copy(0, 0)) { err = 1; break; }
           for (uint64_t off = 0; off < n; off += chunk, b ^= 1) {
             const uint64_t m = std::min(chunk, n - off);
-            CbcMacHost* mp[gsv_drain::GROUP_MAX];
-            const uint8_t* cp[gsv_drain::GROUP_MAX];
-            for (size_t g = 0; g < ng; ++g) { mp[g] = &macs[i0 + g]; cp[g] = static_cast<const uint8_t*>(w.pinned[b][g]); }
-            CbcMacHost::update_many(mp, cp, ng, m);  // sixteen / four chains per step, a ragged last group chain by chain
-            if (dir)
+            if (want_mac) {
+              CbcMacHost* mp[gsv_drain::GROUP_MAX];
+              const uint8_t* cp[gsv_drain::GROUP_MAX];
+              for (size_t g = 0; g < ng; ++g) { mp[g] = &macs[i0 + g]; cp[g] = static_cast<const uint8_t*>(w.pinned[b][g]); }
+              CbcMacHost::update_many(mp, cp, ng, m);  // sixteen / four chains per step, a ragged last group chain by chain
+            }
+            if (sink.dir)
               for (size_t g = 0; g < ng; ++g)
                 if (std::fwrite(w.pinned[b][g], 16, m, files[i0 + g]) != m) { err = 2; break; }
+            if (sink.fn && !err)
+              for (size_t g = 0; g < ng; ++g)
+                if (sink.fn(sink.user, i0 + g, base + off, static_cast<const uint8_t*>(w.pinned[b][g]), m) != 0) { err = 3; break; }
             if (err) break;
             if (off + chunk < n && !copy(off + chunk, b ^ 1)) { err = 1; break; }
           }
@@ -1540,21 +1616,36 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   if (hipEventRecord(s->ev0, s->e->stream) != hipSuccess) { close_files(); return fail(GSV_ERR_DEVICE, "hipEventRecord failed"); }
   for (uint64_t r0 = first; r0 < total && rc == GSV_OK; r0 += seg) {
     const uint64_t r1 = std::min(total, r0 + seg);
-    uint64_t n_records;  // per instance, in this segment
+    uint64_t n_records, base;  // per instance, in this segment; stream index of its first record
     if (s->plan) {
       const size_t w = size_t(r0);
-      rc = launch_plan_window(s, w, gate_id_base, false);
+      void* block = s->CT;
+      if (ev) {
+        // window w goes to block w & 1; the evaluator must be done with what that block held (window w - 2)
+        const int b = int(w & 1);
+        block = b ? s->ct_alt : s->CT;
+        if (w >= pw0 + 2 && hipStreamWaitEvent(s->e->stream, s->pair->evaluated[b], 0) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "hipStreamWaitEvent failed"); break; }
+      }
+      rc = launch_plan_window(s, w, gate_id_base, false, block);
       if (rc != GSV_OK) break;
+      if (ev) {
+        const int b = int(w & 1);
+        if (hipEventRecord(s->pair->garbled[b], s->e->stream) != hipSuccess || hipStreamWaitEvent(s->pair->stream, s->pair->garbled[b], 0) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "event hand-over failed"); break; }
+        rc = launch_plan_window(ev, w, gate_id_base, true, block, s->pair->stream);
+        if (rc != GSV_OK) break;
+        if (hipEventRecord(s->pair->evaluated[b], s->pair->stream) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "hipEventRecord failed"); break; }
+      }
       join(cur);
       n_records = s->sched.windows[w].n_ct;
-      rc = permute_plan_window(s, w, seg_records, 0);
-      if (rc != GSV_OK) break;
+      base = s->sched.windows[w].ct0;
+      if (want_drain) { rc = permute_plan_window(s, w, seg_records, 0, block); if (rc != GSV_OK) break; }
     } else {
       // ring slots are (replay % ct_cap): a segment starts at a multiple of ct_cap, so its replays sit in slots 0..n_rep-1
       rc = launch(s, gate_id_base, false, r0, r1 - r0);
       if (rc != GSV_OK) break;
       join(cur);
       n_records = (r1 - r0) * n_ct;
+      base = r0 * n_ct;
       if (gsvk_gather_segment(s->CT, s->ct_stride(), s->dp.ct_pos, n_ct, uint32_t(r1 - r0), uint32_t(n_inst), s->ct_gate, seg_records, 0, s->e->stream) != 0) {
         rc = fail(GSV_ERR_DEVICE, "ciphertext gather launch failed");
         break;
@@ -1566,9 +1657,10 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
       t_wait_device += secs(t0);
     }
     drained_records += n_records;
-    drain(n_records, cur);
+    if (want_drain) drain(n_records, base, cur);
   }
   join(cur);
+  if (ev && hipStreamSynchronize(s->pair->stream) != hipSuccess && rc == GSV_OK) rc = fail(GSV_ERR_DEVICE, "evaluation kernel failed");
   if (stats) {
     const double tot = secs(t_begin);
     std::fprintf(stderr, "drain: %.2f s for %zu instances x %llu records (%.1f GB/s), %zu MAC workers; host thread waited %.2f s for drains and %.2f s for the device\n", tot, n_inst,
@@ -1576,29 +1668,72 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   }
   if (rc == GSV_OK && s->plan) {
     (void)hipEventRecord(s->ev1, s->e->stream);
-    if (c1 == s->plan->calls.size()) rc = gather_plan_outputs(s, false); else { s->ran = true; s->last_eval = false; }
+    if (c1 == s->plan->calls.size()) {
+      rc = gather_plan_outputs(s, false);
+      if (rc == GSV_OK && ev) rc = gather_plan_outputs(ev, true);
+    } else { s->ran = true; s->last_eval = false; }
   }
   close_files();
   if (rc == GSV_OK && s->plan) rc = check_plan_error(s);
-  if (rc != GSV_OK) return rc;
-  if (err) return fail(err == 2 ? GSV_ERR_INVALID : GSV_ERR_DEVICE, err == 2 ? "short write to a gc file" : "device copy failed while draining ciphertexts");
-  for (size_t i = 0; i < n_inst; ++i) macs[i].digest(hashes + 16 * i);
+  if (rc == GSV_OK && ev) rc = check_plan_error(ev);
+  if (rc == GSV_OK && err) rc = fail(err == 2 ? GSV_ERR_INVALID : err == 3 ? GSV_ERR_INVALID : GSV_ERR_DEVICE,
+                                     err == 2 ? "short write to a gc file" : err == 3 ? "the ciphertext sink reported an error" : "device copy failed while draining ciphertexts");
+  if (rc != GSV_OK) { remove_files(); return rc; }
+  if (want_mac) for (size_t i = 0; i < n_inst; ++i) macs[i].digest(sink.hashes + 16 * i);
   s->garbled = true;
   return GSV_OK;
 }
+static DrainSink mac_file_sink(uint8_t* hashes, const char* dir, uint64_t first_index) { DrainSink k; k.hashes = hashes; k.dir = dir; k.first_index = first_index; return k; }
 int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes) {
   if (!s) return fail(GSV_ERR_INVALID, "null argument");
-  return garble_streaming_range(s, gate_id_base, 0, s->plan ? s->plan->calls.size() : 1, dir, first_index, n_threads, hashes);
+  if (dir && !hashes) return fail(GSV_ERR_INVALID, "null hash buffer");
+  return garble_streaming_range(s, gate_id_base, 0, s->plan ? s->plan->calls.size() : 1, mac_file_sink(hashes, dir, first_index), n_threads);
 }
-int gsv_session_garble_streaming_calls(gsv_session* s, uint64_t gate_id_base, uint64_t first_call, uint64_t n_calls, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes) {
+// a slice must start a new pass or continue where the previous one ended
+static int check_slice(gsv_session* s, uint64_t first_call, uint64_t n_calls) {
   if (!s || !s->plan) return fail(GSV_ERR_INVALID, "null session / not a plan session");
   if (first_call > s->plan->calls.size() || n_calls > s->plan->calls.size() - first_call) return fail(GSV_ERR_INVALID, "call range outside the plan");
   // wires, gate ids and the MAC states continue from slice to slice: a slice either starts a new pass or continues the previous one
   if (first_call != 0 && first_call != s->next_call && !s->unchecked_slices)
     return fail(GSV_ERR_INVALID, "slice starts at call " + std::to_string(first_call) + " but the previous slice ended at call " + std::to_string(s->next_call) +
                                      " (gsv_session_set_unchecked_slices for timing runs)");
-  int rc = garble_streaming_range(s, gate_id_base, size_t(first_call), size_t(first_call + n_calls), dir, first_index, n_threads, hashes);
+  return GSV_OK;
+}
+int gsv_session_garble_streaming_calls(gsv_session* s, uint64_t gate_id_base, uint64_t first_call, uint64_t n_calls, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes) {
+  int rc = check_slice(s, first_call, n_calls);
+  if (rc) return rc;
+  if (dir && !hashes) return fail(GSV_ERR_INVALID, "null hash buffer");
+  rc = garble_streaming_range(s, gate_id_base, size_t(first_call), size_t(first_call + n_calls), mac_file_sink(hashes, dir, first_index), n_threads);
   if (rc == GSV_OK) { s->next_call = first_call + n_calls; s->garbled = s->plan_retain && s->next_call == s->plan->calls.size(); }
+  return rc;
+}
+// The generic CiphertextHandler: every drained run of records is handed to `sink` (gate order, per instance in stream order).
+int gsv_session_garble_streaming_sink(gsv_session* s, uint64_t gate_id_base, uint64_t first_call, uint64_t n_calls, gsv_ct_sink_fn sink, void* user, int n_threads, uint8_t* hashes) {
+  if (!s || !sink) return fail(GSV_ERR_INVALID, "null argument");
+  DrainSink k;
+  k.hashes = hashes; k.fn = sink; k.user = user;
+  if (!s->plan) return garble_streaming_range(s, gate_id_base, 0, 1, k, n_threads);
+  if (first_call == 0 && n_calls == 0) n_calls = s->plan->calls.size();
+  int rc = check_slice(s, first_call, n_calls);
+  if (rc) return rc;
+  rc = garble_streaming_range(s, gate_id_base, size_t(first_call), size_t(first_call + n_calls), k, n_threads);
+  if (rc == GSV_OK) { s->next_call = first_call + n_calls; s->garbled = s->plan_retain && s->next_call == s->plan->calls.size(); }
+  return rc;
+}
+// Garble and evaluate side by side on the device (examples/groth16_garble.rs:171-230: the garbler thread feeds the evaluator thread
+// through a channel; here window k of the garbler's device block is evaluated while window k+1 is garbled).
+int gsv_session_garble_evaluate(gsv_session* gs, gsv_session* es, uint64_t gate_id_base, int n_threads, uint8_t* hashes) {
+  if (!gs || !es || gs == es) return fail(GSV_ERR_INVALID, "null / identical sessions");
+  if (!gs->plan || gs->plan != es->plan || gs->e != es->e || gs->n_inst != es->n_inst || gs->ni != es->ni || gs->hasher != es->hasher)
+    return fail(GSV_ERR_INVALID, "garbler and evaluator must be plan sessions of the same plan, engine, instance count and hasher");
+  if (gs->plan_retain || es->plan_retain) return fail(GSV_ERR_INVALID, "gsv_session_garble_evaluate is for sessions that do not retain the stream (retain_stream = 0)");
+  const auto &wa = gs->sched.windows, &wb = es->sched.windows;
+  if (wa.size() != wb.size() || gs->plan_max_block != es->plan_max_block) return fail(GSV_ERR_INVALID, "garbler and evaluator sessions have different schedules (create both with the same options)");
+  for (size_t i = 0; i < wa.size(); ++i) if (wa[i].call0 != wb[i].call0 || wa[i].call1 != wb[i].call1) return fail(GSV_ERR_INVALID, "garbler and evaluator sessions have different schedules (create both with the same options)");
+  DrainSink k;
+  k.hashes = hashes;
+  int rc = garble_streaming_range(gs, gate_id_base, 0, gs->plan->calls.size(), k, n_threads, es);
+  if (rc == GSV_OK) { gs->next_call = gs->plan->calls.size(); gs->garbled = false; }
   return rc;
 }
 int gsv_plan_call_info(const gsv_plan* p, uint64_t call, uint64_t* gate_offset, uint64_t* n_gates, uint64_t* ct_offset, uint64_t* n_ciphertexts, uint64_t* n_steps) {
@@ -1623,44 +1758,42 @@ int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base) {
   return launch(s, gate_id_base, true);
 }
 
-// Evaluate with the ciphertexts coming from gc_<index>.bin files (EvaluateMode over a FileSource: evaluate_mode.rs:59-196,
-// ciphertext_source.rs:36-107), segment by segment: program sessions one ring at a time, plan sessions one call at a time.  The
-// records are read in gate order, uploaded, scattered to the program-order positions the kernel reads, and — as FileSource
-// does while reading — folded into the per-instance CBC-MAC, returned in `hashes` when it is not NULL.
-int gsv_session_evaluate_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, uint8_t* hashes) {
-  if (!s || !dir) return fail(GSV_ERR_INVALID, "null argument");
+// Evaluate with the ciphertexts coming from a CiphertextSource (ciphertext_source.rs:14-107), segment by segment: program sessions one
+// ring at a time, plan sessions one window of the schedule at a time.  The records arrive in gate order in bounded chunks (a
+// page-locked 16 MiB staging buffer: a window may be gigabytes), are folded into the per-instance CBC-MAC as FileSource does while
+// reading (ciphertext_source.rs:36-107), uploaded, scattered to the program-order positions the kernel reads, and evaluated.
+//   read(instance, first_record, dst, n) -> 0, or non-zero when the source runs dry ("Ciphertext source exhausted", evaluate_mode.rs:139-142)
+static int evaluate_streaming_impl(gsv_session* s, uint64_t gate_id_base, const std::function<int(size_t, uint64_t, uint8_t*, uint64_t)>& read, uint8_t* hashes) {
   const Program& g = s->prog();
-  // plan sessions: one window of the schedule per segment (its calls' blocks are consecutive in the file)
+  // plan sessions: one window of the schedule per segment (its calls' blocks are consecutive in the stream)
   const uint64_t n_ct = s->plan ? s->plan_max_block : g.n_ct, total = s->plan ? s->sched.windows.size() : s->replays, seg = s->plan ? 1 : s->ct_cap;
   const size_t n_inst = s->n_inst;
   HIPCHK(hipSetDevice(s->e->device));
   const uint64_t seg_records = seg * n_ct;
   if (!s->ct_gate && seg_records) DEVALLOC(&s->ct_gate, n_inst * seg_records * 16, "the gate-order ciphertext buffer");
-  std::vector<FILE*> files(n_inst, nullptr);
-  auto close_files = [&]() { for (FILE*& f : files) if (f) { std::fclose(f); f = nullptr; } };
-  for (size_t i = 0; i < n_inst; ++i) {
-    const std::string path = std::string(dir) + "/gc_" + std::to_string(first_index + i) + ".bin";
-    files[i] = std::fopen(path.c_str(), "rb");
-    if (!files[i]) { close_files(); return fail(GSV_ERR_INVALID, "cannot open " + path); }
-  }
+  struct Pinned { void* p[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; ~Pinned() { for (void* q : p) if (q) (void)hipHostFree(q); for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); } } stage;
+  const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(seg_records, 1), CT_STAGE_RECORDS);
+  for (int b = 0; b < 2; ++b) { HIPCHK(hipHostMalloc(&stage.p[b], size_t(chunk) * 16, hipHostMallocDefault)); HIPCHK(hipEventCreateWithFlags(&stage.ev[b], hipEventDisableTiming)); }
   std::vector<CbcMacHost> macs(n_inst);
-  std::vector<uint8_t> host;
-  int rc = GSV_OK;
-  if (hipEventRecord(s->ev0, s->e->stream) != hipSuccess) { close_files(); return fail(GSV_ERR_DEVICE, "hipEventRecord failed"); }
+  if (s->plan) HIPCHK(hipMemsetAsync(s->d_error, 0, 4, s->e->stream));
+  HIPCHK(hipEventRecord(s->ev0, s->e->stream));
+  int rc = GSV_OK, b = 0;
   for (uint64_t r0 = 0; r0 < total && rc == GSV_OK; r0 += seg) {
     const uint64_t r1 = std::min(total, r0 + seg);
     const uint64_t n_records = s->plan ? s->sched.windows[size_t(r0)].n_ct : (r1 - r0) * n_ct;  // per instance
-    host.resize(size_t(n_records) * 16);
-    for (size_t i = 0; i < n_inst && rc == GSV_OK; ++i) {
-      if (n_records && std::fread(host.data(), 16, n_records, files[i]) != n_records) {
-        // EvaluateMode panics with "Ciphertext source exhausted" when the source runs dry (evaluate_mode.rs:139-142)
-        rc = fail(GSV_ERR_EXHAUSTED, "Ciphertext source exhausted: gc file of instance " + std::to_string(i) + " is too short");
-        break;
+    const uint64_t base = s->plan ? s->sched.windows[size_t(r0)].ct0 : r0 * n_ct;
+    // the previous segment's kernel reads the program-order block, not ct_gate: uploads into ct_gate may start right away, the
+    // scatter below is ordered behind that kernel by the stream
+    for (size_t i = 0; i < n_inst && rc == GSV_OK; ++i)
+      for (uint64_t off = 0; off < n_records; off += chunk, b ^= 1) {
+        const uint64_t m = std::min(chunk, n_records - off);
+        HIPCHK(hipEventSynchronize(stage.ev[b]));  // the copy that last used this staging buffer has finished
+        uint8_t* host = static_cast<uint8_t*>(stage.p[b]);
+        if (read(i, base + off, host, m) != 0) { rc = fail(GSV_ERR_EXHAUSTED, "Ciphertext source exhausted: instance " + std::to_string(i) + " ran dry at record " + std::to_string(base + off)); break; }
+        if (hashes) macs[i].update(host, m);
+        if (hipMemcpyAsync(static_cast<uint8_t*>(s->ct_gate) + (i * seg_records + off) * 16, host, m * 16, hipMemcpyHostToDevice, s->e->stream) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "ciphertext upload failed"); break; }
+        HIPCHK(hipEventRecord(stage.ev[b], s->e->stream));
       }
-      macs[i].update(host.data(), n_records);
-      if (n_records && hipMemcpy(static_cast<uint8_t*>(s->ct_gate) + i * seg_records * 16, host.data(), n_records * 16, hipMemcpyHostToDevice) != hipSuccess)
-        rc = fail(GSV_ERR_DEVICE, "ciphertext upload failed");
-    }
     if (rc != GSV_OK) break;
     if (s->plan) {
       rc = permute_plan_window(s, size_t(r0), seg_records, 1);
@@ -1669,13 +1802,40 @@ int gsv_session_evaluate_streaming(gsv_session* s, uint64_t gate_id_base, const 
       if (gsvk_gather_segment(s->CT, s->ct_stride(), s->dp.ct_pos, n_ct, uint32_t(r1 - r0), uint32_t(n_inst), s->ct_gate, seg_records, 1, s->e->stream) != 0) { rc = fail(GSV_ERR_DEVICE, "ciphertext scatter launch failed"); break; }
       rc = launch(s, gate_id_base, true, r0, r1 - r0);
     }
-    if (rc == GSV_OK && hipStreamSynchronize(s->e->stream) != hipSuccess) rc = fail(GSV_ERR_DEVICE, "kernel failed");
   }
-  close_files();
+  if (hipStreamSynchronize(s->e->stream) != hipSuccess && rc == GSV_OK) rc = fail(GSV_ERR_DEVICE, "kernel failed");
   if (rc != GSV_OK) return rc;
   if (s->plan) { HIPCHK(hipEventRecord(s->ev1, s->e->stream)); rc = gather_plan_outputs(s, true); if (rc) return rc; HIPCHK(hipStreamSynchronize(s->e->stream)); rc = check_plan_error(s); if (rc) return rc; }
   if (hashes) for (size_t i = 0; i < n_inst; ++i) macs[i].digest(hashes + 16 * i);
   return GSV_OK;
+}
+// FileSource: instance i reads <dir>/gc_<indexes[i]>.bin (indexes == NULL: first_index + i)
+static int evaluate_from_files(gsv_session* s, uint64_t gate_id_base, const char* dir, const uint64_t* indexes, uint64_t first_index, uint8_t* hashes) {
+  if (!s || !dir) return fail(GSV_ERR_INVALID, "null argument");
+  std::vector<FILE*> files(s->n_inst, nullptr);
+  struct Closer { std::vector<FILE*>& f; ~Closer() { for (FILE*& q : f) if (q) { std::fclose(q); q = nullptr; } } } closer{files};
+  for (size_t i = 0; i < s->n_inst; ++i) {
+    const std::string path = std::string(dir) + "/gc_" + std::to_string(indexes ? indexes[i] : first_index + i) + ".bin";
+    files[i] = std::fopen(path.c_str(), "rb");
+    if (!files[i]) return fail(GSV_ERR_INVALID, "cannot open " + path);
+  }
+  // the reads of one instance are sequential in the stream, but the instances alternate: seek when the position is not the expected one
+  std::vector<uint64_t> pos(s->n_inst, 0);
+  return evaluate_streaming_impl(s, gate_id_base, [&](size_t i, uint64_t first, uint8_t* dst, uint64_t n) -> int {
+    if (pos[i] != first) { if (fseeko(files[i], off_t(first * 16), SEEK_SET) != 0) return 1; pos[i] = first; }
+    if (n && std::fread(dst, 16, n, files[i]) != n) return 1;
+    pos[i] += n;
+    return 0;
+  }, hashes);
+}
+int gsv_session_evaluate_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, uint8_t* hashes) { return evaluate_from_files(s, gate_id_base, dir, nullptr, first_index, hashes); }
+int gsv_session_evaluate_streaming_indexed(gsv_session* s, uint64_t gate_id_base, const char* dir, const uint64_t* indexes, uint8_t* hashes) {
+  if (!indexes) return fail(GSV_ERR_INVALID, "null index list");
+  return evaluate_from_files(s, gate_id_base, dir, indexes, 0, hashes);
+}
+int gsv_session_evaluate_streaming_source(gsv_session* s, uint64_t gate_id_base, gsv_ct_source_fn source, void* user, uint8_t* hashes) {
+  if (!s || !source) return fail(GSV_ERR_INVALID, "null argument");
+  return evaluate_streaming_impl(s, gate_id_base, [&](size_t i, uint64_t first, uint8_t* dst, uint64_t n) -> int { return source(user, i, first, dst, n); }, hashes);
 }
 
 int gsv_session_set_hasher(gsv_session* s, int kind) {

@@ -66,10 +66,12 @@ struct KernelArgs {
   const uint32_t* copy_src;   // wire hand-over lists of the session (absolute slots inside an instance's wire file)
   const uint32_t* copy_dst;
   const uint32_t* deps;
-  uint32_t* flags;            // [gridDim.x][flag_stride] completion flags: flags[x][c] == epoch once call c has finished for instance group x
+  uint32_t* flags;            // [gridDim.x][flag_stride] completion flags: flags[x][c] == epoch once call c has finished for instance group x;
+                              // flags[x][flag_stride - 1] counts the calls group x has completed (the dependency watchdog's progress counter)
   uint32_t* error;            // set to 1 when a dependency wait gives up (never expected: see schedule.hpp)
   uint32_t flag_stride;
   uint32_t epoch;             // launch counter of the session: flags are never reset
+  unsigned long long wait_ticks;  // dependency watchdog: give up when the group's progress counter has not moved for this long (100 MHz ticks)
   uint32_t diag;  // timing experiments only (GSV_DIAG env; honoured by a library built with -DGSV_DIAG_BUILD = `build.py --diag`, ignored by
                   // the production build): 1 = skip AES, 4 = skip label loads, 8 = skip stores, 16 = no multi-lane narrow form,
                   // 32 = no step barrier, 64 = no record prefetch, 128 = no load of an AND record's second half

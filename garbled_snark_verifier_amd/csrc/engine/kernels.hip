@@ -99,22 +99,14 @@ struct WireFile {
   // A label lives EITHER in the LDS window or in the HBM wire file, lane by lane.  Written as `if (lds) v = *win(slot); else v = hbm[slot];`
   // both loads target the same registers, and since LDS and vector-memory results return out of order with respect to each other the
   // compiler puts `s_waitcnt lgkmcnt(0)` between them: a wave that holds both kinds of operands waits for each operand's LDS round trip
-  // before it issues that operand's global load.  Round 3 measured the alternative (GSV_LD_SPLIT_REGS: two register sets and a select,
-  // all ten loads of a gate in flight at once): 24 fewer waits per step body, but +13 VGPRs, 60 more spilled scalars (the lane masks of
-  // the selects) and 20 v_cndmask per gate — 5 % SLOWER on wide programs (9.77 against 10.27 x 10^10 gates/s at 1 024 instances), 6 % on the
-  // ladders, 4 % on the inversions, +-0 for a single instance (tools/kernel_ab3.py): the other waves of the CU already hide those waits.
+  // before it issues that operand's global load.  Round 3 measured the alternative (two register sets and a select, all ten loads of a
+  // gate in flight at once): 24 fewer waits per step body, but +13 VGPRs, 60 more spilled scalars (the lane masks of the selects) and
+  // 20 v_cndmask per gate — 5 % SLOWER on wide programs (9.77 against 10.27 x 10^10 gates/s at 1 024 instances), 6 % on the ladders, 4 %
+  // on the inversions, +-0 for a single instance (profiles/r03_kernel): the other waves of the CU already hide those waits.
   __device__ __forceinline__ Label ld(uint32_t slot) const {
-#ifndef GSV_LD_SPLIT_REGS
     u32x4 v;
     if (slot & GSV_SLOT_LDS_FLAG) v = *win(slot); else v = hbm[slot];
     return Label{{v.x, v.y, v.z, v.w}};
-#else
-    const bool in_lds = (slot & GSV_SLOT_LDS_FLAG) != 0;
-    u32x4 vl, vg;
-    if (in_lds) vl = *win(slot);
-    if (!in_lds) vg = hbm[slot];
-    return Label{{in_lds ? vl.x : vg.x, in_lds ? vl.y : vg.y, in_lds ? vl.z : vg.z, in_lds ? vl.w : vg.w}};
-#endif
   }
   __device__ __forceinline__ void st(uint32_t slot, const Label& l) const {
     const u32x4 v = {l.w[0], l.w[1], l.w[2], l.w[3]};
@@ -122,33 +114,17 @@ struct WireFile {
   }
   // one 32-bit column of a label (narrow-step mode: a label is spread over the 4 lanes of a quad)
   __device__ __forceinline__ uint32_t ld_word(uint32_t slot, uint32_t c) const {
-#ifndef GSV_LD_SPLIT_REGS
     uint32_t v;
     if (slot & GSV_SLOT_LDS_FLAG) v = *win_word(slot, c); else v = ((const glb_u32*)hbm)[slot * 4u + c];
     return v;
-#else
-    const bool in_lds = (slot & GSV_SLOT_LDS_FLAG) != 0;
-    uint32_t vl, vg;
-    if (in_lds) vl = *win_word(slot, c);
-    if (!in_lds) vg = ((const glb_u32*)hbm)[slot * 4u + c];
-    return in_lds ? vl : vg;
-#endif
   }
   __device__ __forceinline__ void st_word(uint32_t slot, uint32_t c, uint32_t v) const {
     if (slot & GSV_SLOT_LDS_FLAG) *win_word(slot, c) = v; else ((glb_u32*)hbm)[slot * 4u + c] = v;
   }
   __device__ __forceinline__ uint32_t ld_bit(uint32_t slot) const {
-#ifndef GSV_LD_SPLIT_REGS
     uint32_t b;
     if (slot & GSV_SLOT_LDS_FLAG) b = *win_bit(slot & GSV_SLOT_INDEX_MASK); else b = hbm_bits[slot];
     return b;
-#else
-    const bool in_lds = (slot & GSV_SLOT_LDS_FLAG) != 0;
-    uint32_t bl, bg;
-    if (in_lds) bl = *win_bit(slot & GSV_SLOT_INDEX_MASK);
-    if (!in_lds) bg = hbm_bits[slot];
-    return in_lds ? bl : bg;
-#endif
   }
   __device__ __forceinline__ void st_bit(uint32_t slot, uint32_t b) const {
     if (slot & GSV_SLOT_LDS_FLAG) *win_bit(slot & GSV_SLOT_INDEX_MASK) = uint8_t(b); else hbm_bits[slot] = uint8_t(b);
@@ -254,15 +230,26 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     // ---- dataflow prologue: wait for the calls this one depends on (same instance group), then fetch the inputs.
     // One lane polls; the flags are written with agent-scope release by the producer's epilogue (possibly on another XCD: the
     // acquire fence below invalidates this CU's L1 and the non-local L2 lines before any wave reads the global wires).
+    // The watchdog is PROGRESS based: the last word of the group's flag row counts the calls the group has completed (any window,
+    // never reset); the wait gives up only when that counter has not moved for ka.wait_ticks (100 MHz; 60 s by default) — a long
+    // window, a second session on the device or a slow hasher stretch the wait but keep the counter moving.
     if (threadIdx.x == 0 && cd->n_deps) {
       const uint32_t* const fl = ka.flags + size_t(blockIdx.x) * ka.flag_stride;
-      const unsigned long long t_start = wall_clock64();
-      for (uint32_t i = 0; i < cd->n_deps; ++i) {
+      const uint32_t* const progress = fl + (ka.flag_stride - 1u);
+      unsigned long long t_start = wall_clock64();
+      uint32_t seen = __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool gave_up = false;
+      for (uint32_t i = 0; i < cd->n_deps && !gave_up; ++i) {
         const uint32_t* const f = fl + ka.deps[cd->dep_off + i];
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ka.epoch) {
           __builtin_amdgcn_s_sleep(16);
-          if (wall_clock64() - t_start > 3000000000ull) {  // 30 s at 100 MHz: a dependency that never completes (violated dispatch-order assumption)
+          if (wall_clock64() - t_start > ka.wait_ticks) {
+            const uint32_t now = __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (now != seen) { seen = now; t_start = wall_clock64(); continue; }
+            // no call of this instance group has completed for the whole interval: a dependency that never completes (violated
+            // dispatch-order assumption).  The host refuses the results (engine.cpp, check_plan_error).
             __hip_atomic_store(ka.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gave_up = true;
             break;
           }
         }
@@ -612,7 +599,11 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(ka.flags + size_t(blockIdx.x) * ka.flag_stride + blockIdx.y, ka.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+      uint32_t* const fl = ka.flags + size_t(blockIdx.x) * ka.flag_stride;
+      __hip_atomic_store(fl + blockIdx.y, ka.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(fl + (ka.flag_stride - 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the group's progress counter (watchdog)
+    }
   }
 }
 

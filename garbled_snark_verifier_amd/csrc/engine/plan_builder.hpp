@@ -520,9 +520,18 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
   // independent calls side by side (schedule.hpp) and sees global ids as memory locations: an id reused right away would chain its
   // new writer behind every reader of the old value (WAR) although the two calls have nothing to do with each other; with the
   // queue the reuse distance is slack / (outputs per call) calls, beyond any scheduling window.  Cost: slack x 16 bytes per instance
-  // (GSV_PLAN_ID_SLACK, default 262 144 ids = 4 MB).
+  // (GSV_PLAN_ID_SLACK, default 262 144 ids = 4 MB per instance: 4.3 GB of the 205 GB a 1 024-instance session takes.  The plan is
+  // built once and serves sessions of every concurrency, so the slack is not derived from one session's in-flight bound; a deployment
+  // that only runs sequential sessions — max_concurrent_calls = 1, where reuse distance buys nothing — builds its plan with
+  // GSV_PLAN_ID_SLACK=0 and gets the smallest wire file).
   std::deque<uint32_t> free_ids;
-  const size_t id_slack = getenv("GSV_PLAN_ID_SLACK") ? size_t(std::max(0, atoi(getenv("GSV_PLAN_ID_SLACK")))) : size_t(262144);
+  size_t id_slack = 262144;
+  if (const char* ev = getenv("GSV_PLAN_ID_SLACK")) {
+    char* end = nullptr;
+    const long long v = std::strtoll(ev, &end, 10);
+    if (end == ev || *end != 0 || v < 0 || v > (1ll << 28)) gsv_panic("GSV_PLAN_ID_SLACK must be an integer in [0, 2^28]");
+    id_slack = size_t(v);
+  }
   auto alloc_global = [&]() -> uint32_t { if (free_ids.size() > id_slack) { uint32_t g = free_ids.front(); free_ids.pop_front(); return g; } return next_global++; };
   // released after segment si has read its inputs; each wire once even when a call names it several times
   auto release_dead_inputs = [&](size_t si) {

@@ -192,69 +192,93 @@ class ConsistencyError(Exception):
         self.kind, self.index, self.details = kind, index, details
 
 
-def _gpu_evaluate(circuit, engine, program, gc_dir):
-    """Default evaluation backend of evaluate_from: EvaluateMode over a FileSource on the GPU (gsv_session_evaluate_streaming)."""
-    from . import Engine, Program, Session
+def _gpu_evaluate_batch(circuit, engine, program, gc_dir):
+    """Default evaluation backend of evaluate_from: EvaluateMode over FileSources on the GPU, ALL finalized instances in one session —
+    one launch per window of the stream for the whole batch (gsv_session_evaluate_streaming_indexed).  The reference evaluates the
+    cases side by side on a rayon pool (`into_par_iter`, cut_and_choose/evaluator.rs:354-475); a one-instance session per case would
+    use one CU of 256 and pay a session per case."""
+    from . import Engine, Plan, Program, Session
     eng = engine or Engine(0)
     prog = program or Program.from_circuit(circuit)
 
-    def run(index, true_active, false_active, input_active, input_bits):
-        sess = Session(eng, prog, 1)
+    def run(indexes, true_active, false_active, input_active, input_bits):
+        B = len(indexes)
+        sess = Session(eng, prog, B, retain_stream=False) if isinstance(prog, Plan) else Session(eng, prog, B)
         try:
-            sess.set_evaluate_inputs(np.stack([false_active, true_active])[None], np.asarray(input_active, np.uint8)[None], np.asarray(input_bits, np.uint8)[None])
-            file_hash = sess.evaluate_streaming(gc_dir, first_index=index)[0]
+            consts = np.stack([np.asarray(false_active, np.uint8).reshape(B, 16), np.asarray(true_active, np.uint8).reshape(B, 16)], axis=1)
+            sess.set_evaluate_inputs(consts, np.asarray(input_active, np.uint8).reshape(B, -1, 16), np.asarray(input_bits, np.uint8).reshape(B, -1))
+            hashes = sess.evaluate_streaming_indexed(gc_dir, [int(i) for i in indexes])
             labels, bits = sess.read_outputs(with_bits=True)
-            return labels[0], bits[0], file_hash
+            return [(labels[k], bits[k], hashes[k]) for k in range(B)]
         finally:
             sess.close()
     return run
 
 
-def evaluate_from(commits, cases, circuit, gc_dir, n_outputs, engine=None, program=None, evaluate=None):
+def evaluate_from(commits, cases, circuit, gc_dir, n_outputs, engine=None, program=None, evaluate=None, evaluate_batch=None):
     """Evaluator::evaluate_from (cut_and_choose/evaluator.rs:338-476): evaluate the finalized instances from their gc_<i>.bin and
     check everything the evaluator was handed against the garbler's commit record BEFORE trusting the result.
     `cases`: list of dicts {index, true_constant_wire[16], false_constant_wire[16], input_active[n_in,16], input_bits[n_in]}
     (EvaluatorCaseInput).  Raises ConsistencyError with the reference's variants — TrueConstantMismatch,
     FalseConstantMismatch, MissingCiphertextHash, InputLabelsCountMismatch, InputLabelsMismatch, CiphertextMismatch,
     OutputLabelMismatch — and returns [(index, output_active[n_out,16], output_bits[n_out])].
-    `evaluate(index, true, false, input_active, input_bits) -> (output_active, output_bits, ciphertext_hash)` defaults to the GPU
-    evaluator; tests without a GPU pass the CPU oracle's."""
+
+    The cases are evaluated TOGETHER (the reference: `into_par_iter`): the checks that need no evaluation run for every case first,
+    then one batch evaluates every case in front of the first failing one, then the remaining checks run case by case — so the error
+    raised is the one a case-by-case run in list order would raise (per case the reference's order of checks, evaluator.rs:371-465).
+    `evaluate_batch(indexes, true[B,16], false[B,16], input_active[B,n_in,16], input_bits[B,n_in]) -> [(output_active, output_bits,
+    ciphertext_hash)]` defaults to the GPU evaluator; `evaluate(index, true, false, input_active, input_bits) -> (..)` is the
+    case-by-case form tests without a GPU pass (the CPU oracle's)."""
     import os
     from . import gc_file_name
     commits = np.asarray(commits, np.uint8)
-    evaluate = evaluate or _gpu_evaluate(circuit, engine, program, gc_dir)
-    results = []
+    if evaluate_batch is None:
+        if evaluate is not None:
+            evaluate_batch = lambda idx, t, f, a, b: [evaluate(idx[k], t[k], f[k], a[k], b[k]) for k in range(len(idx))]  # noqa: E731
+        else:
+            evaluate_batch = _gpu_evaluate_batch(circuit, engine, program, gc_dir)
+    n_in_committed = (commits.shape[1] - record_len(n_outputs, 0)) // 32
+    parsed, first_error = [], None
     for case in cases:
         index = int(case["index"])
         t_act = np.asarray(case["true_constant_wire"], np.uint8).reshape(16)
         f_act = np.asarray(case["false_constant_wire"], np.uint8).reshape(16)
         in_act = np.asarray(case["input_active"], np.uint8).reshape(-1, 16)
         in_bits = np.asarray(case["input_bits"], np.uint8).reshape(-1)
-        n_in_committed = (commits.shape[1] - record_len(n_outputs, 0)) // 32
         _, ct_commit, in_commits, out_commits, true_commit, false_commit = record_fields(commits[index], n_outputs, n_in_committed)
         got = commit_labels(np.stack([t_act, f_act]))
         if bytes(got[0]) != bytes(true_commit):
-            raise ConsistencyError("TrueConstantMismatch", index, expected=bytes(true_commit), actual=bytes(got[0]))
-        if bytes(got[1]) != bytes(false_commit):
-            raise ConsistencyError("FalseConstantMismatch", index, expected=bytes(false_commit), actual=bytes(got[1]))
-        if not os.path.exists(os.path.join(gc_dir, gc_file_name(index))):
-            raise ConsistencyError("MissingCiphertextHash", index)
-        out_act, out_bits, file_hash = evaluate(index, t_act, f_act, in_act, in_bits)
-        if in_act.shape[0] != n_in_committed:
-            raise ConsistencyError("InputLabelsCountMismatch", index, expected=n_in_committed, actual=in_act.shape[0])
-        actual = commit_labels(in_act)
-        expected = in_commits[np.arange(n_in_committed), in_bits.astype(np.int64) & 1]  # commit_for_value(value)
-        bad = np.nonzero((actual != expected).any(axis=1))[0]
-        if bad.size:
-            k = int(bad[0])
-            raise ConsistencyError("InputLabelsMismatch", index, label_index=k, expected=bytes(expected[k]), actual=bytes(actual[k]))
-        if bytes(file_hash) != bytes(ct_commit):
-            raise ConsistencyError("CiphertextMismatch", index, expected=bytes(ct_commit), actual=bytes(file_hash))
-        out_act = np.asarray(out_act, np.uint8).reshape(-1, 16)
-        out_bits = np.asarray(out_bits, np.uint8).reshape(-1)
-        oh = commit_labels(out_act)
-        exp_out = out_commits[np.arange(n_outputs), 1 - (out_bits.astype(np.int64) & 1)]  # value 1 -> label1 commit (stored first)
-        if (oh != exp_out).any():
-            raise ConsistencyError("OutputLabelMismatch", index)
-        results.append((index, out_act, out_bits))
+            first_error = ConsistencyError("TrueConstantMismatch", index, expected=bytes(true_commit), actual=bytes(got[0]))
+        elif bytes(got[1]) != bytes(false_commit):
+            first_error = ConsistencyError("FalseConstantMismatch", index, expected=bytes(false_commit), actual=bytes(got[1]))
+        elif not os.path.exists(os.path.join(gc_dir, gc_file_name(index))):
+            first_error = ConsistencyError("MissingCiphertextHash", index)
+        elif in_act.shape[0] != n_in_committed or in_bits.shape[0] != n_in_committed:
+            # (the reference counts after evaluating; a batch cannot hold a ragged case, and no other check can fire first)
+            first_error = ConsistencyError("InputLabelsCountMismatch", index, expected=n_in_committed, actual=in_act.shape[0])
+        if first_error is not None:
+            break
+        parsed.append((index, t_act, f_act, in_act, in_bits, ct_commit, in_commits, out_commits))
+    results = []
+    if parsed:
+        evaluated = evaluate_batch([c[0] for c in parsed], np.stack([c[1] for c in parsed]), np.stack([c[2] for c in parsed]),
+                                   np.stack([c[3] for c in parsed]), np.stack([c[4] for c in parsed]))
+        for (index, _t, _f, in_act, in_bits, ct_commit, in_commits, out_commits), (out_act, out_bits, file_hash) in zip(parsed, evaluated):
+            actual = commit_labels(in_act)
+            expected = in_commits[np.arange(n_in_committed), in_bits.astype(np.int64) & 1]  # commit_for_value(value)
+            bad = np.nonzero((actual != expected).any(axis=1))[0]
+            if bad.size:
+                k = int(bad[0])
+                raise ConsistencyError("InputLabelsMismatch", index, label_index=k, expected=bytes(expected[k]), actual=bytes(actual[k]))
+            if bytes(file_hash) != bytes(ct_commit):
+                raise ConsistencyError("CiphertextMismatch", index, expected=bytes(ct_commit), actual=bytes(file_hash))
+            out_act = np.asarray(out_act, np.uint8).reshape(-1, 16)
+            out_bits = np.asarray(out_bits, np.uint8).reshape(-1)
+            oh = commit_labels(out_act)
+            exp_out = out_commits[np.arange(n_outputs), 1 - (out_bits.astype(np.int64) & 1)]  # value 1 -> label1 commit (stored first)
+            if (oh != exp_out).any():
+                raise ConsistencyError("OutputLabelMismatch", index)
+            results.append((index, out_act, out_bits))
+    if first_error is not None:
+        raise first_error
     return results

@@ -181,8 +181,10 @@ void gsv_session_destroy(gsv_session* s);
 /* A session over a plan: same calls as a program session (set_*_inputs, garble, evaluate, read_outputs, read / upload
  * ciphertexts, ciphertext_hash; one pass, whole stream retained).  The plan and its programs must outlive the session. */
 int gsv_session_create_plan(gsv_engine* e, const gsv_plan* plan, size_t n_instances, gsv_session** out);
-/* retain_stream = 0: the device keeps ONE call block of ciphertexts (plans of any length); such a session is driven by
- * gsv_session_garble_streaming only (each call's block is drained while the next call runs). */
+/* retain_stream = 0: the device keeps ONE WINDOW of ciphertexts (consecutive calls of the schedule, gsv_plan_session_opts below; plans
+ * of any length); such a session is driven by the streaming calls only (gsv_session_garble_streaming*, _sink, _garble_evaluate,
+ * gsv_session_evaluate_streaming*): each window's block is drained / evaluated while the next window runs.  Passing NULL options to
+ * gsv_session_create_plan_opts means retain_stream = 1. */
 int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_instances, int retain_stream, gsv_session** out);
 /* Call-level concurrency.  The reference gets its width from `total` instances garbled side by side, one per core
  * (cut_and_choose/garbler.rs:206-234); with 1-16 instances on a 256-CU GPU the width has to come from INSIDE an instance.  A plan
@@ -193,9 +195,17 @@ int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_ins
  * sequential run.
  *   retain_stream         as gsv_session_create_plan_ex
  *   max_concurrent_calls  calls of one instance in flight: 0 = as many as give every CU a workgroup (GSV_PLAN_CONCURRENCY overrides);
- *                         1 = sequential (the stream order)
+ *                         1 = sequential (the stream order).
+ *                         ASSUMPTION for values > 1: a workgroup that waits for a dependency only waits for workgroups with a smaller
+ *                         linear index, which the hardware dispatches first (in-order workgroup dispatch — true of every AMD GPU to
+ *                         date, but not an architectural guarantee).  A wait that sees no call of its instance group complete for
+ *                         GSV_DEP_WAIT_SECONDS (default 60) sets an error flag instead of hanging: the next gsv_session_sync /
+ *                         read_outputs / streaming call fails with GSV_ERR_DEVICE and the pass's gc files are removed.
+ *                         max_concurrent_calls = 1 is the safe mode: every call depends on its predecessor only.
  *   window_ct_records     ciphertext records per instance of one window (the device block of a session that does not retain the
- *                         stream; the drain's gate-order copy is as large again); 0 = chosen from the free device memory
+ *                         stream; the drain's gate-order copy is as large again); 0 = a quarter of the free device memory for the
+ *                         two buffers, at most 64 M records (1 GB) per instance — a pass must be many windows for the drain of
+ *                         window k (copies, CBC-MAC chains, files) to run beside the garbling of window k+1
  *   max_scratch_slots     16-byte slots per instance for the ring the calls' scratch regions are carved from; 0 = chosen from the
  *                         free device memory
  *   max_window_calls      0 = 32768 (a launch holds at most 65535 calls) */
@@ -253,11 +263,44 @@ int gsv_session_garble_streaming_calls(gsv_session* s, uint64_t gate_id_base, ui
  * meaningless MACs) say so explicitly: */
 int gsv_session_set_unchecked_slices(gsv_session* s, int on);
 
+/* The generic ciphertext sink: CiphertextHandler::handle (circuit/mod.rs:140-178) for ANY consumer — the reference has three impls, the
+ * CBC-MAC accumulator, the hash + file writer and a channel Sender<S> (circuit/mod.rs:160-170) that feeds an evaluator thread; this is
+ * the third.  The session is garbled window by window (program sessions: ring by ring) exactly as by gsv_session_garble_streaming, no
+ * stream retained on the device, and every drained run of records is handed to `sink`:
+ *     sink(user, instance, first_record, records, n_records)   records = n_records x 16 bytes, S::to_bytes() order, gate order;
+ *                                                               first_record = index of records[0] in the instance's whole stream
+ * The runs of ONE instance arrive in stream order, back to back, from one thread at a time; runs of different instances may arrive
+ * concurrently from different host threads (n_threads = 1: everything from one thread).  `records` is only valid during the call.
+ * A non-zero return aborts the pass (GSV_ERR_INVALID).  hashes (optional, n_instances x 16) additionally receives the CBC-MACs.
+ * Plan sessions: calls [first_call, first_call + n_calls) as gsv_session_garble_streaming_calls (0, 0 = the whole plan). */
+typedef int (*gsv_ct_sink_fn)(void* user, size_t instance, uint64_t first_record, const uint8_t* records, uint64_t n_records);
+int gsv_session_garble_streaming_sink(gsv_session* s, uint64_t gate_id_base, uint64_t first_call, uint64_t n_calls, gsv_ct_sink_fn sink, void* user, int n_threads, uint8_t* hashes);
+
+/* Garble and evaluate side by side on the device — the second phase of the reference's benchmark (examples/groth16_garble.rs:171-230,
+ * tests/garbler_evaluator_connection.rs:64-172: a garbler thread feeds an evaluator thread through a channel of ciphertexts).  Both
+ * sessions are plan sessions of the same plan on the same engine, created with the same options and retain_stream = 0; `evaluator` has
+ * its inputs set (gsv_session_set_evaluate_inputs).  Window k of the garbler's device block is evaluated — on a second HIP stream,
+ * straight from HBM, no PCIe, nothing retained — while window k+1 is garbled into the other one of two blocks.  hashes (optional)
+ * receives the garbler's CBC-MACs (the stream is then drained to the host as well, as by gsv_session_garble_streaming).  Outputs:
+ * gsv_session_read_outputs on either session. */
+int gsv_session_garble_evaluate(gsv_session* garbler, gsv_session* evaluator, uint64_t gate_id_base, int n_threads, uint8_t* hashes);
+
 /* Evaluate with the ciphertexts streamed from <dir>/gc_<first_index + instance>.bin (EvaluateMode over a FileSource:
  * evaluate_mode.rs:59-196, ciphertext_source.rs:36-107), one ring / one plan call at a time, for streams of any length.  Like
  * FileSource the call hashes what it reads: `hashes` (optional, n_instances x 16) receives each file's CBC-MAC so that the caller
  * can compare it with the garbler's commitment.  A file that is too short fails with GSV_ERR_EXHAUSTED. */
 int gsv_session_evaluate_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, uint8_t* hashes);
+/* The same with an index per instance: instance i reads <dir>/gc_<indexes[i]>.bin.  This is how the finalized instances of a
+ * cut-and-choose run — an arbitrary subset of 0..total-1 — are evaluated in ONE session / one launch per window
+ * (Evaluator::evaluate_from is `into_par_iter` over the cases, cut_and_choose/evaluator.rs:354-475). */
+int gsv_session_evaluate_streaming_indexed(gsv_session* s, uint64_t gate_id_base, const char* dir, const uint64_t* indexes, uint8_t* hashes);
+/* The generic ciphertext source: CiphertextSource::recv (ciphertext_source.rs:14-34; the reference's impls are a channel Receiver<S>
+ * and FileSource).  The engine pulls the stream in gate order, per instance, in bounded runs (<= 16 MiB):
+ *     source(user, instance, first_record, records, n_records)   fill records[0 .. n_records x 16); return non-zero when the source
+ *                                                                 has run dry -> GSV_ERR_EXHAUSTED (evaluate_mode.rs:139-142)
+ * called from the calling thread.  hashes (optional) receives the CBC-MAC of what was read (FileSource hashes while reading). */
+typedef int (*gsv_ct_source_fn)(void* user, size_t instance, uint64_t first_record, uint8_t* records, uint64_t n_records);
+int gsv_session_evaluate_streaming_source(gsv_session* s, uint64_t gate_id_base, gsv_ct_source_fn source, void* user, uint8_t* hashes);
 
 /* Gate PRF (`H: GateHasher`, src/hashers/mod.rs:15-20): GSV_HASHER_AES = AesNiHasher (default; the benchmarked
  * path, hashers/mod.rs:54-96), GSV_HASHER_BLAKE3 = Blake3Hasher (hashers/mod.rs:22-51, the crate's DefaultHasher). */

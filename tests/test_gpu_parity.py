@@ -663,6 +663,163 @@ def test_evaluate_streaming_from_gc_files(engine, tmp_path):
     es.close()
 
 
+def test_generic_ciphertext_sink_and_source(engine):
+    """The third CiphertextHandler / CiphertextSource of the reference — the channel Sender<S> / Receiver<S> pair (circuit/mod.rs:160-170,
+    ciphertext_source.rs:14-34) — as host callbacks (gsv_session_garble_streaming_sink / gsv_session_evaluate_streaming_source): a
+    Python handler receives every ciphertext of every instance in gate order, window by window (no stream retained on the device), and
+    must end up with exactly the oracle's stream; a source feeds the evaluator from that memory; a source that runs dry fails like the
+    reference's exhausted receiver; an exception in the handler aborts the pass and is re-raised.  Plan sessions (several windows,
+    calls side by side) and a program session with a two-replay ring."""
+    import garbled_snark_verifier_amd as gsv
+    plan = gsv.Plan.from_circuit("fq12_mix", FINE_UNITS)
+    seeds = [91, 92, 93]
+    B, n_in = len(seeds), plan.info["n_inputs"]
+    labs = [gsv.labels_from_seed(s, n_in) for s in seeds]
+    delta = np.stack([x[0] for x in labs]); consts = np.stack([np.stack([x[1], x[2]]) for x in labs]); inputs = np.stack([x[3] for x in labs])
+    refs = [o.garble("fq12_mix", s) for s in seeds]
+    n_ct = plan.info["n_ciphertexts"]
+    for threads in (1, 2):
+        st = gsv.Session(engine, plan, B, retain_stream=False, concurrent_calls=16, window_ct_records=900_000)
+        assert st.schedule_info()["n_windows"] > 4
+        st.set_garble_inputs(delta, consts, inputs)
+        got = [np.zeros((n_ct, 16), np.uint8) for _ in range(B)]
+        nxt = [0] * B
+
+        def handler(inst, first, recs):
+            assert first == nxt[inst], "runs of one instance must arrive in stream order, back to back"
+            got[inst][first:first + recs.shape[0]] = recs
+            nxt[inst] = first + recs.shape[0]
+
+        hashes = st.garble_to_sink(handler, threads=threads, with_hashes=True)
+        out = st.read_outputs()
+        for i in range(B):
+            assert nxt[i] == n_ct == refs[i].n_ciphertexts and (got[i] == refs[i].ciphertexts).all()
+            assert hashes[i] == refs[i].ct_hash.tobytes() and (out[i] == refs[i].output_label0).all()
+        st.close()
+    # a failing handler aborts the pass with its own exception
+    st = gsv.Session(engine, plan, B, retain_stream=False, window_ct_records=900_000)
+    st.set_garble_inputs(delta, consts, inputs)
+
+    def bad(inst, first, recs):
+        raise KeyError("handler gave up")
+
+    with pytest.raises(KeyError):
+        st.garble_to_sink(bad, threads=1)
+    st.close()
+    # the evaluator pulls the same stream back through a source
+    bits = np.random.default_rng(6).integers(0, 2, size=(B, n_in)).astype(np.uint8)
+    active = np.where(bits[:, :, None] == 1, inputs ^ delta[:, None, :], inputs)
+    es = gsv.Session(engine, plan, B, retain_stream=False, concurrent_calls=16, window_ct_records=900_000)
+    ca = np.stack([consts[:, 0], consts[:, 1] ^ delta], axis=1)
+    es.set_evaluate_inputs(ca, active, bits)
+    fh = es.evaluate_from_source(lambda inst, first, n: got[inst][first:first + n])
+    oa, ob = es.read_outputs(with_bits=True)
+    for i in range(B):
+        eb, _, _ = o.execute("fq12_mix", bits[i])
+        assert fh[i] == refs[i].ct_hash.tobytes() and (ob[i] == eb).all()
+        assert (oa[i] == np.where(ob[i][:, None] == 1, refs[i].output_label0 ^ delta[i][None, :], refs[i].output_label0)).all()
+    es.set_evaluate_inputs(ca, active, bits)
+    with pytest.raises(gsv.GsvError, match="exhausted"):
+        es.evaluate_from_source(lambda inst, first, n: None if (inst == 1 and first + n > n_ct // 2) else got[inst][first:first + n])
+    es.close()
+    plan.close()
+    # program session: a chain of 5 replays through a ring of two
+    prog = gsv.Program.from_circuit("fq2_mul", chain_feedback=True)
+    K, seed = 5, 94
+    d, f, t, inp = gsv.labels_from_seed(seed, prog.info["n_inputs"])
+    ps = gsv.Session(engine, prog, 1, K, 2)
+    ps.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
+    chunks = []
+    ps.garble_to_sink(lambda inst, first, recs: chunks.append((first, recs.copy())))
+    full = gsv.CircuitBuilder.streaming_garbling("fq2_mul", [seed], engine=engine, program=prog, replays=K)
+    stream = np.concatenate([c for _, c in chunks])
+    assert [c[0] for c in chunks] == list(np.cumsum([0] + [c[1].shape[0] for c in chunks[:-1]])) and (stream == full.ciphertexts[0]).all()
+    ps.close()
+
+
+def test_garble_and_evaluate_side_by_side_on_the_device(engine):
+    """examples/groth16_garble.rs:171-230 / tests/garbler_evaluator_connection.rs:64-172: the garbler feeds the evaluator while it
+    garbles.  gsv_session_garble_evaluate: window k of the garbler's device block is evaluated on a second stream while window k+1 is
+    garbled into the other of two blocks; nothing is retained, nothing crosses PCIe unless the commitment is asked for.  Outputs,
+    decoded bits and (when asked for) the CBC-MACs must be the oracle's; sessions with different schedules are refused."""
+    import garbled_snark_verifier_amd as gsv
+    plan = gsv.Plan.from_circuit("fq12_mix", FINE_UNITS)
+    seeds = [95, 96, 97, 98, 99]
+    B, n_in = len(seeds), plan.info["n_inputs"]
+    labs = [gsv.labels_from_seed(s, n_in) for s in seeds]
+    delta = np.stack([x[0] for x in labs]); consts = np.stack([np.stack([x[1], x[2]]) for x in labs]); inputs = np.stack([x[3] for x in labs])
+    refs = [o.garble("fq12_mix", s, capture_ct=False) for s in seeds]
+    bits = np.random.default_rng(7).integers(0, 2, size=(B, n_in)).astype(np.uint8)
+    active = np.where(bits[:, :, None] == 1, inputs ^ delta[:, None, :], inputs)
+    ca = np.stack([consts[:, 0], consts[:, 1] ^ delta], axis=1)
+    for conc, win, with_hashes in ((16, 600_000, True), (1, 0, False), (64, 2_000_000, True)):
+        kw = dict(retain_stream=False, concurrent_calls=conc, window_ct_records=win)
+        gs, es = gsv.Session(engine, plan, B, **kw), gsv.Session(engine, plan, B, **kw)
+        assert gs.schedule_info()["n_windows"] >= 3
+        for _ in range(2):  # a second pass over the same sessions
+            gs.set_garble_inputs(delta, consts, inputs)
+            es.set_evaluate_inputs(ca, active, bits)
+            hashes = gs.garble_evaluate(es, with_hashes=with_hashes)
+            out0 = gs.read_outputs()
+            oa, ob = es.read_outputs(with_bits=True)
+            for i in range(B):
+                eb, _, _ = o.execute("fq12_mix", bits[i])
+                assert (out0[i] == refs[i].output_label0).all() and (ob[i] == eb).all()
+                assert (oa[i] == np.where(ob[i][:, None] == 1, out0[i] ^ delta[i][None, :], out0[i])).all()
+                assert not with_hashes or hashes[i] == refs[i].ct_hash.tobytes()
+        other = gsv.Session(engine, plan, B, retain_stream=False, concurrent_calls=conc, window_ct_records=win + 1_000_000)
+        with pytest.raises(gsv.GsvError, match="schedule"):
+            gs.garble_evaluate(other)
+        for x in (gs, es, other):
+            x.close()
+    plan.close()
+
+
+def test_batched_evaluate_from_finalized_instances(engine, tmp_path):
+    """Evaluator::evaluate_from is `into_par_iter` over the finalized cases (cut_and_choose/evaluator.rs:354-475): here ALL of them are
+    evaluated in ONE session — instance k of the batch reads gc_<index_k>.bin (gsv_session_evaluate_streaming_indexed) — and every
+    consistency check still fires with the reference's variant, in the order a case-by-case run would report them.  16 instances
+    garbled and committed, 8 finalized (an arbitrary subset), a program session and a plan session."""
+    import garbled_snark_verifier_amd as gsv
+    from garbled_snark_verifier_amd import sharding
+    total, keep = 16, [1, 2, 5, 7, 8, 11, 14, 15]
+    for circuit, prog in (("fq_mul", gsv.Program.from_circuit("fq_mul")), ("fq12_mix", gsv.Plan.from_circuit("fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"]))):
+        gc = os.path.join(str(tmp_path), circuit); os.makedirs(gc)
+        seeds = [int(x) for x in sharding.instance_seeds(77, total)]
+        n_in, n_out = prog.info["n_inputs"], prog.info["n_outputs"]
+        commits = sharding.garble_and_commit(circuit, seeds, list(range(total)), engine=engine, program=prog, gc_dir=gc)
+        rng = np.random.default_rng(9)
+
+        def case(i, **over):
+            d, f, t, inp = gsv.labels_from_seed(seeds[i], n_in)
+            bits = rng.integers(0, 2, n_in).astype(np.uint8)
+            c = {"index": i, "true_constant_wire": t ^ d, "false_constant_wire": f, "input_active": np.where(bits[:, None] == 1, inp ^ d[None, :], inp), "input_bits": bits}
+            c.update(over)
+            return c
+
+        cases = [case(i) for i in keep]
+        res = sharding.evaluate_from(commits, cases, circuit, gc, n_out, engine=engine, program=prog)
+        assert [r[0] for r in res] == keep
+        for c, (i, act, ob) in zip(cases, res):
+            eb, _, _ = o.execute(circuit, c["input_bits"])
+            assert (ob == eb).all()
+        # tampering: the first failing case in list order decides, whatever comes later
+        d5 = gsv.labels_from_seed(seeds[5], n_in)
+        bad_in = case(5); bad_in["input_active"] = bad_in["input_active"].copy(); bad_in["input_active"][3] ^= d5[0]
+        with pytest.raises(sharding.ConsistencyError) as ei:
+            sharding.evaluate_from(commits, [case(1), bad_in, case(7, true_constant_wire=np.zeros(16, np.uint8))], circuit, gc, n_out, engine=engine, program=prog)
+        assert (ei.value.kind, ei.value.index) == ("InputLabelsMismatch", 5)
+        with pytest.raises(sharding.ConsistencyError) as ei:
+            sharding.evaluate_from(commits, [case(1), case(7, true_constant_wire=np.zeros(16, np.uint8)), bad_in], circuit, gc, n_out, engine=engine, program=prog)
+        assert (ei.value.kind, ei.value.index) == ("TrueConstantMismatch", 7)
+        path = os.path.join(gc, gsv.gc_file_name(8))
+        raw = bytearray(open(path, "rb").read()); raw[4321] ^= 4; open(path, "wb").write(bytes(raw))
+        with pytest.raises(sharding.ConsistencyError) as ei:
+            sharding.evaluate_from(commits, [case(i) for i in keep], circuit, gc, n_out, engine=engine, program=prog)
+        assert (ei.value.kind, ei.value.index) in (("CiphertextMismatch", 8), ("OutputLabelMismatch", 8))
+        prog.close()
+
+
 def test_plan_recorder_through_the_c_abi(engine):
     """gsv_plan_recorder_*: the plan builder driven the way a host with its own two-pass driver would.
     The gates of Fq::add are pushed one by one as glue (taken from a recording of the component), Fq::mul_montgomery is a
@@ -923,6 +1080,69 @@ def test_compressed_verifier_evaluates_valid_and_tampered_proof(engine, compress
     assert case["expected_output"] == 1 and ob[:, 0].tolist() == [1, 0]
     assert (oa == np.where(ob[:, :, None] == 1, out0 ^ delta[:, None, :], out0)).all()
     sess.close()
+
+
+def test_cc16_verifier_full_size_on_one_gpu(engine, compressed_verifier_plan):
+    """BASELINE config 5 at its REAL size on the hardware that exists: sharding.cut_and_choose_commit — what `bench.py --workload cc16`
+    and the 8-GPU run execute per rank — garbles the 16 instances of master seed 2024 on the FULL one-public-input verifier
+    (11 456 865 898 gates each, 183 B gates) on one GPU, every instance WITH its ciphertext commitment, and gathers the
+    GarbledInstanceCommit records: all 16 must equal the records the CPU oracle built from 16 flat garblings of the same seeds
+    (tests/golden/cc16_verifier_golden.json, tests/golden/make_cc16_verifier_golden.py)."""
+    import hashlib
+    from garbled_snark_verifier_amd import sharding
+    case, plan = compressed_verifier_plan
+    gold = json.load(open(os.path.join(os.path.dirname(GOLDEN), "cc16_verifier_golden.json")))
+    assert gold["gates"] == case["gates"] and gold["n_ciphertexts"] == case["n_ciphertexts"]
+    table, seeds = sharding.cut_and_choose_commit(case["circuit"], gold["master_seed"], gold["total"], 0, 1, engine=engine, program=plan)
+    assert [int(x) for x in seeds] == gold["seeds"] and table.shape == (gold["total"], gold["record_len"])
+    assert [bytes(r[8:24]).hex() for r in table] == gold["ct_hashes"]
+    assert [hashlib.sha256(r.tobytes()).hexdigest() for r in table] == gold["record_sha256"]
+    assert hashlib.sha256(table.tobytes()).hexdigest() == gold["table_sha256"]
+
+
+def test_verifier_garble_evaluate_and_generic_sink_at_full_size(engine, compressed_verifier_plan):
+    """The second phase of the reference's benchmark at verifier size (examples/groth16_garble.rs:171-230): two instances are garbled
+    and — window by window, from the garbler's device block, nothing retained (retain_stream = 0) — evaluated at the same time, one with
+    the valid proof's bits, one with A's sign flag flipped: decoded outputs (1, 0), active output labels = select(label0, bit), and
+    the garbler's commitment of instance 0 == the oracle's flat-stream fixture.  The commitment is computed by a PYTHON handler
+    behind the generic sink (gsv_session_garble_streaming_sink: every 16-byte record of the 48 GB stream passes through the callback
+    in gate order), chained through gsv_cbcmac_update."""
+    import garbled_snark_verifier_amd as gsv
+    case, plan = compressed_verifier_plan
+    n_in = plan.info["n_inputs"]
+    seeds = [case["seed"], case["seed"] + 1]
+    labs = [gsv.labels_from_seed(s, n_in) for s in seeds]
+    delta = np.stack([x[0] for x in labs]); consts = np.stack([np.stack([x[1], x[2]]) for x in labs]); inputs = np.stack([x[3] for x in labs])
+    bits_ok = np.unpackbits(np.frombuffer(bytes.fromhex(case["input_bits_hex"]), np.uint8), bitorder="little")[:n_in].astype(np.uint8)
+    bits_bad = bits_ok.copy(); bits_bad[case["tamper_bit"]] ^= 1
+    bits = np.stack([bits_ok, bits_bad])
+    active = np.where(bits[:, :, None] == 1, inputs ^ delta[:, None, :], inputs)
+    gs, es = gsv.Session(engine, plan, 2, retain_stream=False), gsv.Session(engine, plan, 2, retain_stream=False)
+    assert gs.schedule_info()["n_windows"] >= 32  # the default window: many windows per pass (1 GB per instance at most)
+    gs.set_garble_inputs(delta, consts, inputs)
+    es.set_evaluate_inputs(np.stack([consts[:, 0], consts[:, 1] ^ delta], axis=1), active, bits)
+    hashes = gs.garble_evaluate(es, with_hashes=True)
+    out0 = gs.read_outputs()
+    oa, ob = es.read_outputs(with_bits=True)
+    assert hashes[0].hex() == case["ct_hash"] and hashes[1] != hashes[0]
+    assert out0[0][0].tobytes().hex() == case["first_output_label0"]
+    assert case["expected_output"] == 1 and ob[:, 0].tolist() == [1, 0]
+    assert (oa == np.where(ob[:, :, None] == 1, out0 ^ delta[:, None, :], out0)).all()
+    es.close()
+    # the same garbler session again, its stream through a Python CiphertextHandler (instance 0 only is MAC'ed here: one serial chain)
+    gs.set_garble_inputs(delta, consts, inputs)
+    state = [np.zeros(16, np.uint8)]
+    seen = [0, 0]
+
+    def handler(inst, first, recs):
+        assert first == seen[inst]
+        seen[inst] += recs.shape[0]
+        if inst == 0:
+            state[0] = np.frombuffer(gsv.cbcmac(recs, state[0]), np.uint8).copy()
+
+    gs.garble_to_sink(handler, threads=2)
+    assert seen == [case["n_ciphertexts"]] * 2 and state[0].tobytes().hex() == case["ct_hash"]
+    gs.close()
 
 
 def test_plan_slices_and_plan_file_on_the_device(engine, tmp_path):
