@@ -435,6 +435,35 @@ def mode_rates(gsv, engine, np, instances=256, replays=4):
     return out
 
 
+def cc16_verifier_fixture(case):
+    """tests/golden/cc16_verifier_golden.json (the 16 instances of master seed 2024 on the full verifier, garbled by the CPU oracle), or
+    None when it does not belong to this circuit."""
+    path = os.path.join(ROOT, "tests", "golden", "cc16_verifier_golden.json")
+    if not os.path.exists(path):
+        return None
+    g = json.load(open(path))
+    return g if g.get("gates") == case["gates"] and g.get("n_ciphertexts") == case["n_ciphertexts"] else None
+
+
+def cc16_one_gpu(gsv, engine, plan, case, gold, log):
+    """BASELINE config 5 with all 16 instances on THIS GPU: sharding.cut_and_choose_commit (Garbler::create -> commit,
+    cut_and_choose/garbler.rs:191-257) on the full verifier — 16 seeds from master seed 2024, every instance garbled WITH its ciphertext
+    commitment (stream drained over PCIe, sixteen serial CBC-MAC chains on the host), GarbledInstanceCommit records built — and every
+    record compared with the one built from the CPU oracle's flat garbling of the same seed."""
+    from garbled_snark_verifier_amd import sharding
+    t0 = time.perf_counter()
+    table, seeds = sharding.cut_and_choose_commit(case["circuit"], gold["master_seed"], gold["total"], 0, 1, engine=engine, program=plan)
+    dt = time.perf_counter() - t0
+    rec_ok = [hashlib.sha256(r.tobytes()).hexdigest() == gold["record_sha256"][i] for i, r in enumerate(table)]
+    out = {"seconds": dt, "gates_per_s": case["gates"] * gold["total"] / dt, "instances": gold["total"], "master_seed": gold["master_seed"],
+           "all_16_match": bool(all(rec_ok) and [int(x) for x in seeds] == gold["seeds"]), "records_matching": int(sum(rec_ok)),
+           "table_sha256_match": hashlib.sha256(table.tobytes()).hexdigest() == gold["table_sha256"],
+           "reference_published": "16 instances on 8 physical cores: ~11 m 58 s (README.md:13)",
+           "sample": "the whole job: 16 x %d gates garbled, 16 x %d ciphertexts drained and CBC-MAC'ed, 16 commit records; fixture tests/golden/cc16_verifier_golden.json" % (case["gates"], case["n_ciphertexts"])}
+    log("bench.py: cc16 on one GPU: %.1f s, %.3g gates/s, %d of 16 records match the oracle's" % (dt, out["gates_per_s"], sum(rec_ok)))
+    return out
+
+
 def run_verifier(args):
     import numpy as np
     import torch
@@ -486,6 +515,13 @@ def run_verifier(args):
         try:
             Be = max(1, args.e2e_instances)
             seeds = [case["seed"]] + instance_seeds(rank, Be)[1:]
+            # instances 1..16 carry the 16 seeds of the cut-and-choose fixture (master seed 2024): their commitments are checked against
+            # the CPU oracle's flat garblings too (tests/golden/cc16_verifier_golden.json), so 17 of the pass's MACs are verified
+            cc_gold = cc16_verifier_fixture(case) if compressed and args.workload == "verifier_compressed" else None
+            n_cc = 0
+            if cc_gold is not None:
+                n_cc = min(len(cc_gold["seeds"]), Be - 1)
+                seeds[1:1 + n_cc] = cc_gold["seeds"][:n_cc]
             e2e = VerifierWork(gsv, engine, plan, Be, seeds)
             try:
                 si = e2e.sess.schedule_info()
@@ -493,6 +529,8 @@ def run_verifier(args):
                 dt = e2e.run_pass(commit=True, threads=args.mac_threads)
                 out = e2e.sess.read_outputs()
                 ok = fixture_ok(e2e.ct_hashes[0], out[0])
+                cc_ok = [e2e.ct_hashes[1 + k].hex() == cc_gold["ct_hashes"][k] and out[1 + k][0].tobytes().hex() == cc_gold["first_output_label0"][k] for k in range(n_cc)]
+                ok = bool(ok and all(cc_ok))
                 result["ciphertext_hash_match"] = ok
                 gbs = n_ct * Be * 16 / dt / 1e9
                 # the drain's grouping (engine.cpp gsv_drain::group_for): sixteen chains per worker on VAES hosts from 128 instances up, else four
@@ -513,7 +551,8 @@ def run_verifier(args):
                     "value": gates * Be / dt, "unit": "gates/s", "instances": Be, "instances_per_workgroup": e2e.sess.instances_per_workgroup, "seconds": dt, "passes": 1,
                     "ciphertext_gb_per_s": gbs, "ciphertext_gb_total": n_ct * Be * 16 / 1e9, "mac_workers": workers, "mac_chains_per_worker": chains, "host_cores_quota": quota,
                     "windows": si["n_windows"], "window_ct_records": si["window_ct_records"], "distinct_macs": len(set(e2e.ct_hashes)),
-                    "instance0": {"seed": case["seed"], "ct_hash": e2e.ct_hashes[0].hex(), "fixture_ct_hash": case["ct_hash"], "match": ok},
+                    "instance0": {"seed": case["seed"], "ct_hash": e2e.ct_hashes[0].hex(), "fixture_ct_hash": case["ct_hash"], "match": fixture_ok(e2e.ct_hashes[0], out[0])},
+                    "macs_checked_against_oracle_fixtures": 1 + n_cc, "macs_matching": int(fixture_ok(e2e.ct_hashes[0], out[0])) + sum(cc_ok),
                     "per_node_ceiling_8gpus": {"gates_per_s": min(8 * gates * Be / dt, cores * mac_core / f_nf), "pcie_bound_gates_per_s": 8 * gates * Be / dt,
                                                "mac_bound_gates_per_s": cores * mac_core / f_nf, "mac_blocks_per_s_per_core": mac_core,
                                                "mac_blocks_per_s_per_core_by_chains": {str(k): v for k, v in mac_rate.items()},
@@ -580,6 +619,13 @@ def run_verifier(args):
         except Exception as e:  # noqa: BLE001
             rbi["error"] = repr(e)
         result["rate_by_instances"] = rbi
+    # ---- BASELINE config 5 at its real size on this one GPU, all 16 commit records against the oracle-built fixture
+    if extras and not args.no_cc16 and compressed and time.time() - T_START < args.time_budget * 0.6:
+        try:
+            gold16 = cc16_verifier_fixture(case)
+            result["cc16_one_gpu"] = cc16_one_gpu(gsv, engine, plan, case, gold16, log) if gold16 is not None else {"skipped": "no cc16 fixture for this circuit"}
+        except Exception as e:  # noqa: BLE001
+            result["cc16_one_gpu"] = {"error": repr(e)}
     if extras and not args.no_mode_rates:
         try:
             result["mode_rates"] = mode_rates(gsv, engine, np)
@@ -622,16 +668,29 @@ def run_verifier(args):
         n_launch = sum(win_per_slice[(args.warmup + j) % len(slices)] for j in range(K))
         g_rank = r["gates_per_instance"] * B
         achieved = g_rank * bytes_per_gate / stream_s / 1e9
+        # HBM traffic per launch comes from separate rocprofv3 --pmc passes (tools/profile_r04.sh; counters cannot be read from inside the
+        # process).  It is quoted only when it belongs to THIS build and THIS configuration: the traffic.json records the sha256 of the
+        # libgsv_engine.so that was profiled, the batch and the circuit; anything else leaves `traffic` null.
         traffic, traffic_source = None, None
-        for cand in ("r03_final", "r02_final"):
+        try:
+            import garbled_snark_verifier_amd.build as _b
+            with open(_b.build(), "rb") as fh:
+                lib_sha = hashlib.sha256(fh.read()).hexdigest()
+        except Exception:  # noqa: BLE001
+            lib_sha = None
+        for cand in sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.endswith("_final")), reverse=True):
             tpath = os.path.join(ROOT, "profiles", cand, "traffic.json")
             if os.path.exists(tpath) and compressed:
                 try:
                     tj = json.load(open(tpath))
-                    if int(tj.get("instances_per_gpu", 512)) == B and tj.get("circuit_gates") == gates:  # PMC passes of this very configuration (circuit and batch)
-                        traffic = float(tj["hbm_bytes_per_launch"])
-                        traffic_source = "profiles/%s/traffic.json (separate rocprofv3 --pmc passes of this workload; NOT measured in this run)" % cand
-                        break
+                    if int(tj.get("instances_per_gpu", 512)) != B or tj.get("circuit_gates") != gates:  # PMC passes of this very configuration (circuit and batch)
+                        continue
+                    if not lib_sha or tj.get("engine_library_sha256") != lib_sha:
+                        traffic_source = "profiles/%s/traffic.json belongs to another engine build (library sha256 differs): not quoted; re-run tools/profile_r04.sh" % cand
+                        continue
+                    traffic = float(tj["hbm_bytes_per_launch"])
+                    traffic_source = "profiles/%s/traffic.json (separate rocprofv3 --pmc passes of this workload with this very libgsv_engine.so, sha256 %s...; NOT measured in this run)" % (cand, lib_sha[:12])
+                    break
                 except (KeyError, ValueError):
                     pass
         result.update({
@@ -830,6 +889,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-rate-by-instances", action="store_true")
     ap.add_argument("--no-mode-rates", action="store_true")
+    ap.add_argument("--no-cc16", action="store_true", help="skip the cc16_one_gpu leg (BASELINE config 5 with all 16 instances on this GPU, ~40 s)")
     ap.add_argument("--replays", type=int, default=0, help="synthetic: chain links per instance (0 = enough for 11.17 B gates)")
     ap.add_argument("--ct-ring", type=int, default=2, help="synthetic: replays of ciphertexts kept per instance in HBM")
     ap.add_argument("--component", default="fq12_sqmul", choices=["fq12_sqmul", "fq12_mul"], help="synthetic: link of the chain")

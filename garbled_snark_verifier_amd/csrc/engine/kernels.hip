@@ -273,7 +273,16 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
 #ifdef GSV_DIAG_BUILD
   const bool no_store = (ka.diag & 8u) != 0, no_load = (ka.diag & 4u) != 0, no_aes = (ka.diag & 1u) != 0, no_narrow = (ka.diag & 16u) != 0;
   const bool no_barrier = (ka.diag & 32u) != 0, no_refill = (ka.diag & 64u) != 0, no_hi = (ka.diag & 128u) != 0;  // step skeleton: what is the floor made of?
+  // bit 256: phase clock of the narrow steps.  Wave 0 of workgroup (0, 0) stamps the 100 MHz wall clock (s_memrealtime, consumed only
+  // behind the step barrier: no extra waits) at seven points of every narrow step in which it garbles an AND gate and accumulates the six
+  // intervals + the time between two steps; the sums land in ka.step_clock[0..8] at the end of the kernel (tools/narrow_phase_clock.py).
+  const bool phase_clock = (ka.diag & 256u) != 0 && ka.step_clock && blockIdx.x == 0 && blockIdx.y == 0;
+  unsigned long long pc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc_t[7] = {0, 0, 0, 0, 0, 0, 0}, pc_prev_end = 0;
+  // (each stamp waits for its own result — and with it for the wave's outstanding LDS operations: at the stamp points none are in flight
+  // except the label store of point 4, whose completion the step barrier would wait for anyway)
+#define GSV_PC_STAMP(i, dep) do { if (phase_clock) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pc_t[i]) : "v"(dep) : "memory"); } while (0)
 #else
+#define GSV_PC_STAMP(i, dep) do { } while (0)
   constexpr bool no_store = false, no_load = false, no_aes = false, no_narrow = false, no_barrier = false, no_refill = false, no_hi = false;
 #endif
 
@@ -320,16 +329,35 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     const glb_u8* const and_bytes = (const glb_u8*)ka.ands;
     const glb_u8* const xor_bytes = (const glb_u8*)ka.xors;
     typedef u32x4 Rec;
-    auto load_rec = [&](const u32x4& d) -> Rec {
+    // Narrow steps: AND lanes first (LPG per gate), free-gate lanes behind them — from the next WAVE boundary when the step leaves room
+    // (GSV_NP_XORWAVE), so that no wave runs the AES path and the free-gate path one after the other.
+    auto xor_lane0 = [&](uint32_t na, uint32_t xor_cnt) -> uint32_t {
+#ifdef GSV_NP_XORWAVE
+      const uint32_t up = (na + 63u) & ~63u;
+      return up + xor_cnt <= BT ? up : na;
+#else
+      (void)xor_cnt;
+      return na;
+#endif
+    };
+    auto rec_ptr = [&](const u32x4& d) -> const glb_u8* {
       const glb_u8* p = (const glb_u8*)ka.steps;
       if (is_narrow(d)) {
-        const uint32_t na = d.y * LPG;
+        const uint32_t na = d.y * LPG, x0 = xor_lane0(na, d.w);
         if (tid < na) p = and_bytes + size_t(d.x + tid / LPG) * 32u;
-        else if (tid < na + d.w) p = xor_bytes + size_t(d.z + (tid - na)) * 16u;
+        else if (tid >= x0 && tid < x0 + d.w) p = xor_bytes + size_t(d.z + (tid - x0)) * 16u;
       } else if (d.y >= BT || !small_rem(d.y)) { if (tid < d.y) p = and_bytes + size_t(d.x + tid) * 32u; }  // wide: first one-per-lane pass
       else if (tid / LPG < d.y) p = and_bytes + size_t(d.x + tid / LPG) * 32u;  // wide with only a small remainder: first multi-lane pass
-      return *(const glb_u128*)p;
+      return p;
     };
+    auto load_rec = [&](const u32x4& d) -> Rec { return *(const glb_u128*)rec_ptr(d); };
+#ifdef GSV_NP_HI
+    // ... and the SECOND half of the lane's record with it (an AND record is 32 bytes; free-gate lanes and idle lanes read 16 harmless
+    // bytes behind theirs: every record array carries 32 bytes of padding): a narrow step then starts with its whole record in registers
+    // instead of waiting for a second-half load it could only issue behind the barrier.
+    typedef u32x4 RecHi;
+    auto load_rec2 = [&](const u32x4& d, Rec& lo, RecHi& hi) { const glb_u8* p = rec_ptr(d); lo = *(const glb_u128*)p; hi = *(const glb_u128*)(p + 16); };
+#endif
     auto load_and_rec = [&](uint32_t k) -> Rec { return *(const glb_u128*)(and_bytes + size_t(k) * 32u); };      // record k of the AND array, first half
     auto load_and_hi = [&](uint32_t k) -> u32x4 {  // second half (two-wire form: its first 8 bytes)
       if (no_hi) return u32x4{k, 0u, 0u, 0u};
@@ -342,7 +370,12 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     // would make the compiler wait for the load it has just issued at the top of every step (which is what a rotating
     // r0 <- n0 <- n2r form did, exposing a full L2 round trip per step).
     u32x4 sdA = load_desc(0), sdB = load_desc(1);
+#ifdef GSV_NP_HI
+    Rec recA, recB; RecHi rhiA, rhiB;
+    load_rec2(sdA, recA, rhiA); load_rec2(sdB, recB, rhiB);
+#else
     Rec recA = load_rec(sdA), recB = load_rec(sdB);
+#endif
     // decoded AND record
     // two-wire form: a1 a2 b1 b2 p c | gid, type.  four-wire form: a1 a2 a3 a4 b1 b2 | b3 b4 p, c, gid (a3 a4 b3 b4 are only read when four_wire)
     struct AndOp { uint32_t a1, a2, a3, a4, b1, b2, b3, b4, p, c, t; uint64_t gid; };
@@ -370,11 +403,35 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     // One AND-family gate spread over LPG lanes (garble: two AES blocks x 4 columns, evaluate: one block x 4 columns).
     // Called with LPG-aligned groups of active lanes; `q` is the gate's record (same in all lanes of the group), `cti`
     // its index in the program's AND array.
-    auto and_multilane = [&](const Rec& q, uint32_t cti) {
-      const AndOp o = decode_and(q, load_and_hi(cti));
+    auto and_multilane = [&](const Rec& q, const u32x4& q_hi, uint32_t cti) {
+      const AndOp o = decode_and(q, q_hi);
       const uint32_t t = o.t;
       uint32_t a_c = dq, b_c = dq, p_c = 0;
+      GSV_PC_STAMP(1, o.c ^ o.t);  // the record's second half has arrived and is decoded
       if (!no_load) {
+#ifdef GSV_NP_LOADS
+        // every operand column of the gate in flight at once: LDS reads and wire-file reads go to registers of their own and are
+        // selected afterwards (the shared-destination form of WireFile::ld_word makes each wire-file load wait for the LDS reads
+        // issued before it); a latency-bound step pays ONE round trip of each kind
+        uint32_t vl[9], vg[9];
+        const uint32_t sl[9] = {o.a1, o.a2, o.b1, o.b2, o.p, o.a3, o.a4, o.b3, o.b4};
+        const int n_op = four_wire ? 9 : 5;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          vl[k] = 0u; vg[k] = 0u;
+          if (k < n_op) {
+            if (sl[k] & GSV_SLOT_LDS_FLAG) vl[k] = *wf.win_word(sl[k], col);
+            else vg[k] = ((const glb_u32*)wf.hbm)[sl[k] * 4u + col];
+          }
+        }
+        a_c = (vl[0] ^ vg[0]) ^ (vl[1] ^ vg[1]);
+        b_c = (vl[2] ^ vg[2]) ^ (vl[3] ^ vg[3]);
+        p_c = vl[4] ^ vg[4];
+        if (four_wire) {
+          a_c ^= (vl[5] ^ vg[5]) ^ (vl[6] ^ vg[6]);
+          b_c ^= (vl[7] ^ vg[7]) ^ (vl[8] ^ vg[8]);
+        }
+#else
         a_c = wf.ld_word(o.a1, col) ^ wf.ld_word(o.a2, col);
         b_c = wf.ld_word(o.b1, col) ^ wf.ld_word(o.b2, col);
         p_c = wf.ld_word(o.p, col);
@@ -382,18 +439,22 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           a_c ^= wf.ld_word(o.a3, col) ^ wf.ld_word(o.a4, col);
           b_c ^= wf.ld_word(o.b3, col) ^ wf.ld_word(o.b4, col);
         }
+#endif
       }
       const uint32_t twc = tweak_word(o.gid, col);
       if (!EVAL) {
         uint32_t x = a_c ^ (alpha_a(t) ? dq : 0u);  // selected_a ; lanes of the second quad take other_a
         if (blk) x ^= dq;
+        GSV_PC_STAMP(2, x ^ b_c ^ p_c ^ twc);  // the operands have arrived
         const uint32_t h = no_aes ? (x ^ twc) : aes128_quad(aes, rkc, x ^ twc);
+        GSV_PC_STAMP(3, h);                    // AES done
         const uint32_t o2 = uint32_t(__shfl_xor(int(h), 4));  // the other block's column c
         const uint32_t c0_c = h ^ (alpha_c(t) ? dq : 0u) ^ p_c;
         const uint32_t ct_c = h ^ o2 ^ b_c ^ (alpha_b(t) ? dq : 0u);
         if (!blk && !no_store) wf.st_word(o.c, col, c0_c);
         asm volatile("" ::: "memory");
         if (!blk && !no_store) __builtin_nontemporal_store(ct_c, &CTw[(ct_base + cti) * 4u + col]);
+        GSV_PC_STAMP(4, ct_c);                 // stores issued
       } else {
         uint32_t va = wf.ld_bit(o.a1) ^ wf.ld_bit(o.a2), vb = wf.ld_bit(o.b1) ^ wf.ld_bit(o.b2);
         if (four_wire) { va ^= wf.ld_bit(o.a3) ^ wf.ld_bit(o.a4); vb ^= wf.ld_bit(o.b3) ^ wf.ld_bit(o.b4); }
@@ -420,16 +481,27 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     };
     // One step.  sd: its descriptor; r0: this lane's first record of it — consumed here and refilled, as the wave's youngest
     // vector-memory operation, with the record of step s+2 (descriptor n2sd, a scalar load issued at the top of this step).
+#ifdef GSV_NP_HI
+    auto run_step = [&](const uint32_t s, const u32x4& sd, Rec& r0, RecHi& r0h, const u32x4& n2sd) __attribute__((always_inline)) {
+#else
     auto run_step = [&](const uint32_t s, const u32x4& sd, Rec& r0, const u32x4& n2sd) __attribute__((always_inline)) {
+#endif
       const uint32_t and_off = sd.x, and_cnt = sd.y, xor_off = sd.z, total = sd.y + sd.w;
       (void)total;
+#ifdef GSV_DIAG_BUILD
+      if (!phase_clock)
+#endif
       if (ka.step_clock && blockIdx.x == 0 && threadIdx.x == 0 && rep + 1 == ka.replays) ka.step_clock[s] = wall_clock64();  // older than this step's stores
       if (is_narrow(sd)) {
         // ------------------------------------------------------------------ narrow step: one pass
-        const uint32_t na = and_cnt * LPG;
+        const uint32_t na = and_cnt * LPG, x0 = xor_lane0(na, sd.w);
         if (tid < na) {
-          and_multilane(r0, and_off + tid / LPG);
-        } else if (tid < na + sd.w) {
+#ifdef GSV_NP_HI
+          and_multilane(r0, FW ? r0h : u32x4{r0h.x, r0h.y, 0u, 0u}, and_off + tid / LPG);
+#else
+          and_multilane(r0, load_and_hi(and_off + tid / LPG), and_off + tid / LPG);
+#endif
+        } else if (tid >= x0 && tid < x0 + sd.w) {
           const XorOp o = decode_xor(r0);
           Label c0 = delta;
           if (!no_load) c0 = lxor(lxor(wf.ld(o.x1), wf.ld(o.x2)), lxor(wf.ld(o.x3), wf.ld(o.x4)));
@@ -537,7 +609,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         for (uint32_t g = and_full + tid / LPG; g < and_cnt; g += BT / LPG) {
           // the first remainder record was prefetched two steps ago when the step has no whole pass
           const Rec q = (and_full == 0 && g == tid / LPG) ? r0 : load_and_rec(and_off + g);
-          and_multilane(q, and_off + g);
+          and_multilane(q, load_and_hi(and_off + g), and_off + g);
         }
         // ---- free-gate batches (their label stores are the wave's youngest stores: no young ciphertext store)
         if (xor_cnt) { issue_xor_operands(0); load_xor_recs(uint32_t(XB) * BT, xrn); }
@@ -555,17 +627,42 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       // keep r0's registers reserved through the step: were they handed to a store's data in between, the refill below would
       // have to wait for that store (vmcnt(0) in front of the prefetch) before it could overwrite them
       asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w)::"memory");
+#ifdef GSV_NP_HI
+      asm volatile("" : "+v"(r0h.x), "+v"(r0h.y), "+v"(r0h.z), "+v"(r0h.w)::"memory");
+      if (!no_refill) load_rec2(n2sd, r0, r0h);  // both stay in flight across the barrier and the whole next step
+#else
       if (!no_refill) r0 = load_rec(n2sd);  // stays in flight across the barrier and the whole next step
+#endif
+      GSV_PC_STAMP(5, and_cnt);  // the refill has been issued (ordered by the asm's memory clobber; no dependency on its data)
       if (no_barrier) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef GSV_DIAG_BUILD
+      if (phase_clock) {
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pc_t[6]) : : "memory");
+        if (is_narrow(sd) && and_cnt != 0 && pc_prev_end) {  // wave 0 garbled gate 0 in this step and in the one before: every stamp was taken
+          pc_t[0] = pc_prev_end;  // interval 0 starts behind the previous step's barrier: loop top, descriptor, branch, second-half load, decode
+          for (int i = 0; i < 6; ++i) pc_acc[i] += pc_t[i + 1] - pc_t[i];
+          pc_acc[7] += 1;
+        }
+        pc_prev_end = is_narrow(sd) && and_cnt != 0 ? pc_t[6] : 0;
+      }
+#endif
     };
     for (uint32_t s = 0; s < ka.n_steps; s += 2) {
       const u32x4 sdA2 = load_desc(s + 2);  // lands during the step; the record load that needs it is issued at the step's end
+#ifdef GSV_NP_HI
+      run_step(s, sdA, recA, rhiA, sdA2);
+#else
       run_step(s, sdA, recA, sdA2);
+#endif
       sdA = sdA2;
       if (s + 1 >= ka.n_steps) break;        // wave-uniform: every wave passes the same number of barriers
       const u32x4 sdB2 = load_desc(s + 3);
+#ifdef GSV_NP_HI
+      run_step(s + 1, sdB, recB, rhiB, sdB2);
+#else
       run_step(s + 1, sdB, recB, sdB2);
+#endif
       sdB = sdB2;
     }
     __syncthreads();
@@ -587,6 +684,9 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       __syncthreads();
     }
   }
+#ifdef GSV_DIAG_BUILD
+  if (phase_clock && threadIdx.x == 0) for (int i = 0; i < 8; ++i) ka.step_clock[i] = pc_acc[i];
+#endif
   if (cd) {
     // ---- dataflow epilogue: outputs -> global wires, then publish completion for this instance group (agent-scope release: the
     // consumer may run on another XCD)

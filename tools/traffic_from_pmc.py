@@ -26,5 +26,15 @@ if len(sys.argv) > 4:
 if len(sys.argv) > 2:
     out["algorithmic_bytes_per_launch"] = float(sys.argv[2])
     out["traffic_over_algorithmic"] = out["hbm_bytes_per_launch"] / float(sys.argv[2])
+# the engine build these counters belong to: bench.py refuses a traffic.json whose hash differs from the library it is running
+try:
+    import hashlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from garbled_snark_verifier_amd import build as _b
+    with open(_b.OUT, "rb") as fh:
+        out["engine_library_sha256"] = hashlib.sha256(fh.read()).hexdigest()
+except Exception as e:  # noqa: BLE001
+    out["engine_library_sha256"] = None
+    out["engine_library_sha256_error"] = repr(e)
 json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
