@@ -533,6 +533,16 @@ static int plan_from_circuit_impl(const char* spec, const char* units_csv, const
   if (dbg) std::fprintf(stderr, "plan: background compilations finished at %.1f s\n", since());
   BuiltPlan bp = finish_plan(mode, in_ssa, out_ssa, opt);
   if (dbg) std::fprintf(stderr, "plan: all programs compiled at %.1f s\n", since());
+  if (dbg) {  // per program: how often it is called, its size and shape (latency-bound programs carry four-wire records)
+    std::vector<size_t> n_calls(bp.programs.size(), 0);
+    for (const BuiltPlan::Call& c : bp.calls) if (c.program >= 0) n_calls[size_t(c.program)]++;
+    for (size_t k = 0; k < bp.programs.size(); ++k) {
+      const Program& g = bp.programs[k];
+      std::fprintf(stderr, "plan: program %3zu: %5zu calls, %9llu gates, %8u steps (%.0f records per step), and_terms %u, lds slots %u of %u, label reads from hbm %.0f %%\n", k, n_calls[k],
+                   (unsigned long long)g.n_gates, g.n_steps, g.n_steps ? double(g.n_ct + g.n_fused_free) / g.n_steps : 0.0, g.and_terms, g.n_lds_slots, g.lds_slots_limit,
+                   100.0 * double(g.reads_hbm) / std::max<double>(1.0, double(g.reads_hbm + g.reads_lds)));
+    }
+  }
   std::unique_ptr<gsv_plan> plan(new gsv_plan());
   for (size_t k = 0; k < bp.programs.size(); ++k) {
     gsv_program* q = new gsv_program();

@@ -329,16 +329,12 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     const glb_u8* const and_bytes = (const glb_u8*)ka.ands;
     const glb_u8* const xor_bytes = (const glb_u8*)ka.xors;
     typedef u32x4 Rec;
-    // Narrow steps: AND lanes first (LPG per gate), free-gate lanes behind them — from the next WAVE boundary when the step leaves room
-    // (GSV_NP_XORWAVE), so that no wave runs the AES path and the free-gate path one after the other.
+    // Narrow steps: AND lanes first (LPG per gate), free-gate lanes behind them — from the next WAVE boundary when the step leaves room,
+    // so that no wave runs the AES path and the free-gate path one after the other (round 4: the inversions' one-instance rate +15 %,
+    // the ladders' +5 %, profiles/r04_kernel/kernel_ab_np1.log).
     auto xor_lane0 = [&](uint32_t na, uint32_t xor_cnt) -> uint32_t {
-#ifdef GSV_NP_XORWAVE
       const uint32_t up = (na + 63u) & ~63u;
       return up + xor_cnt <= BT ? up : na;
-#else
-      (void)xor_cnt;
-      return na;
-#endif
     };
     auto rec_ptr = [&](const u32x4& d) -> const glb_u8* {
       const glb_u8* p = (const glb_u8*)ka.steps;
@@ -351,13 +347,6 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       return p;
     };
     auto load_rec = [&](const u32x4& d) -> Rec { return *(const glb_u128*)rec_ptr(d); };
-#ifdef GSV_NP_HI
-    // ... and the SECOND half of the lane's record with it (an AND record is 32 bytes; free-gate lanes and idle lanes read 16 harmless
-    // bytes behind theirs: every record array carries 32 bytes of padding): a narrow step then starts with its whole record in registers
-    // instead of waiting for a second-half load it could only issue behind the barrier.
-    typedef u32x4 RecHi;
-    auto load_rec2 = [&](const u32x4& d, Rec& lo, RecHi& hi) { const glb_u8* p = rec_ptr(d); lo = *(const glb_u128*)p; hi = *(const glb_u128*)(p + 16); };
-#endif
     auto load_and_rec = [&](uint32_t k) -> Rec { return *(const glb_u128*)(and_bytes + size_t(k) * 32u); };      // record k of the AND array, first half
     auto load_and_hi = [&](uint32_t k) -> u32x4 {  // second half (two-wire form: its first 8 bytes)
       if (no_hi) return u32x4{k, 0u, 0u, 0u};
@@ -370,12 +359,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     // would make the compiler wait for the load it has just issued at the top of every step (which is what a rotating
     // r0 <- n0 <- n2r form did, exposing a full L2 round trip per step).
     u32x4 sdA = load_desc(0), sdB = load_desc(1);
-#ifdef GSV_NP_HI
-    Rec recA, recB; RecHi rhiA, rhiB;
-    load_rec2(sdA, recA, rhiA); load_rec2(sdB, recB, rhiB);
-#else
     Rec recA = load_rec(sdA), recB = load_rec(sdB);
-#endif
     // decoded AND record
     // two-wire form: a1 a2 b1 b2 p c | gid, type.  four-wire form: a1 a2 a3 a4 b1 b2 | b3 b4 p, c, gid (a3 a4 b3 b4 are only read when four_wire)
     struct AndOp { uint32_t a1, a2, a3, a4, b1, b2, b3, b4, p, c, t; uint64_t gid; };
@@ -409,29 +393,6 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       uint32_t a_c = dq, b_c = dq, p_c = 0;
       GSV_PC_STAMP(1, o.c ^ o.t);  // the record's second half has arrived and is decoded
       if (!no_load) {
-#ifdef GSV_NP_LOADS
-        // every operand column of the gate in flight at once: LDS reads and wire-file reads go to registers of their own and are
-        // selected afterwards (the shared-destination form of WireFile::ld_word makes each wire-file load wait for the LDS reads
-        // issued before it); a latency-bound step pays ONE round trip of each kind
-        uint32_t vl[9], vg[9];
-        const uint32_t sl[9] = {o.a1, o.a2, o.b1, o.b2, o.p, o.a3, o.a4, o.b3, o.b4};
-        const int n_op = four_wire ? 9 : 5;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          vl[k] = 0u; vg[k] = 0u;
-          if (k < n_op) {
-            if (sl[k] & GSV_SLOT_LDS_FLAG) vl[k] = *wf.win_word(sl[k], col);
-            else vg[k] = ((const glb_u32*)wf.hbm)[sl[k] * 4u + col];
-          }
-        }
-        a_c = (vl[0] ^ vg[0]) ^ (vl[1] ^ vg[1]);
-        b_c = (vl[2] ^ vg[2]) ^ (vl[3] ^ vg[3]);
-        p_c = vl[4] ^ vg[4];
-        if (four_wire) {
-          a_c ^= (vl[5] ^ vg[5]) ^ (vl[6] ^ vg[6]);
-          b_c ^= (vl[7] ^ vg[7]) ^ (vl[8] ^ vg[8]);
-        }
-#else
         a_c = wf.ld_word(o.a1, col) ^ wf.ld_word(o.a2, col);
         b_c = wf.ld_word(o.b1, col) ^ wf.ld_word(o.b2, col);
         p_c = wf.ld_word(o.p, col);
@@ -439,7 +400,6 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           a_c ^= wf.ld_word(o.a3, col) ^ wf.ld_word(o.a4, col);
           b_c ^= wf.ld_word(o.b3, col) ^ wf.ld_word(o.b4, col);
         }
-#endif
       }
       const uint32_t twc = tweak_word(o.gid, col);
       if (!EVAL) {
@@ -481,11 +441,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     };
     // One step.  sd: its descriptor; r0: this lane's first record of it — consumed here and refilled, as the wave's youngest
     // vector-memory operation, with the record of step s+2 (descriptor n2sd, a scalar load issued at the top of this step).
-#ifdef GSV_NP_HI
-    auto run_step = [&](const uint32_t s, const u32x4& sd, Rec& r0, RecHi& r0h, const u32x4& n2sd) __attribute__((always_inline)) {
-#else
     auto run_step = [&](const uint32_t s, const u32x4& sd, Rec& r0, const u32x4& n2sd) __attribute__((always_inline)) {
-#endif
       const uint32_t and_off = sd.x, and_cnt = sd.y, xor_off = sd.z, total = sd.y + sd.w;
       (void)total;
 #ifdef GSV_DIAG_BUILD
@@ -496,11 +452,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         // ------------------------------------------------------------------ narrow step: one pass
         const uint32_t na = and_cnt * LPG, x0 = xor_lane0(na, sd.w);
         if (tid < na) {
-#ifdef GSV_NP_HI
-          and_multilane(r0, FW ? r0h : u32x4{r0h.x, r0h.y, 0u, 0u}, and_off + tid / LPG);
-#else
           and_multilane(r0, load_and_hi(and_off + tid / LPG), and_off + tid / LPG);
-#endif
         } else if (tid >= x0 && tid < x0 + sd.w) {
           const XorOp o = decode_xor(r0);
           Label c0 = delta;
@@ -627,12 +579,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       // keep r0's registers reserved through the step: were they handed to a store's data in between, the refill below would
       // have to wait for that store (vmcnt(0) in front of the prefetch) before it could overwrite them
       asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w)::"memory");
-#ifdef GSV_NP_HI
-      asm volatile("" : "+v"(r0h.x), "+v"(r0h.y), "+v"(r0h.z), "+v"(r0h.w)::"memory");
-      if (!no_refill) load_rec2(n2sd, r0, r0h);  // both stay in flight across the barrier and the whole next step
-#else
       if (!no_refill) r0 = load_rec(n2sd);  // stays in flight across the barrier and the whole next step
-#endif
       GSV_PC_STAMP(5, and_cnt);  // the refill has been issued (ordered by the asm's memory clobber; no dependency on its data)
       if (no_barrier) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -650,19 +597,11 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     };
     for (uint32_t s = 0; s < ka.n_steps; s += 2) {
       const u32x4 sdA2 = load_desc(s + 2);  // lands during the step; the record load that needs it is issued at the step's end
-#ifdef GSV_NP_HI
-      run_step(s, sdA, recA, rhiA, sdA2);
-#else
       run_step(s, sdA, recA, sdA2);
-#endif
       sdA = sdA2;
       if (s + 1 >= ka.n_steps) break;        // wave-uniform: every wave passes the same number of barriers
       const u32x4 sdB2 = load_desc(s + 3);
-#ifdef GSV_NP_HI
-      run_step(s + 1, sdB, recB, rhiB, sdB2);
-#else
       run_step(s + 1, sdB, recB, sdB2);
-#endif
       sdB = sdB2;
     }
     __syncthreads();
