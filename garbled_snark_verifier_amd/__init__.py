@@ -56,10 +56,11 @@ class _ProgramInfo(C.Structure):
 
 class _PlanSessionOpts(C.Structure):
     _fields_ = [("retain_stream", C.c_int), ("max_concurrent_calls", C.c_uint32), ("window_ct_records", C.c_uint64), ("max_scratch_slots", C.c_uint64),
-                ("max_window_calls", C.c_uint32), ("reserved", C.c_uint32)]
+                ("max_window_calls", C.c_uint32), ("drain_segment_records", C.c_uint32)]
 
 
-_SCHED_FIELDS = ["n_calls", "n_windows", "n_dependencies", "max_width", "scratch_slots", "wire_file_slots", "window_ct_records", "critical_steps", "total_steps"]
+_SCHED_FIELDS = ["n_calls", "n_windows", "n_dependencies", "max_width", "scratch_slots", "wire_file_slots", "window_ct_records", "critical_steps", "total_steps",
+                 "n_segments", "segment_ct_records"]
 
 
 class _PlanScheduleInfo(C.Structure):
@@ -524,7 +525,7 @@ class Session:
     """A batch of instances on one program (gsv_session) or, with a Plan, on a sequence of component programs."""
 
     def __init__(self, engine, program, n_instances=1, replays=1, ct_capacity_replays=None, retain_stream=True, concurrent_calls=0, window_ct_records=0,
-                 max_scratch_slots=0, max_window_calls=0):
+                 max_scratch_slots=0, max_window_calls=0, drain_segment_records=0):
         """Plan sessions: concurrent_calls = how many independent calls of the plan may run side by side (0: as many as give every CU a
         workgroup, 1: sequential); window_ct_records / max_scratch_slots / max_window_calls: see gsv_plan_session_opts (0 = automatic)."""
         self.engine, self.program = engine, program
@@ -533,7 +534,7 @@ class Session:
         self.h = C.c_void_p()
         if isinstance(program, Plan):
             assert replays == 1
-            o = _PlanSessionOpts(int(bool(retain_stream)), int(concurrent_calls), int(window_ct_records), int(max_scratch_slots), int(max_window_calls), 0)
+            o = _PlanSessionOpts(int(bool(retain_stream)), int(concurrent_calls), int(window_ct_records), int(max_scratch_slots), int(max_window_calls), int(drain_segment_records))
             _chk(lib().gsv_session_create_plan_opts(engine.h, program.h, n_instances, C.byref(o), C.byref(self.h)))
         else:
             _chk(lib().gsv_session_create(engine.h, program.h, n_instances, replays, self.ct_cap, C.byref(self.h)))

@@ -150,6 +150,9 @@ struct gsv_session {
   uint32_t global_base = 0;  // first slot of the plan's global region
   bool plan_retain = true;   // plan sessions: whole ciphertext stream kept on the device (else one call block: streaming only)
   uint64_t plan_max_block = 0;  // ciphertext records per instance of the device block: the largest WINDOW of the schedule
+  uint64_t plan_max_segment = 0;  // ... of a gate-order buffer: the largest drain SEGMENT (schedule.hpp)
+  hipStream_t aux_stream = nullptr;  // gather kernels and flag polls of the drain, beside the running window
+  uint32_t* host_flags = nullptr;    // page-locked copy of the completion flags (polled while a window runs)
   struct CallDev { DevProgram dp; };
   std::vector<CallDev> call_dev;
   // Call-level schedule (schedule.hpp): windows of consecutive calls; the calls of a window run as a dataflow inside ONE launch
@@ -169,6 +172,7 @@ struct gsv_session {
   int hasher = 0;  // 0 AesNiHasher, 1 Blake3Hasher
   std::vector<uint64_t> ct_uploaded;  // per instance: records supplied by gsv_session_upload_ciphertexts
   struct gsv_drain* drain = nullptr;   // streaming drain: copy streams, pinned buffers, per-instance MAC states (created on first use)
+  std::vector<void*> ct_gate_more;     // further gate-order buffers of the drain pipeline (ct_gate is the first)
   void* ct_alt = nullptr;              // garble -> evaluate on the device: the second program-order ciphertext block
   struct PairState* pair = nullptr;    // ... and its stream / events (created on first use)
   uint64_t ct_stride() const { return plan ? (plan_retain ? plan->n_ct : plan_max_block) : ct_cap * p->prog.n_ct; }  // n_ct does not depend on the variant
@@ -431,6 +435,9 @@ void gsv_session_destroy(gsv_session* s) {
   for (void* q : {s->W, s->VB, s->CT, s->delta, s->out, s->out_bits, s->in_bits, s->step_clock, s->ct_stage, s->ct_gate}) if (q) (void)hipFree(q);
   for (void* q : {s->d_calls, s->d_copy_src, s->d_copy_dst, s->d_deps, s->d_flags, s->d_error}) if (q) (void)hipFree(q);
   if (s->plan_out_slots) (void)hipFree(s->plan_out_slots);
+  for (void* q : s->ct_gate_more) if (q) (void)hipFree(q);
+  if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
+  if (s->host_flags) (void)hipHostFree(s->host_flags);
   destroy_drain(s->drain);
   destroy_pair(s->pair);
   if (s->ct_alt) (void)hipFree(s->ct_alt);
@@ -1007,6 +1014,9 @@ static Schedule make_schedule(const gsv_plan* plan, uint32_t ni, size_t n_instan
   // calls side by side: as many as it takes to give every CU a workgroup (GSV_PLAN_CONCURRENCY / opts override)
   uint32_t conc = o.max_concurrent_calls ? o.max_concurrent_calls : uint32_t(std::max<size_t>(1, size_t(n_cus) / std::max<size_t>(1, n_wg)));
   if (!o.max_concurrent_calls) if (const char* ev = getenv("GSV_PLAN_CONCURRENCY")) conc = uint32_t(std::max(1, atoi(ev)));
+  // a session that drains its stream leaves a few CUs to the gather kernels that bring finished segments into gate order beside the
+  // running window (a workgroup of the garbling kernel takes a whole CU, also while it waits for a dependency)
+  if (!o.max_concurrent_calls && !o.retain_stream && conc > 1 && n_wg * size_t(conc) + 16 > size_t(n_cus)) conc = uint32_t(std::max<size_t>(1, (size_t(n_cus) - std::min<size_t>(16, size_t(n_cus) / 2)) / n_wg));
   sp.max_calls_in_flight = std::min<uint32_t>(conc, 65535u);
   // the scratch ring: at most ~1/16 of the free device memory over all instances, and 2^30 slots (slot offsets are 32 bits)
   uint64_t slots = o.max_scratch_slots ? o.max_scratch_slots : uint64_t(free_bytes / 16 / 16 / std::max<size_t>(1, n_instances));
@@ -1015,14 +1025,25 @@ static Schedule make_schedule(const gsv_plan* plan, uint32_t ni, size_t n_instan
   // ciphertext window: the whole stream when it is retained, else about a quarter of the free memory for the two window buffers
   if (o.retain_stream) sp.max_window_ct = ~0ull;
   else {
-    // Default: about a quarter of the free memory for the two window buffers, but never more than 64 M records (1 GB) per instance: a
-    // pass must be MANY windows, because the drain of window k (D2H copies, the serial CBC-MAC chains, gc files) runs beside the
-    // garbling of window k+1.  With one instance on a 288 GB device the uncapped default was 2.2 G records = 2 windows per verifier
-    // pass, half of the 27-s CBC-MAC chain uncovered: 48.2 s against 37.0 s with 1 GB windows (profiles/r03_e2e/one_instance_commit.log);
-    // it also made gsv_session_evaluate_streaming stage tens of GB on the host.
-    uint64_t w = o.window_ct_records ? o.window_ct_records : std::min<uint64_t>(uint64_t(free_bytes / 4 / 32 / std::max<size_t>(1, n_instances)), 1ull << 26);
+    // Default for sessions that do not retain the stream: the device block (= one window, the scope inside which independent call chains
+    // overlap: schedule.hpp) takes up to 40 % of the free memory, at most 2^31 records (32 GB) per instance.  The stream leaves the
+    // device in SEGMENTS of a window (below), so a large window costs the drain nothing.  Round 3's default cut one instance's pass into
+    // 2 windows and drained whole windows (48.2 s with the commitment: half of the 27-s CBC-MAC chain uncovered); 46 windows of 1 GB hid
+    // the chain but cost the garbling 4.7 s — the verifier's line-coefficient chain precedes the Miller loop in stream order and only
+    // runs beside it inside one window (29.6 s with 2 windows, 33.4 s with 18, 34.3 s with 46: profiles/r04_e2e/one_instance_windows.log).
+    // (... and at most 48 GB over all instances: device memory that has been freed is scrubbed before it is handed out again, ~25 GB/s,
+    // so a session of 16 instances with a 96-GB block took 6 s to create; its garbling is 3 % faster with 6-GB windows than with 2-GB ones)
+    const double block_bytes = std::min(double(free_bytes) * 0.4, 48e9);
+    uint64_t w = o.window_ct_records ? o.window_ct_records : std::min<uint64_t>(uint64_t(block_bytes / 16.0 / double(std::max<size_t>(1, n_instances))), 1ull << 31);
     if (!o.window_ct_records && conc == 1) w = 0;  // sequential sessions keep the one-call block of rounds 1-2 (smallest footprint)
     sp.max_window_ct = std::max<uint64_t>(w, max_block);
+  }
+  // Drain segments: at most 64 M records (1 GB) per instance — the serial CBC-MAC chain of a segment takes 0.6 s —, less when three
+  // gate-order buffers of that size would take more than a tenth of the free memory; never smaller than the largest call.
+  {
+    uint64_t sg = o.drain_segment_records ? o.drain_segment_records : std::min<uint64_t>(uint64_t(double(free_bytes) * 0.1 / (3.0 * 16.0) / double(std::max<size_t>(1, n_instances))), 1ull << 26);
+    if (const char* ev = getenv("GSV_DRAIN_SEGMENT_RECORDS")) if (!o.drain_segment_records) sg = uint64_t(std::max(1ll, atoll(ev)));
+    sp.segment_ct = std::min<uint64_t>(std::max<uint64_t>(sg, max_block), sp.max_window_ct);
   }
   sp.max_window_calls = std::min<uint32_t>(o.max_window_calls ? o.max_window_calls : 32768u, 65535u);
   Schedule sc = schedule_calls(calls, plan->n_globals, plan->outputs, sp);
@@ -1075,6 +1096,7 @@ int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_i
   s->global_base = scratch;
   s->plan_retain = o.retain_stream != 0;
   s->plan_max_block = sc.max_window_ct;
+  s->plan_max_segment = sc.max_segment_ct;
   if (uint64_t(scratch) + plan->n_globals > 0xFFFFFFF0ull) return fail(GSV_ERR_CIRCUIT, "plan wire file too large");
   Program& f = s->facade;
   f.n_slots = scratch + plan->n_globals;
@@ -1152,6 +1174,7 @@ int gsv_session_plan_schedule_info(const gsv_session* s, gsv_plan_schedule_info*
   info->max_width = sc.max_width;
   info->scratch_slots = s->global_base; info->wire_file_slots = s->facade.n_slots; info->window_ct_records = sc.max_window_ct;
   info->critical_steps = sc.critical_steps; info->total_steps = sc.total_steps;
+  info->n_segments = sc.segments.size(); info->segment_ct_records = sc.max_segment_ct;
   return GSV_OK;
 }
 int gsv_session_plan_window(const gsv_session* s, uint64_t window, uint64_t* first_call, uint64_t* n_calls, uint64_t* max_width) {
@@ -1335,16 +1358,19 @@ static int check_plan_error(gsv_session* s) {
   if (err) return fail(GSV_ERR_DEVICE, "a call of the plan waited for a dependency that never completed (dispatch-order assumption of schedule.hpp violated); results are invalid");
   return GSV_OK;
 }
-// Gate order <-> program order for the calls of one window: ct_gate (window-relative, gate order) <-> the window's device block.
-static int permute_plan_window(gsv_session* s, size_t w, uint64_t gate_stride, int scatter, void* ct_block = nullptr) {
+// Gate order <-> program order for calls [k0, k1) of window w (a drain segment, or the whole window): gate-order buffer, records
+// relative to `gate_ct0` (the stream index of the buffer's first record) <-> the window's device block.
+static int permute_plan_calls(gsv_session* s, size_t w, uint32_t k0, uint32_t k1, uint64_t gate_ct0, uint64_t gate_stride, int scatter, void* ct_block, void* gate_buf, hipStream_t stream) {
   const Schedule::Window& win = s->sched.windows[w];
   if (!ct_block) ct_block = s->CT;
-  for (uint32_t k = win.call0; k < win.call1; ++k) {
+  if (!gate_buf) gate_buf = s->ct_gate;
+  if (!stream) stream = s->e->stream;
+  for (uint32_t k = k0; k < k1; ++k) {
     const Program& cp = s->call_prog(k);
     if (!cp.n_ct) continue;
     const uint64_t rel = s->plan->calls[k].ct_off - win.ct0;
     uint8_t* block = static_cast<uint8_t*>(ct_block) + (s->plan_retain ? s->plan->calls[k].ct_off : rel) * 16;
-    if (gsvk_gather_segment(block, s->ct_stride(), s->call_dev[k].dp.ct_pos, cp.n_ct, 1, uint32_t(s->n_inst), static_cast<uint8_t*>(s->ct_gate) + rel * 16, gate_stride, scatter, s->e->stream) != 0)
+    if (gsvk_gather_segment(block, s->ct_stride(), s->call_dev[k].dp.ct_pos, cp.n_ct, 1, uint32_t(s->n_inst), static_cast<uint8_t*>(gate_buf) + (s->plan->calls[k].ct_off - gate_ct0) * 16, gate_stride, scatter, stream) != 0)
       return fail(GSV_ERR_DEVICE, scatter ? "ciphertext scatter launch failed" : "ciphertext gather launch failed");
   }
   return GSV_OK;
@@ -1414,7 +1440,24 @@ struct gsv_drain {
   // VAES + AVX-512 and sessions with at least 128 instances (eight workers' worth), sixteen (update_interleaved16_vaes: one core
   // then MACs ~3 x as many blocks per second, so a node's GPUs need a third of the host cores for their commitments).
   static constexpr int GROUP_MAX = 16;
-  static int group_for(size_t n_inst) { return CbcMacHost::have_vaes() && n_inst >= 128 ? 16 : 4; }
+  // CPUs this process may actually use: the visible ones, capped by the container's CPU bandwidth quota (cgroup cpu.max)
+  static size_t usable_cores() {
+    size_t n = std::max<size_t>(1, std::thread::hardware_concurrency());
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[64] = {0}; double per = 0;
+      if (std::fscanf(f, "%63s %lf", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) n = std::min<size_t>(n, std::max<size_t>(1, size_t(std::atof(q) / per)));
+      std::fclose(f);
+    }
+    return n;
+  }
+  // One chain per worker while there is a core per instance: a chain alone advances at ~1.1e8 blocks/s, one of four interleaved at
+  // ~0.75e8 — sixteen instances (BASELINE config 5 on one GPU) hashed four to a worker took 40 s for 34.8 s of garbling, their
+  // sixteen chains one per core take 27 s.  More instances than cores: four (AES-NI) or sixteen (VAES, >= 128 instances) per worker.
+  static int group_for(size_t n_inst) {
+    if (const char* e = getenv("GSV_DRAIN_GROUP")) { const int v = atoi(e); if (v == 1 || v == 4 || v == 16) return v; }
+    if (n_inst <= usable_cores()) return 1;
+    return CbcMacHost::have_vaes() && n_inst >= 128 ? 16 : 4;
+  }
   int group = 4;
   struct Worker {
     void* pinned[2][GROUP_MAX] = {};  // two sets of pinned chunk buffers: copy set j+1 while set j is hashed
@@ -1529,7 +1572,8 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   // program sessions: segments of one ring (ct_cap replays of n_ct records); plan sessions: one WINDOW of the schedule per segment
   size_t pw0 = 0, pw1 = 0;
   if (s->plan) { int wrc = window_range(s, c0, c1, &pw0, &pw1); if (wrc) return wrc; }
-  const uint64_t n_ct = s->plan ? s->plan_max_block : g.n_ct, seg = s->plan ? 1 : s->ct_cap;
+  // (plan sessions: the stream leaves the device in SEGMENTS of a window, a gate-order buffer holds the largest segment)
+  const uint64_t n_ct = s->plan ? s->plan_max_segment : g.n_ct, seg = s->plan ? 1 : s->ct_cap;
   const uint64_t first = s->plan ? pw0 : 0, total = s->plan ? pw1 : s->replays;
   const bool new_pass = s->plan ? c0 == 0 : true;
   const size_t n_inst = s->n_inst;
@@ -1549,6 +1593,10 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
     if (rc) return rc;
   }
   if (ev) { int rc = ensure_pair(s); if (rc) return rc; }
+  if (s->plan && want_drain) {
+    if (!s->aux_stream) HIPCHK(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
+    if (!s->host_flags) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->host_flags), ((n_inst + s->ni - 1) / s->ni) * size_t(s->flag_stride) * 4 + 64, hipHostMallocDefault));
+  }
   if (s->plan && new_pass) HIPCHK(hipMemsetAsync(s->d_error, 0, 4, s->e->stream));  // a new pass starts with a clean dependency-wait flag
   if (ev && new_pass) HIPCHK(hipMemsetAsync(ev->d_error, 0, 4, s->e->stream));
   std::vector<CbcMacHost> no_macs;
@@ -1567,63 +1615,131 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
     }
   std::atomic<int> err{0};
   const uint64_t chunk = want_drain ? s->drain->chunk : 0;
-  // one drain = all instances x the `n` records per instance sitting in the gate-order buffer; `base` = stream index of the first one
-  auto drain = [&](uint64_t n, uint64_t base, std::vector<std::thread>& pool) {
+  // The drain is a PIPELINE of segments: the device side (garble a window, bring it into gate order in one of `depth` gate-order
+  // buffers) runs ahead of the host side (copy out, CBC-MAC, files, sink) by up to `depth` segments.  A window's ciphertext count is
+  // fixed but its garbling time is not (the ladders and inversions produce a gigabyte of ciphertexts in seconds, the Miller loop in
+  // half a second), while the serial CBC-MAC chain takes the same 0.58 s for every gigabyte: with ONE buffer a pass costs
+  // sum(max(garble_w, mac_w)) — 37.0 s for one instance whose garbling takes 31 s and whose chain takes 27 s — with a few buffers
+  // max(sum garble, sum mac).  Workers are persistent for the call and take the segments strictly in order (an instance's chain must
+  // see its stream in order); a buffer is reused once every worker is done with the segment that held it.
+  std::vector<void*> gate_bufs;
+  if (want_drain) {
+    gate_bufs.push_back(s->ct_gate);
+    size_t want = 1;
+    size_t n_units = size_t((total - first + seg - 1) / seg);  // drain units of this call: segments (plans) or rings
+    if (s->plan) { n_units = 0; for (size_t w = pw0; w < pw1; ++w) n_units += s->sched.windows[w].seg1 - s->sched.windows[w].seg0; }
+    if (seg_records && n_units > 1) {
+      size_t free_b = 0, total_b = 0;
+      (void)hipMemGetInfo(&free_b, &total_b);
+      const size_t buf_bytes = n_inst * size_t(seg_records) * 16;
+      // up to eight buffers, within half of the free memory and 32 GB (allocating device memory takes time too: ~25 GB/s)
+      want = std::min<size_t>(std::min<size_t>(8, 1 + size_t(double(free_b) * 0.5 / double(buf_bytes))), std::max<size_t>(2, size_t(32e9 / double(buf_bytes))));
+      if (const char* e = getenv("GSV_DRAIN_DEPTH")) want = size_t(std::max(1, atoi(e)));
+    }
+    while (1 + s->ct_gate_more.size() < want) {
+      void* q = nullptr;
+      if (hipMalloc(&q, n_inst * size_t(seg_records) * 16) != hipSuccess) { (void)hipGetLastError(); break; }
+      s->ct_gate_more.push_back(q);
+    }
+    for (void* q : s->ct_gate_more) if (gate_bufs.size() < want) gate_bufs.push_back(q);
+  }
+  const size_t depth = std::max<size_t>(1, gate_bufs.size());
+  struct Segment { uint64_t n, base; size_t buf; };
+  std::mutex q_mu;
+  std::condition_variable q_cv;
+  std::vector<Segment> segments;          // pushed by the device side, in stream order
+  std::vector<size_t> seg_done;           // per segment: workers that have finished it
+  bool q_closed = false;
+  auto worker_main = [&](size_t t) {
+    if (hipSetDevice(s->e->device) != hipSuccess) { err = 1; }
     gsv_drain& dr = *s->drain;
-    for (size_t t = 0; t < T; ++t)
-      pool.emplace_back([&, t, n, base]() {
-        if (hipSetDevice(s->e->device) != hipSuccess) { err = 1; return; }
-        gsv_drain::Worker& w = dr.workers[t];
-        for (size_t grp = t; grp < n_groups && !err && n; grp += T) {
-          const size_t i0 = grp * GROUP, ng = std::min(GROUP, n_inst - i0);  // instances i0 .. i0+ng-1 advance together
-          // the copies of one chunk set share a stream of the pool (a set holds a slot of the gate from issue to completion)
-          auto copy = [&](uint64_t off, int b) {
-            hipStream_t st = dr.copy_gate.acquire();
-            bool ok = true;
-            for (size_t g = 0; g < ng && ok; ++g)
-              ok = hipMemcpyAsync(w.pinned[b][g], static_cast<const uint8_t*>(s->ct_gate) + ((i0 + g) * seg_records + off) * 16, std::min(chunk, n - off) * 16,
-                                  hipMemcpyDeviceToHost, st) == hipSuccess;
-            // many workers: sleep on the blocking-sync event (spinning workers eat the cores the MACs need); a handful of
-            // workers (one instance: the whole-stream check) spin instead, a blocking wait's wake-up latency would be paid per chunk
-            ok = ok && (T > 8 ? hipEventRecord(w.done, st) == hipSuccess && hipEventSynchronize(w.done) == hipSuccess : hipStreamSynchronize(st) == hipSuccess);
-            dr.copy_gate.release(st);
-            return ok;
-          };
-          int b = 0;
-          if (!copy(0, 0)) { err = 1; break; }
-          for (uint64_t off = 0; off < n; off += chunk, b ^= 1) {
-            const uint64_t m = std::min(chunk, n - off);
-            if (want_mac) {
-              CbcMacHost* mp[gsv_drain::GROUP_MAX];
-              const uint8_t* cp[gsv_drain::GROUP_MAX];
-              for (size_t g = 0; g < ng; ++g) { mp[g] = &macs[i0 + g]; cp[g] = static_cast<const uint8_t*>(w.pinned[b][g]); }
-              CbcMacHost::update_many(mp, cp, ng, m);  // sixteen / four chains per step, a ragged last group chain by chain
-            }
-            if (sink.dir)
-              for (size_t g = 0; g < ng; ++g)
-                if (std::fwrite(w.pinned[b][g], 16, m, files[i0 + g]) != m) { err = 2; break; }
-            if (sink.fn && !err)
-              for (size_t g = 0; g < ng; ++g)
-                if (sink.fn(sink.user, i0 + g, base + off, static_cast<const uint8_t*>(w.pinned[b][g]), m) != 0) { err = 3; break; }
-            if (err) break;
-            if (off + chunk < n && !copy(off + chunk, b ^ 1)) { err = 1; break; }
+    gsv_drain::Worker& w = dr.workers[t];
+    for (size_t j = 0;; ++j) {
+      Segment sg;
+      {
+        std::unique_lock<std::mutex> lk(q_mu);
+        q_cv.wait(lk, [&] { return j < segments.size() || q_closed; });
+        if (j >= segments.size()) return;
+        sg = segments[j];
+      }
+      const uint64_t n = sg.n, base = sg.base;
+      const uint8_t* const gate = static_cast<const uint8_t*>(gate_bufs[sg.buf]);
+      for (size_t grp = t; grp < n_groups && !err && n; grp += T) {
+        const size_t i0 = grp * GROUP, ng = std::min(GROUP, n_inst - i0);  // instances i0 .. i0+ng-1 advance together
+        // the copies of one chunk set share a stream of the pool (a set holds a slot of the gate from issue to completion)
+        auto copy = [&](uint64_t off, int b) {
+          hipStream_t st = dr.copy_gate.acquire();
+          bool ok = true;
+          for (size_t g = 0; g < ng && ok; ++g)
+            ok = hipMemcpyAsync(w.pinned[b][g], gate + ((i0 + g) * seg_records + off) * 16, std::min(chunk, n - off) * 16, hipMemcpyDeviceToHost, st) == hipSuccess;
+          // many workers: sleep on the blocking-sync event (spinning workers eat the cores the MACs need); a handful of
+          // workers (one instance: the whole-stream check) spin instead, a blocking wait's wake-up latency would be paid per chunk
+          ok = ok && (T > 8 ? hipEventRecord(w.done, st) == hipSuccess && hipEventSynchronize(w.done) == hipSuccess : hipStreamSynchronize(st) == hipSuccess);
+          dr.copy_gate.release(st);
+          return ok;
+        };
+        int b = 0;
+        if (!copy(0, 0)) { err = 1; break; }
+        for (uint64_t off = 0; off < n; off += chunk, b ^= 1) {
+          const uint64_t m = std::min(chunk, n - off);
+          if (want_mac) {
+            CbcMacHost* mp[gsv_drain::GROUP_MAX];
+            const uint8_t* cp[gsv_drain::GROUP_MAX];
+            for (size_t g = 0; g < ng; ++g) { mp[g] = &macs[i0 + g]; cp[g] = static_cast<const uint8_t*>(w.pinned[b][g]); }
+            CbcMacHost::update_many(mp, cp, ng, m);  // sixteen / four chains per step, a ragged last group chain by chain
           }
+          if (sink.dir)
+            for (size_t g = 0; g < ng; ++g)
+              if (std::fwrite(w.pinned[b][g], 16, m, files[i0 + g]) != m) { err = 2; break; }
+          if (sink.fn && !err)
+            for (size_t g = 0; g < ng; ++g)
+              if (sink.fn(sink.user, i0 + g, base + off, static_cast<const uint8_t*>(w.pinned[b][g]), m) != 0) { err = 3; break; }
+          if (err) break;
+          if (off + chunk < n && !copy(off + chunk, b ^ 1)) { err = 1; break; }
         }
-      });
+      }
+      {
+        std::lock_guard<std::mutex> lk(q_mu);
+        seg_done[j]++;
+      }
+      q_cv.notify_all();
+    }
   };
-  // Pipeline: kernel k+1 runs beside drain k.  Drains are serialised (an instance's MAC must see its replays in order);
-  // the gather of segment k+1 needs the gate-order buffer back, i.e. drain k joined.
-  std::vector<std::thread> cur;
-  // GSV_DRAIN_STATS=1: where the host thread of the pipeline waits (for the previous drain = the host side is the slower stage; for
-  // the kernel + gather = the device is), printed once per call
+  std::vector<std::thread> workers;
+  if (want_drain) for (size_t t = 0; t < T; ++t) workers.emplace_back(worker_main, t);
+  // GSV_DRAIN_STATS=1: where the host thread of the pipeline waits (for a free gate-order buffer = the host side is the slower stage;
+  // for the kernel + gather = the device is), printed once per call
   const bool stats = getenv("GSV_DRAIN_STATS") != nullptr;
   double t_wait_drain = 0, t_wait_device = 0;
   uint64_t drained_records = 0;
   const auto t_begin = std::chrono::steady_clock::now();
   auto secs = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
-  auto join = [&](std::vector<std::thread>& p) { const auto t0 = std::chrono::steady_clock::now(); for (auto& th : p) th.join(); p.clear(); t_wait_drain += secs(t0); };
+  // blocks until the segment that last used buffer `b` has been consumed by every worker (segment index = its position in `segments`)
+  auto wait_buffer = [&](size_t n_pushed) {
+    if (!want_drain || n_pushed < depth) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::unique_lock<std::mutex> lk(q_mu);
+    q_cv.wait(lk, [&] { return seg_done[n_pushed - depth] == T; });
+    t_wait_drain += secs(t0);
+  };
+  auto push_segment = [&](uint64_t n, uint64_t base, size_t buf) {
+    { std::lock_guard<std::mutex> lk(q_mu); segments.push_back(Segment{n, base, buf}); seg_done.push_back(0); }
+    q_cv.notify_all();
+  };
+  auto finish_workers = [&]() {
+    { std::lock_guard<std::mutex> lk(q_mu); q_closed = true; }
+    q_cv.notify_all();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (auto& th : workers) th.join();
+    workers.clear();
+    t_wait_drain += secs(t0);
+  };
+  size_t n_pushed = 0;
+  struct BlockingEvent { hipEvent_t ev = nullptr; ~BlockingEvent() { if (ev) (void)hipEventDestroy(ev); } } device_done_owner;
+  if (want_drain && T + 1 > gsv_drain::usable_cores()) (void)hipEventCreateWithFlags(&device_done_owner.ev, hipEventBlockingSync | hipEventDisableTiming);
+  const hipEvent_t device_done = device_done_owner.ev;
   int rc = GSV_OK;
-  if (hipEventRecord(s->ev0, s->e->stream) != hipSuccess) { close_files(); return fail(GSV_ERR_DEVICE, "hipEventRecord failed"); }
+  if (hipEventRecord(s->ev0, s->e->stream) != hipSuccess) { finish_workers(); close_files(); return fail(GSV_ERR_DEVICE, "hipEventRecord failed"); }
   for (uint64_t r0 = first; r0 < total && rc == GSV_OK; r0 += seg) {
     const uint64_t r1 = std::min(total, r0 + seg);
     uint64_t n_records, base;  // per instance, in this segment; stream index of its first record
@@ -1645,36 +1761,81 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
         if (rc != GSV_OK) break;
         if (hipEventRecord(s->pair->evaluated[b], s->pair->stream) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "hipEventRecord failed"); break; }
       }
-      join(cur);
-      n_records = s->sched.windows[w].n_ct;
-      base = s->sched.windows[w].ct0;
-      if (want_drain) { rc = permute_plan_window(s, w, seg_records, 0, block); if (rc != GSV_OK) break; }
+      // The window is running.  Its segments leave the device one after the other, in stream order, each as soon as every call of it
+      // has completed for every instance group: the host follows the completion flags of the running launch (a page-locked copy,
+      // refreshed through a side stream), brings the finished segment into gate order with a gather kernel on that side stream — the
+      // session's schedule leaves it a few CUs — and hands it to the workers, while the window goes on garbling.
+      const Schedule::Window& win = s->sched.windows[w];
+      n_records = win.n_ct;
+      base = win.ct0;
+      if (want_drain) {
+        const size_t n_wg = (n_inst + s->ni - 1) / s->ni;
+        bool window_done = false;
+        for (uint32_t q = win.seg0; q < win.seg1 && rc == GSV_OK; ++q) {
+          const Schedule::Segment& sg = s->sched.segments[q];
+          const bool last = q + 1 == win.seg1;
+          const auto t0 = std::chrono::steady_clock::now();
+          while (!window_done && !last) {
+            if (hipMemcpyAsync(s->host_flags, s->d_flags, n_wg * size_t(s->flag_stride) * 4, hipMemcpyDeviceToHost, s->aux_stream) != hipSuccess || hipStreamSynchronize(s->aux_stream) != hipSuccess) {
+              rc = fail(GSV_ERR_DEVICE, "flag poll failed");
+              break;
+            }
+            bool all = true;
+            for (size_t x = 0; x < n_wg && all; ++x)
+              for (uint32_t k = sg.call0; k < sg.call1 && all; ++k) all = s->host_flags[x * s->flag_stride + (k - win.call0)] == s->epoch;
+            if (all) break;
+            if (hipStreamQuery(s->e->stream) == hipSuccess) { window_done = true; break; }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+          }
+          if (rc != GSV_OK) break;
+          if (last && !window_done) {
+            // the last segment ends with the window: sleep on the stream (on a blocking-sync event when the workers own the cores)
+            const bool ok = device_done ? hipEventRecord(device_done, s->e->stream) == hipSuccess && hipEventSynchronize(device_done) == hipSuccess : hipStreamSynchronize(s->e->stream) == hipSuccess;
+            if (!ok) { rc = fail(GSV_ERR_DEVICE, "kernel failed"); break; }
+            window_done = true;
+          }
+          t_wait_device += secs(t0);
+          wait_buffer(n_pushed);  // the gate-order buffer this segment goes to is free again
+          rc = permute_plan_calls(s, w, sg.call0, sg.call1, sg.ct0, seg_records, 0, block, gate_bufs[n_pushed % depth], s->aux_stream);
+          if (rc != GSV_OK) break;
+          if (hipStreamSynchronize(s->aux_stream) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "ciphertext gather failed"); break; }
+          drained_records += sg.n_ct;
+          push_segment(sg.n_ct, sg.ct0, n_pushed % depth);
+          ++n_pushed;
+        }
+        if (rc != GSV_OK) break;
+      }
+      if (hipStreamSynchronize(s->e->stream) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "kernel failed"); break; }
+      continue;
     } else {
       // ring slots are (replay % ct_cap): a segment starts at a multiple of ct_cap, so its replays sit in slots 0..n_rep-1
       rc = launch(s, gate_id_base, false, r0, r1 - r0);
       if (rc != GSV_OK) break;
-      join(cur);
+      wait_buffer(n_pushed);
       n_records = (r1 - r0) * n_ct;
       base = r0 * n_ct;
-      if (gsvk_gather_segment(s->CT, s->ct_stride(), s->dp.ct_pos, n_ct, uint32_t(r1 - r0), uint32_t(n_inst), s->ct_gate, seg_records, 0, s->e->stream) != 0) {
+      if (gsvk_gather_segment(s->CT, s->ct_stride(), s->dp.ct_pos, n_ct, uint32_t(r1 - r0), uint32_t(n_inst), gate_bufs[n_pushed % depth], seg_records, 0, s->e->stream) != 0) {
         rc = fail(GSV_ERR_DEVICE, "ciphertext gather launch failed");
         break;
       }
     }
     {
+      // the workers own the cores when there is one chain per core: this thread then sleeps on a blocking-sync event instead of
+      // spinning in hipStreamSynchronize
       const auto t0 = std::chrono::steady_clock::now();
-      if (hipStreamSynchronize(s->e->stream) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "kernel failed"); break; }
+      const bool ok = device_done ? hipEventRecord(device_done, s->e->stream) == hipSuccess && hipEventSynchronize(device_done) == hipSuccess : hipStreamSynchronize(s->e->stream) == hipSuccess;
+      if (!ok) { rc = fail(GSV_ERR_DEVICE, "kernel failed"); break; }
       t_wait_device += secs(t0);
     }
     drained_records += n_records;
-    if (want_drain) drain(n_records, base, cur);
+    if (want_drain) { push_segment(n_records, base, n_pushed % depth); ++n_pushed; }
   }
-  join(cur);
+  finish_workers();
   if (ev && hipStreamSynchronize(s->pair->stream) != hipSuccess && rc == GSV_OK) rc = fail(GSV_ERR_DEVICE, "evaluation kernel failed");
   if (stats) {
     const double tot = secs(t_begin);
-    std::fprintf(stderr, "drain: %.2f s for %zu instances x %llu records (%.1f GB/s), %zu MAC workers; host thread waited %.2f s for drains and %.2f s for the device\n", tot, n_inst,
-                 (unsigned long long)drained_records, double(drained_records) * double(n_inst) * 16e-9 / tot, T, t_wait_drain, t_wait_device);
+    std::fprintf(stderr, "drain: %.2f s for %zu instances x %llu records (%.1f GB/s), %zu MAC workers x %zu chains, %zu gate-order buffers; host thread waited %.2f s for drains and %.2f s for the device\n", tot, n_inst,
+                 (unsigned long long)drained_records, double(drained_records) * double(n_inst) * 16e-9 / tot, T, GROUP, depth, t_wait_drain, t_wait_device);
   }
   if (rc == GSV_OK && s->plan) {
     (void)hipEventRecord(s->ev1, s->e->stream);
@@ -1775,11 +1936,11 @@ int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base) {
 //   read(instance, first_record, dst, n) -> 0, or non-zero when the source runs dry ("Ciphertext source exhausted", evaluate_mode.rs:139-142)
 static int evaluate_streaming_impl(gsv_session* s, uint64_t gate_id_base, const std::function<int(size_t, uint64_t, uint8_t*, uint64_t)>& read, uint8_t* hashes) {
   const Program& g = s->prog();
-  // plan sessions: one window of the schedule per segment (its calls' blocks are consecutive in the stream)
-  const uint64_t n_ct = s->plan ? s->plan_max_block : g.n_ct, total = s->plan ? s->sched.windows.size() : s->replays, seg = s->plan ? 1 : s->ct_cap;
+  // plan sessions: one window of the schedule per launch, its ciphertexts uploaded SEGMENT by segment (schedule.hpp: a gate-order buffer
+  // holds the largest segment, the program-order device block the largest window); program sessions: one ring per launch
   const size_t n_inst = s->n_inst;
   HIPCHK(hipSetDevice(s->e->device));
-  const uint64_t seg_records = seg * n_ct;
+  const uint64_t seg_records = s->plan ? s->plan_max_segment : s->ct_cap * g.n_ct;  // per instance: stride of the gate-order buffer
   if (!s->ct_gate && seg_records) DEVALLOC(&s->ct_gate, n_inst * seg_records * 16, "the gate-order ciphertext buffer");
   struct Pinned { void* p[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; ~Pinned() { for (void* q : p) if (q) (void)hipHostFree(q); for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); } } stage;
   const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(seg_records, 1), CT_STAGE_RECORDS);
@@ -1788,27 +1949,37 @@ static int evaluate_streaming_impl(gsv_session* s, uint64_t gate_id_base, const 
   if (s->plan) HIPCHK(hipMemsetAsync(s->d_error, 0, 4, s->e->stream));
   HIPCHK(hipEventRecord(s->ev0, s->e->stream));
   int rc = GSV_OK, b = 0;
-  for (uint64_t r0 = 0; r0 < total && rc == GSV_OK; r0 += seg) {
-    const uint64_t r1 = std::min(total, r0 + seg);
-    const uint64_t n_records = s->plan ? s->sched.windows[size_t(r0)].n_ct : (r1 - r0) * n_ct;  // per instance
-    const uint64_t base = s->plan ? s->sched.windows[size_t(r0)].ct0 : r0 * n_ct;
-    // the previous segment's kernel reads the program-order block, not ct_gate: uploads into ct_gate may start right away, the
-    // scatter below is ordered behind that kernel by the stream
-    for (size_t i = 0; i < n_inst && rc == GSV_OK; ++i)
-      for (uint64_t off = 0; off < n_records; off += chunk, b ^= 1) {
-        const uint64_t m = std::min(chunk, n_records - off);
+  // `n` records per instance starting at stream index `base` -> the gate-order buffer (in bounded, page-locked chunks; hashed as read)
+  auto upload = [&](uint64_t base, uint64_t n) -> int {
+    for (size_t i = 0; i < n_inst; ++i)
+      for (uint64_t off = 0; off < n; off += chunk, b ^= 1) {
+        const uint64_t m = std::min(chunk, n - off);
         HIPCHK(hipEventSynchronize(stage.ev[b]));  // the copy that last used this staging buffer has finished
         uint8_t* host = static_cast<uint8_t*>(stage.p[b]);
-        if (read(i, base + off, host, m) != 0) { rc = fail(GSV_ERR_EXHAUSTED, "Ciphertext source exhausted: instance " + std::to_string(i) + " ran dry at record " + std::to_string(base + off)); break; }
+        if (read(i, base + off, host, m) != 0) return fail(GSV_ERR_EXHAUSTED, "Ciphertext source exhausted: instance " + std::to_string(i) + " ran dry at record " + std::to_string(base + off));
         if (hashes) macs[i].update(host, m);
-        if (hipMemcpyAsync(static_cast<uint8_t*>(s->ct_gate) + (i * seg_records + off) * 16, host, m * 16, hipMemcpyHostToDevice, s->e->stream) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "ciphertext upload failed"); break; }
+        HIPCHK(hipMemcpyAsync(static_cast<uint8_t*>(s->ct_gate) + (i * seg_records + off) * 16, host, m * 16, hipMemcpyHostToDevice, s->e->stream));
         HIPCHK(hipEventRecord(stage.ev[b], s->e->stream));
       }
-    if (rc != GSV_OK) break;
-    if (s->plan) {
-      rc = permute_plan_window(s, size_t(r0), seg_records, 1);
-      if (rc == GSV_OK) rc = launch_plan_window(s, size_t(r0), gate_id_base, true);
-    } else {
+    return GSV_OK;
+  };
+  if (s->plan) {
+    for (size_t w = 0; w < s->sched.windows.size() && rc == GSV_OK; ++w) {
+      const Schedule::Window& win = s->sched.windows[w];
+      for (uint32_t q = win.seg0; q < win.seg1 && rc == GSV_OK; ++q) {
+        const Schedule::Segment& sg = s->sched.segments[q];
+        // (the stream orders this segment's uploads behind the scatter of the previous one, which read the same buffer)
+        rc = upload(sg.ct0, sg.n_ct);
+        if (rc == GSV_OK) rc = permute_plan_calls(s, w, sg.call0, sg.call1, sg.ct0, seg_records, 1, nullptr, nullptr, nullptr);
+      }
+      if (rc == GSV_OK) rc = launch_plan_window(s, w, gate_id_base, true);
+    }
+  } else {
+    const uint64_t n_ct = g.n_ct, total = s->replays, seg = s->ct_cap;
+    for (uint64_t r0 = 0; r0 < total && rc == GSV_OK; r0 += seg) {
+      const uint64_t r1 = std::min(total, r0 + seg);
+      rc = upload(r0 * n_ct, (r1 - r0) * n_ct);
+      if (rc != GSV_OK) break;
       if (gsvk_gather_segment(s->CT, s->ct_stride(), s->dp.ct_pos, n_ct, uint32_t(r1 - r0), uint32_t(n_inst), s->ct_gate, seg_records, 1, s->e->stream) != 0) { rc = fail(GSV_ERR_DEVICE, "ciphertext scatter launch failed"); break; }
       rc = launch(s, gate_id_base, true, r0, r1 - r0);
     }

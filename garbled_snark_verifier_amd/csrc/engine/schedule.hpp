@@ -44,12 +44,22 @@ struct SchedParams {
   uint32_t max_calls_in_flight = 1;   // C above
   uint64_t max_scratch_slots = ~0ull; // size limit of the scratch ring (16-byte slots per instance)
   uint64_t max_window_ct = ~0ull;     // ciphertext records per instance and window (a single larger call still forms a window)
+  // Drain segments: a window is ONE launch and the scope inside which independent call chains overlap (a window boundary joins every
+  // chain: the verifier's line-coefficient chain comes before the Miller loop in stream order and runs beside it only when both lie in
+  // one window), so windows want to be as large as the device block allows; the host side of a drain (copies, the serial CBC-MAC
+  // chains) wants SMALL units, because it can only start on a unit when the device has finished it and the last unit's share is the
+  // pass's tail.  A window is therefore cut into segments of consecutive calls of at most segment_ct ciphertext records: the host
+  // follows the completion flags of a running window and drains segment after segment while the window is still being garbled.
+  uint64_t segment_ct = 0;            // 0 = one segment per window
   uint32_t max_window_calls = 32768;  // (grid.y of a launch is at most 65535)
   uint32_t slot_align = 8;            // scratch regions start on 128-byte lines
 };
 struct Schedule {
-  struct Window { uint32_t call0, call1; uint64_t ct0, n_ct; uint32_t max_width; };  // calls [call0, call1) of the stream
+  struct Window { uint32_t call0, call1; uint64_t ct0, n_ct; uint32_t max_width; uint32_t seg0, seg1; };  // calls [call0, call1) of the stream; segments [seg0, seg1)
   std::vector<Window> windows;
+  struct Segment { uint32_t call0, call1; uint64_t ct0, n_ct; };  // consecutive calls of one window: the unit the stream leaves the device in
+  std::vector<Segment> segments;
+  uint64_t max_segment_ct = 0;
   std::vector<uint32_t> scratch_base;  // per call: first slot of its scratch region
   std::vector<uint32_t> dep_off;       // per call (+1): its dependencies are deps[dep_off[k] .. dep_off[k+1])
   std::vector<uint32_t> deps;          // call indices (stream order, same window, < k)
@@ -161,7 +171,21 @@ inline Schedule schedule_calls(const std::vector<SchedCall>& calls, uint32_t n_i
     std::sort(ev.begin(), ev.end());
     int width = 0, max_width = 0;
     for (auto& e : ev) { width += e.second; max_width = std::max(max_width, width); }
-    s.windows.push_back(Schedule::Window{uint32_t(k0), uint32_t(k1), ct_off, wct, uint32_t(max_width)});
+    const uint32_t seg0 = uint32_t(s.segments.size());
+    {
+      size_t a = k0;
+      uint64_t off = ct_off;
+      while (a < k1) {
+        size_t b = a;
+        uint64_t sct = 0;
+        while (b < k1 && (b == a || p.segment_ct == 0 || sct + calls[b].n_ct <= p.segment_ct)) sct += calls[b++].n_ct;
+        s.segments.push_back(Schedule::Segment{uint32_t(a), uint32_t(b), off, sct});
+        s.max_segment_ct = std::max(s.max_segment_ct, sct);
+        off += sct;
+        a = b;
+      }
+    }
+    s.windows.push_back(Schedule::Window{uint32_t(k0), uint32_t(k1), ct_off, wct, uint32_t(max_width), seg0, uint32_t(s.segments.size())});
     s.max_width = std::max(s.max_width, uint32_t(max_width));
     s.max_window_ct = std::max(s.max_window_ct, wct);
     s.critical_steps += depth;

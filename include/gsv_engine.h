@@ -202,20 +202,23 @@ int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_ins
  *                         GSV_DEP_WAIT_SECONDS (default 60) sets an error flag instead of hanging: the next gsv_session_sync /
  *                         read_outputs / streaming call fails with GSV_ERR_DEVICE and the pass's gc files are removed.
  *                         max_concurrent_calls = 1 is the safe mode: every call depends on its predecessor only.
- *   window_ct_records     ciphertext records per instance of one window (the device block of a session that does not retain the
- *                         stream; the drain's gate-order copy is as large again); 0 = a quarter of the free device memory for the
- *                         two buffers, at most 64 M records (1 GB) per instance — a pass must be many windows for the drain of
- *                         window k (copies, CBC-MAC chains, files) to run beside the garbling of window k+1
+ *   window_ct_records     ciphertext records per instance of one window = ONE launch = the device block of a session that does not
+ *                         retain the stream; independent call chains only overlap inside a window, so windows want to be large;
+ *                         0 = 40 % of the free device memory, at most 2^31 records (32 GB) per instance
  *   max_scratch_slots     16-byte slots per instance for the ring the calls' scratch regions are carved from; 0 = chosen from the
  *                         free device memory
- *   max_window_calls      0 = 32768 (a launch holds at most 65535 calls) */
+ *   max_window_calls      0 = 32768 (a launch holds at most 65535 calls)
+ *   drain_segment_records ciphertext records per instance of a drain SEGMENT: the streaming calls follow the completion flags of a running
+ *                         window and take its stream off the device segment by segment (consecutive calls, gate order), so that the host
+ *                         side — copies, the serial CBC-MAC chains, files, a sink — works beside the window that is still being garbled;
+ *                         0 = 64 M records (1 GB) per instance or less (three gate-order buffers within a tenth of the free memory) */
 typedef struct gsv_plan_session_opts {
   int retain_stream;
   uint32_t max_concurrent_calls;
   uint64_t window_ct_records;
   uint64_t max_scratch_slots;
   uint32_t max_window_calls;
-  uint32_t reserved;
+  uint32_t drain_segment_records;
 } gsv_plan_session_opts;
 int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_instances, const gsv_plan_session_opts* opts, gsv_session** out);
 typedef struct gsv_plan_schedule_info {
@@ -223,6 +226,7 @@ typedef struct gsv_plan_schedule_info {
   uint64_t scratch_slots, wire_file_slots;  /* per instance: scratch area / whole wire file (scratch + global wires) */
   uint64_t window_ct_records;               /* largest window, ciphertext records per instance */
   uint64_t critical_steps, total_steps;     /* device steps: sum over batches of the longest call / sum over all calls */
+  uint64_t n_segments, segment_ct_records;  /* drain segments of the whole schedule; largest segment, ciphertext records per instance */
 } gsv_plan_schedule_info;
 int gsv_session_plan_schedule_info(const gsv_session* s, gsv_plan_schedule_info* info);
 /* Window `window` of the session's schedule: calls [first_call, first_call + n_calls) of the plan.  Slices handed to

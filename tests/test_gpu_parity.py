@@ -509,11 +509,13 @@ def test_concurrent_calls_of_a_plan_match_the_flat_stream(engine, tmp_path, unit
             assert (ob[i] == exp_bits[i]).all() and (oa[i] == np.where(ob[i][:, None] == 1, out[i] ^ delta[i][None, :], out[i])).all()
         sess.close()
     # the stream leaves the device window by window (gate order restored per call), here with windows of about two Fq2 multiplications
-    for conc, win in ((16, 700_000), (64, 0)):
-        st = gsv.Session(engine, plan, B, retain_stream=False, concurrent_calls=conc, window_ct_records=win)
+    # ... and, second setting, segment by segment of ONE running window (the host follows the completion flags of the launch)
+    for conc, win, seg in ((16, 700_000, 0), (64, 0, 500_000)):
+        st = gsv.Session(engine, plan, B, retain_stream=False, concurrent_calls=conc, window_ct_records=win, drain_segment_records=seg)
         info = st.schedule_info()
         gc = os.path.join(str(tmp_path), "gc_%d_%d" % (conc, win))
         os.makedirs(gc)
+        assert seg == 0 or (info["n_windows"] == 1 and info["n_segments"] >= 3)  # (Fq12-level units: a segment is at least one call)
         st.set_garble_inputs(delta, consts, inputs)
         hashes = st.garble_streaming(directory=gc, first_index=3, threads=2)
         out = st.read_outputs()
@@ -533,7 +535,7 @@ def test_concurrent_calls_of_a_plan_match_the_flat_stream(engine, tmp_path, unit
                 with pytest.raises(gsv.GsvError):
                     st.garble_calls(0, wins[0][1] - 1)  # not a window boundary
         # the evaluator reads the gc files back window by window
-        es = gsv.Session(engine, plan, B, retain_stream=False, concurrent_calls=conc, window_ct_records=win)
+        es = gsv.Session(engine, plan, B, retain_stream=False, concurrent_calls=conc, window_ct_records=win, drain_segment_records=seg)
         es.set_evaluate_inputs(np.stack([consts[:, 0], consts[:, 1] ^ delta], axis=1), active, bits)
         fh = es.evaluate_streaming(gc, first_index=3)
         oa, ob = es.read_outputs(with_bits=True)
@@ -679,8 +681,11 @@ def test_generic_ciphertext_sink_and_source(engine):
     refs = [o.garble("fq12_mix", s) for s in seeds]
     n_ct = plan.info["n_ciphertexts"]
     for threads in (1, 2):
-        st = gsv.Session(engine, plan, B, retain_stream=False, concurrent_calls=16, window_ct_records=900_000)
-        assert st.schedule_info()["n_windows"] > 4
+        # threads = 1: windows of 900 k records, each drained whole; threads = 2: ONE window, drained in segments while it runs
+        kw = dict(window_ct_records=900_000) if threads == 1 else dict(drain_segment_records=700_000)
+        st = gsv.Session(engine, plan, B, retain_stream=False, concurrent_calls=16, **kw)
+        si = st.schedule_info()
+        assert (si["n_windows"] > 4) if threads == 1 else (si["n_windows"] == 1 and si["n_segments"] > 8)
         st.set_garble_inputs(delta, consts, inputs)
         got = [np.zeros((n_ct, 16), np.uint8) for _ in range(B)]
         nxt = [0] * B
@@ -753,9 +758,10 @@ def test_garble_and_evaluate_side_by_side_on_the_device(engine):
     active = np.where(bits[:, :, None] == 1, inputs ^ delta[:, None, :], inputs)
     ca = np.stack([consts[:, 0], consts[:, 1] ^ delta], axis=1)
     for conc, win, with_hashes in ((16, 600_000, True), (1, 0, False), (64, 2_000_000, True)):
-        kw = dict(retain_stream=False, concurrent_calls=conc, window_ct_records=win)
+        kw = dict(retain_stream=False, concurrent_calls=conc, window_ct_records=win, drain_segment_records=300_000)
         gs, es = gsv.Session(engine, plan, B, **kw), gsv.Session(engine, plan, B, **kw)
-        assert gs.schedule_info()["n_windows"] >= 3
+        si = gs.schedule_info()
+        assert si["n_windows"] >= 3 and (si["n_segments"] > si["n_windows"] or conc == 1)  # (sequential sessions: one call per window, one segment each)
         for _ in range(2):  # a second pass over the same sessions
             gs.set_garble_inputs(delta, consts, inputs)
             es.set_evaluate_inputs(ca, active, bits)
@@ -1118,7 +1124,8 @@ def test_verifier_garble_evaluate_and_generic_sink_at_full_size(engine, compress
     bits = np.stack([bits_ok, bits_bad])
     active = np.where(bits[:, :, None] == 1, inputs ^ delta[:, None, :], inputs)
     gs, es = gsv.Session(engine, plan, 2, retain_stream=False), gsv.Session(engine, plan, 2, retain_stream=False)
-    assert gs.schedule_info()["n_windows"] >= 32  # the default window: many windows per pass (1 GB per instance at most)
+    si = gs.schedule_info()
+    assert si["n_windows"] <= 8 and si["n_segments"] >= 24 and si["segment_ct_records"] <= 1 << 26  # the default: few large windows (launches), drained in segments of <= 1 GB per instance
     gs.set_garble_inputs(delta, consts, inputs)
     es.set_evaluate_inputs(np.stack([consts[:, 0], consts[:, 1] ^ delta], axis=1), active, bits)
     hashes = gs.garble_evaluate(es, with_hashes=True)
