@@ -25,7 +25,9 @@ Beside it, measured in the same run on rank 0 (N = 1):
                         (examples/groth16_garble.rs:111-129).  Instance 0 carries the fixture's seed: its final MAC and output label
                         are the `ciphertext_hash_match` against the fixture the CPU oracle produced from the flat stream.  Never `value`.
   rate_by_instances     HBM-resident rate of whole passes at 1 and 16 instances (BASELINE configs 4 / 5 at their stated sizes) and
-                        of a sample at 256, next to the headline's 1024.
+                        of a sample at 256, next to the headline's 1024; the single instance also WITH its commitment (one serial chain).
+  cc16_one_gpu          BASELINE config 5 with all 16 instances on this GPU: sharding.cut_and_choose_commit on the full verifier, every
+                        one of the 16 commit records compared with the CPU oracle's (tests/golden/cc16_verifier_golden.json).
   cpu_baseline          the C++ restatement of the reference's per-gate loop on a PREFIX of the same stream, one core and all cores.
   mode_rates            evaluate-mode and Blake3Hasher garble rates on a component chain (rows a9 / f4 of SURVEY.md §8).
 
@@ -464,6 +466,36 @@ def cc16_one_gpu(gsv, engine, plan, case, gold, log):
     return out
 
 
+def garble_then_evaluate(gsv, engine, plan, case, np):
+    """gsv_session_garble_evaluate on the whole verifier, one instance: window k of the garbler's device block is evaluated on a second
+    stream while window k+1 is garbled.  The evaluator holds the valid proof's input bits: the decoded output must be 1 and every active
+    output label select(label0, bit)."""
+    n_in = plan.info["n_inputs"]
+    d, f, t, inp = gsv.labels_from_seed(case["seed"], n_in)
+    bits = np.unpackbits(np.frombuffer(bytes.fromhex(case["input_bits_hex"]), np.uint8), bitorder="little")[:n_in].astype(np.uint8)
+    active = np.where(bits[:, None] == 1, inp ^ d[None, :], inp)
+    # windows of 4 GB: the evaluation of window k overlaps the garbling of window k+1, so the pair wants MORE windows than a garbler alone
+    # (whose default is two: the scope in which its call chains overlap) — twelve here, the last one's evaluation is the tail
+    kw = dict(retain_stream=False, window_ct_records=1 << 28)
+    gs, es = gsv.Session(engine, plan, 1, **kw), gsv.Session(engine, plan, 1, **kw)
+    try:
+        gs.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
+        es.set_evaluate_inputs(np.stack([f, t ^ d])[None], active[None], bits[None])
+        t0 = time.perf_counter()
+        gs.garble_evaluate(es)
+        dt = time.perf_counter() - t0
+        out0 = gs.read_outputs()[0]
+        oa, ob = es.read_outputs(with_bits=True)
+        ok = bool(ob[0][0] == case.get("expected_output", 1) and (oa[0] == np.where(ob[0][:, None] == 1, out0 ^ d[None, :], out0)).all()
+                  and out0[0].tobytes().hex() == case["first_output_label0"])
+        g = plan.info["n_gates"]
+        return {"seconds": dt, "gates_per_s_garbled": g / dt, "gates_per_s_garbled_plus_evaluated": 2 * g / dt, "instances": 1, "decoded_output": int(ob[0][0]),
+                "labels_consistent_and_output_label_matches_fixture": ok, "windows": gs.schedule_info()["n_windows"],
+                "sample": "one whole pass: %d gates garbled and the same %d gates evaluated side by side on the device, retain_stream = 0" % (g, g)}
+    finally:
+        gs.close(); es.close()
+
+
 def run_verifier(args):
     import numpy as np
     import torch
@@ -600,18 +632,19 @@ def run_verifier(args):
                     log("bench.py: %d instance(s): %.3g gates/s" % (Bi, g * Bi / dt))
                     if Bi == 1 and time.time() - T_START < args.time_budget * 0.45:
                         # BASELINE's single-instance target is stated WITH the ciphertext hash: the same pass again, the stream drained and
-                        # folded into ONE serial CBC-MAC chain on one host core (the chain, ~1.1e8 blocks/s = 27 s, is as long as the garbling).
-                        # A session of its own with 1 GB ciphertext windows (46 instead of 2): the chain of window k runs beside the garbling
-                        # of window k+1, so all but the last window's share of it hides (tools/one_instance_commit.py: 37.0 s against 48.2 s)
-                        wc = VerifierWork(gsv, engine, plan, 1, [case["seed"]], window_ct_records=1 << 26)
+                        # folded into ONE serial CBC-MAC chain on one host core (the chain, ~1.1e8 blocks/s = 27 s, is nearly as long as the
+                        # garbling).  The session's default: two launch windows (the scope in which the instance's call chains overlap), the
+                        # stream taken off the device in 1 GB segments of the RUNNING window, eight gate-order buffers between the device and
+                        # the chain (engine.cpp, garble_streaming_range; tools/small_batch_commit.py: 30.4 s against round 3's 36.9 s)
+                        wc = VerifierWork(gsv, engine, plan, 1, [case["seed"]])
                         try:
                             dtc = wc.run_pass(commit=True)
                             okc = fixture_ok(wc.ct_hashes[0], wc.sess.read_outputs()[0])
-                            n_win_c = wc.sess.schedule_info()["n_windows"]
+                            sic = wc.sess.schedule_info()
                         finally:
                             wc.close()
-                        rbi["1"]["with_commitment"] = {"gates_per_s": g / dtc, "seconds": dtc, "ciphertext_hash_match": okc, "vs_reference_published_32M": g / dtc / 32e6, "windows": n_win_c,
-                                                       "window_ct_records": 1 << 26}
+                        rbi["1"]["with_commitment"] = {"gates_per_s": g / dtc, "seconds": dtc, "ciphertext_hash_match": okc, "vs_reference_published_32M": g / dtc / 32e6, "windows": sic["n_windows"],
+                                                       "drain_segments": sic["n_segments"], "segment_ct_records": sic["segment_ct_records"]}
                         rbi["1"]["vs_reference_published_32M"] = g / dt / 32e6
                         log("bench.py: 1 instance with the commitment: %.3g gates/s, hash %s" % (g / dtc, "ok" if okc else "MISMATCH"))
                 finally:
@@ -631,6 +664,14 @@ def run_verifier(args):
             result["mode_rates"] = mode_rates(gsv, engine, np)
         except Exception as e:  # noqa: BLE001
             result["mode_rates"] = {"error": repr(e)}
+        # the second phase of the reference's benchmark (examples/groth16_garble.rs:171-230): ONE instance garbled and — window by window, from
+        # the garbler's device block, nothing retained, nothing over PCIe — evaluated at the same time with the valid proof's input bits
+        if compressed and "input_bits_hex" in case and time.time() - T_START < args.time_budget * 0.62:
+            try:
+                result["mode_rates"]["garble_then_evaluate"] = garble_then_evaluate(gsv, engine, plan, case, np)
+                log("bench.py: garble + evaluate side by side, one instance: %.1f s, decoded output %s" % (result["mode_rates"]["garble_then_evaluate"]["seconds"], result["mode_rates"]["garble_then_evaluate"]["decoded_output"]))
+            except Exception as e:  # noqa: BLE001
+                result["mode_rates"]["garble_then_evaluate"] = {"error": repr(e)}
 
     seeds = instance_seeds(rank, B)
     if rank == 0:

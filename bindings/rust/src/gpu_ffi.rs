@@ -16,15 +16,26 @@ macro_rules! opaque { ($($n:ident),*) => { $( #[repr(C)] pub struct $n { _p: [u8
 opaque!(GsvRecorder, GsvProgram, GsvEngine, GsvSession, GsvPlan, GsvPlanRecorder);
 
 #[repr(C)]
-#[derive(Default)]
 pub struct GsvPlanSessionOpts {
     pub retain_stream: c_int,
     pub max_concurrent_calls: u32,
     pub window_ct_records: u64,
     pub max_scratch_slots: u64,
     pub max_window_calls: u32,
-    pub reserved: u32,
+    pub drain_segment_records: u32,
 }
+// By hand, not derived: the C API's NULL-options default is retain_stream = 1 (a derived Default would say 0 and hand a caller of
+// `..Default::default()` a streaming-only session, on which gsv_session_garble / _evaluate fail with GSV_ERR_INVALID).
+impl Default for GsvPlanSessionOpts {
+    fn default() -> Self {
+        GsvPlanSessionOpts { retain_stream: 1, max_concurrent_calls: 0, window_ct_records: 0, max_scratch_slots: 0, max_window_calls: 0, drain_segment_records: 0 }
+    }
+}
+
+/// CiphertextHandler::handle over a run of records of one instance (include/gsv_engine.h, gsv_ct_sink_fn): non-zero aborts the pass.
+pub type GsvCtSinkFn = unsafe extern "C" fn(user: *mut std::ffi::c_void, instance: usize, first_record: u64, records: *const u8, n_records: u64) -> c_int;
+/// CiphertextSource::recv for a run of records (gsv_ct_source_fn): non-zero = the source has run dry.
+pub type GsvCtSourceFn = unsafe extern "C" fn(user: *mut std::ffi::c_void, instance: usize, first_record: u64, records: *mut u8, n_records: u64) -> c_int;
 
 pub const GSV_HASHER_AES: c_int = 0; // AesNiHasher   (src/hashers/mod.rs:54-96)
 pub const GSV_HASHER_BLAKE3: c_int = 1; // Blake3Hasher  (src/hashers/mod.rs:22-51)
@@ -60,6 +71,10 @@ extern "C" {
     pub fn gsv_session_set_garble_inputs(s: *mut GsvSession, delta: *const u8, const_label0: *const u8, input_label0: *const u8) -> c_int;
     pub fn gsv_session_garble(s: *mut GsvSession, gate_id_base: u64) -> c_int;
     pub fn gsv_session_garble_streaming(s: *mut GsvSession, gate_id_base: u64, dir: *const c_char, first_index: u64, n_threads: c_int, hashes: *mut u8) -> c_int;
+    pub fn gsv_session_garble_streaming_sink(s: *mut GsvSession, gate_id_base: u64, first_call: u64, n_calls: u64, sink: GsvCtSinkFn, user: *mut std::ffi::c_void, n_threads: c_int, hashes: *mut u8) -> c_int;
+    pub fn gsv_session_garble_evaluate(garbler: *mut GsvSession, evaluator: *mut GsvSession, gate_id_base: u64, n_threads: c_int, hashes: *mut u8) -> c_int;
+    pub fn gsv_session_evaluate_streaming_indexed(s: *mut GsvSession, gate_id_base: u64, dir: *const c_char, indexes: *const u64, hashes: *mut u8) -> c_int;
+    pub fn gsv_session_evaluate_streaming_source(s: *mut GsvSession, gate_id_base: u64, source: GsvCtSourceFn, user: *mut std::ffi::c_void, hashes: *mut u8) -> c_int;
     pub fn gsv_session_set_evaluate_inputs(s: *mut GsvSession, const_active: *const u8, input_active: *const u8, input_bits: *const u8) -> c_int;
     pub fn gsv_session_upload_ciphertexts(s: *mut GsvSession, instance: usize, cts: *const u8, n: u64) -> c_int;
     pub fn gsv_session_evaluate(s: *mut GsvSession, gate_id_base: u64) -> c_int;

@@ -108,21 +108,19 @@ impl<CTH: CiphertextHandler> GpuGarbleMode<CTH> {
         let outs: Vec<u64> = self.outputs.iter().map(|w| w.0 as u64).collect();
         let (mut engine, mut sess) = (std::ptr::null_mut(), std::ptr::null_mut());
         chk(unsafe { gsv_engine_create(self.device, &mut engine) });
-        let n_ct: u64;
         match &self.rec {
             Recorder::Flat(r) => {
                 chk(unsafe { gsv_recorder_declare_outputs(*r, outs.as_ptr(), outs.len()) });
                 let mut prog = std::ptr::null_mut();
                 chk(unsafe { gsv_program_compile(*r, std::ptr::null(), std::ptr::null(), 0, &mut prog) });
                 chk(unsafe { gsv_session_create(engine, prog, 1, 1, 1, &mut sess) });
-                n_ct = u64::MAX; // read until the retained stream ends (gsv_program_get_info gives the exact count)
             }
             Recorder::Plan(r, _) => {
                 let mut plan = std::ptr::null_mut();
                 chk(unsafe { gsv_plan_recorder_finish(*r, outs.as_ptr(), outs.len(), &mut plan) });
-                let opts = GsvPlanSessionOpts { retain_stream: 1, ..Default::default() }; // one instance: ~48 GB of ciphertexts stay in HBM
+                // nothing retained: the ~48 GB stream of the verifier leaves the device segment by segment of the running window
+                let opts = GsvPlanSessionOpts { retain_stream: 0, ..Default::default() };
                 chk(unsafe { gsv_session_create_plan_opts(engine, plan, 1, &opts, &mut sess) });
-                n_ct = u64::MAX;
             }
         }
         let label = |s: &S| s.to_bytes();
@@ -130,20 +128,17 @@ impl<CTH: CiphertextHandler> GpuGarbleMode<CTH> {
         let consts: Vec<u8> = [label(&self.false_wire.label0), label(&self.true_wire.label0)].concat();
         let ins: Vec<u8> = self.inputs.iter().flat_map(|(_, l)| label(l)).collect();
         chk(unsafe { gsv_session_set_garble_inputs(sess, delta.as_ptr(), consts.as_ptr(), ins.as_ptr()) });
-        chk(unsafe { gsv_session_garble(sess, 0) });
-        chk(unsafe { gsv_session_sync(sess) });
-        // CiphertextHandler::handle in gate order, 1 Mi records at a time (AESAccumulatingHash could instead take
-        // gsv_session_ciphertext_hash, a FileCiphertextHandler gsv_session_garble_streaming(dir): same bytes)
-        let mut handler = self.handler.take().expect("already finalised");
-        let mut buf = vec![0u8; 16 << 20];
-        let mut first = 0u64;
-        loop {
-            let n = ((buf.len() / 16) as u64).min(n_ct - first);
-            let rc = unsafe { gsv_session_read_ciphertexts(sess, 0, first, n, buf.as_mut_ptr()) };
-            if rc != 0 { break; } // past the end of the stream (use the exact count from gsv_program_get_info / gsv_plan_counts in production)
-            for rec in buf[..(n as usize) * 16].chunks_exact(16) { handler.handle(S::from_bytes(rec.try_into().unwrap())); }
-            first += n;
+        // CiphertextHandler::handle (circuit/mod.rs:140-178) in gate order: the engine garbles, drains the stream beside the running
+        // launch and hands every run of records to this callback — any handler, channel Sender<S> included (circuit/mod.rs:160-170).
+        // (AESAccumulatingHash alone could take `hashes` of gsv_session_garble_streaming, a file handler its `dir`: same bytes.)
+        unsafe extern "C" fn sink<H: CiphertextHandler>(user: *mut std::ffi::c_void, _instance: usize, _first: u64, records: *const u8, n: u64) -> c_int {
+            let handler = &mut *(user as *mut H);
+            let bytes = std::slice::from_raw_parts(records, (n as usize) * 16);
+            for rec in bytes.chunks_exact(16) { handler.handle(S::from_bytes(rec.try_into().unwrap())); }
+            0
         }
+        let mut handler = self.handler.take().expect("already finalised");
+        chk(unsafe { gsv_session_garble_streaming_sink(sess, 0, 0, 0, sink::<CTH>, &mut handler as *mut CTH as *mut std::ffi::c_void, 1, std::ptr::null_mut()) });
         self.handler = Some(handler);
         let mut out = vec![0u8; outs.len() * 16];
         chk(unsafe { gsv_session_read_outputs(sess, out.as_mut_ptr(), std::ptr::null_mut()) });

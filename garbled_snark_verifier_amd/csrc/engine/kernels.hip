@@ -315,7 +315,8 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     // never waits for store acknowledgements (~1 us each), and the record prefetch and the ciphertext stores stay in
     // flight across the barrier by themselves.
     const uint32_t last_step = ka.n_steps - 1;
-    auto is_narrow = [&](const u32x4& d) -> bool { return HASH == 0 && !no_narrow && d.y != 0 && d.y * LPG + d.w <= BT; };
+    // narrow step: its AND gates in the multi-lane form (LPG lanes each) and — from the next wave boundary — its free gates fit ONE pass
+    auto is_narrow = [&](const u32x4& d) -> bool { return HASH == 0 && !no_narrow && d.y != 0 && ((d.y * LPG + 63u) & ~63u) + d.w <= BT; };
     // wide steps: is the AND remainder small enough for the multi-lane form?
     auto small_rem = [&](uint32_t n_and) -> bool { return HASH == 0 && (n_and % BT) <= 2u * (BT / LPG); };
     auto load_desc = [&](uint32_t s) -> u32x4 {
@@ -329,17 +330,14 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     const glb_u8* const and_bytes = (const glb_u8*)ka.ands;
     const glb_u8* const xor_bytes = (const glb_u8*)ka.xors;
     typedef u32x4 Rec;
-    // Narrow steps: AND lanes first (LPG per gate), free-gate lanes behind them — from the next WAVE boundary when the step leaves room,
-    // so that no wave runs the AES path and the free-gate path one after the other (round 4: the inversions' one-instance rate +15 %,
-    // the ladders' +5 %, profiles/r04_kernel/kernel_ab_np1.log).
-    auto xor_lane0 = [&](uint32_t na, uint32_t xor_cnt) -> uint32_t {
-      const uint32_t up = (na + 63u) & ~63u;
-      return up + xor_cnt <= BT ? up : na;
-    };
+    // Narrow steps: AND lanes first (LPG per gate), free-gate lanes behind them from the next WAVE boundary, so that no wave runs the AES
+    // path and the free-gate path one after the other (round 4: the inversions' one-instance rate +15 %, the ladders' +5 %,
+    // profiles/r04_kernel/kernel_ab_np1.log).
+    auto xor_lane0 = [&](uint32_t na) -> uint32_t { return (na + 63u) & ~63u; };
     auto rec_ptr = [&](const u32x4& d) -> const glb_u8* {
       const glb_u8* p = (const glb_u8*)ka.steps;
       if (is_narrow(d)) {
-        const uint32_t na = d.y * LPG, x0 = xor_lane0(na, d.w);
+        const uint32_t na = d.y * LPG, x0 = xor_lane0(na);
         if (tid < na) p = and_bytes + size_t(d.x + tid / LPG) * 32u;
         else if (tid >= x0 && tid < x0 + d.w) p = xor_bytes + size_t(d.z + (tid - x0)) * 16u;
       } else if (d.y >= BT || !small_rem(d.y)) { if (tid < d.y) p = and_bytes + size_t(d.x + tid) * 32u; }  // wide: first one-per-lane pass
@@ -450,7 +448,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       if (ka.step_clock && blockIdx.x == 0 && threadIdx.x == 0 && rep + 1 == ka.replays) ka.step_clock[s] = wall_clock64();  // older than this step's stores
       if (is_narrow(sd)) {
         // ------------------------------------------------------------------ narrow step: one pass
-        const uint32_t na = and_cnt * LPG, x0 = xor_lane0(na, sd.w);
+        const uint32_t na = and_cnt * LPG, x0 = xor_lane0(na);
         if (tid < na) {
           and_multilane(r0, load_and_hi(and_off + tid / LPG), and_off + tid / LPG);
         } else if (tid >= x0 && tid < x0 + sd.w) {

@@ -125,6 +125,93 @@ def test_cc16_cut_and_choose_commit_world2():
         assert (res[0][0][i] == exp).all(), "record %d differs from the oracle's" % i
 
 
+def test_cc16_cut_and_choose_commit_world8():
+    """BASELINE config 5 at its stated rank count: 16 instances over EIGHT ranks (two per rank, instance i -> rank i mod 8), gloo on
+    CPU with the host interpreter as the garbler (u254 adder: eight processes share this container's cores): every rank ends up with
+    the same 16-record table, ordered by instance index, each record equal to the one built from the CPU oracle's garbling — the
+    rank logic the driver's 8-GPU run executes, exercised before it ever meets eight GPUs."""
+    world, total, master, circuit = 8, 16, 2024, "u254_add"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cc16_worker, args=(r, world, port, total, master, circuit, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, table, seeds = q.get(timeout=600)
+        res[r] = (table, seeds)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    from garbled_snark_verifier_amd import sharding
+    assert all((res[r][0] == res[0][0]).all() and res[r][1] == res[0][1] for r in range(world))
+    assert res[0][0].shape == (total, sharding.record_len(255, 508)) and len(set(res[0][1])) == total
+    assert [int.from_bytes(bytes(rec[:8]), "little") for rec in res[0][0]] == list(range(total))
+    for i in range(total):
+        g = o.garble(circuit, res[0][1][i])
+        exp = sharding.commit_record(i, g.ct_hash.tobytes(), g.output_label0, g.delta, g.false_label0, g.true_label0, g.input_label0)
+        assert (res[0][0][i] == exp).all(), "record %d differs from the oracle's" % i
+
+
+def _plan_failure_worker(rank, world, port, bad_rank, tmpdir, q):
+    """bench.get_plan with a stand-in engine module: local rank 0 "builds" the plan file, every other rank loads it; `bad_rank`'s load
+    raises.  Every rank must come back with the same RuntimeError instead of waiting in a barrier."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(world)
+    import argparse
+    import bench
+
+    class FakePlan:
+        @staticmethod
+        def build_file(circuit, units, path, window_div=4):
+            open(path, "wb").write(b"plan")
+
+        @staticmethod
+        def load(path, engine):
+            if rank == bad_rank:
+                raise OSError("rank %d: cannot map the plan file" % rank)
+            assert open(path, "rb").read() == b"plan"
+            return "plan@%d" % rank
+
+    class FakeGsv:
+        Plan = FakePlan
+
+    d = bench.Dist(world, "gloo", "cpu")
+    args = argparse.Namespace(no_plan_cache=False, plan_cache=tmpdir)
+    try:
+        plan, info, _ = bench.get_plan(FakeGsv, None, args, "circuit", ["u"], rank, rank, world, d, lambda m: None)
+        q.put((rank, "ok", plan))
+    except RuntimeError as e:
+        q.put((rank, "error", str(e)))
+    d.barrier()
+    d.close()
+
+
+@pytest.mark.parametrize("bad_rank", [0, 5])
+def test_cc16_ranks_agree_on_a_failed_plan_load_world8(bad_rank, tmp_path):
+    """One plan per node: local rank 0 builds the plan file, every rank loads it (bench.get_plan, used by `--workload cc16` and the
+    headline).  A rank whose load fails — rank 0 itself, or one of the others — must take ALL EIGHT ranks out with an error they agree
+    on (min over ranks) before anyone waits in a barrier; a hang here would cost the 8-GPU run its whole time limit."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_plan_failure_worker, args=(r, world, port, bad_rank, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r, (st, msg)) for r, st, msg in (q.get(timeout=300) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(res[r][0] == "error" for r in range(world)), res
+    assert "plan" in res[0][1] and "failed on a rank" in res[0][1]
+
+
 def test_shard_instances_partition():
     sys.path.insert(0, ROOT)
     from garbled_snark_verifier_amd import sharding

@@ -1123,9 +1123,10 @@ def test_verifier_garble_evaluate_and_generic_sink_at_full_size(engine, compress
     bits_bad = bits_ok.copy(); bits_bad[case["tamper_bit"]] ^= 1
     bits = np.stack([bits_ok, bits_bad])
     active = np.where(bits[:, :, None] == 1, inputs ^ delta[:, None, :], inputs)
-    gs, es = gsv.Session(engine, plan, 2, retain_stream=False), gsv.Session(engine, plan, 2, retain_stream=False)
+    kw = dict(retain_stream=False, window_ct_records=1 << 28)  # 4 GB windows: the evaluation of window k runs beside the garbling of window k+1
+    gs, es = gsv.Session(engine, plan, 2, **kw), gsv.Session(engine, plan, 2, **kw)
     si = gs.schedule_info()
-    assert si["n_windows"] <= 8 and si["n_segments"] >= 24 and si["segment_ct_records"] <= 1 << 26  # the default: few large windows (launches), drained in segments of <= 1 GB per instance
+    assert 8 <= si["n_windows"] <= 16 and si["n_segments"] >= 40 and si["segment_ct_records"] <= 1 << 26  # launches of <= 4 GB, drained in segments of <= 1 GB per instance
     gs.set_garble_inputs(delta, consts, inputs)
     es.set_evaluate_inputs(np.stack([consts[:, 0], consts[:, 1] ^ delta], axis=1), active, bits)
     hashes = gs.garble_evaluate(es, with_hashes=True)
