@@ -65,6 +65,13 @@ VERIFIER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cycl
                   "inverse_iteration", "inverse::divide_result_by_2^k::chunk", "inverse::divide_result_by_even_part::chunk"]
 
 
+# The same circuit with the Fq12 multiplications and squarings entered one level finer, as their three fq6::mul_montgomery units (a component
+# boundary the reference does not have: stream-neutral): 3 751 calls instead of 3 147, more width for the call-level dataflow
+# and 19 % more device steps.  ONE instance garbles 7.6 % faster, sixteen 8.7 % (profiles/r04_e2e/verifier_mixed_units.log); a full GPU pays
+# for the extra steps.  bench.py builds this plan for its small-batch legs (--small-batch-units fq6, the default) beside the Fq12-level one.
+SMALL_BATCH_UNITS = ["fq6::mul_montgomery"] + [u for u in VERIFIER_UNITS if u not in ("fq12::square_montgomery", "fq12::mul_montgomery")]
+
+
 # ---------------------------------------------------------------------------------------------------------- rank logic (no GPU)
 def plan_slices(call_gates, n_slices):
     """Cut calls 0..n-1 into `n_slices` consecutive groups of nearly equal gate count: [(first_call, n_calls, gates)]."""
@@ -511,7 +518,7 @@ def run_verifier(args):
 
     compressed = args.workload.startswith("verifier_compressed")
     case = json.load(open(os.path.join(ROOT, "tests", "golden", FIXTURE[args.workload])))
-    units = VERIFIER_UNITS + (["fp254::exp_chunk"] if compressed else [])
+    units = (SMALL_BATCH_UNITS if args.units == "fq6" else VERIFIER_UNITS) + (["fp254::exp_chunk"] if compressed else [])
     engine = gsv.Engine(local_rank)  # raises without a HIP device: no CPU fallback
     plan, plan_info, save_later = get_plan(gsv, engine, args, case["circuit"], units, rank, local_rank, local_world, dist, log)
     t_first_launch = time.time() - T_START
@@ -531,6 +538,16 @@ def run_verifier(args):
 
     result = {}
     extras = rank == 0 and world == 1
+    # the small-batch plan: the same circuit with Fq6-level units (SMALL_BATCH_UNITS) for the legs with 1 and 16 instances — more width for
+    # the call-level dataflow; the stream is the same stream (every leg below checks its output label / MAC / records against the fixtures)
+    plan_small, plan_small_info = None, None
+    if extras and compressed and args.small_batch_units == "fq6" and args.units == "fq12" and not (args.no_rate_by_instances and args.no_cc16 and args.no_mode_rates):
+        try:
+            plan_small, plan_small_info, _ = get_plan(gsv, engine, args, case["circuit"], SMALL_BATCH_UNITS + ["fp254::exp_chunk"], rank, local_rank, local_world, dist, log)
+            log("bench.py: small-batch plan (Fq6-level units) %s in %.1f s (%d calls)" % (plan_small_info["how"], plan_small_info["seconds"], plan_small.info["n_calls"]))
+        except Exception as e:  # noqa: BLE001 - the legs fall back to the headline's plan
+            plan_small, plan_small_info = None, {"error": repr(e)}
+    plan_sb = plan_small or plan
     # ---- CPU baseline: the restated per-gate loop on a prefix of the very stream the GPU garbles (rank 0 at N = 1 only)
     if extras and not args.no_cpu_baseline:
         try:
@@ -609,7 +626,7 @@ def run_verifier(args):
                 if time.time() - T_START > args.time_budget * 0.55:
                     rbi[str(Bi)] = {"skipped": "time budget"}
                     continue
-                w = VerifierWork(gsv, engine, plan, Bi, [case["seed"]] + instance_seeds(rank, Bi)[1:])
+                w = VerifierWork(gsv, engine, plan_sb if Bi <= 16 else plan, Bi, [case["seed"]] + instance_seeds(rank, Bi)[1:])
                 try:
                     si = w.sess.schedule_info()
                     if whole:
@@ -628,6 +645,7 @@ def run_verifier(args):
                         g = sum(x[2] for x in pick)
                         okl = None
                     rbi[str(Bi)] = {"gates_per_s": g * Bi / dt, "seconds": dt, "gates_per_instance": g, "whole_pass": whole, "output_label_match": okl, "instances_per_workgroup": w.sess.instances_per_workgroup,
+                                    "plan_units": "fq6 (small-batch plan, %d calls)" % plan_small.info["n_calls"] if (plan_small is not None and Bi <= 16) else "fq12 (%d calls)" % n_calls,
                                     "max_width": si["max_width"], "windows": si["n_windows"], "depth_steps": si["critical_steps"], "total_steps": si["total_steps"]}
                     log("bench.py: %d instance(s): %.3g gates/s" % (Bi, g * Bi / dt))
                     if Bi == 1 and time.time() - T_START < args.time_budget * 0.45:
@@ -636,7 +654,7 @@ def run_verifier(args):
                         # garbling).  The session's default: two launch windows (the scope in which the instance's call chains overlap), the
                         # stream taken off the device in 1 GB segments of the RUNNING window, eight gate-order buffers between the device and
                         # the chain (engine.cpp, garble_streaming_range; tools/small_batch_commit.py: 30.4 s against round 3's 36.9 s)
-                        wc = VerifierWork(gsv, engine, plan, 1, [case["seed"]])
+                        wc = VerifierWork(gsv, engine, plan_sb, 1, [case["seed"]])
                         try:
                             dtc = wc.run_pass(commit=True)
                             okc = fixture_ok(wc.ct_hashes[0], wc.sess.read_outputs()[0])
@@ -656,7 +674,9 @@ def run_verifier(args):
     if extras and not args.no_cc16 and compressed and time.time() - T_START < args.time_budget * 0.6:
         try:
             gold16 = cc16_verifier_fixture(case)
-            result["cc16_one_gpu"] = cc16_one_gpu(gsv, engine, plan, case, gold16, log) if gold16 is not None else {"skipped": "no cc16 fixture for this circuit"}
+            result["cc16_one_gpu"] = cc16_one_gpu(gsv, engine, plan_sb, case, gold16, log) if gold16 is not None else {"skipped": "no cc16 fixture for this circuit"}
+            if gold16 is not None:
+                result["cc16_one_gpu"]["plan_units"] = "fq6 (small-batch plan)" if plan_small is not None else "fq12"
         except Exception as e:  # noqa: BLE001
             result["cc16_one_gpu"] = {"error": repr(e)}
     if extras and not args.no_mode_rates:
@@ -668,11 +688,14 @@ def run_verifier(args):
         # the garbler's device block, nothing retained, nothing over PCIe — evaluated at the same time with the valid proof's input bits
         if compressed and "input_bits_hex" in case and time.time() - T_START < args.time_budget * 0.62:
             try:
-                result["mode_rates"]["garble_then_evaluate"] = garble_then_evaluate(gsv, engine, plan, case, np)
+                result["mode_rates"]["garble_then_evaluate"] = garble_then_evaluate(gsv, engine, plan_sb, case, np)
                 log("bench.py: garble + evaluate side by side, one instance: %.1f s, decoded output %s" % (result["mode_rates"]["garble_then_evaluate"]["seconds"], result["mode_rates"]["garble_then_evaluate"]["decoded_output"]))
             except Exception as e:  # noqa: BLE001
                 result["mode_rates"]["garble_then_evaluate"] = {"error": repr(e)}
 
+    if plan_small is not None:
+        plan_small.close()  # its 41 GB of program records make room for the headline's session
+        plan_small = None
     seeds = instance_seeds(rank, B)
     if rank == 0:
         seeds[0] = case["seed"]  # the fixture's seed: the timed kernel's output label is checked once a whole pass has run
@@ -746,6 +769,7 @@ def run_verifier(args):
                        "public_inputs": n_pub, "instances_per_gpu": B, "instances_per_workgroup": ni, "gates_per_instance": gates, "reference_published_gates": VERIFIER_GATES, "nonfree_fraction": f_nf,
                        "plan_calls": n_calls, "plan_programs": n_programs, "plan_windows": sched["n_windows"],
                        "slices_per_pass": len(slices), "gates_per_step_per_instance": [s[2] for s in slices], "steps_requested": args.steps,
+                       "small_batch_plan": plan_small_info,
                        "passes_timed": r["gates_per_instance"] / gates, "step_device_ms": [round(x, 1) for x in r["step_ms"]], "plan": plan_info, "plan_image_gb": image_bytes / 1e9, "seconds_to_first_launch": t_first_launch,
                        "wire_file_mb_per_instance": sched["wire_file_slots"] * 16 / 1e6, "ciphertext_window_mb_per_instance": sched["window_ct_records"] * 16 / 1e6,
                        "host_peak_rss_gb": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1e6},
@@ -930,6 +954,9 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-rate-by-instances", action="store_true")
     ap.add_argument("--no-mode-rates", action="store_true")
+    ap.add_argument("--small-batch-units", default="fq6", choices=["fq6", "fq12"], help="unit granularity of the plan the legs with 1 and 16 instances run (rate_by_instances, cc16_one_gpu, "
+                    "garble_then_evaluate): fq6 (default) builds a second plan with the Fq12 multiplications and squarings entered as fq6::mul_montgomery units, fq12 uses the headline's plan")
+    ap.add_argument("--units", default="fq12", choices=["fq12", "fq6"], help="unit granularity of the headline's plan: fq12 (default) or fq6 (experiments: the small-batch plan at full occupancy)")
     ap.add_argument("--no-cc16", action="store_true", help="skip the cc16_one_gpu leg (BASELINE config 5 with all 16 instances on this GPU, ~40 s)")
     ap.add_argument("--replays", type=int, default=0, help="synthetic: chain links per instance (0 = enough for 11.17 B gates)")
     ap.add_argument("--ct-ring", type=int, default=2, help="synthetic: replays of ciphertexts kept per instance in HBM")
