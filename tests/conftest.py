@@ -12,6 +12,18 @@ for p in (HERE, ROOT):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "slow: CPU tests of several minutes each (run with `-m slow`; their log is committed under profiles/)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`-m slow` runs the slow set; without it (the driver's `-m "not gpu"`) slow tests are skipped unless GSV_SLOW_TESTS=1."""
+    import os
+    if "slow" in (config.getoption("-m") or "") or os.environ.get("GSV_SLOW_TESTS") == "1":
+        return
+    skip = pytest.mark.skip(reason="slow: run with `-m slow` (or GSV_SLOW_TESTS=1); this round's log: profiles/r04_parity/ref_gadgets_slow.log")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

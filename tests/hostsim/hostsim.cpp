@@ -226,6 +226,17 @@ static uint32_t plan_n_globals(const BuiltPlan& bp) {
 // way the device may — window by window, inside a window ANY order the dependencies allow: here always the ready call with the
 // LARGEST stream index, all calls in one shared scratch ring.  info: n_windows n_dependencies max_width scratch_slots
 // critical_steps total_steps max_window_ct.
+static uint64_t g_segment_ct = 0;  // hostsim_set_segment_ct: SchedParams::segment_ct of the next hostsim_plan_schedule
+void hostsim_set_segment_ct(uint64_t v) { g_segment_ct = v; }
+// The drain segments of the last schedule: per segment {window, call0, call1, ct0, n_ct}; returns their number (out may be NULL).
+uint64_t hostsim_plan_segments(SimPlan* sp, uint64_t* out, uint64_t cap) {
+  const Schedule& sc = sp->sched;
+  uint64_t n = 0;
+  for (size_t w = 0; w < sc.windows.size(); ++w)
+    for (uint32_t q = sc.windows[w].seg0; q < sc.windows[w].seg1; ++q, ++n)
+      if (out && n < cap) { out[5 * n] = w; out[5 * n + 1] = sc.segments[q].call0; out[5 * n + 2] = sc.segments[q].call1; out[5 * n + 3] = sc.segments[q].ct0; out[5 * n + 4] = sc.segments[q].n_ct; }
+  return n;
+}
 int hostsim_plan_schedule(SimPlan* sp, uint32_t max_calls, uint64_t max_slots, uint64_t window_ct, uint32_t window_calls, uint64_t* info /* 7 */) {
   try {
     const BuiltPlan& bp = sp->bp;
@@ -240,6 +251,7 @@ int hostsim_plan_schedule(SimPlan* sp, uint32_t max_calls, uint64_t max_slots, u
     SchedParams p;
     p.max_calls_in_flight = max_calls; p.max_scratch_slots = max_slots ? max_slots : ~0ull; p.max_window_ct = window_ct ? window_ct : ~0ull;
     p.max_window_calls = window_calls ? window_calls : 32768;
+    p.segment_ct = g_segment_ct;
     const uint32_t n_ids = plan_n_globals(bp);
     sp->sched = schedule_calls(calls, n_ids, bp.outputs, p);
     const std::string err = verify_schedule(calls, n_ids, bp.outputs, sp->sched);

@@ -159,6 +159,22 @@ class SimPlan:
             raise RuntimeError(lib().hostsim_last_error().decode())
         return dict(zip(["n_windows", "n_dependencies", "max_width", "scratch_slots", "critical_steps", "total_steps", "max_window_ct"], (int(x) for x in info)))
 
+    def segments(self, segment_ct, **kw):
+        """schedule(**kw) with drain segments of at most `segment_ct` ciphertext records (schedule.hpp, SchedParams::segment_ct):
+        returns (schedule info, [(window, call0, call1, ct0, n_ct)])."""
+        lib().hostsim_set_segment_ct.argtypes = [C.c_uint64]
+        lib().hostsim_plan_segments.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64]
+        lib().hostsim_plan_segments.restype = C.c_uint64
+        lib().hostsim_set_segment_ct(segment_ct)
+        try:
+            info = self.schedule(**kw)
+        finally:
+            lib().hostsim_set_segment_ct(0)
+        n = int(lib().hostsim_plan_segments(self.h, None, 0))
+        out = np.zeros((n, 5), np.uint64)
+        lib().hostsim_plan_segments(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), n)
+        return info, [tuple(int(x) for x in row) for row in out]
+
     def garble(self, delta, consts, inputs, gid_base=0):
         cts = np.zeros((self.info["n_ct"], 16), np.uint8)
         out = np.zeros((self.info["n_outputs"], 16), np.uint8)

@@ -290,6 +290,30 @@ def test_schedule_finds_the_independent_calls():
     assert info["max_width"] >= 5 and info["critical_steps"] < info["total_steps"] // 2
 
 
+def test_drain_segments_partition_the_windows():
+    """schedule.hpp, SchedParams::segment_ct: a window (one launch, the scope in which calls overlap) is cut into drain segments of
+    consecutive calls — the unit in which the stream leaves the device while the window runs.  The segments of a window partition its
+    calls in stream order, their ciphertext ranges are contiguous and add up to the window's, none exceeds the limit unless it is a
+    single call, and cutting segments changes neither the windows nor the dependencies."""
+    sp = h.SimPlan("fq12_mul", ["fq2::mul_montgomery"])
+    base = sp.schedule(max_calls=16, window_ct=1_500_000)
+    n_ct = sp.info["n_ct"]
+    for seg_ct in (0, 50_000, 400_000, 10**9):
+        info, segs = sp.segments(seg_ct, max_calls=16, window_ct=1_500_000)
+        assert info == base
+        assert [s[0] for s in segs] == sorted(s[0] for s in segs) and len({s[0] for s in segs}) == info["n_windows"]
+        call, ct = 0, 0
+        for w, c0, c1, ct0, n in segs:
+            assert c0 == call and c1 > c0 and ct0 == ct
+            call, ct = c1, ct + n
+            assert seg_ct == 0 or n <= seg_ct or c1 - c0 == 1
+        assert ct == n_ct and call == sp.info["n_calls"]
+        if seg_ct in (0, 10**9):
+            assert len(segs) == info["n_windows"]  # one segment per window
+        else:
+            assert len(segs) > info["n_windows"]
+
+
 def test_warmup_recorders_give_the_same_plan(monkeypatch):
     """plan_builder.hpp record_plan: a circuit's warm-up mini-circuits (circuits.hpp NamedCircuit::warmups; the verifier's 178 constant
     line functions, here fq12_mix's square and multiplication) are recorded by other threads while the driver walks the circuit, with

@@ -24,12 +24,12 @@ def _product_stream(spec):
 
 
 FAST = ["u254_add", "bigint_mul:22", "bigint_mul:40", "fq_add", "fq_sub", "fq_neg", "fq_double", "fq_half", "fq_triple", "fq_div6", "fq_mul", "fq2_mul", "fq6_mul", "g1_add", "fq12_mul"]
-# The verifier's larger building blocks (8-23 M gates each; 6 minutes of Python in total): run with GSV_SLOW_TESTS=1; the log of this
-# round's run is committed as profiles/r03_parity/ref_gadgets_slow.log.
+# The verifier's larger building blocks (8-23 M gates each; 6 minutes of Python in total): `python -m pytest tests/test_ref_gadgets.py -m slow`
+# (tests/conftest.py: skipped in the default run); the log of this round's run is committed as profiles/r04_parity/ref_gadgets_slow.log.
 SLOW = ["fq12_square", "fq12_cyclotomic_square", "g2_double", "g2_add", "ell_eval", "ell_const:0", "ell_const:3", "fq_inverse"]
 
 
-@pytest.mark.parametrize("spec", FAST + [pytest.param(x, marks=pytest.mark.skipif(os.environ.get("GSV_SLOW_TESTS") != "1", reason="slow: set GSV_SLOW_TESTS=1")) for x in SLOW])
+@pytest.mark.parametrize("spec", FAST + [pytest.param(x, marks=pytest.mark.slow) for x in SLOW])
 def test_product_gate_stream_equals_independent_restatement(spec):
     got, got_out = _product_stream(spec)
     exp, exp_out = R.emit(spec)
