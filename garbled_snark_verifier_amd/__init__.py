@@ -60,7 +60,7 @@ class _PlanSessionOpts(C.Structure):
 
 
 _SCHED_FIELDS = ["n_calls", "n_windows", "n_dependencies", "max_width", "scratch_slots", "wire_file_slots", "window_ct_records", "critical_steps", "total_steps",
-                 "n_segments", "segment_ct_records"]
+                 "n_segments", "segment_ct_records", "ct_ring_records"]
 
 
 class _PlanScheduleInfo(C.Structure):

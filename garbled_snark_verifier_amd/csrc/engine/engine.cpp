@@ -65,6 +65,17 @@ static int dev_alloc(void** p, size_t bytes, const char* what) {
   return fail(GSV_ERR_DEVICE, msg);
 }
 #define DEVALLOC(p, bytes, what) do { int _rc = dev_alloc(reinterpret_cast<void**>(p), (bytes), (what)); if (_rc) return _rc; } while (0)
+// A stream that must make progress WHILE a window runs on the engine's stream (the drain's gathers and copies, the other half of a
+// garble -> evaluate pair).  The runtime multiplexes streams onto a few hardware queues per priority level, in order within a queue: a
+// side stream that lands on the main stream's queue would sit behind the running window — which, with a ciphertext ring, itself waits
+// for that side stream's work (observed: the ring stalls until the device watchdog fires, depending on how many streams the process
+// had created before).  Streams of another priority level come from another pool of hardware queues, so these ask for the highest.
+static hipError_t create_side_stream(hipStream_t* st) {
+  int least = 0, greatest = 0;
+  const char* off = getenv("GSV_SIDE_STREAM_PRIORITY");
+  if ((off && off[0] == '0') || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || greatest == least) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+  return hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest);
+}
 
 struct gsv_recorder {
   RecordMode mode;
@@ -151,8 +162,12 @@ struct gsv_session {
   bool plan_retain = true;   // plan sessions: whole ciphertext stream kept on the device (else one call block: streaming only)
   uint64_t plan_max_block = 0;  // ciphertext records per instance of the device block: the largest WINDOW of the schedule
   uint64_t plan_max_segment = 0;  // ... of a gate-order buffer: the largest drain SEGMENT (schedule.hpp)
+  bool ct_ring = false;              // the device block is a ring of plan_max_block records (schedule.hpp, SchedParams::ring_ct)
+  unsigned long long* host_ct_pos = nullptr;  // ring mode: the host's stream-position counter (page-locked, mapped into the device)
+  unsigned long long* dev_ct_pos = nullptr;   // ... its device address
   hipStream_t aux_stream = nullptr;  // gather kernels and flag polls of the drain, beside the running window
-  uint32_t* host_flags = nullptr;    // page-locked copy of the completion flags (polled while a window runs)
+  uint32_t* host_done = nullptr;     // per call of the running window: workgroups that have finished it (mapped host memory, written by the device)
+  uint32_t* dev_done = nullptr;      // ... its device address
   struct CallDev { DevProgram dp; };
   std::vector<CallDev> call_dev;
   // Call-level schedule (schedule.hpp): windows of consecutive calls; the calls of a window run as a dataflow inside ONE launch
@@ -437,7 +452,8 @@ void gsv_session_destroy(gsv_session* s) {
   if (s->plan_out_slots) (void)hipFree(s->plan_out_slots);
   for (void* q : s->ct_gate_more) if (q) (void)hipFree(q);
   if (s->aux_stream) (void)hipStreamDestroy(s->aux_stream);
-  if (s->host_flags) (void)hipHostFree(s->host_flags);
+  if (s->host_done) (void)hipHostFree(s->host_done);
+  if (s->host_ct_pos) (void)hipHostFree(s->host_ct_pos);
   destroy_drain(s->drain);
   destroy_pair(s->pair);
   if (s->ct_alt) (void)hipFree(s->ct_alt);
@@ -1045,6 +1061,18 @@ static Schedule make_schedule(const gsv_plan* plan, uint32_t ni, size_t n_instan
     if (const char* ev = getenv("GSV_DRAIN_SEGMENT_RECORDS")) if (!o.drain_segment_records) sg = uint64_t(std::max(1ll, atoll(ev)));
     sp.segment_ct = std::min<uint64_t>(std::max<uint64_t>(sg, max_block), sp.max_window_ct);
   }
+  // Ciphertext ring (schedule.hpp), GSV_CT_RING=1: a session that does not retain the stream and runs calls side by side keeps THREE
+  // segments' worth of ciphertexts on the device instead of a window's, and the window becomes the whole pass (one instance: 48 GB of
+  // device block -> 3.2 GB, 2 windows -> 1; sixteen: 17 windows -> 1 over a 27-GB ring).  Opt-in: with large windows + segments the
+  // pass is already bounded by the dependent depth and the host's MAC chain (tools/ring_ab.py: 30.7 s either way for one instance,
+  // 32.9 s vs 32.5-33.4 s for sixteen), and a ring makes the running launch WAIT for the host — it must never share a hardware queue
+  // with the side streams (create_side_stream).  Not with an explicit window_ct_records (the caller sizes the launches: garble ||
+  // evaluate pairs, tests), not for sequential sessions, and not when the whole stream fits the ring anyway.
+  if (!o.retain_stream && !o.window_ct_records && conc > 1 && getenv("GSV_CT_RING") && atoi(getenv("GSV_CT_RING")) == 1) {
+    uint64_t ring = std::max<uint64_t>(3 * sp.segment_ct, 2 * sp.segment_ct + max_block);
+    if (const char* ev = getenv("GSV_CT_RING_RECORDS")) ring = std::max<uint64_t>(uint64_t(std::max(1ll, atoll(ev))), 2 * sp.segment_ct + max_block);  // tests: small rings on small circuits
+    if (ring < plan->n_ct && ring <= sp.max_window_ct) { sp.ring_ct = ring; sp.max_window_ct = ~0ull; }
+  }
   sp.max_window_calls = std::min<uint32_t>(o.max_window_calls ? o.max_window_calls : 32768u, 65535u);
   Schedule sc = schedule_calls(calls, plan->n_globals, plan->outputs, sp);
   if (getenv("GSV_PLAN_DEBUG") || getenv("GSV_VERIFY_SCHEDULE")) {
@@ -1095,8 +1123,14 @@ int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_i
   const uint32_t scratch = uint32_t((std::max<uint64_t>(sc.scratch_slots, SLOT_FIRST_INPUT) + 7) / 8 * 8);
   s->global_base = scratch;
   s->plan_retain = o.retain_stream != 0;
-  s->plan_max_block = sc.max_window_ct;
+  s->ct_ring = sc.ring_ct != 0;
+  s->plan_max_block = s->ct_ring ? sc.ring_ct : sc.max_window_ct;
   s->plan_max_segment = sc.max_segment_ct;
+  if (s->ct_ring) {
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->host_ct_pos), 64, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&s->dev_ct_pos), s->host_ct_pos, 0));
+    *s->host_ct_pos = 0;
+  }
   if (uint64_t(scratch) + plan->n_globals > 0xFFFFFFF0ull) return fail(GSV_ERR_CIRCUIT, "plan wire file too large");
   Program& f = s->facade;
   f.n_slots = scratch + plan->n_globals;
@@ -1114,6 +1148,13 @@ int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_i
     const size_t n = plan->calls.size();
     std::vector<dev::CallDesc> cds(n);
     std::vector<uint32_t> csrc, cdst, deps;
+    {
+      // the device-written completion counters of a running window (one per call of the widest window), in mapped host memory
+      uint32_t widest = 0;
+      for (const Schedule::Window& w : sc.windows) widest = std::max(widest, w.call1 - w.call0);
+      HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->host_done), size_t(widest) * 4 + 64, hipHostMallocMapped | hipHostMallocCoherent));
+      HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&s->dev_done), s->host_done, 0));
+    }
     for (const Schedule::Window& w : sc.windows) {
       for (uint32_t k = w.call0; k < w.call1; ++k) {
         const PlanCall& c = plan->calls[k];
@@ -1122,7 +1163,9 @@ int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_i
         dev::CallDesc& d = cds[k];
         std::memset(&d, 0, sizeof d);
         d.steps = s->call_dev[k].dp.steps; d.ands = s->call_dev[k].dp.ands; d.xors = s->call_dev[k].dp.xors;
-        d.gid_off = c.gid_off; d.ct_off = s->plan_retain ? c.ct_off : c.ct_off - w.ct0;
+        d.gid_off = c.gid_off; d.ct_off = s->plan_retain ? c.ct_off : s->ct_ring ? sc.ring_off[k] : c.ct_off - w.ct0;
+        if (s->ct_ring) { d.ct_need = sc.ring_need[k]; d.ct_ready = sc.seg_end[k]; d.ct_pos = s->dev_ct_pos; }
+        d.done_host = s->dev_done + (k - w.call0);
         d.w_base = base; d.n_steps = g.n_steps; d.and_terms = g.and_terms;
         d.pre_off = uint32_t(csrc.size());
         if (base != 0)  // the call's own copies of the constant labels (FALSE, TRUE, the all-zero label) in front of its scratch region
@@ -1175,6 +1218,7 @@ int gsv_session_plan_schedule_info(const gsv_session* s, gsv_plan_schedule_info*
   info->scratch_slots = s->global_base; info->wire_file_slots = s->facade.n_slots; info->window_ct_records = sc.max_window_ct;
   info->critical_steps = sc.critical_steps; info->total_steps = sc.total_steps;
   info->n_segments = sc.segments.size(); info->segment_ct_records = sc.max_segment_ct;
+  info->ct_ring_records = sc.ring_ct;
   return GSV_OK;
 }
 int gsv_session_plan_window(const gsv_session* s, uint64_t window, uint64_t* first_call, uint64_t* n_calls, uint64_t* max_width) {
@@ -1334,6 +1378,10 @@ static int launch_plan_window(gsv_session* s, size_t w, uint64_t gate_id_base, b
   ka.calls = static_cast<const dev::CallDesc*>(s->d_calls) + win.call0;
   ka.copy_src = static_cast<const uint32_t*>(s->d_copy_src); ka.copy_dst = static_cast<const uint32_t*>(s->d_copy_dst);
   ka.deps = static_cast<const uint32_t*>(s->d_deps); ka.flags = static_cast<uint32_t*>(s->d_flags); ka.error = static_cast<uint32_t*>(s->d_error);
+  if (s->host_done) {  // (launches of one session are serialised: the previous window has finished before the host gets here)
+    std::memset(s->host_done, 0, size_t(win.call1 - win.call0) * 4);
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+  }
   ka.flag_stride = s->flag_stride; ka.epoch = ++s->epoch;
   {
     // dependency watchdog (kernels.hip): seconds without ANY completed call of the instance group before a wait gives up
@@ -1355,6 +1403,19 @@ static int launch_plan_window(gsv_session* s, size_t w, uint64_t gate_id_base, b
 static int check_plan_error(gsv_session* s) {
   uint32_t err = 0;
   HIPCHK(hipMemcpy(&err, s->d_error, 4, hipMemcpyDeviceToHost));
+  if (err == 2) {
+    // which calls of the last window have not finished everywhere, and where the host's position stood (diagnostics)
+    std::string open_calls;
+    if (s->host_done && !s->sched.windows.empty()) {
+      const uint32_t n_wg = uint32_t((s->n_inst + s->ni - 1) / s->ni);
+      const Schedule::Window& win = s->sched.windows.back();
+      int shown = 0;
+      for (uint32_t k = win.call0; k < win.call1 && shown < 12; ++k)
+        if (s->host_done[k - win.call0] != n_wg) { open_calls += " " + std::to_string(k) + "(" + std::to_string(s->host_done[k - win.call0]) + "/" + std::to_string(n_wg) + ", need " + std::to_string(s->sched.ring_need[k]) + ")"; ++shown; }
+    }
+    return fail(GSV_ERR_DEVICE, "a call waited for the host's stream position (ciphertext ring) and saw it stand still at " + std::to_string(s->host_ct_pos ? *s->host_ct_pos : 0) +
+                                    "; unfinished calls:" + open_calls + "; results are invalid");
+  }
   if (err) return fail(GSV_ERR_DEVICE, "a call of the plan waited for a dependency that never completed (dispatch-order assumption of schedule.hpp violated); results are invalid");
   return GSV_OK;
 }
@@ -1369,7 +1430,7 @@ static int permute_plan_calls(gsv_session* s, size_t w, uint32_t k0, uint32_t k1
     const Program& cp = s->call_prog(k);
     if (!cp.n_ct) continue;
     const uint64_t rel = s->plan->calls[k].ct_off - win.ct0;
-    uint8_t* block = static_cast<uint8_t*>(ct_block) + (s->plan_retain ? s->plan->calls[k].ct_off : rel) * 16;
+    uint8_t* block = static_cast<uint8_t*>(ct_block) + (s->plan_retain ? s->plan->calls[k].ct_off : s->ct_ring ? s->sched.ring_off[k] : rel) * 16;
     if (gsvk_gather_segment(block, s->ct_stride(), s->call_dev[k].dp.ct_pos, cp.n_ct, 1, uint32_t(s->n_inst), static_cast<uint8_t*>(gate_buf) + (s->plan->calls[k].ct_off - gate_ct0) * 16, gate_stride, scatter, stream) != 0)
       return fail(GSV_ERR_DEVICE, scatter ? "ciphertext scatter launch failed" : "ciphertext gather launch failed");
   }
@@ -1495,7 +1556,7 @@ static int ensure_drain(gsv_session* s, size_t T, uint64_t seg_records, int grou
   bool ok = true;
   for (int k = 0; k < n_copy_streams && ok; ++k) {
     hipStream_t st;
-    ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    ok = create_side_stream(&st) == hipSuccess;
     if (ok) { d.copy_streams.push_back(st); d.copy_gate.idle.push_back(st); }
   }
   d.workers.resize(T);
@@ -1515,6 +1576,7 @@ static int garble_discard(gsv_session* s, uint64_t gate_id_base, size_t c0, size
   if (s->plan) {
     size_t w0 = 0, w1 = 0;
     if (c0 == 0) HIPCHK(hipMemsetAsync(s->d_error, 0, 4, s->e->stream));
+    if (s->ct_ring) __atomic_store_n(s->host_ct_pos, ~0ull, __ATOMIC_RELEASE);  // nothing reads the ciphertexts: every block of the ring is free at once
     rc = window_range(s, c0, c1, &w0, &w1);
     for (size_t w = w0; w < w1 && rc == GSV_OK; ++w) rc = launch_plan_window(s, w, gate_id_base, false);
     if (rc == GSV_OK) {
@@ -1548,7 +1610,7 @@ static int ensure_pair(gsv_session* s) {
   if (!s->ct_alt) DEVALLOC(&s->ct_alt, s->n_inst * size_t(s->ct_stride()) * 16, "the second ciphertext block (garble -> evaluate)");
   if (!s->pair) {
     std::unique_ptr<PairState> ps(new PairState());
-    HIPCHK(hipStreamCreateWithFlags(&ps->stream, hipStreamNonBlocking));
+    HIPCHK(create_side_stream(&ps->stream));
     for (int b = 0; b < 2; ++b) {
       HIPCHK(hipEventCreateWithFlags(&ps->garbled[b], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&ps->evaluated[b], hipEventDisableTiming));
@@ -1562,6 +1624,36 @@ static void destroy_pair(PairState* ps) {
   for (int b = 0; b < 2; ++b) { if (ps->garbled[b]) (void)hipEventDestroy(ps->garbled[b]); if (ps->evaluated[b]) (void)hipEventDestroy(ps->evaluated[b]); }
   if (ps->stream) (void)hipStreamDestroy(ps->stream);
   delete ps;
+}
+
+// Follows the RUNNING window w through the completion counters its workgroups write into mapped host memory (kernels.hip, epilogue)
+// until calls [k0, k1) of the plan have completed for every instance group, or the window's launch itself has finished (*window_done).
+static int wait_calls_done(gsv_session* s, size_t w, uint32_t k0, uint32_t k1, bool* window_done) {
+  const Schedule::Window& win = s->sched.windows[w];
+  const uint32_t n_wg = uint32_t((s->n_inst + s->ni - 1) / s->ni);
+  const auto t0 = std::chrono::steady_clock::now();
+  bool reported = false;
+  while (!*window_done && k0 < k1) {
+    bool all = true;
+    for (uint32_t k = k0; k < k1 && all; ++k) all = __atomic_load_n(s->host_done + (k - win.call0), __ATOMIC_ACQUIRE) == n_wg;
+    if (all) break;
+    if (hipStreamQuery(s->e->stream) == hipSuccess) { *window_done = true; break; }
+    std::this_thread::sleep_for(std::chrono::microseconds(100));
+    if (!reported && getenv("GSV_DRAIN_DEBUG") && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 3.0) {
+      reported = true;
+      std::string msg;
+      for (uint32_t k = win.call0; k < win.call1; ++k)
+        if (s->host_done[k - win.call0] != n_wg) msg += " " + std::to_string(k) + "(" + std::to_string(s->host_done[k - win.call0]) + "/" + std::to_string(n_wg) + (s->ct_ring ? ",need " + std::to_string(s->sched.ring_need[k]) + ",ready " + std::to_string(s->sched.seg_end[k]) : "") + ")";
+      std::fprintf(stderr, "drain debug: waiting > 3 s for calls [%u, %u) of window %zu; host position %llu; unfinished:%s\n", k0, k1, w, s->host_ct_pos ? (unsigned long long)*s->host_ct_pos : 0ull, msg.substr(0, 1500).c_str());
+    }
+  }
+  return GSV_OK;
+}
+// the side stream and the device-written completion counters of a session whose stream leaves the device while a window runs
+static int ensure_aux(gsv_session* s) {
+  if (!s->aux_stream) HIPCHK(create_side_stream(&s->aux_stream));
+  if (!s->host_done) return fail(GSV_ERR_INVALID, "internal: a plan session without completion counters");  // (allocated with its call descriptors)
+  return GSV_OK;
 }
 
 // `ev`: an evaluator session over the same plan / schedule (plan sessions that do not retain the stream): every window is evaluated
@@ -1592,11 +1684,10 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
     int rc = ensure_drain(s, T, seg_records, int(GROUP));
     if (rc) return rc;
   }
+  if (ev && (s->ct_ring || ev->ct_ring)) return fail(GSV_ERR_INVALID, "garble || evaluate pairs need sessions with explicit launch windows (window_ct_records, e.g. 1 << 28): the default is one whole-pass window over a ciphertext ring");
   if (ev) { int rc = ensure_pair(s); if (rc) return rc; }
-  if (s->plan && want_drain) {
-    if (!s->aux_stream) HIPCHK(hipStreamCreateWithFlags(&s->aux_stream, hipStreamNonBlocking));
-    if (!s->host_flags) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->host_flags), ((n_inst + s->ni - 1) / s->ni) * size_t(s->flag_stride) * 4 + 64, hipHostMallocDefault));
-  }
+  if (s->ct_ring) __atomic_store_n(s->host_ct_pos, (unsigned long long)(s->plan && pw0 < s->sched.windows.size() ? s->sched.windows[pw0].ct0 : 0), __ATOMIC_RELEASE);
+  if (s->plan && want_drain) { int rc = ensure_aux(s); if (rc) return rc; }
   if (s->plan && new_pass) HIPCHK(hipMemsetAsync(s->d_error, 0, 4, s->e->stream));  // a new pass starts with a clean dependency-wait flag
   if (ev && new_pass) HIPCHK(hipMemsetAsync(ev->d_error, 0, 4, s->e->stream));
   std::vector<CbcMacHost> no_macs;
@@ -1710,7 +1801,7 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   // GSV_DRAIN_STATS=1: where the host thread of the pipeline waits (for a free gate-order buffer = the host side is the slower stage;
   // for the kernel + gather = the device is), printed once per call
   const bool stats = getenv("GSV_DRAIN_STATS") != nullptr;
-  double t_wait_drain = 0, t_wait_device = 0;
+  double t_wait_drain = 0, t_wait_device = 0, t_gather = 0;
   uint64_t drained_records = 0;
   const auto t_begin = std::chrono::steady_clock::now();
   auto secs = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
@@ -1769,24 +1860,12 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
       n_records = win.n_ct;
       base = win.ct0;
       if (want_drain) {
-        const size_t n_wg = (n_inst + s->ni - 1) / s->ni;
         bool window_done = false;
         for (uint32_t q = win.seg0; q < win.seg1 && rc == GSV_OK; ++q) {
           const Schedule::Segment& sg = s->sched.segments[q];
           const bool last = q + 1 == win.seg1;
           const auto t0 = std::chrono::steady_clock::now();
-          while (!window_done && !last) {
-            if (hipMemcpyAsync(s->host_flags, s->d_flags, n_wg * size_t(s->flag_stride) * 4, hipMemcpyDeviceToHost, s->aux_stream) != hipSuccess || hipStreamSynchronize(s->aux_stream) != hipSuccess) {
-              rc = fail(GSV_ERR_DEVICE, "flag poll failed");
-              break;
-            }
-            bool all = true;
-            for (size_t x = 0; x < n_wg && all; ++x)
-              for (uint32_t k = sg.call0; k < sg.call1 && all; ++k) all = s->host_flags[x * s->flag_stride + (k - win.call0)] == s->epoch;
-            if (all) break;
-            if (hipStreamQuery(s->e->stream) == hipSuccess) { window_done = true; break; }
-            std::this_thread::sleep_for(std::chrono::microseconds(200));
-          }
+          if (!last) rc = wait_calls_done(s, w, sg.call0, sg.call1, &window_done);
           if (rc != GSV_OK) break;
           if (last && !window_done) {
             // the last segment ends with the window: sleep on the stream (on a blocking-sync event when the workers own the cores)
@@ -1796,9 +1875,12 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
           }
           t_wait_device += secs(t0);
           wait_buffer(n_pushed);  // the gate-order buffer this segment goes to is free again
+          const auto tg = std::chrono::steady_clock::now();
           rc = permute_plan_calls(s, w, sg.call0, sg.call1, sg.ct0, seg_records, 0, block, gate_bufs[n_pushed % depth], s->aux_stream);
           if (rc != GSV_OK) break;
           if (hipStreamSynchronize(s->aux_stream) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "ciphertext gather failed"); break; }
+          t_gather += secs(tg);
+          if (s->ct_ring) __atomic_store_n(s->host_ct_pos, (unsigned long long)(sg.ct0 + sg.n_ct), __ATOMIC_RELEASE);  // the calls whose blocks overlap this segment's may write now
           drained_records += sg.n_ct;
           push_segment(sg.n_ct, sg.ct0, n_pushed % depth);
           ++n_pushed;
@@ -1830,12 +1912,17 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
     drained_records += n_records;
     if (want_drain) { push_segment(n_records, base, n_pushed % depth); ++n_pushed; }
   }
+  if (s->ct_ring && rc != GSV_OK) {
+    // a failed pass: calls of the running window may still wait for room in the ring — let them run out (the results are discarded)
+    __atomic_store_n(s->host_ct_pos, ~0ull, __ATOMIC_RELEASE);
+    (void)hipStreamSynchronize(s->e->stream);
+  }
   finish_workers();
   if (ev && hipStreamSynchronize(s->pair->stream) != hipSuccess && rc == GSV_OK) rc = fail(GSV_ERR_DEVICE, "evaluation kernel failed");
   if (stats) {
     const double tot = secs(t_begin);
-    std::fprintf(stderr, "drain: %.2f s for %zu instances x %llu records (%.1f GB/s), %zu MAC workers x %zu chains, %zu gate-order buffers; host thread waited %.2f s for drains and %.2f s for the device\n", tot, n_inst,
-                 (unsigned long long)drained_records, double(drained_records) * double(n_inst) * 16e-9 / tot, T, GROUP, depth, t_wait_drain, t_wait_device);
+    std::fprintf(stderr, "drain: %.2f s for %zu instances x %llu records (%.1f GB/s), %zu MAC workers x %zu chains, %zu gate-order buffers; host thread waited %.2f s for drains, %.2f s for the device and %.2f s for the gathers of running windows\n", tot, n_inst,
+                 (unsigned long long)drained_records, double(drained_records) * double(n_inst) * 16e-9 / tot, T, GROUP, depth, t_wait_drain, t_wait_device, t_gather);
   }
   if (rc == GSV_OK && s->plan) {
     (void)hipEventRecord(s->ev1, s->e->stream);
@@ -1963,7 +2050,50 @@ static int evaluate_streaming_impl(gsv_session* s, uint64_t gate_id_base, const 
       }
     return GSV_OK;
   };
-  if (s->plan) {
+  if (s->plan && s->ct_ring) {
+    // Ring mode: the window (the whole pass) is launched FIRST; its calls wait on the device until the host's position counter says their
+    // segment has been uploaded.  Segment after segment: wait until the calls whose blocks this segment's blocks overwrite have
+    // completed (their flags), upload and scatter on the side stream, publish the segment's end.
+    rc = ensure_aux(s);
+    for (size_t w = 0; w < s->sched.windows.size() && rc == GSV_OK; ++w) {
+      const Schedule::Window& win = s->sched.windows[w];
+      __atomic_store_n(s->host_ct_pos, (unsigned long long)win.ct0, __ATOMIC_RELEASE);
+      rc = launch_plan_window(s, w, gate_id_base, true);
+      bool window_done = false;
+      for (uint32_t q = win.seg0; q < win.seg1 && rc == GSV_OK; ++q) {
+        const Schedule::Segment& sg = s->sched.segments[q];
+        uint32_t o0 = ~0u, o1 = 0;
+        for (uint32_t k = sg.call0; k < sg.call1; ++k) if (s->sched.ovl1[k] > s->sched.ovl0[k]) { o0 = std::min(o0, s->sched.ovl0[k]); o1 = std::max(o1, s->sched.ovl1[k]); }
+        // [ovl0, ovl1) is a RANGE around the overwritten calls: the calls it spans beside them are earlier calls too, but those of this
+        // very segment cannot run before this upload — and are never among the overwritten ones (the ring holds two segments and a call)
+        o1 = std::min(o1, sg.call0);
+        if (o1 > o0) rc = wait_calls_done(s, w, o0, o1, &window_done);
+        if (rc != GSV_OK) break;
+        if (window_done) { rc = fail(GSV_ERR_DEVICE, "internal: the window finished before its ciphertexts were uploaded"); break; }
+        // uploads and the scatter go through the side stream (the main stream holds the running window)
+        for (size_t i = 0; i < n_inst && rc == GSV_OK; ++i)
+          for (uint64_t off = 0; off < sg.n_ct; off += chunk, b ^= 1) {
+            const uint64_t m = std::min(chunk, sg.n_ct - off);
+            if (hipEventSynchronize(stage.ev[b]) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "event wait failed"); break; }
+            uint8_t* host = static_cast<uint8_t*>(stage.p[b]);
+            if (read(i, sg.ct0 + off, host, m) != 0) { rc = fail(GSV_ERR_EXHAUSTED, "Ciphertext source exhausted: instance " + std::to_string(i) + " ran dry at record " + std::to_string(sg.ct0 + off)); break; }
+            if (hashes) macs[i].update(host, m);
+            if (hipMemcpyAsync(static_cast<uint8_t*>(s->ct_gate) + (i * seg_records + off) * 16, host, m * 16, hipMemcpyHostToDevice, s->aux_stream) != hipSuccess ||
+                hipEventRecord(stage.ev[b], s->aux_stream) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "ciphertext upload failed"); break; }
+          }
+        if (rc == GSV_OK) rc = permute_plan_calls(s, w, sg.call0, sg.call1, sg.ct0, seg_records, 1, nullptr, nullptr, s->aux_stream);
+        if (rc == GSV_OK && hipStreamSynchronize(s->aux_stream) != hipSuccess) rc = fail(GSV_ERR_DEVICE, "ciphertext scatter failed");
+        if (rc == GSV_OK) __atomic_store_n(s->host_ct_pos, (unsigned long long)(sg.ct0 + sg.n_ct), __ATOMIC_RELEASE);
+      }
+      if (rc != GSV_OK) {
+        // let the calls that still wait for ciphertexts run out (their results are discarded with the error) instead of hanging the stream
+        __atomic_store_n(s->host_ct_pos, ~0ull, __ATOMIC_RELEASE);
+        (void)hipStreamSynchronize(s->e->stream);
+        break;
+      }
+      if (hipStreamSynchronize(s->e->stream) != hipSuccess) rc = fail(GSV_ERR_DEVICE, "kernel failed");
+    }
+  } else if (s->plan) {
     for (size_t w = 0; w < s->sched.windows.size() && rc == GSV_OK; ++w) {
       const Schedule::Window& win = s->sched.windows[w];
       for (uint32_t q = win.seg0; q < win.seg1 && rc == GSV_OK; ++q) {

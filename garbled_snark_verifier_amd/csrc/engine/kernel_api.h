@@ -29,9 +29,18 @@ struct CallDesc {
   uint32_t dep_off, n_deps;   // KernelArgs::deps[dep_off .. +n_deps): window-relative indices (= blockIdx.y) of the calls to wait for
   uint32_t and_terms;         // record form of the call's program: 2 (pack_and) or 4 (pack_and4), program.hpp
   uint32_t pad0_;
-  uint64_t pad_[2];
+  // ciphertext ring (schedule.hpp, SchedParams::ring_ct): the stream position the host's counter (*ct_pos) must have reached before
+  // the call may touch its block — garbling: everything its block overwrites has been gathered off the device (0 = nothing to wait
+  // for); evaluating: its own segment has been uploaded
+  uint64_t ct_need;
+  uint64_t ct_ready;
+  // Both live in host memory mapped into the device (fine-grained, system scope) and are the same for every launch of the session.
+  // They sit here and not in the kernel arguments because the descriptor's address is held across the step loop anyway: as arguments
+  // they stayed live in SGPRs and pushed loop-resident scalars into VGPR lanes (58 v_readlane per step in the four-wire kernels).
+  const unsigned long long* ct_pos;  // ring mode: the host's stream-position counter, null = no ring
+  uint32_t* done_host;               // the call's counter of finished workgroups: how the host follows a RUNNING window (drain segments)
 };
-static_assert(sizeof(CallDesc) == 96, "CallDesc layout");
+static_assert(sizeof(CallDesc) == 112, "CallDesc layout");
 
 struct KernelArgs {
   const void* steps;   // StepDesc[n_steps]   {and_off, and_cnt, xor_off, xor_cnt}
@@ -68,7 +77,7 @@ struct KernelArgs {
   const uint32_t* deps;
   uint32_t* flags;            // [gridDim.x][flag_stride] completion flags: flags[x][c] == epoch once call c has finished for instance group x;
                               // flags[x][flag_stride - 1] counts the calls group x has completed (the dependency watchdog's progress counter)
-  uint32_t* error;            // set to 1 when a dependency wait gives up (never expected: see schedule.hpp)
+  uint32_t* error;            // set to 1 when a dependency wait gives up (never expected: see schedule.hpp), to 2 when a ciphertext-ring wait does
   uint32_t flag_stride;
   uint32_t epoch;             // launch counter of the session: flags are never reset
   unsigned long long wait_ticks;  // dependency watchdog: give up when the group's progress counter has not moved for this long (100 MHz ticks)

@@ -255,6 +255,23 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         }
       }
     }
+    // ---- ciphertext ring: the call's block inside the ring is free (garbling: what it held on the previous lap has been gathered off
+    // the device) / filled (evaluating: the call's segment has been uploaded) once the host's position counter says so.  The counter
+    // lives in host memory mapped into the device (fine-grained, system scope); the same progress rule as above bounds the wait.
+    const unsigned long long* const ct_pos = threadIdx.x == 0 ? cd->ct_pos : nullptr;
+    if (ct_pos) {
+      const unsigned long long want = EVAL ? cd->ct_ready : cd->ct_need;
+      unsigned long long t_start = wall_clock64(), seen = __hip_atomic_load(ct_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      while (seen < want) {
+        __builtin_amdgcn_s_sleep(64);
+        const unsigned long long now = __hip_atomic_load(ct_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (now != seen) { seen = now; t_start = wall_clock64(); continue; }
+        if (wall_clock64() - t_start > ka.wait_ticks) {  // (the host publishes a position per drain segment: fractions of a second apart)
+          __hip_atomic_store(ka.error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const uint32_t n_pre = inst_active ? cd->n_pre : 0u;
@@ -640,6 +657,8 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       uint32_t* const fl = ka.flags + size_t(blockIdx.x) * ka.flag_stride;
       __hip_atomic_store(fl + blockIdx.y, ka.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(fl + (ka.flag_stride - 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the group's progress counter (watchdog)
+      // the host's view of the running window (drain segments, ring positions): one more finished workgroup of this call
+      if (cd->done_host) __hip_atomic_fetch_add(cd->done_host, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -684,6 +703,10 @@ __global__ void permute_ciphertexts_kernel(uint4* stream, const uint32_t* ct_pos
 // program-order ring go to a gate-order buffer: out[inst][r * n_ct + g] = ring[inst][r * n_ct + ct_pos[g]].
 // scatter != 0 is the evaluator's direction: gate-order records (read from gc_<i>.bin) go to their program-order positions.
 __global__ void gather_segment_kernel(uint4* ring, uint64_t ring_stride, const uint32_t* ct_pos, uint64_t n_ct, uint32_t n_rep, uint4* out, uint64_t out_stride, int scatter) {
+  // The source may have been written by workgroups of a garbling launch that is STILL RUNNING, on other XCDs, into addresses this XCD
+  // has read before (a ciphertext ring reuses its blocks lap after lap).  Their epilogue released the records at agent scope before the
+  // completion counter the host saw, and this launch's own dispatch acquires at agent scope: no fence here (one per wave cost 5 s of
+  // L2 invalidations over a 16-instance pass and slowed the garbling beside it).
   const uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (g >= n_ct) return;
   const uint32_t pos = ct_pos[g];

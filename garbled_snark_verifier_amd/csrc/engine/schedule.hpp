@@ -28,6 +28,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -51,6 +52,14 @@ struct SchedParams {
   // pass's tail.  A window is therefore cut into segments of consecutive calls of at most segment_ct ciphertext records: the host
   // follows the completion flags of a running window and drains segment after segment while the window is still being garbled.
   uint64_t segment_ct = 0;            // 0 = one segment per window
+  // Ciphertext RING (sessions that do not retain the stream): the device's program-order block holds ring_ct records per instance
+  // instead of a whole window's, so a window — the scope in which independent call chains overlap — can span the whole pass whatever
+  // the number of instances.  A call's block sits at ring_off inside the ring; before a garbling call writes it, everything the ring
+  // held there on the previous lap must have left the device: the call waits (kernels.hip, prologue) until the host's "gathered up to"
+  // position has reached ring_need (the END of the drain segment that holds the last overlapped call).  An evaluating call waits until
+  // its own segment has been uploaded: seg_end.  ring_ct >= 2 x the largest segment + the largest call, so that the segment a call
+  // waits for never contains the call itself (or a call behind it).  0 = no ring: the block is one window.
+  uint64_t ring_ct = 0;
   uint32_t max_window_calls = 32768;  // (grid.y of a launch is at most 65535)
   uint32_t slot_align = 8;            // scratch regions start on 128-byte lines
 };
@@ -60,6 +69,12 @@ struct Schedule {
   struct Segment { uint32_t call0, call1; uint64_t ct0, n_ct; };  // consecutive calls of one window: the unit the stream leaves the device in
   std::vector<Segment> segments;
   uint64_t max_segment_ct = 0;
+  // ring mode (SchedParams::ring_ct): per call its block's offset inside the ring, the stream position that must have been gathered off
+  // the device before a garbling call may write there (0 = nothing), the end of the call's own segment (what an evaluating call waits
+  // for), and — for the host side of an evaluation — the calls of the previous lap the call's block overlaps: [ovl0, ovl1)
+  uint64_t ring_ct = 0;
+  std::vector<uint64_t> ring_off, ring_need, seg_end;
+  std::vector<uint32_t> ovl0, ovl1;
   std::vector<uint32_t> scratch_base;  // per call: first slot of its scratch region
   std::vector<uint32_t> dep_off;       // per call (+1): its dependencies are deps[dep_off[k] .. dep_off[k+1])
   std::vector<uint32_t> deps;          // call indices (stream order, same window, < k)
@@ -75,6 +90,8 @@ inline Schedule schedule_calls(const std::vector<SchedCall>& calls, uint32_t n_i
   const size_t n = calls.size();
   s.scratch_base.assign(n, 0);
   s.dep_off.assign(n + 1, 0);
+  s.ring_ct = p.ring_ct;
+  if (p.ring_ct) { s.ring_off.assign(n, 0); s.ring_need.assign(n, 0); s.seg_end.assign(n, 0); s.ovl0.assign(n, 0); s.ovl1.assign(n, 0); }
   const uint32_t C = std::max<uint32_t>(1, p.max_calls_in_flight);
   auto align_up = [&](uint64_t v) { const uint64_t a = std::max<uint32_t>(1, p.slot_align); return (v + a - 1) / a * a; };
   // ids that are read by some call or are outputs of the plan; the rest (trash ids) carry no WAW hazard
@@ -185,6 +202,43 @@ inline Schedule schedule_calls(const std::vector<SchedCall>& calls, uint32_t n_i
         a = b;
       }
     }
+    if (p.ring_ct) {
+      // ring placement of the window's calls, in stream order; a block never wraps (a call that does not fit the rest of the ring starts
+      // at 0 and leaves a gap).  `lap` holds the calls whose blocks are still in the ring, oldest first.
+      struct Held { uint32_t call; uint64_t lo, hi; };
+      std::vector<Held> held;  // blocks still in the ring (a few hundred at most: the ring holds a few segments)
+      uint64_t pos = 0;
+      std::vector<uint64_t> end_of_seg_of(k1 - k0, 0);
+      for (uint32_t q = seg0; q < s.segments.size(); ++q)
+        for (uint32_t k = s.segments[q].call0; k < s.segments[q].call1; ++k) end_of_seg_of[k - k0] = s.segments[q].ct0 + s.segments[q].n_ct;
+      for (size_t k = k0; k < k1; ++k) {
+        const uint64_t nct = calls[k].n_ct;
+        if (nct > p.ring_ct) throw std::runtime_error("internal: ciphertext ring smaller than a call's block");
+        if (pos + nct > p.ring_ct) pos = 0;
+        const uint64_t lo = pos, hi = pos + nct;
+        uint64_t need = 0;
+        uint32_t o0 = uint32_t(k), o1 = uint32_t(k);
+        const size_t n_held = held.size();
+        size_t keep = 0;
+        for (size_t i = 0; i < n_held; ++i) {
+          const Held h = held[i];
+          if (nct && h.lo < hi && lo < h.hi) {  // (partly) overwritten by this call: its segment must have left the device / its call must be done
+            need = std::max(need, end_of_seg_of[h.call - k0]);
+            o0 = std::min(o0, h.call);
+            o1 = std::max(o1, h.call + 1);
+            // what this call leaves of the block still holds that call's records: calls run in any order the dependencies allow, so a
+            // later call that takes the rest has to wait for the same segment itself
+            if (h.lo < lo) held.push_back(Held{h.call, h.lo, lo});
+            if (h.hi > hi) held.push_back(Held{h.call, hi, h.hi});
+          } else held[keep++] = h;
+        }
+        for (size_t i = n_held; i < held.size(); ++i) held[keep++] = held[i];
+        held.resize(keep);
+        s.ring_off[k] = lo; s.ring_need[k] = need; s.seg_end[k] = end_of_seg_of[k - k0]; s.ovl0[k] = o0; s.ovl1[k] = o1 > o0 ? o1 : o0;
+        if (nct) held.push_back(Held{uint32_t(k), lo, hi});
+        pos = hi;
+      }
+    }
     s.windows.push_back(Schedule::Window{uint32_t(k0), uint32_t(k1), ct_off, wct, uint32_t(max_width), seg0, uint32_t(s.segments.size())});
     s.max_width = std::max(s.max_width, uint32_t(max_width));
     s.max_window_ct = std::max(s.max_window_ct, wct);
@@ -251,6 +305,52 @@ inline std::string verify_schedule(const std::vector<SchedCall>& calls, uint32_t
     }
   }
   if (covered != n) return "windows do not cover every call";
+  // segments partition every window's calls and ciphertexts in stream order
+  for (const Schedule::Window& w : s.windows) {
+    uint32_t c = w.call0;
+    uint64_t ct = w.ct0;
+    for (uint32_t q = w.seg0; q < w.seg1; ++q) {
+      if (q >= s.segments.size() || s.segments[q].call0 != c || s.segments[q].call1 <= c || s.segments[q].ct0 != ct) return "segments do not partition a window";
+      uint64_t sum = 0;
+      for (uint32_t k = s.segments[q].call0; k < s.segments[q].call1; ++k) sum += calls[k].n_ct;
+      if (sum != s.segments[q].n_ct) return "a segment's ciphertext count is wrong";
+      c = s.segments[q].call1; ct += sum;
+    }
+    if (c != w.call1 || ct != w.ct0 + w.n_ct) return "segments do not cover a window";
+  }
+  // ring mode, by simulation (record by record: small rings only — the tests'): when call k takes its block, every record it overwrites
+  // belongs to a call whose segment ends at or before ring_need[k], that segment does not contain k or a later call, the overwritten
+  // calls lie in [ovl0, ovl1), and an evaluating call's own segment ends at seg_end[k]
+  if (s.ring_ct && s.ring_ct <= (1u << 22)) {
+    if (s.ring_off.size() != n || s.ring_need.size() != n || s.seg_end.size() != n || s.ovl0.size() != n || s.ovl1.size() != n) return "ring tables do not cover every call";
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    for (const Schedule::Window& w : s.windows) {
+      std::vector<uint32_t> owner(size_t(s.ring_ct), NONE);
+      std::vector<uint64_t> seg_end_of(w.call1 - w.call0, 0), seg_first_of(w.call1 - w.call0, 0);
+      for (uint32_t q = w.seg0; q < w.seg1; ++q)
+        for (uint32_t k = s.segments[q].call0; k < s.segments[q].call1; ++k) { seg_end_of[k - w.call0] = s.segments[q].ct0 + s.segments[q].n_ct; seg_first_of[k - w.call0] = s.segments[q].call0; }
+      for (uint32_t k = w.call0; k < w.call1; ++k) {
+        const uint64_t lo = s.ring_off[k], hi = lo + calls[k].n_ct;
+        if (hi > s.ring_ct) return "a call's block leaves the ring";
+        if (s.seg_end[k] != seg_end_of[k - w.call0]) return "seg_end of a call is not the end of its segment";
+        for (uint64_t r = lo; r < hi; ++r) {
+          const uint32_t i = owner[size_t(r)];
+          if (i != NONE && i != k) {
+            if (seg_end_of[i - w.call0] > s.ring_need[k]) return "ring: a call overwrites records of a segment it does not wait for";
+            if (i < s.ovl0[k] || i >= s.ovl1[k]) return "ring: an overwritten call lies outside [ovl0, ovl1)";
+          }
+        }
+        for (uint64_t r = lo; r < hi; ++r) owner[size_t(r)] = k;
+        // the wait must be satisfiable without call k (or anything behind it) having completed: the awaited position ends in front of k's segment
+        if (s.ring_need[k] > s.segments[0].ct0 && s.ring_need[k] != 0) {
+          // the segment that ends at ring_need[k] must end at or before the first call of k's own segment
+          uint64_t first_ct_of_own_seg = 0;
+          for (uint32_t q = w.seg0; q < w.seg1; ++q) if (s.segments[q].call0 == seg_first_of[k - w.call0]) first_ct_of_own_seg = s.segments[q].ct0;
+          if (s.ring_need[k] > first_ct_of_own_seg) return "ring: a call waits for its own segment (ring too small)";
+        }
+      }
+    }
+  }
   return std::string();
 }
 

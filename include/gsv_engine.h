@@ -204,7 +204,14 @@ int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_ins
  *                         max_concurrent_calls = 1 is the safe mode: every call depends on its predecessor only.
  *   window_ct_records     ciphertext records per instance of one window = ONE launch = the device block of a session that does not
  *                         retain the stream; independent call chains only overlap inside a window, so windows want to be large;
- *                         0 = 40 % of the free device memory, at most 2^31 records (32 GB) per instance
+ *                         0 = 40 % of the free device memory, at most 48 GB over all instances and 2^31 records.
+ *                         With GSV_CT_RING=1 in the environment when the session is created, 0 instead means the whole pass as ONE
+ *                         window over a ciphertext RING of three drain segments (sessions with max_concurrent_calls != 1 whose
+ *                         stream is longer than the ring; 3 GB instead of 48 for one instance): a garbling call waits until what
+ *                         its block of the ring held on the previous lap has been taken off the device, an evaluating call until its
+ *                         segment has been uploaded — the host publishes its stream position in mapped host memory.  Same pass time
+ *                         as large windows, so it is opt-in.  gsv_session_garble_evaluate pairs need plain windows
+ *                         (an explicit value)
  *   max_scratch_slots     16-byte slots per instance for the ring the calls' scratch regions are carved from; 0 = chosen from the
  *                         free device memory
  *   max_window_calls      0 = 32768 (a launch holds at most 65535 calls)
@@ -227,6 +234,7 @@ typedef struct gsv_plan_schedule_info {
   uint64_t window_ct_records;               /* largest window, ciphertext records per instance */
   uint64_t critical_steps, total_steps;     /* device steps: sum over batches of the longest call / sum over all calls */
   uint64_t n_segments, segment_ct_records;  /* drain segments of the whole schedule; largest segment, ciphertext records per instance */
+  uint64_t ct_ring_records;                 /* 0, or the size of the device's ciphertext ring (records per instance): see window_ct_records */
 } gsv_plan_schedule_info;
 int gsv_session_plan_schedule_info(const gsv_session* s, gsv_plan_schedule_info* info);
 /* Window `window` of the session's schedule: calls [first_call, first_call + n_calls) of the plan.  Slices handed to

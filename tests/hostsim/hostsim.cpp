@@ -226,8 +226,16 @@ static uint32_t plan_n_globals(const BuiltPlan& bp) {
 // way the device may — window by window, inside a window ANY order the dependencies allow: here always the ready call with the
 // LARGEST stream index, all calls in one shared scratch ring.  info: n_windows n_dependencies max_width scratch_slots
 // critical_steps total_steps max_window_ct.
-static uint64_t g_segment_ct = 0;  // hostsim_set_segment_ct: SchedParams::segment_ct of the next hostsim_plan_schedule
+static uint64_t g_segment_ct = 0, g_ring_ct = 0;  // hostsim_set_segment_ct / _ring_ct: SchedParams::segment_ct / ring_ct of the next hostsim_plan_schedule
 void hostsim_set_segment_ct(uint64_t v) { g_segment_ct = v; }
+void hostsim_set_ring_ct(uint64_t v) { g_ring_ct = v; }
+// ring tables of the last schedule: per call {ring_off, ring_need, seg_end, ovl0, ovl1}
+uint64_t hostsim_plan_ring(SimPlan* sp, uint64_t* out, uint64_t cap) {
+  const Schedule& sc = sp->sched;
+  if (!sc.ring_ct) return 0;
+  for (size_t k = 0; k < sc.ring_off.size() && out && k < cap; ++k) { out[5 * k] = sc.ring_off[k]; out[5 * k + 1] = sc.ring_need[k]; out[5 * k + 2] = sc.seg_end[k]; out[5 * k + 3] = sc.ovl0[k]; out[5 * k + 4] = sc.ovl1[k]; }
+  return sc.ring_off.size();
+}
 // The drain segments of the last schedule: per segment {window, call0, call1, ct0, n_ct}; returns their number (out may be NULL).
 uint64_t hostsim_plan_segments(SimPlan* sp, uint64_t* out, uint64_t cap) {
   const Schedule& sc = sp->sched;
@@ -252,6 +260,7 @@ int hostsim_plan_schedule(SimPlan* sp, uint32_t max_calls, uint64_t max_slots, u
     p.max_calls_in_flight = max_calls; p.max_scratch_slots = max_slots ? max_slots : ~0ull; p.max_window_ct = window_ct ? window_ct : ~0ull;
     p.max_window_calls = window_calls ? window_calls : 32768;
     p.segment_ct = g_segment_ct;
+    p.ring_ct = g_ring_ct;
     const uint32_t n_ids = plan_n_globals(bp);
     sp->sched = schedule_calls(calls, n_ids, bp.outputs, p);
     const std::string err = verify_schedule(calls, n_ids, bp.outputs, sp->sched);

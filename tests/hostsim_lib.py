@@ -159,6 +159,22 @@ class SimPlan:
             raise RuntimeError(lib().hostsim_last_error().decode())
         return dict(zip(["n_windows", "n_dependencies", "max_width", "scratch_slots", "critical_steps", "total_steps", "max_window_ct"], (int(x) for x in info)))
 
+    def ring(self, segment_ct, ring_ct, **kw):
+        """schedule(**kw) with drain segments and a ciphertext ring of `ring_ct` records (schedule.hpp, SchedParams::ring_ct; the
+        schedule's own verification simulates the ring record by record).  Returns (info, segments, [(ring_off, ring_need, seg_end, ovl0, ovl1)] per call)."""
+        lib().hostsim_set_ring_ct.argtypes = [C.c_uint64]
+        lib().hostsim_plan_ring.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64]
+        lib().hostsim_plan_ring.restype = C.c_uint64
+        lib().hostsim_set_ring_ct(ring_ct)
+        try:
+            info, segs = self.segments(segment_ct, **kw)
+        finally:
+            lib().hostsim_set_ring_ct(0)
+        n = int(lib().hostsim_plan_ring(self.h, None, 0))
+        out = np.zeros((n, 5), np.uint64)
+        lib().hostsim_plan_ring(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), n)
+        return info, segs, [tuple(int(x) for x in row) for row in out]
+
     def segments(self, segment_ct, **kw):
         """schedule(**kw) with drain segments of at most `segment_ct` ciphertext records (schedule.hpp, SchedParams::segment_ct):
         returns (schedule info, [(window, call0, call1, ct0, n_ct)])."""

@@ -742,6 +742,70 @@ def test_generic_ciphertext_sink_and_source(engine):
     ps.close()
 
 
+def test_ciphertext_ring_whole_pass_in_one_window(engine, tmp_path, monkeypatch):
+    """GSV_CT_RING=1: sessions that do not retain the stream run the WHOLE pass as one launch — the scope in which an instance's independent call
+    chains overlap — over a ciphertext RING of a few drain segments (schedule.hpp, SchedParams::ring_ct): a garbling call waits on the
+    device until what its block of the ring held on the previous lap has been gathered off the device, an evaluating call until its
+    segment has been uploaded; the host publishes its stream position in mapped host memory.  fq12_mix with Fq2-level units (14 M
+    ciphertexts) through a ring of ~1.6 M records (nine laps; sized by GSV_CT_RING_RECORDS here, by the free memory in production): the
+    stream through a sink, the CBC-MACs, gc files, the discarding form, evaluation from the files and from a source — everything equal
+    to the oracle's flat stream, twice over the same sessions."""
+    import garbled_snark_verifier_amd as gsv
+    monkeypatch.setenv("GSV_CT_RING", "1")
+    monkeypatch.setenv("GSV_CT_RING_RECORDS", "1000000")
+    plan = gsv.Plan.from_circuit("fq12_mix", FINE_UNITS)
+    seeds = [101, 102, 103]
+    B, n_in = len(seeds), plan.info["n_inputs"]
+    labs = [gsv.labels_from_seed(s, n_in) for s in seeds]
+    delta = np.stack([x[0] for x in labs]); consts = np.stack([np.stack([x[1], x[2]]) for x in labs]); inputs = np.stack([x[3] for x in labs])
+    refs = [o.garble("fq12_mix", s) for s in seeds]
+    n_ct = plan.info["n_ciphertexts"]
+    kw = dict(retain_stream=False, concurrent_calls=16, drain_segment_records=300_000)
+    st = gsv.Session(engine, plan, B, **kw)
+    si = st.schedule_info()
+    assert si["n_windows"] == 1 and si["ct_ring_records"] >= 1_000_000 and si["ct_ring_records"] * 5 < n_ct and si["n_segments"] > 20
+    gc = str(tmp_path)
+    for rep in range(2):
+        st.set_garble_inputs(delta, consts, inputs)
+        got = [np.zeros((n_ct, 16), np.uint8) for _ in range(B)]
+
+        def handler(inst, first, recs):
+            got[inst][first:first + recs.shape[0]] = recs
+
+        hashes = st.garble_to_sink(handler, threads=2, with_hashes=True)
+        out = st.read_outputs()
+        for i in range(B):
+            assert (got[i] == refs[i].ciphertexts).all() and hashes[i] == refs[i].ct_hash.tobytes() and (out[i] == refs[i].output_label0).all()
+    st.set_garble_inputs(delta, consts, inputs)
+    assert st.garble_streaming(directory=gc, first_index=5, threads=2) == [r.ct_hash.tobytes() for r in refs]
+    st.set_garble_inputs(delta, consts, inputs)
+    st.garble_streaming(discard=True)  # nothing leaves the device: every block of the ring is free at once
+    assert (st.read_outputs() == np.stack([r.output_label0 for r in refs])).all()
+    # the evaluator: the window is launched first, its calls wait for their segments' uploads
+    bits = np.random.default_rng(11).integers(0, 2, size=(B, n_in)).astype(np.uint8)
+    active = np.where(bits[:, :, None] == 1, inputs ^ delta[:, None, :], inputs)
+    ca = np.stack([consts[:, 0], consts[:, 1] ^ delta], axis=1)
+    es = gsv.Session(engine, plan, B, **kw)
+    assert es.schedule_info()["ct_ring_records"] == si["ct_ring_records"]
+    for how in ("files", "source", "files"):
+        es.set_evaluate_inputs(ca, active, bits)
+        fh = es.evaluate_streaming(gc, first_index=5) if how == "files" else es.evaluate_from_source(lambda inst, first, n: got[inst][first:first + n])
+        oa, ob = es.read_outputs(with_bits=True)
+        for i in range(B):
+            eb, _, _ = o.execute("fq12_mix", bits[i])
+            assert fh[i] == refs[i].ct_hash.tobytes() and (ob[i] == eb).all()
+            assert (oa[i] == np.where(ob[i][:, None] == 1, refs[i].output_label0 ^ delta[i][None, :], refs[i].output_label0)).all()
+    # a source that runs dry in the middle of the pass: the error comes back and the launch does not hang
+    es.set_evaluate_inputs(ca, active, bits)
+    with pytest.raises(gsv.GsvError, match="exhausted"):
+        es.evaluate_from_source(lambda inst, first, n: None if first + n > n_ct // 2 else got[inst][first:first + n])
+    # a pair needs explicit windows
+    with pytest.raises(gsv.GsvError, match="window"):
+        st.garble_evaluate(es)
+    es.close(); st.close()
+    plan.close()
+
+
 def test_garble_and_evaluate_side_by_side_on_the_device(engine):
     """examples/groth16_garble.rs:171-230 / tests/garbler_evaluator_connection.rs:64-172: the garbler feeds the evaluator while it
     garbles.  gsv_session_garble_evaluate: window k of the garbler's device block is evaluated on a second stream while window k+1 is
