@@ -70,6 +70,8 @@ static int dev_alloc(void** p, size_t bytes, const char* what) {
 // side stream that lands on the main stream's queue would sit behind the running window — which, with a ciphertext ring, itself waits
 // for that side stream's work (observed: the ring stalls until the device watchdog fires, depending on how many streams the process
 // had created before).  Streams of another priority level come from another pool of hardware queues, so these ask for the highest.
+// (Not for the evaluator of a garble -> evaluate pair: two long launches on queues of DIFFERENT priority, whichever way round, took
+// 46.5 s for the verifier instead of 42.9 s on equal terms — ensure_pair probes for a stream of the same priority that overlaps.)
 static hipError_t create_side_stream(hipStream_t* st) {
   int least = 0, greatest = 0;
   const char* off = getenv("GSV_SIDE_STREAM_PRIORITY");
@@ -1042,7 +1044,8 @@ static Schedule make_schedule(const gsv_plan* plan, uint32_t ni, size_t n_instan
   if (o.retain_stream) sp.max_window_ct = ~0ull;
   else {
     // Default for sessions that do not retain the stream: the device block (= one window, the scope inside which independent call chains
-    // overlap: schedule.hpp) takes up to 40 % of the free memory, at most 2^31 records (32 GB) per instance.  The stream leaves the
+    // overlap: schedule.hpp) takes up to 40 % of the free memory, at most 48 GB over all instances (one instance of the verifier, 47.7 GB
+    // of ciphertexts, is ONE window: 26.7 s instead of the 27.6 s of two — profiles/r04_e2e/verifier_mixed_units.log).  The stream leaves the
     // device in SEGMENTS of a window (below), so a large window costs the drain nothing.  Round 3's default cut one instance's pass into
     // 2 windows and drained whole windows (48.2 s with the commitment: half of the 27-s CBC-MAC chain uncovered); 46 windows of 1 GB hid
     // the chain but cost the garbling 4.7 s — the verifier's line-coefficient chain precedes the Miller loop in stream order and only
@@ -1050,7 +1053,7 @@ static Schedule make_schedule(const gsv_plan* plan, uint32_t ni, size_t n_instan
     // (... and at most 48 GB over all instances: device memory that has been freed is scrubbed before it is handed out again, ~25 GB/s,
     // so a session of 16 instances with a 96-GB block took 6 s to create; its garbling is 3 % faster with 6-GB windows than with 2-GB ones)
     const double block_bytes = std::min(double(free_bytes) * 0.4, 48e9);
-    uint64_t w = o.window_ct_records ? o.window_ct_records : std::min<uint64_t>(uint64_t(block_bytes / 16.0 / double(std::max<size_t>(1, n_instances))), 1ull << 31);
+    uint64_t w = o.window_ct_records ? o.window_ct_records : uint64_t(block_bytes / 16.0 / double(std::max<size_t>(1, n_instances)));
     if (!o.window_ct_records && conc == 1) w = 0;  // sequential sessions keep the one-call block of rounds 1-2 (smallest footprint)
     sp.max_window_ct = std::max<uint64_t>(w, max_block);
   }
@@ -1610,7 +1613,28 @@ static int ensure_pair(gsv_session* s) {
   if (!s->ct_alt) DEVALLOC(&s->ct_alt, s->n_inst * size_t(s->ct_stride()) * 16, "the second ciphertext block (garble -> evaluate)");
   if (!s->pair) {
     std::unique_ptr<PairState> ps(new PairState());
-    HIPCHK(create_side_stream(&ps->stream));
+    // The evaluator's stream: same priority as the engine's, on ANOTHER hardware queue.  Which queue a new stream lands on is the
+    // runtime's business (round-robin over a few), so every candidate is probed — a one-thread kernel on the engine's stream waits up to
+    // 5 ms for a one-thread kernel on the candidate — and the ones that queue up behind the engine's stream are kept alive until a
+    // good one is found (the round-robin moves on), then destroyed.  No overlapping stream among eight: the last one serves (the pair
+    // is still correct, window k is then evaluated after window k+1 has been garbled instead of beside it).
+    {
+      std::vector<hipStream_t> rejected;
+      uint32_t* const word = static_cast<uint32_t*>(s->d_error) + 4;
+      for (int attempt = 0; attempt < 8 && !ps->stream; ++attempt) {
+        hipStream_t cand = nullptr;
+        if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
+        uint32_t result[2] = {0, 0};
+        const bool probed = hipMemsetAsync(word, 0, 8, s->e->stream) == hipSuccess && hipStreamSynchronize(s->e->stream) == hipSuccess &&
+                            gsvk_probe_overlap(word, 500000ull, s->e->stream, cand) == 0 && hipStreamSynchronize(cand) == hipSuccess &&
+                            hipStreamSynchronize(s->e->stream) == hipSuccess && hipMemcpy(result, word, 8, hipMemcpyDeviceToHost) == hipSuccess;
+        if (!probed || result[1] == 1u || attempt == 7) ps->stream = cand;
+        else rejected.push_back(cand);
+        if (getenv("GSV_DRAIN_DEBUG")) std::fprintf(stderr, "garble -> evaluate: candidate stream %d %s\n", attempt, !probed ? "could not be probed" : result[1] == 1u ? "overlaps the engine's stream" : "queues behind the engine's stream");
+      }
+      for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+      if (!ps->stream) return fail(GSV_ERR_DEVICE, "cannot create the evaluator's stream");
+    }
     for (int b = 0; b < 2; ++b) {
       HIPCHK(hipEventCreateWithFlags(&ps->garbled[b], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&ps->evaluated[b], hipEventDisableTiming));

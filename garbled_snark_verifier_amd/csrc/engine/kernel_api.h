@@ -102,6 +102,9 @@ int gsvk_permute_ciphertexts(void* stream, const void* ct_pos, uint64_t n_ct, ui
 int gsvk_gather_segment(void* ring, uint64_t ring_stride, const void* ct_pos, uint64_t n_ct, uint32_t n_rep, uint32_t n_instances, void* out,
                         uint64_t out_stride, int scatter, hipStream_t s);
 // W[inst][dst[i]] = W[inst][src[i]] (and the plaintext bits when VB != null) for every instance: wire hand-over between the calls of a plan
+// word[0] = 0 before the call; a one-thread kernel on `first` waits up to `ticks` (100 MHz) for the one-thread kernel on `second` to set it
+// and leaves word[1] = 1 (the two streams run side by side) or 2 (the second launch waited behind the first: one hardware queue)
+int gsvk_probe_overlap(void* word, unsigned long long ticks, hipStream_t first, hipStream_t second);
 int gsvk_copy_slots(void* W, void* VB, uint32_t n_slots, const uint32_t* src, const uint32_t* dst, uint32_t n, uint32_t n_instances, hipStream_t s);
 int gsvk_scatter_bits(void* VB, uint32_t n_slots, uint32_t first_slot, const void* bits, uint32_t n, uint32_t n_instances, hipStream_t stream);
 }

@@ -718,6 +718,17 @@ __global__ void gather_segment_kernel(uint4* ring, uint64_t ring_stride, const u
   }
 }
 
+// Do two streams run side by side?  (engine.cpp, streams_overlap: the runtime multiplexes streams onto a few hardware queues, in order
+// within a queue.)  One thread waits — bounded — for a word the other kernel, launched on the other stream AFTER it, sets:
+// result 1 = saw it (the streams overlap), 2 = gave up (the second launch sat behind this one).
+__global__ void probe_wait_kernel(uint32_t* word, unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  uint32_t seen = 0;
+  while (!(seen = __hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+  word[1] = seen ? 1u : 2u;
+}
+__global__ void probe_set_kernel(uint32_t* word) { __hip_atomic_store(word, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
 }  // namespace dev
 }  // namespace gsv
 
@@ -800,6 +811,13 @@ int gsvk_scatter_bits(void* VB, uint32_t n_slots, uint32_t first_slot, const voi
   dim3 grid((n + 255) / 256, n_instances);
   hipLaunchKernelGGL(gsv::dev::scatter_bits_kernel, grid, dim3(256), 0, stream, static_cast<uint8_t*>(VB), n_slots, first_slot,
                      static_cast<const uint8_t*>(bits), n);
+  return int(hipGetLastError());
+}
+
+int gsvk_probe_overlap(void* word, unsigned long long ticks, hipStream_t first, hipStream_t second) {
+  hipLaunchKernelGGL(gsv::dev::probe_wait_kernel, dim3(1), dim3(1), 0, first, static_cast<uint32_t*>(word), ticks);
+  if (hipGetLastError() != hipSuccess) return 1;
+  hipLaunchKernelGGL(gsv::dev::probe_set_kernel, dim3(1), dim3(1), 0, second, static_cast<uint32_t*>(word));
   return int(hipGetLastError());
 }
 

@@ -204,7 +204,7 @@ int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_ins
  *                         max_concurrent_calls = 1 is the safe mode: every call depends on its predecessor only.
  *   window_ct_records     ciphertext records per instance of one window = ONE launch = the device block of a session that does not
  *                         retain the stream; independent call chains only overlap inside a window, so windows want to be large;
- *                         0 = 40 % of the free device memory, at most 48 GB over all instances and 2^31 records.
+ *                         0 = 40 % of the free device memory, at most 48 GB over all instances (one instance of the verifier: one window).
  *                         With GSV_CT_RING=1 in the environment when the session is created, 0 instead means the whole pass as ONE
  *                         window over a ciphertext RING of three drain segments (sessions with max_concurrent_calls != 1 whose
  *                         stream is longer than the ring; 3 GB instead of 48 for one instance): a garbling call waits until what
