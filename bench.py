@@ -207,14 +207,14 @@ def timed_steps(work, slices, warmup, steps, dist, sync, time_budget_s=None, t_s
 class VerifierWork:
     """`B` instances of the verifier plan on one GPU (the object timed_steps drives).  seeds[i] seeds instance i."""
 
-    def __init__(self, gsv, engine, plan, B, seeds, **session_kw):
+    def __init__(self, gsv, engine, plan, B, seeds, retain_stream=False, **session_kw):
         import numpy as np
         self.np, self.gsv, self.plan, self.B = np, gsv, plan, B
         n_in = plan.info["n_inputs"]
         self.delta = np.zeros((B, 16), np.uint8); self.consts = np.zeros((B, 2, 16), np.uint8); self.inputs = np.zeros((B, n_in, 16), np.uint8)
         for i, sd in enumerate(seeds):
             self.delta[i], self.consts[i, 0], self.consts[i, 1], self.inputs[i] = gsv.labels_from_seed(sd, n_in)
-        self.sess = gsv.Session(engine, plan, B, retain_stream=False, **session_kw)
+        self.sess = gsv.Session(engine, plan, B, retain_stream=retain_stream, **session_kw)  # False: windows; "ring": one launch over a ciphertext ring
         self.seeds = seeds
         self.ct_hashes = None  # set by a pass that drained and MAC'ed the stream
 
@@ -251,7 +251,7 @@ class VerifierWork:
         self.sess.close()
 
 
-def _plan_cache_path(args, circuit, units):
+def _plan_cache_path(args, circuit, units, window_div=4):
     if args.no_plan_cache:
         return None
     if os.environ.get("GSV_PLAN_FILE"):  # experiments: one plan file for several engine builds (the key below includes the library)
@@ -260,7 +260,7 @@ def _plan_cache_path(args, circuit, units):
     h = hashlib.sha256()
     with open(b.build(), "rb") as f:
         h.update(f.read())  # the file format and the compiler live in the library: any rebuild invalidates the cache
-    h.update(("|".join([circuit, ",".join(units), "window/4"])).encode())
+    h.update(("|".join([circuit, ",".join(units), "window/%d" % window_div])).encode())
     name = "plan_%s.gsvplan" % h.hexdigest()[:24]
     cands = [args.plan_cache] if args.plan_cache else [os.environ.get("GSV_PLAN_CACHE"), "/dev/shm", "/tmp"]
     for d in cands:
@@ -283,13 +283,13 @@ def _plan_cache_path(args, circuit, units):
     return None
 
 
-def get_plan(gsv, engine, args, circuit, units, rank, local_rank, local_world, dist, log):
+def get_plan(gsv, engine, args, circuit, units, rank, local_rank, local_world, dist, log, window_div=4):
     """Local rank 0 loads the node's plan file or builds the plan straight into that file; every rank of the node then streams the
     file into its GPU's memory (without a cache directory a single rank builds the plan in memory).  Returns (plan, {how, seconds, ...}, save_later).  A failure on any rank is
     agreed on by all (min over ranks) before anyone waits in a barrier: every rank exits non-zero together."""
-    path = _plan_cache_path(args, circuit, units)
+    path = _plan_cache_path(args, circuit, units, window_div)
     t0 = time.time()
-    info = {"cache_file": path}
+    info = {"cache_file": path, "window_div": window_div}
     plan, save_later, err = None, None, None
     if local_rank == 0:
         try:
@@ -302,14 +302,14 @@ def get_plan(gsv, engine, args, circuit, units, rank, local_rank, local_world, d
                     # host never holds the 41 GB of records (gsv_plan_build_file: ~25 GB peak instead of ~54 GB); then every rank —
                     # this one too — streams the file into its GPU's memory
                     t1 = time.time()
-                    gsv.Plan.build_file(circuit, units, path, window_div=4)  # one image per program, good for 1, 2 and 4 instances per workgroup
+                    gsv.Plan.build_file(circuit, units, path, window_div=window_div)  # one image per program: 4 = good for 1, 2 and 4 instances per workgroup
                     info["build_s"] = time.time() - t1
                     plan = gsv.Plan.load(path, engine)
                     info["how"] = "built to file, loaded"
                 else:
                     if local_world > 1:
                         raise RuntimeError("no directory with room for the plan file the other ranks load (set --plan-cache)")
-                    plan = gsv.Plan.from_circuit(circuit, units, window_div=4)  # no directory for a plan file: ~54 GB of host memory
+                    plan = gsv.Plan.from_circuit(circuit, units, window_div=window_div)  # no directory for a plan file: ~54 GB of host memory
                     info["how"] = "built"
         except Exception as e:  # noqa: BLE001
             err = e
@@ -543,7 +543,9 @@ def run_verifier(args):
     plan_small, plan_small_info = None, None
     if extras and compressed and args.small_batch_units == "fq6" and args.units == "fq12" and not (args.no_rate_by_instances and args.no_cc16 and args.no_mode_rates):
         try:
-            plan_small, plan_small_info, _ = get_plan(gsv, engine, args, case["circuit"], SMALL_BATCH_UNITS + ["fp254::exp_chunk"], rank, local_rank, local_world, dist, log)
+            # (its programs keep the FULL LDS label window — window_div 1, one instance per workgroup, which is what 1 and 16 instances run:
+            # 3 % faster steps than the quarter-window image the full GPU's four instances per workgroup need)
+            plan_small, plan_small_info, _ = get_plan(gsv, engine, args, case["circuit"], SMALL_BATCH_UNITS + ["fp254::exp_chunk"], rank, local_rank, local_world, dist, log, window_div=1)
             log("bench.py: small-batch plan (Fq6-level units) %s in %.1f s (%d calls)" % (plan_small_info["how"], plan_small_info["seconds"], plan_small.info["n_calls"]))
         except Exception as e:  # noqa: BLE001 - the legs fall back to the headline's plan
             plan_small, plan_small_info = None, {"error": repr(e)}
@@ -626,7 +628,10 @@ def run_verifier(args):
                 if time.time() - T_START > args.time_budget * 0.55:
                     rbi[str(Bi)] = {"skipped": "time budget"}
                     continue
-                w = VerifierWork(gsv, engine, plan_sb if Bi <= 16 else plan, Bi, [case["seed"]] + instance_seeds(rank, Bi)[1:])
+                # sixteen instances: the session as a ciphertext RING (gsv_plan_session_opts.retain_stream = GSV_STREAM_RING) — the whole pass one
+                # launch, so the instances' independent call chains overlap as far as one instance's do; sixteen default windows cannot each
+                # be as large as one instance's (17 launches, +12 % depth): that figure follows as "default_windows"
+                w = VerifierWork(gsv, engine, plan_sb if Bi <= 16 else plan, Bi, [case["seed"]] + instance_seeds(rank, Bi)[1:], retain_stream="ring" if Bi == 16 else False)
                 try:
                     si = w.sess.schedule_info()
                     if whole:
@@ -648,6 +653,15 @@ def run_verifier(args):
                                     "plan_units": "fq6 (small-batch plan, %d calls)" % plan_small.info["n_calls"] if (plan_small is not None and Bi <= 16) else "fq12 (%d calls)" % n_calls,
                                     "max_width": si["max_width"], "windows": si["n_windows"], "depth_steps": si["critical_steps"], "total_steps": si["total_steps"]}
                     log("bench.py: %d instance(s): %.3g gates/s" % (Bi, g * Bi / dt))
+                    if Bi == 16:
+                        rbi["16"]["ciphertext_ring_records"] = si["ct_ring_records"]
+                        if time.time() - T_START < args.time_budget * 0.5:
+                            w.close()
+                            w = VerifierWork(gsv, engine, plan_sb, Bi, [case["seed"]] + instance_seeds(rank, Bi)[1:])
+                            dtw, siw = w.run_pass(), w.sess.schedule_info()
+                            rbi["16"]["default_windows"] = {"gates_per_s": gates * Bi / dtw, "seconds": dtw, "windows": siw["n_windows"], "depth_steps": siw["critical_steps"],
+                                                            "output_label_match": hashlib.sha256(w.sess.read_outputs()[0].tobytes()).hexdigest() == case["output_label0_sha256"]}
+                            log("bench.py: 16 instances in default windows: %.3g gates/s" % (gates * Bi / dtw))
                     if Bi == 1 and time.time() - T_START < args.time_budget * 0.45:
                         # BASELINE's single-instance target is stated WITH the ciphertext hash: the same pass again, the stream drained and
                         # folded into ONE serial CBC-MAC chain on one host core (the chain, ~1.1e8 blocks/s = 27 s, is nearly as long as the

@@ -17,7 +17,7 @@ opaque!(GsvRecorder, GsvProgram, GsvEngine, GsvSession, GsvPlan, GsvPlanRecorder
 
 #[repr(C)]
 pub struct GsvPlanSessionOpts {
-    pub retain_stream: c_int,
+    pub retain_stream: c_int, // 0 = windows, 1 = the whole stream stays on the device, 2 = GSV_STREAM_RING (one launch over a ciphertext ring)
     pub max_concurrent_calls: u32,
     pub window_ct_records: u64,
     pub max_scratch_slots: u64,

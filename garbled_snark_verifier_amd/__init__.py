@@ -370,8 +370,8 @@ class Plan:
     def build_file(spec, units, path, window_div=4):
         """Build the plan of a built-in circuit straight into the plan file `path` (gsv_plan_build_file): every program is written
         by the worker that compiled it and dropped from memory.  Load it with Plan.load(path, engine)."""
-        if int(window_div) not in (2, 4):
-            raise ValueError("window_div must be 2 or 4 (one image per program)")
+        if int(window_div) not in (1, 2, 4):
+            raise ValueError("window_div must be 1, 2 or 4 (one image per program; 1 = full LDS window, one instance per workgroup only)")
         saved = {k: os.environ.get(k) for k in ("GSV_PLAN_WINDOW_DIV", "GSV_PLAN_HALF_WINDOW")}
         os.environ["GSV_PLAN_WINDOW_DIV"] = str(int(window_div))
         os.environ.pop("GSV_PLAN_HALF_WINDOW", None)
@@ -526,15 +526,16 @@ class Session:
 
     def __init__(self, engine, program, n_instances=1, replays=1, ct_capacity_replays=None, retain_stream=True, concurrent_calls=0, window_ct_records=0,
                  max_scratch_slots=0, max_window_calls=0, drain_segment_records=0):
-        """Plan sessions: concurrent_calls = how many independent calls of the plan may run side by side (0: as many as give every CU a
-        workgroup, 1: sequential); window_ct_records / max_scratch_slots / max_window_calls: see gsv_plan_session_opts (0 = automatic)."""
+        """Plan sessions: retain_stream = True (the whole stream stays on the device), False (one window of it) or "ring" (GSV_STREAM_RING:
+        the whole pass as one launch over a ciphertext ring); concurrent_calls = how many independent calls of the plan may run side by
+        side (0: as many as give every CU a workgroup, 1: sequential); window_ct_records / max_scratch_slots / max_window_calls: see gsv_plan_session_opts (0 = automatic)."""
         self.engine, self.program = engine, program
         self.n, self.replays = n_instances, replays
         self.ct_cap = replays if ct_capacity_replays is None else ct_capacity_replays
         self.h = C.c_void_p()
         if isinstance(program, Plan):
             assert replays == 1
-            o = _PlanSessionOpts(int(bool(retain_stream)), int(concurrent_calls), int(window_ct_records), int(max_scratch_slots), int(max_window_calls), int(drain_segment_records))
+            o = _PlanSessionOpts(2 if retain_stream == "ring" else int(bool(retain_stream)), int(concurrent_calls), int(window_ct_records), int(max_scratch_slots), int(max_window_calls), int(drain_segment_records))
             _chk(lib().gsv_session_create_plan_opts(engine.h, program.h, n_instances, C.byref(o), C.byref(self.h)))
         else:
             _chk(lib().gsv_session_create(engine.h, program.h, n_instances, replays, self.ct_cap, C.byref(self.h)))

@@ -542,8 +542,9 @@ static int plan_from_circuit_impl(const char* spec, const char* units_csv, const
   // GSV_PLAN_HALF_WINDOW=1 is the older spelling of GSV_PLAN_WINDOW_DIV=2.
   uint32_t window_div = 1;
   { int rc = plan_window_div(&window_div); if (rc) return rc; }
-  const bool single_image = window_div > 1;
-  if (sink && !single_image) return fail(GSV_ERR_INVALID, "a plan is built straight to a file only with one image per program (GSV_PLAN_WINDOW_DIV=2|4)");
+  // (a plan built straight into a file keeps ONE image per program and no trace: with GSV_PLAN_WINDOW_DIV=1 that image has the full LDS
+  // window and serves one instance per workgroup only — the small-batch plan of bench.py: 3 % faster steps for 1 and 16 instances)
+  const bool single_image = window_div > 1 || bool(sink);
   mode.cache()->sink = sink;
   if (single_image) opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / window_div);
   mode.compile_in_background(opt, single_image);  // units are compiled while the driver records the rest of the circuit
@@ -1034,14 +1035,14 @@ static Schedule make_schedule(const gsv_plan* plan, uint32_t ni, size_t n_instan
   if (!o.max_concurrent_calls) if (const char* ev = getenv("GSV_PLAN_CONCURRENCY")) conc = uint32_t(std::max(1, atoi(ev)));
   // a session that drains its stream leaves a few CUs to the gather kernels that bring finished segments into gate order beside the
   // running window (a workgroup of the garbling kernel takes a whole CU, also while it waits for a dependency)
-  if (!o.max_concurrent_calls && !o.retain_stream && conc > 1 && n_wg * size_t(conc) + 16 > size_t(n_cus)) conc = uint32_t(std::max<size_t>(1, (size_t(n_cus) - std::min<size_t>(16, size_t(n_cus) / 2)) / n_wg));
+  if (!o.max_concurrent_calls && o.retain_stream != 1 && conc > 1 && n_wg * size_t(conc) + 16 > size_t(n_cus)) conc = uint32_t(std::max<size_t>(1, (size_t(n_cus) - std::min<size_t>(16, size_t(n_cus) / 2)) / n_wg));
   sp.max_calls_in_flight = std::min<uint32_t>(conc, 65535u);
   // the scratch ring: at most ~1/16 of the free device memory over all instances, and 2^30 slots (slot offsets are 32 bits)
   uint64_t slots = o.max_scratch_slots ? o.max_scratch_slots : uint64_t(free_bytes / 16 / 16 / std::max<size_t>(1, n_instances));
   sp.max_scratch_slots = std::min<uint64_t>(std::max<uint64_t>(slots, max_slots), 1ull << 30);
   if (conc == 1) sp.max_scratch_slots = max_slots;
   // ciphertext window: the whole stream when it is retained, else about a quarter of the free memory for the two window buffers
-  if (o.retain_stream) sp.max_window_ct = ~0ull;
+  if (o.retain_stream == 1) sp.max_window_ct = ~0ull;
   else {
     // Default for sessions that do not retain the stream: the device block (= one window, the scope inside which independent call chains
     // overlap: schedule.hpp) takes up to 40 % of the free memory, at most 48 GB over all instances (one instance of the verifier, 47.7 GB
@@ -1064,14 +1065,16 @@ static Schedule make_schedule(const gsv_plan* plan, uint32_t ni, size_t n_instan
     if (const char* ev = getenv("GSV_DRAIN_SEGMENT_RECORDS")) if (!o.drain_segment_records) sg = uint64_t(std::max(1ll, atoll(ev)));
     sp.segment_ct = std::min<uint64_t>(std::max<uint64_t>(sg, max_block), sp.max_window_ct);
   }
-  // Ciphertext ring (schedule.hpp), GSV_CT_RING=1: a session that does not retain the stream and runs calls side by side keeps THREE
+  // Ciphertext ring (schedule.hpp), retain_stream = GSV_STREAM_RING or GSV_CT_RING=1 in the environment: a session that does not
+  // retain the stream and runs calls side by side keeps THREE
   // segments' worth of ciphertexts on the device instead of a window's, and the window becomes the whole pass (one instance: 48 GB of
   // device block -> 3.2 GB, 2 windows -> 1; sixteen: 17 windows -> 1 over a 27-GB ring).  Opt-in: with large windows + segments the
   // pass is already bounded by the dependent depth and the host's MAC chain (tools/ring_ab.py: 30.7 s either way for one instance,
   // 32.9 s vs 32.5-33.4 s for sixteen), and a ring makes the running launch WAIT for the host — it must never share a hardware queue
   // with the side streams (create_side_stream).  Not with an explicit window_ct_records (the caller sizes the launches: garble ||
   // evaluate pairs, tests), not for sequential sessions, and not when the whole stream fits the ring anyway.
-  if (!o.retain_stream && !o.window_ct_records && conc > 1 && getenv("GSV_CT_RING") && atoi(getenv("GSV_CT_RING")) == 1) {
+  const bool ring_wanted = o.retain_stream == GSV_STREAM_RING || (o.retain_stream == 0 && getenv("GSV_CT_RING") && atoi(getenv("GSV_CT_RING")) == 1);
+  if (ring_wanted && !o.window_ct_records && conc > 1) {
     uint64_t ring = std::max<uint64_t>(3 * sp.segment_ct, 2 * sp.segment_ct + max_block);
     if (const char* ev = getenv("GSV_CT_RING_RECORDS")) ring = std::max<uint64_t>(uint64_t(std::max(1ll, atoll(ev))), 2 * sp.segment_ct + max_block);  // tests: small rings on small circuits
     if (ring < plan->n_ct && ring <= sp.max_window_ct) { sp.ring_ct = ring; sp.max_window_ct = ~0ull; }
@@ -1125,7 +1128,7 @@ int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_i
   const Schedule& sc = s->sched;
   const uint32_t scratch = uint32_t((std::max<uint64_t>(sc.scratch_slots, SLOT_FIRST_INPUT) + 7) / 8 * 8);
   s->global_base = scratch;
-  s->plan_retain = o.retain_stream != 0;
+  s->plan_retain = o.retain_stream == 1;
   s->ct_ring = sc.ring_ct != 0;
   s->plan_max_block = s->ct_ring ? sc.ring_ct : sc.max_window_ct;
   s->plan_max_segment = sc.max_segment_ct;

@@ -149,7 +149,8 @@ int gsv_plan_save(const gsv_plan* p, const char* path);
 int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out);
 /* gsv_plan_from_circuit + gsv_plan_save without ever holding the plan: each program is appended to the file by the worker that
  * compiled it and its records are released at once, so the build's host memory is the programs still being compiled (the verifier:
- * ~25 GB instead of ~54 GB).  Needs one image per program (GSV_PLAN_WINDOW_DIV=2|4).  Then gsv_plan_load(path, engine). */
+ * ~25 GB instead of ~54 GB).  One image per program: GSV_PLAN_WINDOW_DIV=2|4 as below, or 1 = the full window, for sessions with one
+ * instance per workgroup only (small batches: 3 % faster steps).  Then gsv_plan_load(path, engine). */
 int gsv_plan_build_file(const char* circuit_spec, const char* units_csv, const char* path);
 
 /* Call operands naming the constant wires instead of a global wire. */
@@ -193,7 +194,10 @@ int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_ins
  * / WAR on the global ids) and otherwise runs side by side with the others, each in a scratch region of its own inside the
  * instance's wire file.  Gate ids and ciphertext positions are those of the stream order, so the result is bit-identical to the
  * sequential run.
- *   retain_stream         as gsv_session_create_plan_ex
+ *   retain_stream         as gsv_session_create_plan_ex; GSV_STREAM_RING (2): like 0, and the whole pass is ONE launch over a ciphertext
+ *                         ring (see window_ct_records).  A pass that only garbles (no sink: output labels, device rates) never waits in
+ *                         the ring and gets the single launch's overlap scope for any number of instances (sixteen instances of the
+ *                         verifier: 17 windows -> 1)
  *   max_concurrent_calls  calls of one instance in flight: 0 = as many as give every CU a workgroup (GSV_PLAN_CONCURRENCY overrides);
  *                         1 = sequential (the stream order).
  *                         ASSUMPTION for values > 1: a workgroup that waits for a dependency only waits for workgroups with a smaller
@@ -205,7 +209,8 @@ int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_ins
  *   window_ct_records     ciphertext records per instance of one window = ONE launch = the device block of a session that does not
  *                         retain the stream; independent call chains only overlap inside a window, so windows want to be large;
  *                         0 = 40 % of the free device memory, at most 48 GB over all instances (one instance of the verifier: one window).
- *                         With GSV_CT_RING=1 in the environment when the session is created, 0 instead means the whole pass as ONE
+ *                         With retain_stream = GSV_STREAM_RING (or GSV_CT_RING=1 in the environment when a retain_stream = 0 session
+ *                         is created), 0 instead means the whole pass as ONE
  *                         window over a ciphertext RING of three drain segments (sessions with max_concurrent_calls != 1 whose
  *                         stream is longer than the ring; 3 GB instead of 48 for one instance): a garbling call waits until what
  *                         its block of the ring held on the previous lap has been taken off the device, an evaluating call until its
@@ -219,8 +224,9 @@ int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_ins
  *                         window and take its stream off the device segment by segment (consecutive calls, gate order), so that the host
  *                         side — copies, the serial CBC-MAC chains, files, a sink — works beside the window that is still being garbled;
  *                         0 = 64 M records (1 GB) per instance or less (three gate-order buffers within a tenth of the free memory) */
+#define GSV_STREAM_RING 2
 typedef struct gsv_plan_session_opts {
-  int retain_stream;
+  int retain_stream;                        /* 0 = windows, 1 = the whole stream stays on the device, GSV_STREAM_RING = one launch over a ring */
   uint32_t max_concurrent_calls;
   uint64_t window_ct_records;
   uint64_t max_scratch_slots;

@@ -743,7 +743,7 @@ def test_generic_ciphertext_sink_and_source(engine):
 
 
 def test_ciphertext_ring_whole_pass_in_one_window(engine, tmp_path, monkeypatch):
-    """GSV_CT_RING=1: sessions that do not retain the stream run the WHOLE pass as one launch — the scope in which an instance's independent call
+    """retain_stream = GSV_STREAM_RING (or GSV_CT_RING=1): sessions that do not retain the stream run the WHOLE pass as one launch — the scope in which an instance's independent call
     chains overlap — over a ciphertext RING of a few drain segments (schedule.hpp, SchedParams::ring_ct): a garbling call waits on the
     device until what its block of the ring held on the previous lap has been gathered off the device, an evaluating call until its
     segment has been uploaded; the host publishes its stream position in mapped host memory.  fq12_mix with Fq2-level units (14 M
@@ -751,7 +751,6 @@ def test_ciphertext_ring_whole_pass_in_one_window(engine, tmp_path, monkeypatch)
     stream through a sink, the CBC-MACs, gc files, the discarding form, evaluation from the files and from a source — everything equal
     to the oracle's flat stream, twice over the same sessions."""
     import garbled_snark_verifier_amd as gsv
-    monkeypatch.setenv("GSV_CT_RING", "1")
     monkeypatch.setenv("GSV_CT_RING_RECORDS", "1000000")
     plan = gsv.Plan.from_circuit("fq12_mix", FINE_UNITS)
     seeds = [101, 102, 103]
@@ -760,7 +759,7 @@ def test_ciphertext_ring_whole_pass_in_one_window(engine, tmp_path, monkeypatch)
     delta = np.stack([x[0] for x in labs]); consts = np.stack([np.stack([x[1], x[2]]) for x in labs]); inputs = np.stack([x[3] for x in labs])
     refs = [o.garble("fq12_mix", s) for s in seeds]
     n_ct = plan.info["n_ciphertexts"]
-    kw = dict(retain_stream=False, concurrent_calls=16, drain_segment_records=300_000)
+    kw = dict(retain_stream="ring", concurrent_calls=16, drain_segment_records=300_000)  # gsv_plan_session_opts.retain_stream = GSV_STREAM_RING
     st = gsv.Session(engine, plan, B, **kw)
     si = st.schedule_info()
     assert si["n_windows"] == 1 and si["ct_ring_records"] >= 1_000_000 and si["ct_ring_records"] * 5 < n_ct and si["n_segments"] > 20
@@ -785,7 +784,9 @@ def test_ciphertext_ring_whole_pass_in_one_window(engine, tmp_path, monkeypatch)
     bits = np.random.default_rng(11).integers(0, 2, size=(B, n_in)).astype(np.uint8)
     active = np.where(bits[:, :, None] == 1, inputs ^ delta[:, None, :], inputs)
     ca = np.stack([consts[:, 0], consts[:, 1] ^ delta], axis=1)
-    es = gsv.Session(engine, plan, B, **kw)
+    monkeypatch.setenv("GSV_CT_RING", "1")  # the other way to ask for it: the environment, for sessions created with retain_stream = 0
+    es = gsv.Session(engine, plan, B, **dict(kw, retain_stream=False))
+    monkeypatch.delenv("GSV_CT_RING")
     assert es.schedule_info()["ct_ring_records"] == si["ct_ring_records"]
     for how in ("files", "source", "files"):
         es.set_evaluate_inputs(ca, active, bits)
