@@ -196,7 +196,12 @@ def test_plan_built_straight_to_a_file(tmp_path):
         gsv.Plan.build_file(spec, us, a, window_div=4)
         pa, pr = gsv.Plan.load(a), gsv.Plan.from_circuit(spec, us, window_div=4)
         assert pa.info == pr.info and pa.image_bytes() == pr.image_bytes() and (pa.call_info() == pr.call_info()).all()
+    # window_div = 1: one image with the FULL LDS window (sessions with one instance per workgroup: small batches) — the program images
+    # of the plan built in memory for the full window
+    gsv.Plan.build_file("fq12_mix", units, a, window_div=1)
+    pa, pr = gsv.Plan.load(a), gsv.Plan.from_circuit("fq12_mix", units)
+    assert pa.info == pr.info and pa.image_bytes() == pr.image_bytes() and (pa.call_info() == pr.call_info()).all() and pa.wire_file() == pr.wire_file()
     with pytest.raises(ValueError):
-        gsv.Plan.build_file("fq12_mix", units, a, window_div=1)
+        gsv.Plan.build_file("fq12_mix", units, a, window_div=3)
     with pytest.raises(gsv.GsvError):
         gsv.Plan.build_file("fq12_mix", units, os.path.join(str(tmp_path), "no_such_dir", "x.gsvplan"))
