@@ -756,6 +756,10 @@ def run_verifier(args):
                 lib_sha = hashlib.sha256(fh.read()).hexdigest()
         except Exception:  # noqa: BLE001
             lib_sha = None
+        try:
+            src_sha = _b.source_sha256()  # the same sources built elsewhere give another library hash (paths are compiled in): either match counts
+        except Exception:  # noqa: BLE001
+            src_sha = None
         for cand in sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.endswith("_final")), reverse=True):
             tpath = os.path.join(ROOT, "profiles", cand, "traffic.json")
             if os.path.exists(tpath) and compressed:
@@ -763,11 +767,14 @@ def run_verifier(args):
                     tj = json.load(open(tpath))
                     if int(tj.get("instances_per_gpu", 512)) != B or tj.get("circuit_gates") != gates:  # PMC passes of this very configuration (circuit and batch)
                         continue
-                    if not lib_sha or tj.get("engine_library_sha256") != lib_sha:
-                        traffic_source = "profiles/%s/traffic.json belongs to another engine build (library sha256 differs): not quoted; re-run tools/profile_r04.sh" % cand
+                    same_lib = bool(lib_sha) and tj.get("engine_library_sha256") == lib_sha
+                    same_src = bool(src_sha) and tj.get("engine_source_sha256") == src_sha
+                    if not (same_lib or same_src):
+                        traffic_source = "profiles/%s/traffic.json belongs to another engine build (library and source sha256 differ): not quoted; re-run tools/profile_r04.sh" % cand
                         continue
                     traffic = float(tj["hbm_bytes_per_launch"])
-                    traffic_source = "profiles/%s/traffic.json (separate rocprofv3 --pmc passes of this workload with this very libgsv_engine.so, sha256 %s...; NOT measured in this run)" % (cand, lib_sha[:12])
+                    traffic_source = ("profiles/%s/traffic.json (separate rocprofv3 --pmc passes of this workload with %s; NOT measured in this run)"
+                                      % (cand, "this very libgsv_engine.so, sha256 %s..." % lib_sha[:12] if same_lib else "a library built from these very engine sources, source sha256 %s..." % src_sha[:12]))
                     break
                 except (KeyError, ValueError):
                     pass

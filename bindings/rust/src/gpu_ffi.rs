@@ -37,6 +37,7 @@ pub type GsvCtSinkFn = unsafe extern "C" fn(user: *mut std::ffi::c_void, instanc
 /// CiphertextSource::recv for a run of records (gsv_ct_source_fn): non-zero = the source has run dry.
 pub type GsvCtSourceFn = unsafe extern "C" fn(user: *mut std::ffi::c_void, instance: usize, first_record: u64, records: *mut u8, n_records: u64) -> c_int;
 
+pub const GSV_STREAM_RING: c_int = 2; // GsvPlanSessionOpts::retain_stream: the whole pass as one launch over a ciphertext ring (gsv_engine.h)
 pub const GSV_HASHER_AES: c_int = 0; // AesNiHasher   (src/hashers/mod.rs:54-96)
 pub const GSV_HASHER_BLAKE3: c_int = 1; // Blake3Hasher  (src/hashers/mod.rs:22-51)
 

@@ -31,6 +31,21 @@ def _all_sources():
     return srcs
 
 
+def source_sha256():
+    """sha256 over the engine's sources (path relative to the package + contents, in sorted order).  The same tree gives the same value
+    on any machine and in any directory; the library's own hash does not (build paths are compiled in).  profiles/*/traffic.json carries
+    both, bench.py accepts either as "these counters belong to this build"."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.dirname(HERE)
+    for path in sorted(_all_sources(), key=lambda q: os.path.relpath(q, base)):
+        h.update(os.path.relpath(path, base).replace(os.sep, "/").encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
 def disassemble_kernels(obj=None):
     """gfx950 ISA of the kernels object as text (llvm-objdump of the code object inside the offload bundle)."""
     import shutil

@@ -205,3 +205,16 @@ def test_plan_built_straight_to_a_file(tmp_path):
         gsv.Plan.build_file("fq12_mix", units, a, window_div=3)
     with pytest.raises(gsv.GsvError):
         gsv.Plan.build_file("fq12_mix", units, os.path.join(str(tmp_path), "no_such_dir", "x.gsvplan"))
+
+
+def test_traffic_counters_are_bound_to_the_engine_sources():
+    """profiles/*_final/traffic.json is quoted by bench.py only for the engine it was measured on: by the library's sha256 (the same file)
+    or by the sha256 of the engine's sources (the same tree built on another machine: build paths are compiled into the library).  The
+    source hash depends on relative paths and contents only; the committed file of this round carries both."""
+    import json
+    from garbled_snark_verifier_amd import build as b
+    h = b.source_sha256()
+    assert len(h) == 64 and h == b.source_sha256()
+    finals = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.endswith("_final"))
+    tj = json.load(open(os.path.join(ROOT, "profiles", finals[-1], "traffic.json")))
+    assert len(tj["engine_library_sha256"]) == 64 and len(tj["engine_source_sha256"]) == 64 and tj["hbm_bytes_per_launch"] > 0

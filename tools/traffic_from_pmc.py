@@ -33,6 +33,7 @@ try:
     from garbled_snark_verifier_amd import build as _b
     with open(_b.OUT, "rb") as fh:
         out["engine_library_sha256"] = hashlib.sha256(fh.read()).hexdigest()
+    out["engine_source_sha256"] = _b.source_sha256()  # reproducible across machines and directories, unlike the library's own hash
 except Exception as e:  # noqa: BLE001
     out["engine_library_sha256"] = None
     out["engine_library_sha256_error"] = repr(e)
