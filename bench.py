@@ -800,7 +800,7 @@ def run_verifier(args):
                          # (grid.y = its calls) for all instances of the GPU: `launches_timed` dispatches, what rocprofv3 --kernel-trace counts
                          "kernel": "run_program_kernel<false, %d, 0, FW>" % ni, "launches_timed": n_launch, "kernel_ms_avg": stream_s * 1e3 / max(1, n_launch),
                          "kernel_note": "one kernel, two instantiations: FW = true for the windows that hold a program in the four-wire record form (191 of a pass's 672), false for the others; "
-                                        "kernel_ms_avg is over all window launches = the dispatch-weighted mean of the two rows of profiles/r03_final/kernel_stats.csv",
+                                        "kernel_ms_avg is over all window launches = the dispatch-weighted mean of the two rows of profiles/r04_final/kernel_stats.csv",
                          "algorithmic_bytes_per_launch": g_rank * bytes_per_gate / max(1, n_launch), "bytes_per_gate": bytes_per_gate, "calls_timed": n_calls_timed,
                          "note": "algorithmic-bytes accounting of SURVEY.md §8(d); fusion and the LDS label window keep most of those bytes off HBM, the limit that binds is T-table AES issue (DESIGN.md §3)",
                          "binding_limit": "aes-issue", "aes_ceiling_gates_per_s": AES_CEILING_AND_PER_S / f_nf, "aes_ceiling_frac": (g_rank / stream_s) / (AES_CEILING_AND_PER_S / f_nf)},

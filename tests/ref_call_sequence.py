@@ -80,6 +80,27 @@ def _flatten(x, out):
             _flatten(y, out)
 
 
+def _sig(x):
+    """Structure of a wire argument, cheap to build and hashable: a flat list of n wires is n, a nested one the tuple of its parts."""
+    if isinstance(x, int):
+        return None
+    if all(type(y) is int for y in x):
+        return len(x)
+    return tuple(_sig(y) for y in x)
+
+
+def _const_class(x):
+    """What the SHAPE of a unit's outputs may depend on in an off-circuit argument: its structure and the bit lengths in it, not the
+    values (182 line functions and 1 304 multiplications by constants would otherwise each cost a counting walk of their body).  A unit
+    whose output shape did depend on a value would end up with the wrong arity — which is hashed, so the comparison would fail."""
+    if isinstance(x, int):
+        return x.bit_length()
+    return tuple(_const_class(y) for y in x)
+
+
+_SHAPES = {}  # (unit, structure of the wire arguments, class of the off-circuit arguments) -> shape of the outputs
+
+
 def _install(units):
     """Wrap the unit functions of ref_gadgets (module globals: calls between gadgets go through them) for walks under a ProvCtx."""
     for cpp, name in units.items():
@@ -90,8 +111,11 @@ def _install(units):
         def wrapper(c, *args, _inner=inner, _consts=consts, _nh=nh, _cpp=cpp):
             if not isinstance(c, ProvCtx):
                 return _inner(c, *args)
-            scratch = V.CountCtx()
-            shape = V._shape(_inner(scratch, *[a if i in _consts else scratch.fresh(V._shape(a)) for i, a in enumerate(args)]))
+            key = (_cpp,) + tuple(("k", _const_class(a)) if i in _consts else _sig(a) for i, a in enumerate(args))
+            shape = _SHAPES.get(key)
+            if shape is None:  # the unit's output shape, from a counting walk of its body (memoised there) — not part of THIS walk
+                scratch = V.CountCtx()
+                shape = _SHAPES[key] = V._shape(_inner(scratch, *[a if i in _consts else scratch.fresh(V._shape(a)) for i, a in enumerate(args)]))
             ins = []
             for i, a in enumerate(args):
                 if i not in _consts:
@@ -110,14 +134,14 @@ def _install(units):
         setattr(R, name, wrapper)
 
 
-def walk(units=None, n_pub=1, seed=6):
+def walk(units=None, n_pub=1, seed=6, compressed=True):
     units = dict(UNITS) if units is None else units
     saved = {name: getattr(R, name) for name in units.values()}
     _install(units)
     try:
         inst = V.G.make_instance(n_pub=n_pub, seed=seed)
-        c = ProvCtx(n_inputs=254 * (n_pub + 4) + 3)
-        out = V.groth16_verify_compressed(c, inst)
+        c = ProvCtx(n_inputs=254 * (n_pub + 4) + 3 if compressed else 254 * n_pub + 762 + 1524 + 762)
+        out = (V.groth16_verify_compressed if compressed else V.groth16_verify)(c, inst)
     finally:
         for name, fn in saved.items():
             setattr(R, name, fn)

@@ -407,15 +407,7 @@ def fq12_equal_constant(c, a, b_flat):  # fq12.rs:158-168 -> fq6.rs:136-152 -> f
     return w
 
 
-def groth16_verify_compressed(c, inst):  # groth16.rs:250-268 then :58-110
-    def fq(): return [c.issue() for _ in range(N)]
-    public = [fq() for _ in range(inst["n_pub"])]
-    ax, aflag = fq(), c.issue()
-    bx, bflag = [fq(), fq()], c.issue()
-    cx, cflag = fq(), c.issue()
-    a = decompress_g1(c, ax, aflag)
-    b = decompress_g2(c, bx, bflag)
-    cc = decompress_g1(c, cx, cflag)
+def _verify(c, inst, public, a, b, cc):  # groth16.rs:57-110
     msm_temp = msm(c, public)
     gamma0 = [R.const_wires(0)] * 3
     before = sum(c.counts)
@@ -426,6 +418,27 @@ def groth16_verify_compressed(c, inst):  # groth16.rs:250-268 then :58-110
     f = miller_loop(c, m_aff, cc, a, neg(inst["gamma"]), neg(inst["delta"]), b)
     f = final_exponentiation(c, f)
     return fq12_equal_constant(c, f, [mont(v) for v in inst["alpha_beta"]])
+
+
+def groth16_verify_compressed(c, inst):  # groth16.rs:250-268 then :58-110
+    def fq(): return [c.issue() for _ in range(N)]
+    public = [fq() for _ in range(inst["n_pub"])]
+    ax, aflag = fq(), c.issue()
+    bx, bflag = [fq(), fq()], c.issue()
+    cx, cflag = fq(), c.issue()
+    a = decompress_g1(c, ax, aflag)
+    b = decompress_g2(c, bx, bflag)
+    cc = decompress_g1(c, cx, cflag)
+    return _verify(c, inst, public, a, b, cc)
+
+
+def groth16_verify(c, inst):  # groth16.rs:57-110, inputs in CircuitInput order (:290-318): public scalars, A, B, C as projective wire points
+    def fq(): return [c.issue() for _ in range(N)]
+    public = [fq() for _ in range(inst["n_pub"])]
+    a = [fq(), fq(), fq()]
+    b = [[fq(), fq()] for _ in range(3)]
+    cc = [fq(), fq(), fq()]
+    return _verify(c, inst, public, a, b, cc)
 
 
 def count(n_pub=1, seed=6):

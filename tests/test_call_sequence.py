@@ -20,9 +20,9 @@ def cpp_tool(tmp_path_factory):
     return exe
 
 
-def _cpp_events(exe, units):
+def _cpp_events(exe, units, fixture="groth16_verify_compressed_1pub_golden.json"):
     import json
-    spec = json.load(open(os.path.join(ROOT, "tests", "golden", "groth16_verify_compressed_1pub_golden.json")))["circuit"]
+    spec = json.load(open(os.path.join(ROOT, "tests", "golden", fixture)))["circuit"]
     out = subprocess.run([exe, spec] + list(units), check=True, capture_output=True, text=True).stdout
     return [(ln.rsplit(" ", 1)[0], int(ln.rsplit(" ", 1)[1], 16)) for ln in out.splitlines()]
 
@@ -53,6 +53,17 @@ def test_verifier_call_sequence_equals_the_independent_restatement(cpp_tool, mon
     bad, _ = S.walk()
     d = _first_difference(cpp, bad)
     assert d is not None and 0 < d < len(cpp) - 1 and cpp[:d] == bad[:d] and bad[-1] != cpp[-1]
+
+
+@pytest.mark.slow
+def test_uncompressed_verifier_call_sequence(cpp_tool):
+    """`groth16_verify` (groth16.rs:57-110; two public inputs, the proof's points as projective wire points, no decompression): 4 949
+    unit calls, the same in both walks."""
+    import ref_call_sequence as S
+    cpp = _cpp_events(cpp_tool, S.UNITS, "groth16_verify_golden.json")
+    py, glue = S.walk(n_pub=2, compressed=False)
+    assert len(cpp) == 4950 and glue == 703
+    assert _first_difference(cpp, py) is None
 
 
 @pytest.mark.slow
