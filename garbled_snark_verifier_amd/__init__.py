@@ -83,6 +83,7 @@ EXPORTS = [
     "gsv_session_garble_streaming", "gsv_session_garble_streaming_calls", "gsv_plan_call_info", "gsv_plan_image_bytes", "gsv_plan_wire_file", "gsv_plan_save", "gsv_plan_load", "gsv_plan_build_file", "gsv_cbcmac_chains_per_step", "gsv_session_evaluate_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
     "gsv_session_create_plan_opts", "gsv_session_plan_schedule_info", "gsv_session_plan_window", "gsv_session_set_unchecked_slices",
     "gsv_session_garble_streaming_sink", "gsv_session_garble_evaluate", "gsv_session_evaluate_streaming_indexed", "gsv_session_evaluate_streaming_source",
+    "gsv_recorder_allocate_wires", "gsv_plan_recorder_allocate_wires", "gsv_program_compile_opts", "gsv_program_wait", "gsv_plan_recorder_create_opts",
 ]
 
 # CiphertextHandler / CiphertextSource as host callbacks (include/gsv_engine.h: gsv_ct_sink_fn, gsv_ct_source_fn)

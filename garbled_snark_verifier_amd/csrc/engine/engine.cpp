@@ -111,6 +111,16 @@ struct gsv_program {
   std::unique_ptr<ProgramSource> src;
   std::mutex mu;
   std::map<std::pair<int, int>, DevProgram> dev;  // per (device, instances per workgroup)
+  // gsv_program_compile_opts(background = 1): the handle exists at once, `prog` is filled by a worker of the library's compile pool.  What a
+  // plan recorder needs to take a call of the program (arity, gate count) is known from the recording and kept here; everything that
+  // reads `prog` goes through program_ready() first.
+  uint64_t decl_inputs = 0, decl_outputs = 0, decl_gates = 0;
+  bool has_feedback = false, has_decl = false;
+  std::mutex cmu;
+  std::condition_variable ccv;
+  bool compiling = false;
+  int compile_rc = 0;
+  std::string compile_err;
   size_t image_bytes() const {
     if (device_only) return size_t(loaded_image_bytes);
     return prog.steps.size() * sizeof(StepDesc) + prog.ands.size() * sizeof(AndRec) + prog.xors.size() * sizeof(XorRec) +
@@ -221,6 +231,14 @@ int gsv_recorder_allocate_wire(gsv_recorder* r, uint16_t credits, uint64_t* wire
   return GSV_OK;
   GSV_CATCH
 }
+int gsv_recorder_allocate_wires(gsv_recorder* r, size_t n, uint64_t* first_wire_out) {
+  if (!r || !first_wire_out || n == 0) return fail(GSV_ERR_INVALID, "null argument / n == 0");
+  GSV_TRY
+  *first_wire_out = r->mode.allocate_wire(1);
+  for (size_t i = 1; i < n; ++i) (void)r->mode.allocate_wire(1);
+  return GSV_OK;
+  GSV_CATCH
+}
 int gsv_recorder_declare_input(gsv_recorder* r, uint64_t wire) {
   if (!r) return fail(GSV_ERR_INVALID, "null recorder");
   GSV_TRY
@@ -271,30 +289,10 @@ int gsv_recorder_counts(const gsv_recorder* r, uint64_t* n_inputs, uint64_t* n_o
 }
 
 // ---------------------------------------------------------------- program
-int gsv_program_compile(gsv_recorder* r, const uint32_t* fb_out_idx, const uint32_t* fb_in_idx, size_t n_feedback, gsv_program** out) {
-  if (!r || !out) return fail(GSV_ERR_INVALID, "null argument");
-  if (!r->outputs_declared) return fail(GSV_ERR_INVALID, "outputs not declared");
-  GSV_TRY
-  std::vector<std::pair<uint32_t, uint32_t>> fb;
-  for (size_t i = 0; i < n_feedback; ++i) fb.push_back({fb_out_idx[i], fb_in_idx[i]});
-  std::unique_ptr<gsv_program> p(new gsv_program());
-  CompileOptions opt;
-  if (const char* e = getenv("GSV_LDS_LIFETIME")) opt.lds_max_lifetime = uint32_t(atoi(e));  // tuning knobs (defaults are the measured best)
-  if (const char* e = getenv("GSV_FUSE")) opt.fuse = atoi(e) != 0;
-  if (const char* e = getenv("GSV_FUSE_DUP")) opt.fuse_dup_fanout = uint32_t(atoi(e));
-  if (const char* e = getenv("GSV_ORDER_BY_READER")) opt.order_by_reader = atoi(e) != 0;
-  if (const char* e = getenv("GSV_HBM_ARENA")) opt.hbm_arena_factor = uint32_t(atoi(e));
-  if (const char* e = getenv("GSV_LDS_SLOTS")) opt.lds_slots = std::min<uint32_t>(uint32_t(atoi(e)), LDS_WINDOW_SLOTS);
-  p->prog = compile_program(r->mode.trace(), r->inputs, r->outputs, fb, opt);
-  for (size_t i = 0; i < p->prog.input_slots.size(); ++i)
-    if (p->prog.input_slots[i] != SLOT_FIRST_INPUT + i) return fail(GSV_ERR_CIRCUIT, "internal: inputs are not slot-contiguous");
-  p->src.reset(new ProgramSource{r->mode.trace(), r->inputs, r->outputs, fb, opt});
-  *out = p.release();
-  return GSV_OK;
-  GSV_CATCH
-}
+static int program_ready(const gsv_program* cp);
 void gsv_program_destroy(gsv_program* p) {
   if (!p) return;
+  (void)program_ready(p);  // a background compilation still writes into it
   std::set<void*> freed;  // a half-window image loaded from a plan file is filed under both layouts
   for (auto& kv : p->dev) {
     (void)hipSetDevice(kv.first.first);
@@ -305,6 +303,7 @@ void gsv_program_destroy(gsv_program* p) {
 }
 int gsv_program_get_info(const gsv_program* p, gsv_program_info* info) {
   if (!p || !info) return fail(GSV_ERR_INVALID, "null argument");
+  { int rc = program_ready(p); if (rc) return rc; }
   const Program& g = p->prog;
   std::memset(info, 0, sizeof *info);
   info->n_inputs = g.input_slots.size(); info->n_outputs = g.output_slots.size();
@@ -383,6 +382,7 @@ static int upload_program(gsv_engine* e, gsv_program* p, uint32_t ni, DevProgram
   auto it = p->dev.find({e->device, key});
   if (it != p->dev.end()) { *out = it->second; return GSV_OK; }
   // a program loaded by gsv_plan_load(path, engine) has no host copy of its records: there is nothing to upload to another device
+  if (p->prog.spilled) return fail(GSV_ERR_INVALID, "this program's records were written to a plan file and dropped (gsv_plan_build_file / a plan recorder with a plan file): load the file with gsv_plan_load");
   if (p->device_only) return fail(GSV_ERR_INVALID, "this program was loaded straight into another device's memory (gsv_plan_load with an engine): it has no image for device " + std::to_string(e->device));
   if (ni > p->window_div) {  // first session with this many instances per workgroup: compile for that share of the LDS window
     GSV_TRY
@@ -415,6 +415,7 @@ static int upload_program(gsv_engine* e, gsv_program* p, uint32_t ni, DevProgram
 int gsv_session_create(gsv_engine* e, const gsv_program* cp, size_t n_instances, uint64_t replays, uint64_t ct_capacity_replays, gsv_session** out) {
   if (!e || !cp || !out || n_instances == 0 || replays == 0) return fail(GSV_ERR_INVALID, "bad argument");
   gsv_program* p = const_cast<gsv_program*>(cp);
+  { int rc = program_ready(p); if (rc) return rc; }
   if (ct_capacity_replays == 0 || ct_capacity_replays > replays) ct_capacity_replays = replays;
   if (replays > 0xFFFFFFFFull) return fail(GSV_ERR_INVALID, "too many replays");
   HIPCHK(hipSetDevice(e->device));
@@ -477,6 +478,7 @@ void gsv_plan_destroy(gsv_plan* p) {
 }
 int gsv_plan_add_call(gsv_plan* p, const gsv_program* prog, const uint32_t* in_globals, const uint32_t* out_globals) {
   if (!p || !prog || p->finished) return fail(GSV_ERR_INVALID, "bad argument / plan already finished");
+  { int rc = program_ready(prog); if (rc) return rc; }
   const Program& g = prog->prog;
   if ((!in_globals && !g.input_slots.empty()) || (!out_globals && !g.output_slots.empty())) return fail(GSV_ERR_INVALID, "null wire list");
   if (!g.fb_src_slot.empty()) return fail(GSV_ERR_INVALID, "a program compiled with feedback cannot be a plan call");
@@ -592,87 +594,6 @@ static int plan_from_circuit_impl(const char* spec, const char* units_csv, const
   GSV_CATCH
 }
 int gsv_plan_from_circuit(const char* spec, const char* units_csv, gsv_plan** out) { return plan_from_circuit_impl(spec, units_csv, nullptr, out); }
-// ---- plan recorder: the plan builder behind the C ABI, for a host that runs its own two-pass driver (INTEGRATION.md §5)
-struct gsv_plan_recorder {
-  PlanRecordMode mode{std::vector<std::string>()};
-  std::vector<uint32_t> inputs;
-  std::vector<const gsv_program*> externals;
-  std::map<const gsv_program*, int> unit_of;
-};
-int gsv_plan_recorder_create(gsv_plan_recorder** out) {
-  if (!out) return fail(GSV_ERR_INVALID, "null out");
-  *out = new gsv_plan_recorder();
-  return GSV_OK;
-}
-void gsv_plan_recorder_destroy(gsv_plan_recorder* r) { delete r; }
-int gsv_plan_recorder_allocate_wire(gsv_plan_recorder* r, uint16_t credits, uint64_t* wire_out) {
-  if (!r || !wire_out) return fail(GSV_ERR_INVALID, "null argument");
-  GSV_TRY
-  *wire_out = r->mode.allocate_wire(credits);
-  return GSV_OK;
-  GSV_CATCH
-}
-int gsv_plan_recorder_declare_input(gsv_plan_recorder* r, uint64_t wire) {
-  if (!r) return fail(GSV_ERR_INVALID, "null recorder");
-  GSV_TRY
-  r->inputs.push_back(r->mode.define_input(wire));
-  return GSV_OK;
-  GSV_CATCH
-}
-int gsv_plan_recorder_push_gates(gsv_plan_recorder* r, const gsv_gate* gates, size_t n) {
-  if (!r || (!gates && n)) return fail(GSV_ERR_INVALID, "null argument");
-  GSV_TRY
-  for (size_t i = 0; i < n; ++i) {
-    if (gates[i].gate_type >= GATE_TYPE_COUNT) return fail(GSV_ERR_INVALID, "unknown gate type");
-    r->mode.evaluate_gate(Gate{gates[i].wire_a, gates[i].wire_b, gates[i].wire_c, static_cast<GateType>(gates[i].gate_type)});
-  }
-  return GSV_OK;
-  GSV_CATCH
-}
-int gsv_plan_recorder_call(gsv_plan_recorder* r, const gsv_program* program, const uint64_t* in_wires, uint64_t* out_wires) {
-  if (!r || !program) return fail(GSV_ERR_INVALID, "null argument");
-  const Program& g = program->prog;
-  if ((!in_wires && !g.input_slots.empty()) || (!out_wires && !g.output_slots.empty())) return fail(GSV_ERR_INVALID, "null wire list");
-  if (!g.fb_src_slot.empty()) return fail(GSV_ERR_INVALID, "a program compiled with feedback cannot be a plan call");
-  GSV_TRY
-  auto it = r->unit_of.find(program);
-  if (it == r->unit_of.end()) {
-    r->externals.push_back(program);
-    it = r->unit_of.emplace(program, r->mode.add_external_unit(int(r->externals.size()) - 1, g.n_gates, g.output_slots.size())).first;
-  }
-  Wires in(in_wires, in_wires + g.input_slots.size()), out;
-  r->mode.call_external(it->second, in, out);
-  for (size_t i = 0; i < out.size(); ++i) out_wires[i] = out[i];
-  return GSV_OK;
-  GSV_CATCH
-}
-int gsv_plan_recorder_finish(gsv_plan_recorder* r, const uint64_t* output_wires, size_t n_outputs, gsv_plan** out) {
-  if (!r || !out || (!output_wires && n_outputs)) return fail(GSV_ERR_INVALID, "null argument");
-  GSV_TRY
-  std::vector<uint32_t> out_ssa;
-  for (size_t i = 0; i < n_outputs; ++i) out_ssa.push_back(r->mode.current(output_wires[i]));
-  CompileOptions opt;
-  if (const char* e = getenv("GSV_FUSE")) opt.fuse = atoi(e) != 0;
-  BuiltPlan bp = finish_plan(r->mode, r->inputs, out_ssa, opt);
-  std::unique_ptr<gsv_plan> plan(new gsv_plan());
-  for (size_t k = 0; k < bp.programs.size(); ++k) {
-    gsv_program* q = new gsv_program();
-    plan->owned.push_back(q);
-    q->prog = std::move(bp.programs[k]);
-    q->src.reset(new ProgramSource{std::move(bp.traces[k]), bp.prog_inputs[k], bp.prog_outputs[k], {}, opt});
-  }
-  for (const BuiltPlan::Call& c : bp.calls) {
-    const gsv_program* q = c.program >= 0 ? plan->owned[size_t(c.program)] : r->externals[size_t(-1 - c.program)];
-    int rc = gsv_plan_add_call(plan.get(), q, c.in_globals.data(), c.out_globals.data());
-    if (rc) { gsv_plan_destroy(plan.release()); return rc; }
-  }
-  int rc = gsv_plan_finish(plan.get(), bp.n_inputs, bp.outputs.data(), bp.outputs.size());
-  if (rc) { gsv_plan_destroy(plan.release()); return rc; }
-  *out = plan.release();
-  return GSV_OK;
-  GSV_CATCH
-}
-
 int gsv_plan_io(const gsv_plan* p, uint64_t* n_inputs, uint64_t* n_outputs) {
   if (!p || !p->finished) return fail(GSV_ERR_INVALID, "plan not finished");
   if (n_inputs) *n_inputs = p->n_inputs;
@@ -788,6 +709,250 @@ class PlanFileWriter {
   std::atomic<bool> bad_{false};
 };
 }  // namespace
+
+// ---- background compilation (gsv_program_compile_opts) -------------------------------------------------------------------------------
+// One pool for the process, created on first use: GSV_COMPILE_THREADS workers (default: the hardware's, at most 16).  submit() blocks while
+// as many jobs as workers are queued, which bounds the traces and compiler temporaries in flight.
+static CompilePool& abi_compile_pool() {
+  static CompilePool pool(plan_compile_threads());
+  return pool;
+}
+// Waits for a program's background compilation (no-op otherwise) and returns its status.
+static int program_ready(const gsv_program* cp) {
+  gsv_program* p = const_cast<gsv_program*>(cp);
+  std::unique_lock<std::mutex> lk(p->cmu);
+  p->ccv.wait(lk, [p] { return !p->compiling; });
+  if (p->compile_rc) return fail(p->compile_rc, p->compile_err);
+  return GSV_OK;
+}
+
+// ---- plan recorder: the plan builder behind the C ABI, for a host that runs its own two-pass driver (INTEGRATION.md §5)
+struct gsv_plan_recorder {
+  PlanRecordMode mode{std::vector<std::string>()};
+  std::vector<uint32_t> inputs;
+  std::vector<const gsv_program*> externals;
+  std::map<const gsv_program*, int> unit_of;
+  uint32_t window_div = 1;
+  bool single_image = false;             // every program of the plan exists as ONE image (window_div > 1 or a plan file): no trace is kept
+  std::unique_ptr<PlanFileWriter> file;  // set: programs are appended to the plan file as soon as they are compiled, their records dropped
+  std::mutex mu;
+  std::vector<gsv_program*> compiled_for;  // programs compiled with gsv_compile_opts.for_plan = this recorder: their jobs write to `file`
+  bool finished = false;
+  void spill(Program& g) const {
+    g.file_off = file->append_program(g, window_div);
+    g.spilled = true;
+    std::vector<StepDesc>().swap(g.steps); std::vector<AndRec>().swap(g.ands); std::vector<XorRec>().swap(g.xors); std::vector<uint32_t>().swap(g.ct_pos);
+  }
+  void wait_for_compilations() {
+    std::vector<gsv_program*> v;
+    { std::lock_guard<std::mutex> lk(mu); v = compiled_for; }
+    for (gsv_program* q : v) (void)program_ready(q);
+  }
+};
+int gsv_plan_recorder_create_opts(const gsv_plan_recorder_opts* o, gsv_plan_recorder** out) {
+  if (!out) return fail(GSV_ERR_INVALID, "null out");
+  if (o && o->struct_size != sizeof(gsv_plan_recorder_opts)) return fail(GSV_ERR_INVALID, "gsv_plan_recorder_opts.struct_size does not match this library");
+  std::unique_ptr<gsv_plan_recorder> r(new gsv_plan_recorder());
+  if (o) {
+    if (o->window_div != 0 && o->window_div != 1 && o->window_div != 2 && o->window_div != 4) return fail(GSV_ERR_INVALID, "window_div must be 0, 1, 2 or 4");
+    r->window_div = std::max<uint32_t>(1, o->window_div);
+    if (o->plan_file) {
+      r->file.reset(new PlanFileWriter());
+      int rc = r->file->open_file(o->plan_file);
+      if (rc) return rc;
+      gsv_plan_recorder* rp = r.get();
+      r->mode.cache()->sink = [rp](Program& g) { rp->spill(g); };  // the glue programs finish_plan compiles
+    }
+  }
+  r->single_image = r->window_div > 1 || bool(r->file);
+  *out = r.release();
+  return GSV_OK;
+}
+int gsv_plan_recorder_create(gsv_plan_recorder** out) { return gsv_plan_recorder_create_opts(nullptr, out); }
+void gsv_plan_recorder_destroy(gsv_plan_recorder* r) {
+  if (!r) return;
+  r->wait_for_compilations();  // their jobs hold a pointer to this recorder's plan file
+  delete r;
+}
+int gsv_plan_recorder_allocate_wire(gsv_plan_recorder* r, uint16_t credits, uint64_t* wire_out) {
+  if (!r || !wire_out) return fail(GSV_ERR_INVALID, "null argument");
+  GSV_TRY
+  *wire_out = r->mode.allocate_wire(credits);
+  return GSV_OK;
+  GSV_CATCH
+}
+int gsv_plan_recorder_allocate_wires(gsv_plan_recorder* r, size_t n, uint64_t* first_wire_out) {
+  if (!r || !first_wire_out || n == 0) return fail(GSV_ERR_INVALID, "null argument / n == 0");
+  GSV_TRY
+  *first_wire_out = r->mode.allocate_wire(1);
+  for (size_t i = 1; i < n; ++i) (void)r->mode.allocate_wire(1);
+  return GSV_OK;
+  GSV_CATCH
+}
+int gsv_plan_recorder_declare_input(gsv_plan_recorder* r, uint64_t wire) {
+  if (!r) return fail(GSV_ERR_INVALID, "null recorder");
+  GSV_TRY
+  r->inputs.push_back(r->mode.define_input(wire));
+  return GSV_OK;
+  GSV_CATCH
+}
+int gsv_plan_recorder_push_gates(gsv_plan_recorder* r, const gsv_gate* gates, size_t n) {
+  if (!r || (!gates && n)) return fail(GSV_ERR_INVALID, "null argument");
+  GSV_TRY
+  for (size_t i = 0; i < n; ++i) {
+    if (gates[i].gate_type >= GATE_TYPE_COUNT) return fail(GSV_ERR_INVALID, "unknown gate type");
+    r->mode.evaluate_gate(Gate{gates[i].wire_a, gates[i].wire_b, gates[i].wire_c, static_cast<GateType>(gates[i].gate_type)});
+  }
+  return GSV_OK;
+  GSV_CATCH
+}
+int gsv_plan_recorder_call(gsv_plan_recorder* r, const gsv_program* program, const uint64_t* in_wires, uint64_t* out_wires) {
+  if (!r || !program) return fail(GSV_ERR_INVALID, "null argument");
+  // arity and gate count come from the recording (a program whose compilation still runs in the background is accepted as it is)
+  uint64_t n_in = program->decl_inputs, n_out = program->decl_outputs, n_gates = program->decl_gates;
+  bool fb = program->has_feedback;
+  if (!program->has_decl) {  // loaded / built elsewhere: read the image's own tables
+    const Program& g = program->prog;
+    n_in = g.input_slots.size(); n_out = g.output_slots.size(); n_gates = g.n_gates; fb = !g.fb_src_slot.empty();
+  }
+  if ((!in_wires && n_in) || (!out_wires && n_out)) return fail(GSV_ERR_INVALID, "null wire list");
+  if (fb) return fail(GSV_ERR_INVALID, "a program compiled with feedback cannot be a plan call");
+  GSV_TRY
+  auto it = r->unit_of.find(program);
+  if (it == r->unit_of.end()) {
+    r->externals.push_back(program);
+    it = r->unit_of.emplace(program, r->mode.add_external_unit(int(r->externals.size()) - 1, n_gates, size_t(n_out))).first;
+  }
+  Wires in(in_wires, in_wires + n_in), out;
+  r->mode.call_external(it->second, in, out);
+  for (size_t i = 0; i < out.size(); ++i) out_wires[i] = out[i];
+  return GSV_OK;
+  GSV_CATCH
+}
+int gsv_plan_recorder_finish(gsv_plan_recorder* r, const uint64_t* output_wires, size_t n_outputs, gsv_plan** out) {
+  if (!r || !out || (!output_wires && n_outputs)) return fail(GSV_ERR_INVALID, "null argument");
+  if (r->finished) return fail(GSV_ERR_INVALID, "plan recorder already finished");
+  GSV_TRY
+  std::vector<uint32_t> out_ssa;
+  for (size_t i = 0; i < n_outputs; ++i) out_ssa.push_back(r->mode.current(output_wires[i]));
+  CompileOptions opt;
+  if (const char* e = getenv("GSV_FUSE")) opt.fuse = atoi(e) != 0;
+  if (r->single_image) opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / r->window_div);
+  r->wait_for_compilations();
+  for (const gsv_program* q : r->externals) { int rc = program_ready(q); if (rc) return rc; }
+  BuiltPlan bp = finish_plan(r->mode, r->inputs, out_ssa, opt);
+  r->finished = true;
+  std::unique_ptr<gsv_plan> plan(new gsv_plan());
+  for (size_t k = 0; k < bp.programs.size(); ++k) {
+    gsv_program* q = new gsv_program();
+    plan->owned.push_back(q);
+    q->prog = std::move(bp.programs[k]);
+    q->window_div = r->window_div;
+    if (!r->single_image) q->src.reset(new ProgramSource{std::move(bp.traces[k]), bp.prog_inputs[k], bp.prog_outputs[k], {}, opt});
+  }
+  for (const BuiltPlan::Call& c : bp.calls) {
+    const gsv_program* q = c.program >= 0 ? plan->owned[size_t(c.program)] : r->externals[size_t(-1 - c.program)];
+    int rc = gsv_plan_add_call(plan.get(), q, c.in_globals.data(), c.out_globals.data());
+    if (rc) { gsv_plan_destroy(plan.release()); return rc; }
+  }
+  int rc = gsv_plan_finish(plan.get(), bp.n_inputs, bp.outputs.data(), bp.outputs.size());
+  if (rc) { gsv_plan_destroy(plan.release()); return rc; }
+  if (r->file) {
+    // the offset table in the order of the programs' first calls — the order gsv_plan_build_file and gsv_plan_save use
+    std::vector<uint64_t> off;
+    std::map<const gsv_program*, uint32_t> index;
+    for (const PlanCall& c : plan->calls)
+      if (index.emplace(c.prog, uint32_t(off.size())).second) {
+        if (!c.prog->prog.spilled) { gsv_plan_destroy(plan.release()); return fail(GSV_ERR_INVALID, "a unit program of this plan was not compiled for its recorder (gsv_compile_opts.for_plan): its records are not in the plan file"); }
+        off.push_back(c.prog->prog.file_off);
+      }
+    rc = r->file->finish(plan.get(), off, index);
+    r->file.reset();
+    if (rc) { gsv_plan_destroy(plan.release()); return rc; }
+  }
+  *out = plan.release();
+  return GSV_OK;
+  GSV_CATCH
+}
+
+// ---- compile with options: one image for a share of the LDS window, background compilation, records straight into a plan file
+static int compile_impl(gsv_recorder* r, const uint32_t* fb_out_idx, const uint32_t* fb_in_idx, size_t n_feedback, const gsv_compile_opts* o, gsv_program** out) {
+  if (!r || !out) return fail(GSV_ERR_INVALID, "null argument");
+  if (!r->outputs_declared) return fail(GSV_ERR_INVALID, "outputs not declared");
+  if (o && o->struct_size != sizeof(gsv_compile_opts)) return fail(GSV_ERR_INVALID, "gsv_compile_opts.struct_size does not match this library");
+  GSV_TRY
+  gsv_plan_recorder* const pr = o ? o->for_plan : nullptr;
+  uint32_t window_div = o ? o->window_div : 0;
+  if (window_div != 0 && window_div != 1 && window_div != 2 && window_div != 4) return fail(GSV_ERR_INVALID, "window_div must be 0, 1, 2 or 4");
+  if (pr) {
+    if (window_div != 0 && std::max<uint32_t>(1, window_div) != pr->window_div) return fail(GSV_ERR_INVALID, "window_div differs from the plan recorder's");
+    if (pr->finished) return fail(GSV_ERR_INVALID, "plan recorder already finished");
+    if (n_feedback) return fail(GSV_ERR_INVALID, "a program compiled with feedback cannot be a plan call");
+    window_div = pr->window_div;
+  }
+  window_div = std::max<uint32_t>(1, window_div);
+  const bool spill = pr && pr->file;
+  const bool keep = !spill && (!o || o->keep_trace) && !(pr && pr->single_image);
+  auto fb = std::make_shared<std::vector<std::pair<uint32_t, uint32_t>>>();
+  for (size_t i = 0; i < n_feedback; ++i) fb->push_back({fb_out_idx[i], fb_in_idx[i]});
+  std::unique_ptr<gsv_program> p(new gsv_program());
+  CompileOptions opt;
+  if (const char* e = getenv("GSV_LDS_LIFETIME")) opt.lds_max_lifetime = uint32_t(atoi(e));  // tuning knobs (defaults are the measured best)
+  if (const char* e = getenv("GSV_FUSE")) opt.fuse = atoi(e) != 0;
+  if (const char* e = getenv("GSV_FUSE_DUP")) opt.fuse_dup_fanout = uint32_t(atoi(e));
+  if (const char* e = getenv("GSV_ORDER_BY_READER")) opt.order_by_reader = atoi(e) != 0;
+  if (const char* e = getenv("GSV_HBM_ARENA")) opt.hbm_arena_factor = uint32_t(atoi(e));
+  if (const char* e = getenv("GSV_LDS_SLOTS")) opt.lds_slots = std::min<uint32_t>(uint32_t(atoi(e)), LDS_WINDOW_SLOTS);
+  if (window_div > 1 || (pr && pr->single_image)) opt.lds_slots = std::min<uint32_t>(opt.lds_slots, LDS_WINDOW_SLOTS / window_div);
+  p->window_div = window_div;
+  p->has_decl = true;
+  p->decl_inputs = r->inputs.size(); p->decl_outputs = r->outputs.size(); p->decl_gates = r->mode.trace().size();
+  p->has_feedback = n_feedback != 0;
+  // the trace: moved out of the recorder (consume_recorder) or copied
+  auto trace = std::make_shared<Trace>();
+  if (o && o->consume_recorder) { *trace = std::move(r->mode.trace()); r->mode.trace() = Trace(); }
+  else *trace = r->mode.trace();
+  auto inputs = std::make_shared<std::vector<uint32_t>>(r->inputs), outputs = std::make_shared<std::vector<uint32_t>>(r->outputs);
+  gsv_program* const q = p.get();
+  auto work = [q, trace, inputs, outputs, fb, opt, keep, spill, pr]() -> std::pair<int, std::string> {
+    try {
+      q->prog = compile_program(*trace, *inputs, *outputs, *fb, opt);
+      for (size_t i = 0; i < q->prog.input_slots.size(); ++i)
+        if (q->prog.input_slots[i] != SLOT_FIRST_INPUT + i) return {GSV_ERR_CIRCUIT, "internal: inputs are not slot-contiguous"};
+      if (keep) q->src.reset(new ProgramSource{std::move(*trace), *inputs, *outputs, *fb, opt});
+      else *trace = Trace();
+      if (spill) pr->spill(q->prog);
+      return {GSV_OK, std::string()};
+    } catch (const std::exception& e) { return {GSV_ERR_CIRCUIT, e.what()};
+    } catch (...) { return {GSV_ERR_CIRCUIT, "unknown exception"}; }
+  };
+  if (pr) { std::lock_guard<std::mutex> lk(pr->mu); pr->compiled_for.push_back(q); }
+  if (o && o->background) {
+    q->compiling = true;
+    abi_compile_pool().submit([q, work] {
+      auto res = work();
+      { std::lock_guard<std::mutex> lk(q->cmu); q->compile_rc = res.first; q->compile_err = res.second; q->compiling = false; }
+      q->ccv.notify_all();
+    });
+  } else {
+    auto res = work();
+    if (res.first) {
+      if (pr) { std::lock_guard<std::mutex> lk(pr->mu); pr->compiled_for.pop_back(); }
+      return fail(res.first, res.second);
+    }
+  }
+  *out = p.release();
+  return GSV_OK;
+  GSV_CATCH
+}
+int gsv_program_compile(gsv_recorder* r, const uint32_t* fb_out_idx, const uint32_t* fb_in_idx, size_t n_feedback, gsv_program** out) {
+  return compile_impl(r, fb_out_idx, fb_in_idx, n_feedback, nullptr, out);
+}
+int gsv_program_compile_opts(gsv_recorder* r, const gsv_compile_opts* opts, gsv_program** out) { return compile_impl(r, nullptr, nullptr, 0, opts, out); }
+int gsv_program_wait(gsv_program* p) {
+  if (!p) return fail(GSV_ERR_INVALID, "null program");
+  return program_ready(p);
+}
 
 int gsv_plan_wire_file(const gsv_plan* p, uint64_t* n_global_wires, uint64_t* max_program_slots) {
   if (!p || !p->finished) return fail(GSV_ERR_INVALID, "plan not finished");
@@ -2210,6 +2375,7 @@ int gsv_session_read_step_clock(gsv_session* s, uint64_t* out) {
 // Diagnostics: per step {and_cnt, xor_cnt, lds_reads, hbm_reads, lds_writes, hbm_writes} decoded from the compiled records.
 int gsv_program_step_stats(const gsv_program* p, uint32_t* out6) {
   if (!p || !out6) return fail(GSV_ERR_INVALID, "null argument");
+  { int rc = program_ready(p); if (rc) return rc; }
   const Program& g = p->prog;
   for (size_t s = 0; s < g.steps.size(); ++s) {
     const StepDesc& d = g.steps[s];

@@ -64,6 +64,9 @@ int gsv_recorder_create(gsv_recorder** out);
 void gsv_recorder_destroy(gsv_recorder* r);
 /* CircuitMode::allocate_wire (modes.rs:38; storage.rs:119-133): credits == 0 -> GSV_WIRE_UNREACHABLE. */
 int gsv_recorder_allocate_wire(gsv_recorder* r, uint16_t credits, uint64_t* wire_out);
+/* The same for n wires with non-zero credits at once: they get consecutive ids from *first_wire_out (a host that asks per wire pays a
+ * call per wire of the circuit; wires with zero credits are GSV_WIRE_UNREACHABLE and never reach the recorder). */
+int gsv_recorder_allocate_wires(gsv_recorder* r, size_t n, uint64_t* first_wire_out);
 /* CircuitMode::feed_wire for a root input (EncodeInput::encode): declares `wire` as the next circuit input. */
 int gsv_recorder_declare_input(gsv_recorder* r, uint64_t wire);
 /* CircuitMode::evaluate_gate (modes.rs:36), batched: n gates in stream order. */
@@ -81,6 +84,31 @@ int gsv_recorder_counts(const gsv_recorder* r, uint64_t* n_inputs, uint64_t* n_o
  * program garbled with `replays = K` equals K chained calls of the component (gate ids and the
  * ciphertext stream continue across replays). n_feedback may be 0. */
 int gsv_program_compile(gsv_recorder* r, const uint32_t* fb_out_idx, const uint32_t* fb_in_idx, size_t n_feedback, gsv_program** out);
+/* Compile with options (no feedback) — what a host that builds a PLAN of many unit programs needs (gsv_plan_recorder_* below; the
+ * reference-side hook is StreamingMode::with_named_child, streaming_mode.rs:189-241):
+ *   struct_size       sizeof(gsv_compile_opts) (a mismatch is GSV_ERR_INVALID)
+ *   window_div        0 / 1: compiled for the full LDS label window (other layouts are compiled on first use from the kept trace);
+ *                     2 / 4: ONE image for half / a quarter of the window that serves sessions with up to that many instances per workgroup
+ *   keep_trace        0: the recorded trace is released once the image exists (no further variant can be compiled)
+ *   background        1: the call returns at once and the compilation runs on the library's worker pool (GSV_COMPILE_THREADS, default: the
+ *                     hardware's threads, at most 16; the call blocks while as many jobs as workers are queued).  The handle can be passed to
+ *                     gsv_plan_recorder_call right away; everything that needs the image waits for it.  gsv_program_wait returns its status.
+ *   consume_recorder  1: the trace is moved out of the recorder instead of copied (13 bytes per gate); the recorder is empty afterwards
+ *   for_plan          the plan recorder the program is a unit of: window_div is the recorder's, and if the recorder writes a plan file the
+ *                     records are appended to it the moment the image exists and dropped from memory.  The recorder must outlive the
+ *                     compilation (gsv_plan_recorder_finish and _destroy wait for it). */
+typedef struct gsv_plan_recorder gsv_plan_recorder;
+typedef struct gsv_compile_opts {
+  uint32_t struct_size;
+  uint32_t window_div;
+  uint32_t keep_trace;
+  uint32_t background;
+  uint32_t consume_recorder;
+  uint32_t reserved;
+  gsv_plan_recorder* for_plan;
+} gsv_compile_opts;
+int gsv_program_compile_opts(gsv_recorder* r, const gsv_compile_opts* opts, gsv_program** out);
+int gsv_program_wait(gsv_program* p);
 void gsv_program_destroy(gsv_program* p);
 typedef struct gsv_program_info {
   uint64_t n_inputs, n_outputs;
@@ -122,10 +150,22 @@ int gsv_plan_io(const gsv_plan* p, uint64_t* n_inputs, uint64_t* n_outputs);
  * (gsv_recorder_* + gsv_program_compile, outputs = the wires the body PRODUCES): in_wires name the parent's wires, out_wires
  * receive one fresh parent wire per program output.  finish computes the global wires and returns the plan (which owns the
  * glue programs; the unit programs stay the caller's and must outlive the plan). */
-typedef struct gsv_plan_recorder gsv_plan_recorder;
 int gsv_plan_recorder_create(gsv_plan_recorder** out);
+/* With options: window_div as in gsv_compile_opts (the glue programs the recorder compiles itself, and every unit compiled with
+ * for_plan = this recorder); plan_file (may be NULL): every program of the plan is appended to this file when it has been compiled and its
+ * records are dropped — the host never holds the plan's images (the verifier: 41 GB).  gsv_plan_recorder_finish then completes the file
+ * (atomically: temp file + rename) and returns a plan that holds metadata only (counts, calls; gsv_plan_counts / _call_info / _io work,
+ * sessions do not): load the file with gsv_plan_load(path, engine).  The file equals the one gsv_plan_build_file writes for the same
+ * circuit, units and window_div. */
+typedef struct gsv_plan_recorder_opts {
+  uint32_t struct_size;   /* sizeof(gsv_plan_recorder_opts) */
+  uint32_t window_div;    /* 0 / 1, 2, 4 */
+  const char* plan_file;
+} gsv_plan_recorder_opts;
+int gsv_plan_recorder_create_opts(const gsv_plan_recorder_opts* opts, gsv_plan_recorder** out);
 void gsv_plan_recorder_destroy(gsv_plan_recorder* r);
 int gsv_plan_recorder_allocate_wire(gsv_plan_recorder* r, uint16_t credits, uint64_t* wire_out);
+int gsv_plan_recorder_allocate_wires(gsv_plan_recorder* r, size_t n, uint64_t* first_wire_out);  /* as gsv_recorder_allocate_wires */
 int gsv_plan_recorder_declare_input(gsv_plan_recorder* r, uint64_t wire);
 int gsv_plan_recorder_push_gates(gsv_plan_recorder* r, const gsv_gate* gates, size_t n);
 int gsv_plan_recorder_call(gsv_plan_recorder* r, const gsv_program* program, const uint64_t* in_wires, uint64_t* out_wires);

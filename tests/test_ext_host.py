@@ -1,0 +1,155 @@
+"""The public C ABI driven by an EXTERNAL host (tests/ext_host/ext_host.cpp): a program that links only libgsv_engine.so, includes only
+include/gsv_engine.h from the engine and implements `CircuitMode` (src/circuit/modes.rs:26-51) plus the `with_named_child` unit hook
+(src/circuit/streaming_mode.rs:189-241) over gsv_recorder_* / gsv_program_compile_opts / gsv_plan_recorder_* — what
+bindings/rust/src/gpu_garble_mode.rs does on the Rust side.  The circuit itself comes from the shared, mode-generic driver + gadget
+headers (the restated reference layers above the seam).
+
+CPU (`not gpu`): the plan the external host builds through the ABI is, byte for byte, the plan the engine's built-in builder
+(gsv_plan_build_file) writes for the same circuit, units and window share — tools/plan_digest.py: same header, same program blocks,
+same calls, whatever order the compile workers appended the blocks in.
+GPU: BASELINE config 4 — the whole groth16_verify_compressed circuit (1 public input, 11 456 865 898 gates, 3 147 calls of 296 programs)
+recorded through the ABI, loaded, ONE instance garbled with nothing retained on the device through gsv_session_garble_streaming_sink
+into the host program's own CBC-MAC: MAC and output label == the oracle's flat-stream fixture."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+EXT_DIR = os.path.join(ROOT, "tests", "ext_host")
+EXT = os.path.join(EXT_DIR, "ext_host")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+VERIFIER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cyclotomic_square_montgomery", "fq12::mul_by_034_montgomery",
+                  "pairing::ell_by_constant_montgomery", "pairing::double_in_place_circuit_montgomery", "pairing::add_in_place_montgomery", "pairing::mul_by_char_montgomery",
+                  "bigint::multiplexer", "g1::add_montgomery", "inverse_iteration", "inverse::divide_result_by_2^k::chunk", "inverse::divide_result_by_even_part::chunk", "fp254::exp_chunk"]
+
+
+@pytest.fixture(scope="module")
+def ext_host():
+    import garbled_snark_verifier_amd  # noqa: F401 - builds libgsv_engine.so if needed
+    subprocess.check_call(["make", "-C", EXT_DIR], stdout=subprocess.DEVNULL)
+    return EXT
+
+
+def run_ext(exe, spec, units, path, *more):
+    r = subprocess.run([exe, spec, ",".join(units), path] + [str(x) for x in more], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_ext_host_links_only_the_public_library(ext_host):
+    """The external host's only engine dependency is libgsv_engine.so (the HIP runtime comes in through that library), and its source
+    includes nothing of csrc/engine."""
+    needed = subprocess.check_output(["readelf", "-d", ext_host], text=True)
+    libs = [ln.split("[")[1].split("]")[0] for ln in needed.splitlines() if "(NEEDED)" in ln]
+    assert "libgsv_engine.so" in libs and not [x for x in libs if "hostsim" in x or "oracle" in x or "amdhip" in x]
+    src = open(os.path.join(EXT_DIR, "ext_host.cpp")).read()
+    incs = [ln for ln in src.splitlines() if ln.startswith("#include \"")]
+    assert all("csrc/engine" not in ln for ln in incs) and any("include/gsv_engine.h" in ln for ln in incs)
+
+
+@pytest.mark.parametrize("window_div", [4, 1])
+def test_abi_route_plan_equals_the_builtin_builders(ext_host, tmp_path, window_div):
+    """Units with glue between them, a second liveness pattern of the same component (fq12_mix); no unit at all; one gate; the in-place
+    NOT; units whose outputs are dead / constants / passed-through inputs, nested components (driver_mix); 145 calls of 72 programs
+    (random_circuit); unit inputs that are the constant wires (the MSM's tables behind multiplexers, g1_mux_add)."""
+    import garbled_snark_verifier_amd as gsv
+    import plan_digest
+    a, b = os.path.join(str(tmp_path), "abi.gsvplan"), os.path.join(str(tmp_path), "builtin.gsvplan")
+    cases = [("fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"]), ("fq_mul", ["no::such_unit"]), ("gate:0", ["x::y"]), ("gate:10", ["x::y"]),
+             ("driver_mix", ["test::inner", "bigint::add"]), ("driver_mix", ["test::mixed_outputs"]), ("random_circuit:3", ["test::random_block"]),
+             ("g1_mux_add", ["bigint::multiplexer", "g1::add_montgomery"]), ("fq_complex", ["fp254::montgomery_reduce", "bigint::mul_karatsuba"])]
+    for spec, units in cases:
+        j = run_ext(ext_host, spec, units, a, "--window-div", window_div)
+        gsv.Plan.build_file(spec, units, b, window_div=window_div)
+        da, db = plan_digest.digest(a), plan_digest.digest(b)
+        assert da == db and da["unreferenced_bytes"] == 0, (spec, units, da, db)
+        ref = gsv.Plan.load(b)
+        assert (j["n_gates"], j["n_ciphertexts"], j["n_calls"]) == (ref.info["n_gates"], ref.info["n_ciphertexts"], ref.info["n_calls"])
+        ref.close()
+    assert not [f for f in os.listdir(str(tmp_path)) if ".tmp." in f]
+
+
+def test_abi_misuse_is_refused(tmp_path):
+    """struct_size guards both option structs; a spilled program cannot be run; a finished plan recorder takes no more units."""
+    import ctypes as C
+    import garbled_snark_verifier_amd as gsv
+    L = gsv.lib()
+
+    class RecOpts(C.Structure):
+        _fields_ = [("struct_size", C.c_uint32), ("window_div", C.c_uint32), ("plan_file", C.c_char_p)]
+
+    class CompOpts(C.Structure):
+        _fields_ = [("struct_size", C.c_uint32), ("window_div", C.c_uint32), ("keep_trace", C.c_uint32), ("background", C.c_uint32), ("consume_recorder", C.c_uint32),
+                    ("reserved", C.c_uint32), ("for_plan", C.c_void_p)]
+
+    pr = C.c_void_p()
+    assert L.gsv_plan_recorder_create_opts(C.byref(RecOpts(4, 4, None)), C.byref(pr)) == 1  # wrong struct_size
+    assert L.gsv_plan_recorder_create_opts(C.byref(RecOpts(C.sizeof(RecOpts), 3, None)), C.byref(pr)) == 1  # window_div 3
+    path = os.path.join(str(tmp_path), "p.gsvplan").encode()
+    assert L.gsv_plan_recorder_create_opts(C.byref(RecOpts(C.sizeof(RecOpts), 4, path)), C.byref(pr)) == 0
+    rec = C.c_void_p()
+    assert L.gsv_recorder_create(C.byref(rec)) == 0
+    assert L.gsv_recorder_record_circuit(rec, b"fq_add") == 0
+    prog = C.c_void_p()
+    assert L.gsv_program_compile_opts(rec, C.byref(CompOpts(8, 0, 0, 0, 0, 0, None)), C.byref(prog)) == 1  # wrong struct_size
+    assert L.gsv_program_compile_opts(rec, C.byref(CompOpts(C.sizeof(CompOpts), 2, 0, 1, 0, 0, pr)), C.byref(prog)) == 1  # window_div differs from the recorder's
+    assert L.gsv_program_compile_opts(rec, C.byref(CompOpts(C.sizeof(CompOpts), 0, 0, 1, 0, 0, pr)), C.byref(prog)) == 0  # background, spilled into the plan file
+    assert L.gsv_program_wait(prog) == 0
+    # a plan of one call of it: two inputs of 254 wires, one output
+    first = C.c_uint64()
+    assert L.gsv_plan_recorder_allocate_wires(pr, 508, C.byref(first)) == 0
+    for i in range(508):
+        assert L.gsv_plan_recorder_declare_input(pr, first.value + i) == 0
+    ins = (C.c_uint64 * 508)(*[first.value + i for i in range(508)])
+    outs = (C.c_uint64 * 254)()
+    assert L.gsv_plan_recorder_call(pr, prog, ins, outs) == 0
+    plan = C.c_void_p()
+    assert L.gsv_plan_recorder_finish(pr, outs, 254, C.byref(plan)) == 0
+    assert L.gsv_plan_recorder_finish(pr, outs, 254, C.byref(plan)) == 1  # already finished
+    prog2 = C.c_void_p()
+    assert L.gsv_program_compile_opts(rec, C.byref(CompOpts(C.sizeof(CompOpts), 0, 0, 0, 0, 0, pr)), C.byref(prog2)) == 1  # recorder finished
+    loaded = gsv.Plan.load(path.decode())
+    ref = gsv.Plan.from_circuit("fq_add", ["no::unit"], window_div=4)
+    assert loaded.info == ref.info
+    loaded.close(); ref.close()
+    L.gsv_plan_destroy(plan); L.gsv_plan_recorder_destroy(pr); L.gsv_program_destroy(prog); L.gsv_recorder_destroy(rec)
+
+
+@pytest.mark.gpu
+def test_full_verifier_through_the_public_abi(ext_host, tmp_path):
+    """BASELINE config 4 from an external host: record -> plan file through gsv_plan_recorder_* (3 147 calls, 296 programs, 11.46 B
+    gates), gsv_plan_load, one instance garbled with retain_stream = 0 through gsv_session_garble_streaming_sink into the host's own
+    CBC-MAC.  MAC and output label == the CPU oracle's flat-stream fixture; the plan file == the built-in builder's; build time and host
+    RSS reported (profiles/r05_e2e/ext_host_verifier.json keeps one run)."""
+    import garbled_snark_verifier_amd as gsv
+    import plan_digest
+    case = json.load(open(os.path.join(GOLDEN, "groth16_verify_compressed_1pub_golden.json")))
+    d = "/dev/shm" if os.path.isdir("/dev/shm") and os.statvfs("/dev/shm").f_bavail * os.statvfs("/dev/shm").f_frsize > 100e9 else str(tmp_path)
+    a, b = os.path.join(d, "gsv_ext_host_%d_abi.gsvplan" % os.getpid()), os.path.join(d, "gsv_ext_host_%d_builtin.gsvplan" % os.getpid())
+    try:
+        j = run_ext(ext_host, case["circuit"], VERIFIER_UNITS, a, "--window-div", 4, "--garble", case["seed"])
+        assert (j["n_gates"], j["n_ciphertexts"]) == (case["gates"], case["n_ciphertexts"]) == (11_456_865_898, 2_980_165_547)
+        assert j["ct_hash"] == case["ct_hash"] == j["engine_ct_hash"] and j["sink_in_order"] and j["sink_records"] == case["n_ciphertexts"]
+        out = bytes.fromhex(j["output_label0"])
+        assert hashlib.sha256(out).hexdigest() == case["output_label0_sha256"] and out[:16].hex() == case["first_output_label0"]
+        import time
+        t0 = time.time()
+        gsv.Plan.build_file(case["circuit"], VERIFIER_UNITS, b, window_div=4)
+        j["builtin_build_s"] = time.time() - t0
+        da, db = plan_digest.digest(a, threads=16), plan_digest.digest(b, threads=16)
+        j["plan_digest"], j["builtin_plan_digest"] = da["digest"], db["digest"]
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out_dir):
+            json.dump(j, open(os.path.join(out_dir, "ext_host_verifier.json"), "w"), indent=1)
+        assert da == db
+        assert j["build_s"] <= 2.0 * j["builtin_build_s"] + 10.0, j
+    finally:
+        for f in (a, b):
+            if os.path.exists(f):
+                os.remove(f)
