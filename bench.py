@@ -54,15 +54,37 @@ VERIFIER_GATES = 11_174_708_821  # README.md:12 of the reference (its own 1-publ
 FIXTURE = {"verifier_compressed": "groth16_verify_compressed_1pub_golden.json",  # ONE public input: the reference's benchmark configuration
            "verifier_compressed_2pub": "groth16_verify_compressed_golden.json", "verifier": "groth16_verify_golden.json"}
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s
-AES_CEILING_AND_PER_S = 4.82e10  # tools/ubench/aes_forms.hip on MI355X (profiles/r02_final/aes_forms.txt): 9.65e10 T-table AES blocks/s with every CU full, two blocks per garbled AND
+AES_CEILING_AND_PER_S_R02 = 4.82e10  # round 2's measurement (profiles/r02_final/aes_forms.txt): only quoted when the micro-benchmark cannot run
+
+
+def measure_aes_ceiling(log):
+    """The T-table AES ceiling of THIS box, measured in this run, outside the timed region: tools/ubench/aes_forms (built by
+    __graft_entry__.build()) runs the production cipher form alone with every CU full and prints blocks/s; a garbled AND is two blocks.
+    Runs as a child process (it owns its HIP context).  Returns (ANDs per second, source string)."""
+    exe = os.path.join(ROOT, "tools", "ubench", "aes_forms")
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+        for ln in out.splitlines():
+            if ln.startswith("T-table"):
+                blocks = float(ln.split(":")[1].split("blocks/s")[0])
+                if "matches host AES" not in ln:
+                    raise ValueError("micro-benchmark output did not validate: %s" % ln)
+                return blocks / 2.0, "tools/ubench/aes_forms in this run: %.4g T-table AES blocks/s with every CU full" % blocks
+        raise ValueError("no T-table line in %r" % out[-200:])
+    except Exception as e:  # noqa: BLE001 - the ceiling is context, not the result
+        log("bench.py: AES micro-benchmark did not run (%r): quoting round 2's ceiling" % (e,))
+        return AES_CEILING_AND_PER_S_R02, "round-2 constant (the micro-benchmark did not run here: %r)" % (e,)
+
 
 VERIFIER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cyclotomic_square_montgomery", "fq12::mul_by_034_montgomery",
                   "pairing::ell_by_constant_montgomery", "pairing::double_in_place_circuit_montgomery", "pairing::add_in_place_montgomery", "pairing::mul_by_char_montgomery",
                   "bigint::multiplexer", "g1::add_montgomery",
-                  # the Fq inversions (binary extended Euclid, fp254impl.rs:333-690) enter as their own 4-iteration components: as ONE unit an
-                  # inversion (11 M ciphertexts) — or the Fq12 inversion around it (21 M) — would set the size of every instance's device
-                  # ciphertext block (340 MB x 512 instances); their chunks keep the largest block at an Fq12 multiplication's 5.4 M records
-                  "inverse_iteration", "inverse::divide_result_by_2^k::chunk", "inverse::divide_result_by_even_part::chunk"]
+                  # the Fq inversions (binary extended Euclid, fp254impl.rs:333-690).  As ONE unit an inversion would be 11.2 M ciphertexts — twice an Fq12
+                  # multiplication's 5.4 M, which sets every instance's device ciphertext block — so it enters as three calls: two groups of 64
+                  # `inverse_iteration` components (3.9 M ciphertexts each) and the two division chains together (3.2 M); these wrappers are
+                  # component boundaries the reference does not have (stream-neutral, bn254_ext.hpp).  Round 4 entered the 318 four-iteration
+                  # components themselves: 36 % more device steps (a call boundary ends the overlap of chained adders)
+                  "inverse::iteration_group", "inverse::divide_chains"]
 
 
 # The same circuit with the Fq12 multiplications and squarings entered one level finer, as their three fq6::mul_montgomery units (a component
@@ -445,7 +467,7 @@ def mode_rates(gsv, engine, np, instances=256, replays=4):
 
 
 def cc16_verifier_fixture(case):
-    """tests/golden/cc16_verifier_golden.json (the 16 instances of master seed 2024 on the full verifier, garbled by the CPU oracle), or
+    """tests/golden/cc16_verifier_golden.json (the 16 instances of master seed 1234 on the full verifier, garbled by the CPU oracle), or
     None when it does not belong to this circuit."""
     path = os.path.join(ROOT, "tests", "golden", "cc16_verifier_golden.json")
     if not os.path.exists(path):
@@ -456,7 +478,7 @@ def cc16_verifier_fixture(case):
 
 def cc16_one_gpu(gsv, engine, plan, case, gold, log):
     """BASELINE config 5 with all 16 instances on THIS GPU: sharding.cut_and_choose_commit (Garbler::create -> commit,
-    cut_and_choose/garbler.rs:191-257) on the full verifier — 16 seeds from master seed 2024, every instance garbled WITH its ciphertext
+    cut_and_choose/garbler.rs:191-257) on the full verifier — 16 seeds from master seed 1234, every instance garbled WITH its ciphertext
     commitment (stream drained over PCIe, sixteen serial CBC-MAC chains on the host), GarbledInstanceCommit records built — and every
     record compared with the one built from the CPU oracle's flat garbling of the same seed."""
     from garbled_snark_verifier_amd import sharding
@@ -520,8 +542,26 @@ def run_verifier(args):
     case = json.load(open(os.path.join(ROOT, "tests", "golden", FIXTURE[args.workload])))
     units = (SMALL_BATCH_UNITS if args.units == "fq6" else VERIFIER_UNITS) + (["fp254::exp_chunk"] if compressed else [])
     engine = gsv.Engine(local_rank)  # raises without a HIP device: no CPU fallback
+    extras = rank == 0 and world == 1
+    want_small = extras and compressed and args.small_batch_units == "fq6" and args.units == "fq12" and not (args.no_rate_by_instances and args.no_cc16 and args.no_mode_rates)
+    # The small-batch plan's FILE is built beside the headline's (two builders, one worker pool each: ~1.3 x one build instead of 2 x on
+    # the 16-core quota); it is loaded when the headline's legs need it.  Only the file: nothing here touches the device.
+    small_build = {"thread": None, "seconds": None, "error": None}
+    if want_small:
+        sp = _plan_cache_path(args, case["circuit"], SMALL_BATCH_UNITS + ["fp254::exp_chunk"], 1)
+        if sp and not os.path.exists(sp):
+            def _build_small():
+                t1 = time.time()
+                try:
+                    gsv.Plan.build_file(case["circuit"], SMALL_BATCH_UNITS + ["fp254::exp_chunk"], sp, window_div=1)
+                    small_build["seconds"] = time.time() - t1
+                except Exception as e:  # noqa: BLE001 - get_plan below builds it again (and reports) if the file is not there
+                    small_build["error"] = repr(e)
+            small_build["thread"] = threading.Thread(target=_build_small, daemon=True)
+            small_build["thread"].start()
     plan, plan_info, save_later = get_plan(gsv, engine, args, case["circuit"], units, rank, local_rank, local_world, dist, log)
     t_first_launch = time.time() - T_START
+    aes_and_per_s, aes_src = measure_aes_ceiling(log) if rank == 0 else (AES_CEILING_AND_PER_S_R02, "not measured on this rank")
     B, n_in, gates = args.instances, plan.info["n_inputs"], plan.info["n_gates"]
     n_calls = plan.info["n_calls"]
     n_ct = plan.info["n_ciphertexts"]
@@ -537,16 +577,19 @@ def run_verifier(args):
         return bool(hash_bytes.hex() == case["ct_hash"] and hashlib.sha256(out_labels.tobytes()).hexdigest() == case["output_label0_sha256"])
 
     result = {}
-    extras = rank == 0 and world == 1
     # the small-batch plan: the same circuit with Fq6-level units (SMALL_BATCH_UNITS) for the legs with 1 and 16 instances — more width for
     # the call-level dataflow; the stream is the same stream (every leg below checks its output label / MAC / records against the fixtures)
     plan_small, plan_small_info = None, None
-    if extras and compressed and args.small_batch_units == "fq6" and args.units == "fq12" and not (args.no_rate_by_instances and args.no_cc16 and args.no_mode_rates):
+    if want_small:
         try:
+            if small_build["thread"] is not None:
+                small_build["thread"].join()
             # (its programs keep the FULL LDS label window — window_div 1, one instance per workgroup, which is what 1 and 16 instances run:
             # 3 % faster steps than the quarter-window image the full GPU's four instances per workgroup need)
             plan_small, plan_small_info, _ = get_plan(gsv, engine, args, case["circuit"], SMALL_BATCH_UNITS + ["fp254::exp_chunk"], rank, local_rank, local_world, dist, log, window_div=1)
-            log("bench.py: small-batch plan (Fq6-level units) %s in %.1f s (%d calls)" % (plan_small_info["how"], plan_small_info["seconds"], plan_small.info["n_calls"]))
+            plan_small_info["built_beside_the_headline_plan_s"] = small_build["seconds"]
+            plan_small_info["seconds_from_process_start_to_ready"] = time.time() - T_START
+            log("bench.py: small-batch plan (Fq6-level units) %s in %.1f s (%d calls); its file was built beside the headline's in %s s" % (plan_small_info["how"], plan_small_info["seconds"], plan_small.info["n_calls"], small_build["seconds"]))
         except Exception as e:  # noqa: BLE001 - the legs fall back to the headline's plan
             plan_small, plan_small_info = None, {"error": repr(e)}
     plan_sb = plan_small or plan
@@ -566,7 +609,7 @@ def run_verifier(args):
         try:
             Be = max(1, args.e2e_instances)
             seeds = [case["seed"]] + instance_seeds(rank, Be)[1:]
-            # instances 1..16 carry the 16 seeds of the cut-and-choose fixture (master seed 2024): their commitments are checked against
+            # instances 1..16 carry the 16 seeds of the cut-and-choose fixture (master seed 1234): their commitments are checked against
             # the CPU oracle's flat garblings too (tests/golden/cc16_verifier_golden.json), so 17 of the pass's MACs are verified
             cc_gold = cc16_verifier_fixture(case) if compressed and args.workload == "verifier_compressed" else None
             n_cc = 0
@@ -711,8 +754,15 @@ def run_verifier(args):
         plan_small.close()  # its 41 GB of program records make room for the headline's session
         plan_small = None
     seeds = instance_seeds(rank, B)
+    head_gold = None
     if rank == 0:
         seeds[0] = case["seed"]  # the fixture's seed: the timed kernel's output label is checked once a whole pass has run
+        # instances 1..7 — workgroup positions 1, 2, 3 of the first workgroup and all four of the second — carry seeds of the cut-and-choose
+        # fixture, whose whole-stream MACs the CPU oracle computed: the timed configuration's CIPHERTEXTS are checked after the timed steps
+        head_gold = cc16_verifier_fixture(case) if compressed and args.workload == "verifier_compressed" else None
+        if head_gold is not None:
+            for k in range(min(7, B - 1, len(head_gold["seeds"]))):
+                seeds[1 + k] = head_gold["seeds"][k]
     work = VerifierWork(gsv, engine, plan, B, seeds)
     ni = work.sess.instances_per_workgroup
     slices = work.slices(ci[:, 1], args.slices)
@@ -735,6 +785,28 @@ def run_verifier(args):
         _, _, _, outc, _, _ = sharding.record_fields(rec, plan.info["n_outputs"], n_in)
         exp = sharding.commit_labels(np.frombuffer(bytes.fromhex(case["first_output_label0"]), np.uint8)[None, :])[0]
         label_match = bool((outc[0, 1] == exp).all())
+    # ---- the timed configuration's ciphertexts (examples/groth16_garble.rs:255-263 compares the garbler's and the evaluator's ciphertext
+    # hash): ONE MORE whole pass of the very session that was timed — same instances, same kernel instantiation, same windows — with the
+    # streams of its first instances drained and CBC-MAC'ed (gsv_session_set_drain_instances: every instance is garbled, 8 x 47.7 GB cross
+    # PCIe instead of 1 024 x), against the oracle's flat-stream fixtures.  Outside the timed region.
+    head_ct = None
+    if rank == 0 and world == 1 and not args.no_headline_ct_check and time.time() - T_START < args.time_budget + 60:
+        try:
+            n_chk = min(8, B) if head_gold is not None else 1
+            work.sess.set_drain_instances(n_chk)
+            work.sess.set_unchecked_slices(False)
+            t0 = time.perf_counter()
+            dt = work.run_pass(commit=True, threads=args.mac_threads)
+            out = work.sess.read_outputs()
+            ok0 = fixture_ok(work.ct_hashes[0], out[0])
+            oks = [ok0] + [work.ct_hashes[1 + k].hex() == head_gold["ct_hashes"][k] and out[1 + k][0].tobytes().hex() == head_gold["first_output_label0"][k] for k in range(n_chk - 1)]
+            head_ct = {"match": bool(all(oks)), "instances_checked": n_chk, "instances_matching": int(sum(oks)), "workgroup_positions_checked": sorted({i % ni for i in range(n_chk)}),
+                       "ciphertexts_checked": n_chk * n_ct, "seconds": dt, "instances_garbled": B, "instances_per_workgroup": ni,
+                       "sample": "one more whole pass of the timed session (%d instances, %d per workgroup, the timed windows); the streams of instances 0..%d drained over PCIe and CBC-MAC'ed: "
+                                 "instance 0 = the single-instance fixture's seed, the others = seeds of tests/golden/cc16_verifier_golden.json" % (B, ni, n_chk - 1)}
+            log("bench.py: headline ciphertext check: %d of %d instances match the oracle's MACs (%.1f s)" % (sum(oks), n_chk, dt))
+        except Exception as e:  # noqa: BLE001
+            head_ct = {"error": repr(e)}
     work.close()
     if rank == 0:
         el, K = r["elapsed"], r["steps_run"]
@@ -778,11 +850,42 @@ def run_verifier(args):
                     break
                 except (KeyError, ValueError):
                     pass
+        # LDS / VALU pipe utilisation of the wide windows: separate rocprofv3 --pmc passes (tools/profile_r05_pipe.sh), quoted as they were
+        # measured (profiles/<round>_final/pipe_util_summary.json names the build they belong to)
+        pipe_util = None
+        for cand in sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.endswith("_final")), reverse=True):
+            pp = os.path.join(ROOT, "profiles", cand, "pipe_util_summary.json")
+            if os.path.exists(pp):
+                try:
+                    pipe_util = json.load(open(pp))
+                    pipe_util["source"] = "profiles/%s/pipe_util_summary.json (separate rocprofv3 --pmc passes; NOT measured in this run)" % cand
+                except ValueError:
+                    pipe_util = None
+                break
+        # cold start: process start -> one (sixteen) instance(s) garbled, as this run paid it (the small-batch plan's file was built BESIDE the
+        # headline's, which slows both builds; alone it is the `build_s` of a run with --no-... legs)
+        cold_start = None
+        try:
+            rbi_ = result.get("rate_by_instances") or {}
+            if plan_small_info and "seconds" in plan_small_info:
+                ready = (small_build["seconds"] or 0.0) + plan_small_info["seconds"]
+                cold_start = {"plan_file_build_s": small_build["seconds"], "plan_load_s": plan_small_info["seconds"],
+                              "1": None if "1" not in rbi_ or "seconds" not in rbi_["1"] else ready + rbi_["1"]["seconds"],
+                              "1_with_commitment": None if "with_commitment" not in rbi_.get("1", {}) else ready + rbi_["1"]["with_commitment"]["seconds"],
+                              "16": None if "16" not in rbi_ or "seconds" not in rbi_["16"] else ready + rbi_["16"]["seconds"],
+                              "note": "plan file build (beside the headline plan's build when the file did not exist) + load into HBM + one whole pass; reference: ~350 s for one instance on one core"}
+        except Exception as e:  # noqa: BLE001
+            cold_start = {"error": repr(e)}
         result.update({
             "metric": "gates/sec (garble) on Groth16/BN254 verifier at 1/2/4/8 GPUs; ciphertext-hash match", "value": g_rank * world / el, "unit": "gates/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "headline_output_label_match": label_match,
+            "headline_ciphertext_hash_match": None if head_ct is None else head_ct.get("match"), "headline_ciphertext_check": head_ct,
+            # the like-for-like of the reference's timed garble (hash included, garbler.rs:219-222) next to `value`, which is the commitment-free device rate
+            "value_with_commitment": (result.get("e2e_with_commitment") or {}).get("value"),
+            "single_instance_with_commitment": ((result.get("rate_by_instances") or {}).get("1") or {}).get("with_commitment", {}).get("gates_per_s"),
+            "cold_start_s": cold_start,
             "config": {"workload": "restated %s circuit, %s public input(s) (synthetic verifying key / proof of tests/groth16_ref.py; %d gates per instance as this tree's gadgets emit them, the reference "
                                    "quotes 11,174,708,821 for the same configuration: DESIGN.md §2, tools/gate_counts --json), %d cut-and-choose instances per GPU, ciphertexts produced into HBM; one step = "
                                    "one of %d slices of the plan's %d calls, %d consecutive steps = one full verifier pass per instance"
@@ -795,7 +898,12 @@ def run_verifier(args):
                        "wire_file_mb_per_instance": sched["wire_file_slots"] * 16 / 1e6, "ciphertext_window_mb_per_instance": sched["window_ct_records"] * 16 / 1e6,
                        "host_peak_rss_gb": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1e6},
             "commit_records_gathered": None if r["commit_table"] is None else list(r["commit_table"].shape),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+            # `bound`: what binds is the issue of the T-table AES (LDS lookups + the VALU work around them), not HBM: the §8(d) algorithmic-bytes
+            # figure (achieved / peak / frac) is kept as the contract asks, the bytes that really cross the HBM interface are hbm_measured_*
+            "roofline": {"bound": "lds-aes-issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "hbm_measured_gbps": None if traffic is None else traffic / (stream_s / max(1, n_launch)) / 1e9,
+                         "hbm_measured_frac": None if traffic is None else traffic / (stream_s / max(1, n_launch)) / 1e9 / HBM_PEAK_GBS,
+                         "pipe_utilisation": pipe_util,
                          # one step = the window launches of one slice, all of the same kernel over different component programs; a launch = one WINDOW of the schedule
                          # (grid.y = its calls) for all instances of the GPU: `launches_timed` dispatches, what rocprofv3 --kernel-trace counts
                          "kernel": "run_program_kernel<false, %d, 0, FW>" % ni, "launches_timed": n_launch, "kernel_ms_avg": stream_s * 1e3 / max(1, n_launch),
@@ -803,7 +911,7 @@ def run_verifier(args):
                                         "kernel_ms_avg is over all window launches = the dispatch-weighted mean of the two rows of profiles/r04_final/kernel_stats.csv",
                          "algorithmic_bytes_per_launch": g_rank * bytes_per_gate / max(1, n_launch), "bytes_per_gate": bytes_per_gate, "calls_timed": n_calls_timed,
                          "note": "algorithmic-bytes accounting of SURVEY.md §8(d); fusion and the LDS label window keep most of those bytes off HBM, the limit that binds is T-table AES issue (DESIGN.md §3)",
-                         "binding_limit": "aes-issue", "aes_ceiling_gates_per_s": AES_CEILING_AND_PER_S / f_nf, "aes_ceiling_frac": (g_rank / stream_s) / (AES_CEILING_AND_PER_S / f_nf)},
+                         "binding_limit": "aes-issue", "aes_ceiling_gates_per_s": aes_and_per_s / f_nf, "aes_ceiling_frac": (g_rank / stream_s) / (aes_and_per_s / f_nf), "aes_ceiling_source": aes_src},
         })
         print(json.dumps(result), flush=True)
         if save_later:  # after the result line: the next process on this machine starts from the file
@@ -941,6 +1049,7 @@ def run_synthetic(args):
         stream_s = sum(r["step_ms"]) / 1e3
         g_rank = r["gates_per_instance"] * B
         achieved = g_rank * bytes_per_gate / stream_s / 1e9
+        aes_and_per_s, aes_src = measure_aes_ceiling(lambda m: print(m, file=sys.stderr))
         result = {"metric": "gates/sec (garble) on Groth16/BN254 verifier at 1/2/4/8 GPUs; ciphertext-hash match", "value": g_rank * world / el, "unit": "gates/s", "n_gpus": world,
                   "steps": K, "warmup": args.warmup, "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
                   "config": {"workload": "Groth16-shaped SYNTHETIC: chain of %d %s links = %d gates per instance; %d cut-and-choose instances per GPU" % (replays, args.component, gpr * replays, B),
@@ -948,7 +1057,7 @@ def run_synthetic(args):
                   "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                                "kernel": "run_program_kernel<false, %d, 0, %s>" % (ni, "true" if prog.info.get("and_terms", 2) == 4 else "false"), "kernel_ms_avg": stream_s * 1e3 / K, "bytes_per_gate": bytes_per_gate,
                                "algorithmic_bytes_per_launch": g_rank / K * bytes_per_gate, "binding_limit": "aes-issue",
-                               "aes_ceiling_gates_per_s": AES_CEILING_AND_PER_S / f_nf, "aes_ceiling_frac": (g_rank / stream_s) / (AES_CEILING_AND_PER_S / f_nf)}}
+                               "aes_ceiling_gates_per_s": aes_and_per_s / f_nf, "aes_ceiling_frac": (g_rank / stream_s) / (aes_and_per_s / f_nf), "aes_ceiling_source": aes_src}}
         if not args.no_check:
             import oracle_lib as o
             os.environ["GSV_INSTANCES_PER_WG"] = str(ni)
@@ -989,6 +1098,7 @@ def main():
     ap.add_argument("--small-batch-units", default="fq6", choices=["fq6", "fq12"], help="unit granularity of the plan the legs with 1 and 16 instances run (rate_by_instances, cc16_one_gpu, "
                     "garble_then_evaluate): fq6 (default) builds a second plan with the Fq12 multiplications and squarings entered as fq6::mul_montgomery units, fq12 uses the headline's plan")
     ap.add_argument("--units", default="fq12", choices=["fq12", "fq6"], help="unit granularity of the headline's plan: fq12 (default) or fq6 (experiments: the small-batch plan at full occupancy)")
+    ap.add_argument("--no-headline-ct-check", action="store_true", help="skip the extra whole pass after the timed steps that checks the timed configuration's ciphertexts (~2 min)")
     ap.add_argument("--no-cc16", action="store_true", help="skip the cc16_one_gpu leg (BASELINE config 5 with all 16 instances on this GPU, ~40 s)")
     ap.add_argument("--replays", type=int, default=0, help="synthetic: chain links per instance (0 = enough for 11.17 B gates)")
     ap.add_argument("--ct-ring", type=int, default=2, help="synthetic: replays of ciphertexts kept per instance in HBM")

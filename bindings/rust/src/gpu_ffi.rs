@@ -32,6 +32,24 @@ impl Default for GsvPlanSessionOpts {
     }
 }
 
+/// gsv_compile_opts (include/gsv_engine.h): one image for a share of the LDS window, background compilation, records into a plan file.
+#[repr(C)]
+pub struct GsvCompileOpts {
+    pub struct_size: u32, // size_of::<GsvCompileOpts>()
+    pub window_div: u32,
+    pub keep_trace: u32,
+    pub background: u32,
+    pub consume_recorder: u32,
+    pub reserved: u32,
+    pub for_plan: *mut GsvPlanRecorder,
+}
+#[repr(C)]
+pub struct GsvPlanRecorderOpts {
+    pub struct_size: u32, // size_of::<GsvPlanRecorderOpts>()
+    pub window_div: u32,
+    pub plan_file: *const c_char,
+}
+
 /// CiphertextHandler::handle over a run of records of one instance (include/gsv_engine.h, gsv_ct_sink_fn): non-zero aborts the pass.
 pub type GsvCtSinkFn = unsafe extern "C" fn(user: *mut std::ffi::c_void, instance: usize, first_record: u64, records: *const u8, n_records: u64) -> c_int;
 /// CiphertextSource::recv for a run of records (gsv_ct_source_fn): non-zero = the source has run dry.
@@ -47,20 +65,26 @@ extern "C" {
     pub fn gsv_recorder_create(out: *mut *mut GsvRecorder) -> c_int;
     pub fn gsv_recorder_destroy(r: *mut GsvRecorder);
     pub fn gsv_recorder_allocate_wire(r: *mut GsvRecorder, credits: u16, wire_out: *mut u64) -> c_int;
+    pub fn gsv_recorder_allocate_wires(r: *mut GsvRecorder, n: usize, first_wire_out: *mut u64) -> c_int;
     pub fn gsv_recorder_declare_input(r: *mut GsvRecorder, wire: u64) -> c_int;
     pub fn gsv_recorder_push_gates(r: *mut GsvRecorder, gates: *const GsvGate, n: usize) -> c_int;
     pub fn gsv_recorder_declare_outputs(r: *mut GsvRecorder, wires: *const u64, n: usize) -> c_int;
     pub fn gsv_program_compile(r: *mut GsvRecorder, fb_out: *const u32, fb_in: *const u32, n_fb: usize, out: *mut *mut GsvProgram) -> c_int;
+    pub fn gsv_program_compile_opts(r: *mut GsvRecorder, opts: *const GsvCompileOpts, out: *mut *mut GsvProgram) -> c_int;
+    pub fn gsv_program_wait(p: *mut GsvProgram) -> c_int;
     pub fn gsv_program_destroy(p: *mut GsvProgram);
     // plans: component-level programs (the verifier)
     pub fn gsv_plan_recorder_create(out: *mut *mut GsvPlanRecorder) -> c_int;
+    pub fn gsv_plan_recorder_create_opts(opts: *const GsvPlanRecorderOpts, out: *mut *mut GsvPlanRecorder) -> c_int;
     pub fn gsv_plan_recorder_destroy(r: *mut GsvPlanRecorder);
+    pub fn gsv_plan_recorder_allocate_wires(r: *mut GsvPlanRecorder, n: usize, first_wire_out: *mut u64) -> c_int;
     pub fn gsv_plan_recorder_allocate_wire(r: *mut GsvPlanRecorder, credits: u16, wire_out: *mut u64) -> c_int;
     pub fn gsv_plan_recorder_declare_input(r: *mut GsvPlanRecorder, wire: u64) -> c_int;
     pub fn gsv_plan_recorder_push_gates(r: *mut GsvPlanRecorder, gates: *const GsvGate, n: usize) -> c_int;
     pub fn gsv_plan_recorder_call(r: *mut GsvPlanRecorder, program: *const GsvProgram, in_wires: *const u64, out_wires: *mut u64) -> c_int;
     pub fn gsv_plan_recorder_finish(r: *mut GsvPlanRecorder, output_wires: *const u64, n_outputs: usize, out: *mut *mut GsvPlan) -> c_int;
     pub fn gsv_plan_destroy(p: *mut GsvPlan);
+    pub fn gsv_plan_load(path: *const c_char, e: *mut GsvEngine, out: *mut *mut GsvPlan) -> c_int;
     pub fn gsv_plan_io(p: *const GsvPlan, n_inputs: *mut u64, n_outputs: *mut u64) -> c_int;
     // engine + sessions
     pub fn gsv_engine_create(device: c_int, out: *mut *mut GsvEngine) -> c_int;

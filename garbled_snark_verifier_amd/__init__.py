@@ -83,7 +83,7 @@ EXPORTS = [
     "gsv_session_garble_streaming", "gsv_session_garble_streaming_calls", "gsv_plan_call_info", "gsv_plan_image_bytes", "gsv_plan_wire_file", "gsv_plan_save", "gsv_plan_load", "gsv_plan_build_file", "gsv_cbcmac_chains_per_step", "gsv_session_evaluate_streaming", "gsv_session_instances_per_workgroup", "gsv_session_enable_step_clock", "gsv_session_read_step_clock", "gsv_program_step_stats",
     "gsv_session_create_plan_opts", "gsv_session_plan_schedule_info", "gsv_session_plan_window", "gsv_session_set_unchecked_slices",
     "gsv_session_garble_streaming_sink", "gsv_session_garble_evaluate", "gsv_session_evaluate_streaming_indexed", "gsv_session_evaluate_streaming_source",
-    "gsv_recorder_allocate_wires", "gsv_plan_recorder_allocate_wires", "gsv_program_compile_opts", "gsv_program_wait", "gsv_plan_recorder_create_opts",
+    "gsv_recorder_allocate_wires", "gsv_plan_recorder_allocate_wires", "gsv_program_compile_opts", "gsv_program_wait", "gsv_plan_recorder_create_opts", "gsv_session_set_drain_instances",
 ]
 
 # CiphertextHandler / CiphertextSource as host callbacks (include/gsv_engine.h: gsv_ct_sink_fn, gsv_ct_source_fn)
@@ -168,6 +168,7 @@ def lib():
         L.gsv_session_plan_schedule_info.argtypes = [vp, C.POINTER(_PlanScheduleInfo)]
         L.gsv_session_plan_window.argtypes = [vp, C.c_uint64] + [C.POINTER(C.c_uint64)] * 3
         L.gsv_session_set_unchecked_slices.argtypes = [vp, C.c_int]
+        L.gsv_session_set_drain_instances.argtypes = [vp, C.c_size_t]
         L.gsv_session_garble_streaming_sink.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, CT_SINK_FN, vp, C.c_int, u8p]
         L.gsv_session_garble_evaluate.argtypes = [vp, vp, C.c_uint64, C.c_int, u8p]
         L.gsv_session_evaluate_streaming_indexed.argtypes = [vp, C.c_uint64, C.c_char_p, C.POINTER(C.c_uint64), u8p]
@@ -536,7 +537,13 @@ class Session:
         self.h = C.c_void_p()
         if isinstance(program, Plan):
             assert replays == 1
-            o = _PlanSessionOpts(2 if retain_stream == "ring" else int(bool(retain_stream)), int(concurrent_calls), int(window_ct_records), int(max_scratch_slots), int(max_window_calls), int(drain_segment_records))
+            if retain_stream == "ring" or (retain_stream is not True and retain_stream is not False and retain_stream == 2):
+                rs = 2  # GSV_STREAM_RING
+            elif retain_stream in (True, False, 0, 1):
+                rs = int(bool(retain_stream))
+            else:
+                raise ValueError("retain_stream must be True, False, 0, 1, 2 or \"ring\"")
+            o = _PlanSessionOpts(rs, int(concurrent_calls), int(window_ct_records), int(max_scratch_slots), int(max_window_calls), int(drain_segment_records))
             _chk(lib().gsv_session_create_plan_opts(engine.h, program.h, n_instances, C.byref(o), C.byref(self.h)))
         else:
             _chk(lib().gsv_session_create(engine.h, program.h, n_instances, replays, self.ct_cap, C.byref(self.h)))
@@ -654,6 +661,12 @@ class Session:
             _chk(lib().gsv_session_plan_window(self.h, w, C.byref(a), C.byref(b), C.byref(c)))
             out.append((a.value, b.value, c.value))
         return out
+
+    def set_drain_instances(self, n):
+        """The streaming calls garble every instance but only the first `n` instances' ciphertext streams leave the device (0 = all):
+        their hashes / gc files / sink runs are what the calls then return (a checked SAMPLE of a full-GPU batch)."""
+        _chk(lib().gsv_session_set_drain_instances(self.h, int(n)))
+        self.n_drain = int(n) or self.n
 
     def set_unchecked_slices(self, on=True):
         """Timing harnesses only: allow garble_calls slices that do not continue the previous one (stale wires, meaningless MACs)."""

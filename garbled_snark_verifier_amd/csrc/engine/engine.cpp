@@ -189,6 +189,7 @@ struct gsv_session {
   Schedule sched;
   void *d_calls = nullptr, *d_copy_src = nullptr, *d_copy_dst = nullptr, *d_deps = nullptr, *d_flags = nullptr, *d_error = nullptr;
   uint32_t flag_stride = 0, epoch = 0;
+  size_t drain_instances = 0;               // streaming calls: only the first this-many instances' streams leave the device (0 = all)
   uint64_t next_call = 0;                   // streaming slices: the call the next slice must start with
   bool unchecked_slices = false;            // benchmarks may garble slices out of order (results are then meaningless)
   void* plan_out_slots = nullptr;
@@ -1246,6 +1247,10 @@ static Schedule make_schedule(const gsv_plan* plan, uint32_t ni, size_t n_instan
   }
   sp.max_window_calls = std::min<uint32_t>(o.max_window_calls ? o.max_window_calls : 32768u, 65535u);
   Schedule sc = schedule_calls(calls, plan->n_globals, plan->outputs, sp);
+  {  // always: the O(calls) ring checks (a violation would otherwise show up as a 60 s device stall and status 2)
+    const std::string err = verify_ring_bounds(calls, sc);
+    if (!err.empty()) gsv_panic("plan schedule: " + err);
+  }
   if (getenv("GSV_PLAN_DEBUG") || getenv("GSV_VERIFY_SCHEDULE")) {
     const std::string err = verify_schedule(calls, plan->n_globals, plan->outputs, sc);
     if (!err.empty()) gsv_panic("internal: plan schedule violates a hazard: " + err);
@@ -1398,6 +1403,13 @@ int gsv_session_plan_window(const gsv_session* s, uint64_t window, uint64_t* fir
   if (first_call) *first_call = w.call0;
   if (n_calls) *n_calls = w.call1 - w.call0;
   if (max_width) *max_width = w.max_width;
+  return GSV_OK;
+}
+int gsv_session_set_drain_instances(gsv_session* s, size_t n) {
+  if (!s || n > s->n_inst) return fail(GSV_ERR_INVALID, "null session / more instances than the session holds");
+  if (s->ct_gate && (n == 0 ? s->n_inst : n) > (s->drain_instances ? s->drain_instances : s->n_inst))
+    return fail(GSV_ERR_INVALID, "the session's gate-order buffers were sized for fewer instances: set this before the first streaming call");
+  s->drain_instances = n;
   return GSV_OK;
 }
 int gsv_session_set_unchecked_slices(gsv_session* s, int on) {
@@ -1602,7 +1614,8 @@ static int permute_plan_calls(gsv_session* s, size_t w, uint32_t k0, uint32_t k1
     if (!cp.n_ct) continue;
     const uint64_t rel = s->plan->calls[k].ct_off - win.ct0;
     uint8_t* block = static_cast<uint8_t*>(ct_block) + (s->plan_retain ? s->plan->calls[k].ct_off : s->ct_ring ? s->sched.ring_off[k] : rel) * 16;
-    if (gsvk_gather_segment(block, s->ct_stride(), s->call_dev[k].dp.ct_pos, cp.n_ct, 1, uint32_t(s->n_inst), static_cast<uint8_t*>(gate_buf) + (s->plan->calls[k].ct_off - gate_ct0) * 16, gate_stride, scatter, stream) != 0)
+    const size_t n_gather = (!scatter && s->drain_instances) ? std::min(s->drain_instances, s->n_inst) : s->n_inst;  // gsv_session_set_drain_instances
+    if (gsvk_gather_segment(block, s->ct_stride(), s->call_dev[k].dp.ct_pos, cp.n_ct, 1, uint32_t(n_gather), static_cast<uint8_t*>(gate_buf) + (s->plan->calls[k].ct_off - gate_ct0) * 16, gate_stride, scatter, stream) != 0)
       return fail(GSV_ERR_DEVICE, scatter ? "ciphertext scatter launch failed" : "ciphertext gather launch failed");
   }
   return GSV_OK;
@@ -1825,12 +1838,34 @@ static int wait_calls_done(gsv_session* s, size_t w, uint32_t k0, uint32_t k1, b
   const uint32_t n_wg = uint32_t((s->n_inst + s->ni - 1) / s->ni);
   const auto t0 = std::chrono::steady_clock::now();
   bool reported = false;
+  // Host-side deadline, progress based like the device's watchdog (kernels.hip) and longer than it: the device gives up after
+  // GSV_DEP_WAIT_SECONDS (default 60) without a completed call of an instance group and then ENDS its launch, which the stream query below
+  // sees; this deadline covers the device that never comes back at all (no counter of the window has moved for twice that time + 30 s).
+  double dev_secs = 60.0;
+  if (const char* ev = getenv("GSV_DEP_WAIT_SECONDS")) { char* end = nullptr; const double v = std::strtod(ev, &end); if (end != ev && v > 0) dev_secs = std::min(v, 86400.0); }
+  const double deadline = 2.0 * dev_secs + 30.0;
+  uint64_t last_sum = ~0ull;
+  auto last_move = t0;
+  uint32_t polls = 0;
   while (!*window_done && k0 < k1) {
     bool all = true;
     for (uint32_t k = k0; k < k1 && all; ++k) all = __atomic_load_n(s->host_done + (k - win.call0), __ATOMIC_ACQUIRE) == n_wg;
     if (all) break;
-    if (hipStreamQuery(s->e->stream) == hipSuccess) { *window_done = true; break; }
+    const hipError_t q = hipStreamQuery(s->e->stream);
+    if (q == hipSuccess) { *window_done = true; break; }
+    if (q != hipErrorNotReady) {  // a failed launch / a lost device is neither "done" nor "running": the caller's error path must run
+      (void)hipGetLastError();
+      return fail(GSV_ERR_DEVICE, std::string("the window's launch failed while its stream was being drained: ") + hipGetErrorString(q));
+    }
     std::this_thread::sleep_for(std::chrono::microseconds(100));
+    if ((++polls & 1023u) == 0) {  // every ~0.1 s: has any call of the window completed for another workgroup?
+      uint64_t sum = 0;
+      for (uint32_t k = win.call0; k < win.call1; ++k) sum += __atomic_load_n(s->host_done + (k - win.call0), __ATOMIC_RELAXED);
+      const auto now = std::chrono::steady_clock::now();
+      if (sum != last_sum) { last_sum = sum; last_move = now; }
+      else if (std::chrono::duration<double>(now - last_move).count() > deadline)
+        return fail(GSV_ERR_DEVICE, "no call of the running window has completed for " + std::to_string(int(deadline)) + " s and its launch has not ended: giving up on the device");
+    }
     if (!reported && getenv("GSV_DRAIN_DEBUG") && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 3.0) {
       reported = true;
       std::string msg;
@@ -1860,7 +1895,8 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   const uint64_t n_ct = s->plan ? s->plan_max_segment : g.n_ct, seg = s->plan ? 1 : s->ct_cap;
   const uint64_t first = s->plan ? pw0 : 0, total = s->plan ? pw1 : s->replays;
   const bool new_pass = s->plan ? c0 == 0 : true;
-  const size_t n_inst = s->n_inst;
+  // the instances whose streams leave the device: all of them, or the first drain_instances (every instance is garbled either way)
+  const size_t n_inst = s->drain_instances ? std::min(s->drain_instances, s->n_inst) : s->n_inst;
   const bool want_drain = sink.any();
   const bool want_mac = sink.hashes != nullptr;
   const size_t GROUP = size_t(gsv_drain::group_for(n_inst));

@@ -108,6 +108,16 @@ struct WireFile {
     if (slot & GSV_SLOT_LDS_FLAG) v = *win(slot); else v = hbm[slot];
     return Label{{v.x, v.y, v.z, v.w}};
   }
+  // Branch-free form of ld() (GSV_BF_LD builds): BOTH locations are read — the one that does not hold the label reads an all-zero label
+  // (window entry 0 / wire-file slot 2, program.hpp) — and the caller XORs the two.  No exec-mask juggling, no wait between the LDS read
+  // and the global load of one operand: all operand loads of a gate are in flight at once.
+  __device__ __forceinline__ void ld2(uint32_t slot, u32x4& l, u32x4& g) const {
+    const bool in_lds = (slot & GSV_SLOT_LDS_FLAG) != 0;
+    const uint32_t la = in_lds ? (slot << 4) + (win_base - (GSV_SLOT_LDS_FLAG << 4)) : win_base;
+    const uint32_t gs = in_lds ? 2u : slot;
+    l = *reinterpret_cast<lds_u128*>(uintptr_t(la));
+    g = hbm[gs];
+  }
   __device__ __forceinline__ void st(uint32_t slot, const Label& l) const {
     const u32x4 v = {l.w[0], l.w[1], l.w[2], l.w[3]};
     if (slot & GSV_SLOT_LDS_FLAG) *win(slot) = v; else hbm[slot] = v;
@@ -525,6 +535,14 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           }
         };
         load_xor_recs(0, xr);
+#ifdef GSV_SKEW_XOR
+        // Odd waves run the step's free gates BEFORE its AND passes, even waves after (the two are the same dependency level): the waves
+        // of a CU then do not all sit in their memory-bound phase / in their AES passes at the same time.
+        const bool xor_first = __builtin_amdgcn_readfirstlane(int((threadIdx.x >> 6) & 1u)) != 0;
+#pragma unroll 1
+        for (int ph = 0; ph < 2; ++ph) {
+          if ((ph == 0) != xor_first) {
+#endif
         // ---- AND-family gates: whole passes of BT gates in the one-gate-per-lane form (two interleaved AES blocks
         // per lane), then the remainder in the LPG-lanes-per-gate form: a partly filled one-gate-per-lane pass would
         // cost the full ~5 us AES latency for a handful of waves, the multi-lane form ~1 us per BT/LPG gates.
@@ -538,13 +556,38 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           const Rec q = qnext;
           if (i + BT < and_full) qnext = load_and_rec(and_off + i + BT);
           const uint32_t cti = and_off + i;
+#if defined(GSV_BF_LD)
+          // every load of the gate — the record's second half, five LDS reads, five wire-file reads — is issued before anything waits
+          // for one of them (the scheduling barrier keeps the compiler from sinking a use, and with it a wait, between them)
+          constexpr bool BF = !FW;  // (the four-wire instantiations keep the branching loads: with both forms they spill 31 VGPRs)
+          const u32x4 hi_q = load_and_hi(cti);
+          u32x4 l0, l1, l2, l3, l4, g0, g1, g2, g3, g4;
+          if (BF && !no_load) {
+            const AndOp os = decode_and(q, u32x4{0u, 0u, 0u, 0u});  // the slots of a two-wire record sit in its first half
+            wf.ld2(os.a1, l0, g0); wf.ld2(os.a2, l1, g1); wf.ld2(os.b1, l2, g2); wf.ld2(os.b2, l3, g3); wf.ld2(os.p, l4, g4);
+          }
+          if (BF) __builtin_amdgcn_sched_barrier(0);
+          const AndOp o = decode_and(q, hi_q);
+#else
           const AndOp o = decode_and(q, load_and_hi(cti));
+#endif
           const uint32_t t = o.t;
           Label a = delta, b = delta, pl{{0, 0, 0, 0}};
           if (!no_load) {
+#ifdef GSV_BF_LD
+            if (BF) {
+              const u32x4 av = (l0 ^ l1) ^ (g0 ^ g1), bv = (l2 ^ l3) ^ (g2 ^ g3), pv = l4 ^ g4;
+              a = Label{{av.x, av.y, av.z, av.w}}; b = Label{{bv.x, bv.y, bv.z, bv.w}}; pl = Label{{pv.x, pv.y, pv.z, pv.w}};
+            } else {
+              a = lxor(wf.ld(o.a1), wf.ld(o.a2));
+              b = lxor(wf.ld(o.b1), wf.ld(o.b2));
+              pl = wf.ld(o.p);
+            }
+#else
             a = lxor(wf.ld(o.a1), wf.ld(o.a2));
             b = lxor(wf.ld(o.b1), wf.ld(o.b2));
             pl = wf.ld(o.p);
+#endif
             if (four_wire) {
               a = lxor(a, lxor(wf.ld(o.a3), wf.ld(o.a4)));
               b = lxor(b, lxor(wf.ld(o.b3), wf.ld(o.b4)));
@@ -578,6 +621,9 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           const Rec q = (and_full == 0 && g == tid / LPG) ? r0 : load_and_rec(and_off + g);
           and_multilane(q, load_and_hi(and_off + g), and_off + g);
         }
+#ifdef GSV_SKEW_XOR
+          } else {
+#endif
         // ---- free-gate batches (their label stores are the wave's youngest stores: no young ciphertext store)
         if (xor_cnt) { issue_xor_operands(0); load_xor_recs(uint32_t(XB) * BT, xrn); }
         for (uint32_t base = 0; base < xor_cnt; base += XB * BT) {
@@ -590,6 +636,10 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
             load_xor_recs(nb + XB * BT, xrn);
           }
         }
+#ifdef GSV_SKEW_XOR
+          }
+        }
+#endif
       }
       // keep r0's registers reserved through the step: were they handed to a store's data in between, the refill below would
       // have to wait for that store (vmcnt(0) in front of the prefetch) before it could overwrite them

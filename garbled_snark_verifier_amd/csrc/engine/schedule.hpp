@@ -354,4 +354,26 @@ inline std::string verify_schedule(const std::vector<SchedCall>& calls, uint32_t
   return std::string();
 }
 
+// The O(calls) part of the ring checks, run for EVERY session with a ciphertext ring (verify_schedule's record-by-record simulation only
+// fits the tests' small rings): every call's block lies inside the ring, seg_end is the end of the call's own drain segment, and the
+// position a garbling call waits for (ring_need) ends at or before its OWN segment's first record — a call that waited for its own
+// segment would wait for itself: the 60 s device stall + status 2 that a ring too small for the plan used to end in.
+inline std::string verify_ring_bounds(const std::vector<SchedCall>& calls, const Schedule& s) {
+  if (!s.ring_ct) return std::string();
+  const size_t n = calls.size();
+  if (s.ring_off.size() != n || s.ring_need.size() != n || s.seg_end.size() != n) return "ring tables do not cover every call";
+  for (const Schedule::Window& w : s.windows)
+    for (uint32_t q = w.seg0; q < w.seg1; ++q) {
+      if (q >= s.segments.size()) return "a window names a segment that does not exist";
+      const Schedule::Segment& sg = s.segments[q];
+      for (uint32_t k = sg.call0; k < sg.call1; ++k) {
+        if (k >= n) return "a segment names a call that does not exist";
+        if (s.ring_off[k] + calls[k].n_ct > s.ring_ct) return "ring: the block of call " + std::to_string(k) + " leaves the ring";
+        if (s.seg_end[k] != sg.ct0 + sg.n_ct) return "ring: seg_end of call " + std::to_string(k) + " is not the end of its segment";
+        if (s.ring_need[k] > sg.ct0) return "ring: call " + std::to_string(k) + " waits for its own drain segment (the ring is too small for this plan: raise window_ct_records / GSV_CT_RING_RECORDS)";
+      }
+    }
+  return std::string();
+}
+
 }  // namespace gsv

@@ -438,6 +438,67 @@ inline Fq12 multi_miller_loop_groth16_evaluate_montgomery_fast(CircuitContext& c
   });
   return Fq12::from_wires(out);
 }
+
+// ---- pairing.rs functions that are NOT on the verifier's path, restated for `tools/gate_counts --pairing-csv` (the rows of the reference's
+// examples/pairing_gate_counts.rs).  Plain functions here: the reference wraps the two const-Q loops in #[component(offcircuit_args)]
+// (pairing.rs:737, 775), which changes neither the gate stream nor the count.
+inline G1Wires g1_normalize_to_affine(CircuitContext& c, const G1Wires& p) {  // pairing.rs:173-186
+  Wires inv_z = fq::inverse_montgomery(c, p.z);
+  Wires inv_z2 = fq::square_montgomery(c, inv_z);
+  Wires inv_z3 = fq::mul_montgomery(c, inv_z2, inv_z);
+  Wires x = fq::mul_montgomery(c, p.x, inv_z2);
+  Wires y = fq::mul_montgomery(c, p.y, inv_z3);
+  return G1Wires{x, y, constant_wires(fq_as_montgomery_const(BigU(1)), 254)};
+}
+inline Fq12 ell_eval_const(CircuitContext& c, const Fq12& f, const HEllCoeff& coeffs, const G1Wires& p) {  // pairing.rs:134-151
+  Fq2 c0_fq2 = fq2::mul_constant_by_fq_montgomery(c, coeffs.c0, p.y);
+  Fq2 c3_fq2 = fq2::mul_constant_by_fq_montgomery(c, coeffs.c1, p.x);
+  return fq12::mul_by_034_constant4_montgomery(c, f, c0_fq2, c3_fq2, coeffs.c2.as_montgomery_const());
+}
+// pairing.rs:776-843 (one P per constant Q; every P normalised to affine first); with one pair it is miller_loop_const_q's stream (:738-774)
+inline Fq12 multi_miller_loop_const_q(CircuitContext& c, const std::vector<G1Wires>& ps, const std::vector<std::pair<HFq2, HFq2>>& qs) {
+  if (ps.size() != qs.size()) gsv_panic("multi_miller_loop_const_q: |ps| != |qs|");
+  if (ps.empty()) return fq12::one_constant();
+  std::vector<std::vector<HEllCoeff>> qells;
+  for (const auto& q : qs) qells.push_back(h_ell_coeffs(q.first, q.second));
+  std::vector<G1Wires> ps_aff;
+  for (const G1Wires& p : ps) ps_aff.push_back(g1_normalize_to_affine(c, p));
+  Fq12 f = fq12::one_constant();
+  size_t step = 0;
+  auto eval_step = [&]() { for (size_t k = 0; k < ps_aff.size(); ++k) f = ell_eval_const(c, f, qells[k][step], ps_aff[k]); ++step; };
+  for (int i = 64; i >= 1; --i) {
+    if (i != 64) f = fq12::square_montgomery(c, f);
+    eval_step();
+    const int8_t bit = ATE_LOOP_COUNT[i - 1];
+    if (bit == 1 || bit == -1) eval_step();
+  }
+  eval_step();
+  eval_step();
+  if (step != qells[0].size()) gsv_panic("internal: line coefficient count mismatch");
+  return f;
+}
+inline Fq12 miller_loop_const_q(CircuitContext& c, const G1Wires& p, const HFq2& qx, const HFq2& qy) {  // pairing.rs:738-774
+  return multi_miller_loop_const_q(c, {p}, {{qx, qy}});
+}
+// pairing.rs:640-698 (variable Qs: their line coefficients come from ell_coeffs_montgomery, all of them BEFORE the loop; inputs assumed
+// affine, no normalisation); with one pair it is miller_loop_montgomery_fast's stream (:845-878)
+inline Fq12 multi_miller_loop_montgomery_fast(CircuitContext& c, const std::vector<G1Wires>& ps, const std::vector<G2Wires>& qs) {
+  std::vector<std::vector<Fq6>> qells;
+  for (const G2Wires& q : qs) qells.push_back(ell_coeffs_montgomery(c, q));
+  Fq12 f = fq12::one_constant();
+  size_t step = 0;
+  auto eval_step = [&]() { for (size_t k = 0; k < ps.size(); ++k) f = ell_montgomery(c, f, qells[k][step], ps[k]); ++step; };
+  for (int i = 64; i >= 1; --i) {
+    if (i != 64) f = fq12::square_montgomery(c, f);
+    eval_step();
+    const int8_t bit = ATE_LOOP_COUNT[i - 1];
+    if (bit == 1 || bit == -1) eval_step();
+  }
+  eval_step();
+  eval_step();
+  return f;
+}
+inline Fq12 miller_loop_montgomery_fast(CircuitContext& c, const G1Wires& p, const G2Wires& q) { return multi_miller_loop_montgomery_fast(c, {p}, {q}); }  // pairing.rs:845-878
 }  // namespace pairing
 
 }  // namespace gadgets

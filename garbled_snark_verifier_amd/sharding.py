@@ -22,11 +22,32 @@ import torch.distributed as dist
 from . import lib as _lib  # noqa: F401  (host AES for label commits lives behind the C ABI)
 
 
-def instance_seeds(master_seed, total):
-    """`total` u64 seeds drawn up front by the garbler (garbler.rs:201-203 draws rng.gen::<u64>() per instance).
-    The stand-alone harness uses numpy's PCG64 here; a Rust host passes its own seeds."""
-    rng = np.random.Generator(np.random.PCG64(master_seed))
-    return rng.integers(0, 2**63, size=total, dtype=np.uint64)
+def u64_stream_from_labels(labels, total):
+    """The first `total` values of `rng.next_u64()` given the first ceil(total / 2) values of `rng.gen::<u128>()` as 16-byte big-endian
+    labels (S::to_bytes): rand 0.8.5 draws a u128 as next_u64() | next_u64() << 64 — the first call is the LOW half."""
+    out = []
+    for lab in np.asarray(labels, np.uint8).reshape(-1, 16):
+        b = bytes(lab)
+        out += [int.from_bytes(b[8:16], "big"), int.from_bytes(b[0:8], "big")]
+    return np.array(out[:total], dtype=np.uint64)
+
+
+def instance_seeds(master_seed, total, rng="chacha"):
+    """`total` u64 seeds drawn up front by the garbler, as the reference draws them: `rng.gen::<u64>()` per instance on the caller's RNG
+    (cut_and_choose/garbler.rs:201-203), which the reference's own test seeds as `ChaCha20Rng::seed_from_u64(1234)`
+    (cut_and_choose/tests.rs:102).  The ChaCha stream is the product's own (gsv_labels_from_seed: the generator behind
+    GarbleMode::new); tests compare it with the oracle's independent restatement.  rng="numpy" keeps the pre-round-5 PCG64 draw for
+    callers that stored such seeds."""
+    if rng == "numpy":
+        g = np.random.Generator(np.random.PCG64(master_seed))
+        return g.integers(0, 2**63, size=total, dtype=np.uint64)
+    if rng != "chacha":
+        raise ValueError("rng must be \"chacha\" or \"numpy\"")
+    from . import labels_from_seed
+    n128 = (int(total) + 1) // 2
+    d, f, t, inp = labels_from_seed(int(master_seed), max(0, n128 - 3))
+    labels = np.concatenate([np.stack([d, f, t]), np.asarray(inp, np.uint8).reshape(-1, 16)])[:n128]
+    return u64_stream_from_labels(labels, int(total))
 
 
 def shard_instances(total, rank, world):

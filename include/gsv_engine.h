@@ -151,8 +151,8 @@ int gsv_plan_io(const gsv_plan* p, uint64_t* n_inputs, uint64_t* n_outputs);
  * receive one fresh parent wire per program output.  finish computes the global wires and returns the plan (which owns the
  * glue programs; the unit programs stay the caller's and must outlive the plan). */
 int gsv_plan_recorder_create(gsv_plan_recorder** out);
-/* With options: window_div as in gsv_compile_opts (the glue programs the recorder compiles itself, and every unit compiled with
- * for_plan = this recorder); plan_file (may be NULL): every program of the plan is appended to this file when it has been compiled and its
+/* With options: window_div as in struct gsv_compile_opts — for the glue programs the recorder compiles itself and for every unit compiled with
+ * for_plan = this recorder; plan_file (may be NULL): every program of the plan is appended to this file when it has been compiled and its
  * records are dropped — the host never holds the plan's images (the verifier: 41 GB).  gsv_plan_recorder_finish then completes the file
  * (atomically: temp file + rename) and returns a plan that holds metadata only (counts, calls; gsv_plan_counts / _call_info / _io work,
  * sessions do not): load the file with gsv_plan_load(path, engine).  The file equals the one gsv_plan_build_file writes for the same
@@ -320,6 +320,12 @@ int gsv_session_garble_streaming_calls(gsv_session* s, uint64_t gate_id_base, ui
  * of the session's schedule; anything else is GSV_ERR_INVALID.  Timing harnesses that garble slices out of order (stale wires,
  * meaningless MACs) say so explicitly: */
 int gsv_session_set_unchecked_slices(gsv_session* s, int on);
+/* Drain a SAMPLE of a large batch: the streaming calls (gsv_session_garble_streaming*, _sink) garble every instance but only the streams of
+ * the first n instances leave the device (hashes then receives n x 16 bytes, gc files / the sink see instances 0 .. n-1); 0 = all (the
+ * default).  For checking the ciphertexts of a full-GPU batch whose whole stream (1 024 x 47.7 GB) no PCIe link carries in reasonable
+ * time: the reference holds no counterpart (its garbler hashes every instance, cut_and_choose/garbler.rs:219-222).  Set it before the
+ * session's first streaming call (the gate-order buffers are sized by it). */
+int gsv_session_set_drain_instances(gsv_session* s, size_t n);
 
 /* The generic ciphertext sink: CiphertextHandler::handle (circuit/mod.rs:140-178) for ANY consumer — the reference has three impls, the
  * CBC-MAC accumulator, the hash + file writer and a channel Sender<S> (circuit/mod.rs:160-170) that feeds an evaluator thread; this is

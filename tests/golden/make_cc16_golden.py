@@ -1,5 +1,5 @@
 """Generates cc16_golden.json: the GarbledInstanceCommit table of BASELINE config 5 on a SHORTENED circuit (Fq12 multiplication),
-built from the CPU oracle's garblings — 16 seeds from master seed 2024 exactly as sharding.cut_and_choose_commit draws them.
+built from the CPU oracle's garblings — 16 seeds from master seed 1234 exactly as sharding.cut_and_choose_commit draws them.
 bench.py --workload cc16 compares the table its ranks gather (GPU garbling, ciphertext commitments, one all-gather) with the
 sha256 stored here; tests/test_gpu_parity.py compares record by record.
 
@@ -16,11 +16,14 @@ import numpy as np  # noqa: E402
 import oracle_lib as o  # noqa: E402
 from garbled_snark_verifier_amd import sharding  # noqa: E402
 
-CIRCUIT, MASTER, TOTAL = "fq12_mul", 2024, 16
+CIRCUIT, MASTER, TOTAL = "fq12_mul", 1234, 16  # cut_and_choose/tests.rs:102: ChaCha20Rng::seed_from_u64(1234)
 
 
 def main():
-    seeds = sharding.instance_seeds(MASTER, TOTAL)
+    # the seeds as the reference draws them (garbler.rs:201-203: rng.gen::<u64>() per instance), from the ORACLE's ChaCha stream — the
+    # product's sharding.instance_seeds must reproduce them (tests/test_distributed_cpu.py)
+    import oracle_lib as _o
+    seeds = sharding.u64_stream_from_labels(_o.chacha_labels(MASTER, (TOTAL + 1) // 2), TOTAL)
     recs = []
     for i in range(TOTAL):
         g = o.garble(CIRCUIT, int(seeds[i]), capture_ct=False)

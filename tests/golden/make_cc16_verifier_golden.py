@@ -1,5 +1,5 @@
 """Generates cc16_verifier_golden.json: BASELINE config 5 at its REAL size — the GarbledInstanceCommit records of the 16 instances
-of master seed 2024 on the FULL one-public-input `groth16_verify_compressed` circuit (11 456 865 898 gates each), every one garbled
+of master seed 1234 on the FULL one-public-input `groth16_verify_compressed` circuit (11 456 865 898 gates each), every one garbled
 by the CPU oracle from the flat gate stream (≈14 min of one core per instance; `-j` worker processes, each result cached under
 /tmp so an interrupted run resumes).
 
@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import numpy as np  # noqa: E402
 
-MASTER, TOTAL = 2024, 16
+MASTER, TOTAL = 1234, 16  # cut_and_choose/tests.rs:102: ChaCha20Rng::seed_from_u64(1234)
 CACHE = "/tmp/gsv_cc16_verifier_cache"
 
 
@@ -48,7 +48,10 @@ def main():
     from garbled_snark_verifier_amd import sharding
     j = int(sys.argv[sys.argv.index("-j") + 1]) if "-j" in sys.argv else 8
     os.makedirs(CACHE, exist_ok=True)
-    seeds = sharding.instance_seeds(MASTER, TOTAL)
+    # the seeds as the reference draws them (garbler.rs:201-203: rng.gen::<u64>() per instance), from the ORACLE's ChaCha stream — the
+    # product's sharding.instance_seeds must reproduce them (tests/test_distributed_cpu.py)
+    import oracle_lib as _o
+    seeds = sharding.u64_stream_from_labels(_o.chacha_labels(MASTER, (TOTAL + 1) // 2), TOTAL)
     with mp.get_context("spawn").Pool(j) as pool:
         res = pool.map(one, [(i, int(seeds[i])) for i in range(TOTAL)], chunksize=1)
     res.sort(key=lambda d: d["index"])

@@ -215,6 +215,6 @@ def test_traffic_counters_are_bound_to_the_engine_sources():
     from garbled_snark_verifier_amd import build as b
     h = b.source_sha256()
     assert len(h) == 64 and h == b.source_sha256()
-    finals = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.endswith("_final"))
+    finals = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.endswith("_final") and os.path.exists(os.path.join(ROOT, "profiles", d, "traffic.json")))
     tj = json.load(open(os.path.join(ROOT, "profiles", finals[-1], "traffic.json")))
     assert len(tj["engine_library_sha256"]) == 64 and len(tj["engine_source_sha256"]) == 64 and tj["hbm_bytes_per_launch"] > 0

@@ -101,7 +101,7 @@ def test_cc16_cut_and_choose_commit_world2():
     instance i -> rank i mod 2, every instance garbled WITH its ciphertext commitment, one all-gather of the GarbledInstanceCommit
     records.  Here on gloo with the host interpreter as the garbler and a shortened circuit (Fq multiplication): both ranks end up
     with the same table, and all 16 records equal the ones built from the CPU oracle's garbling."""
-    world, total, master, circuit = 2, 16, 2024, "fq_mul"
+    world, total, master, circuit = 2, 16, 1234, "fq_mul"
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -130,7 +130,7 @@ def test_cc16_cut_and_choose_commit_world8():
     CPU with the host interpreter as the garbler (u254 adder: eight processes share this container's cores): every rank ends up with
     the same 16-record table, ordered by instance index, each record equal to the one built from the CPU oracle's garbling — the
     rank logic the driver's 8-GPU run executes, exercised before it ever meets eight GPUs."""
-    world, total, master, circuit = 8, 16, 2024, "u254_add"
+    world, total, master, circuit = 8, 16, 1234, "u254_add"
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -210,6 +210,31 @@ def test_cc16_ranks_agree_on_a_failed_plan_load_world8(bad_rank, tmp_path):
         assert p.exitcode == 0
     assert all(res[r][0] == "error" for r in range(world)), res
     assert "plan" in res[0][1] and "failed on a rank" in res[0][1]
+
+
+def test_instance_seeds_are_drawn_as_the_reference_draws_them():
+    """Garbler::create draws `rng.gen::<u64>()` per instance (cut_and_choose/garbler.rs:201-203) on the caller's RNG — the reference's
+    own test: ChaCha20Rng::seed_from_u64(1234) (cut_and_choose/tests.rs:102).  sharding.instance_seeds (the product's ChaCha stream,
+    gsv_labels_from_seed) equals the oracle's independent ChaCha restatement value for value, the committed cut-and-choose fixtures were
+    built from exactly these seeds, an odd count takes the low half of the last u128, and the pre-round-5 numpy draw is still there
+    behind an explicit argument."""
+    import json
+    import oracle_lib as o
+    from garbled_snark_verifier_amd import sharding
+    ref = sharding.u64_stream_from_labels(o.chacha_labels(1234, 8), 16)
+    got = sharding.instance_seeds(1234, 16)
+    assert got.dtype == np.uint64 and (got == ref).all() and len(set(int(x) for x in got)) == 16
+    # next_u64 pairs: u128 = lo | hi << 64 with the FIRST call the low half; delta is the first u128 GarbleMode::new draws from the same stream
+    lab = o.chacha_labels(1234, 1)[0]
+    assert int(got[0]) == int.from_bytes(bytes(lab[8:16]), "big") and int(got[1]) == int.from_bytes(bytes(lab[0:8]), "big")
+    assert (sharding.instance_seeds(1234, 5) == got[:5]).all() and len(sharding.instance_seeds(1234, 0)) == 0
+    for name in ("cc16_golden.json", "cc16_verifier_golden.json"):
+        g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)))
+        assert g["master_seed"] == 1234 and g["seeds"] == [int(x) for x in sharding.instance_seeds(g["master_seed"], g["total"])]
+    old = sharding.instance_seeds(2024, 16, rng="numpy")
+    assert (old == np.random.Generator(np.random.PCG64(2024)).integers(0, 2**63, size=16, dtype=np.uint64)).all()
+    with pytest.raises(ValueError):
+        sharding.instance_seeds(1, 1, rng="mt19937")
 
 
 def test_shard_instances_partition():

@@ -26,7 +26,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 VERIFIER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cyclotomic_square_montgomery", "fq12::mul_by_034_montgomery",
                   "pairing::ell_by_constant_montgomery", "pairing::double_in_place_circuit_montgomery", "pairing::add_in_place_montgomery", "pairing::mul_by_char_montgomery",
-                  "bigint::multiplexer", "g1::add_montgomery", "inverse_iteration", "inverse::divide_result_by_2^k::chunk", "inverse::divide_result_by_even_part::chunk", "fp254::exp_chunk"]
+                  "bigint::multiplexer", "g1::add_montgomery", "inverse::iteration_group", "inverse::divide_chains", "fp254::exp_chunk"]
 
 
 @pytest.fixture(scope="module")

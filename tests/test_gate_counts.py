@@ -21,6 +21,8 @@ def counter(tmp_path_factory):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "garbled_snark_verifier_amd", "csrc"), os.path.join(ROOT, "tools", "gate_counts.cpp"), "-o", exe])
 
     def run(spec, depth=2):
+        if spec == "--pairing-csv":
+            return subprocess.check_output([exe, spec], text=True)
         out = subprocess.check_output([exe, spec, str(depth)], text=True)
         total, nonfree = map(int, re.search(r"total gates (\d+)\s+non-free (\d+)", out).groups())
         tree = {}
@@ -101,3 +103,29 @@ def test_independent_python_count_of_the_whole_verifier(counter):
     for name, gates in r["top"].items():
         assert top[name] == gates, name
     assert sum(r["top"].values()) + 3_047 == total  # + Fq12::equal_constant: twelve 254-bit comparisons (253 gates each) and the 11 ANDs of the tree above them
+
+
+def test_pairing_csv(counter):
+    """tools/gate_counts --pairing-csv: the rows of the reference's examples/pairing_gate_counts.rs (the committed
+    profiles/r05_parity/pairing_gate_counts.csv is this output: what first contact with cargo diffs).  Pinned against the rest of this
+    tree: rows that name a gadget the verifier uses equal that gadget's count from the two-pass driver / the component table; the
+    single-pair multi loops equal the single loops; the variable-Q loop = its coefficient chain + 64 doubling and 27 addition evaluations
+    of the line + 63 squarings."""
+    out = counter("--pairing-csv")
+    assert out == open(os.path.join(ROOT, "profiles", "r05_parity", "pairing_gate_counts.csv")).read()
+    rows = dict(ln.split(",") for ln in out.strip().splitlines()[1:])
+    rows = {k: int(v) for k, v in rows.items()}
+    assert len(rows) == 15
+    n_in, _ = o.circuit_info("fq_mul")
+    assert rows["fq_mul_montgomery"] == int(o.execute("fq_mul", np.zeros(n_in, np.uint8))[1].sum()) == 414_284
+    for name, spec in (("test_double_in_place_montgomery", "g2_double"), ("test_add_in_place_montgomery", "g2_add"), ("test_mul_by_char_montgomery", "g2_mul_by_char")):
+        n_in, _ = o.circuit_info(spec)
+        assert rows[name] == int(o.execute(spec, np.zeros(n_in, np.uint8))[1].sum())
+    assert rows["test_ell_coeffs_evaluate_montgomery_fast"] == 1_077_650_918 and rows["test_deserialized_compressed_g2"] == 473_589_412  # DESIGN.md §2's table
+    n_in, _ = o.circuit_info("ell_eval")
+    ell = int(o.execute("ell_eval", np.zeros(n_in, np.uint8))[1].sum())
+    assert rows["test_ell_montgomery"] == rows["test_ell_coeffs_evaluate_montgomery_fast"] + ell
+    n_in, _ = o.circuit_info("fq12_square")
+    sq = int(o.execute("fq12_square", np.zeros(n_in, np.uint8))[1].sum())
+    assert rows["test_miller_loop_evaluate_montgomery_fast"] == rows["test_multi_miller_loop_evaluate_montgomery_fast"] == rows["test_ell_coeffs_evaluate_montgomery_fast"] + 91 * ell + 63 * sq
+    assert rows["test_miller_loop"] == rows["test_multi_miller_loop"]

@@ -891,6 +891,51 @@ def test_batched_evaluate_from_finalized_instances(engine, tmp_path):
         prog.close()
 
 
+def test_drain_instances_checks_a_sample_of_a_batch(engine, tmp_path, monkeypatch):
+    """gsv_session_set_drain_instances: a streaming pass garbles EVERY instance but only the first n instances' ciphertext streams leave the
+    device — how bench.py checks the ciphertexts of its timed 1 024-instance, four-per-workgroup configuration (8 x 47.7 GB over PCIe
+    instead of 1 024 x).  Five instances of fq12_mix, four per workgroup, two drained: their MACs and gc files equal the oracle's flat
+    streams, the other three report no MAC and write no file, every instance's output labels equal the oracle's; the sink form sees
+    instances 0 and 1 only; raising the sample after the gate-order buffers exist is refused."""
+    import garbled_snark_verifier_amd as gsv
+    monkeypatch.setenv("GSV_INSTANCES_PER_WG", "4")
+    plan = gsv.Plan.from_circuit("fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"], window_div=4)
+    seeds = [71, 72, 73, 74, 75]
+    B, n_in = len(seeds), plan.info["n_inputs"]
+    labs = [gsv.labels_from_seed(s, n_in) for s in seeds]
+    delta = np.stack([x[0] for x in labs]); consts = np.stack([np.stack([x[1], x[2]]) for x in labs]); inputs = np.stack([x[3] for x in labs])
+    refs = [o.garble("fq12_mix", s, capture_ct=False) for s in seeds]
+    sess = gsv.Session(engine, plan, B, retain_stream=False, window_ct_records=6_000_000)
+    assert sess.instances_per_workgroup == 4
+    sess.set_drain_instances(2)
+    sess.set_garble_inputs(delta, consts, inputs)
+    gc = str(tmp_path)
+    hashes = sess.garble_streaming(directory=gc)
+    out = sess.read_outputs()
+    for i in range(B):
+        assert (out[i] == refs[i].output_label0).all()
+        if i < 2:
+            assert hashes[i] == refs[i].ct_hash.tobytes() and os.path.getsize(os.path.join(gc, gsv.gc_file_name(i))) == 16 * refs[i].n_ciphertexts
+        else:
+            assert hashes[i] == bytes(16) and not os.path.exists(os.path.join(gc, gsv.gc_file_name(i)))
+    seen = {}
+
+    def handler(inst, first, recs):
+        assert first == seen.get(inst, 0)
+        seen[inst] = first + len(recs)
+
+    sess.set_garble_inputs(delta, consts, inputs)
+    h2 = sess.garble_to_sink(handler, with_hashes=True)
+    assert seen == {0: refs[0].n_ciphertexts, 1: refs[1].n_ciphertexts} and h2[:2] == hashes[:2]
+    with pytest.raises(gsv.GsvError):
+        sess.set_drain_instances(4)  # the gate-order buffers were sized for two
+    sess.set_drain_instances(1)
+    sess.set_garble_inputs(delta, consts, inputs)
+    assert sess.garble_streaming()[0] == refs[0].ct_hash.tobytes()
+    sess.close()
+    plan.close()
+
+
 def test_plan_recorder_through_the_c_abi(engine):
     """gsv_plan_recorder_*: the plan builder driven the way a host with its own two-pass driver would.
     The gates of Fq::add are pushed one by one as glue (taken from a recording of the component), Fq::mul_montgomery is a
@@ -1037,7 +1082,7 @@ VERIFIER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cycl
                   # the Fq inversions (binary extended Euclid, fp254impl.rs:333-690) enter as their own 4-iteration components: as ONE unit an
                   # inversion (11 M ciphertexts) — or the Fq12 inversion around it (21 M) — would set the size of every instance's device
                   # ciphertext block (340 MB x 512 instances); their chunks keep the largest block at an Fq12 multiplication's 5.4 M records
-                  "inverse_iteration", "inverse::divide_result_by_2^k::chunk", "inverse::divide_result_by_even_part::chunk"]
+                  "inverse::iteration_group", "inverse::divide_chains"]
 
 
 @pytest.fixture(scope="module")
@@ -1125,6 +1170,34 @@ def test_verifier_lockstep_two_instances_per_workgroup(engine, compressed_verifi
     par.close()
 
 
+def test_verifier_whole_pass_four_per_workgroup_ciphertexts(engine, compressed_verifier_plan):
+    """The bench's TIMED configuration over a WHOLE pass with its ciphertexts checked: 1 024 instances of the verifier, four per workgroup
+    (run_program_kernel<false, 4, 0, *>, the default schedule's windows), every instance garbled, the streams of instances 0..7 — all four
+    workgroup positions, two workgroups — drained and CBC-MAC'ed (gsv_session_set_drain_instances).  Instance 0 carries the
+    single-instance fixture's seed, instances 1..7 seeds of the cut-and-choose fixture: MAC over all 2 980 165 547 ciphertexts and the
+    output label of each == the CPU oracle's flat stream (examples/groth16_garble.rs:255-263 compares exactly this hash).  The other
+    1 016 instances carry the fixture's seed as well: their output labels must equal instance 0's."""
+    import garbled_snark_verifier_amd as gsv
+    case, plan = compressed_verifier_plan
+    gold = json.load(open(os.path.join(os.path.dirname(GOLDEN), "cc16_verifier_golden.json")))
+    assert gold["gates"] == case["gates"] == plan.info["n_gates"]
+    B, n_in = 1024, plan.info["n_inputs"]
+    seeds = [case["seed"]] + [int(x) for x in gold["seeds"][:7]] + [case["seed"]] * (B - 8)
+    labs = {sd: gsv.labels_from_seed(sd, n_in) for sd in set(seeds)}
+    delta = np.stack([labs[sd][0] for sd in seeds]); consts = np.stack([np.stack([labs[sd][1], labs[sd][2]]) for sd in seeds]); inputs = np.stack([labs[sd][3] for sd in seeds])
+    sess = gsv.Session(engine, plan, B, retain_stream=False)
+    assert sess.instances_per_workgroup == 4
+    sess.set_drain_instances(8)
+    sess.set_garble_inputs(delta, consts, inputs)
+    hashes = sess.garble_streaming()
+    out = sess.read_outputs()
+    assert hashes[0].hex() == case["ct_hash"] and out[0][0].tobytes().hex() == case["first_output_label0"]
+    for k in range(7):
+        assert hashes[1 + k].hex() == gold["ct_hashes"][k] and out[1 + k][0].tobytes().hex() == gold["first_output_label0"][k], "instance %d (workgroup position %d)" % (1 + k, (1 + k) % 4)
+    assert (out[8:] == out[0][None]).all()
+    sess.close()
+
+
 def test_compressed_verifier_evaluates_valid_and_tampered_proof(engine, compressed_verifier_plan):
     """BASELINE config 4, evaluator side (EvaluateMode over the whole circuit, evaluate_mode.rs:123-158): two instances of the
     verifier are garbled with their 49 GB ciphertext streams retained in HBM and evaluated — one with the valid proof's input bits,
@@ -1155,7 +1228,7 @@ def test_compressed_verifier_evaluates_valid_and_tampered_proof(engine, compress
 
 def test_cc16_verifier_full_size_on_one_gpu(engine, compressed_verifier_plan):
     """BASELINE config 5 at its REAL size on the hardware that exists: sharding.cut_and_choose_commit — what `bench.py --workload cc16`
-    and the 8-GPU run execute per rank — garbles the 16 instances of master seed 2024 on the FULL one-public-input verifier
+    and the 8-GPU run execute per rank — garbles the 16 instances of master seed 1234 on the FULL one-public-input verifier
     (11 456 865 898 gates each, 183 B gates) on one GPU, every instance WITH its ciphertext commitment, and gathers the
     GarbledInstanceCommit records: all 16 must equal the records the CPU oracle built from 16 flat garblings of the same seeds
     (tests/golden/cc16_verifier_golden.json, tests/golden/make_cc16_verifier_golden.py)."""

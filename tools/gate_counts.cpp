@@ -2,6 +2,9 @@
 //
 //   g++ -O2 -std=c++17 -I garbled_snark_verifier_amd/csrc tools/gate_counts.cpp -o /tmp/gate_counts
 //   /tmp/gate_counts <circuit spec> [depth] [--json] [--verified true|false]
+//   /tmp/gate_counts --pairing-csv      the `test_name,total_gates` rows of the reference's examples/pairing_gate_counts.rs (same operations,
+//                                       same deterministic inputs: g1 = 5 G, g2 = 7 G2, the Fq2 constant (123, 456), ...), so that first contact
+//                                       with cargo is `cargo run --release --example pairing_gate_counts | sort | diff - <(sort this)`
 //
 // --json prints the schema of the reference's own counter (examples/groth16_gc_gate_count.rs:126-141: circuit_size, gate_count
 // {nonfree, free, total, *_formatted, breakdown = the eleven per-GateType counts in discriminant order}, verification_result,
@@ -18,6 +21,7 @@
 // non-free gates; then the call tree down to [depth].  Used for DESIGN.md's reconciliation table against the reference's
 // published 11,174,708,821 (README.md:12).
 #include <cstdio>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -119,8 +123,85 @@ static void json_tree(const Node& n, int depth, int max_depth) {
   std::printf("]}");
 }
 
+
+// ---- --pairing-csv: examples/pairing_gate_counts.rs, row for row (the reference prints the rows as its threads finish: compare sorted)
+namespace {
+using namespace gsv::gadgets;
+HFq hfq_inv(const HFq& a) {  // a^(p-2): the host only needs it for 7 G2 in affine form
+  const BigU e = HFq::sub_raw(HFq::p(), HFq::from_u64(2)).to_bigu();
+  HFq r = HFq::from_u64(1);
+  for (size_t i = e.bits(); i-- > 0;) { r = HFq::mul(r, r); if (e.bit(i)) r = HFq::mul(r, a); }
+  return r;
+}
+HFq2 hfq2_inv(const HFq2& a) {
+  const HFq n = hfq_inv(HFq::add(HFq::mul(a.c0, a.c0), HFq::mul(a.c1, a.c1)));
+  return {HFq::mul(a.c0, n), HFq::neg(HFq::mul(a.c1, n))};
+}
+uint64_t count_of(const std::function<void(CircuitContext&, const G1Wires&, const G2Wires&)>& body) {
+  CountCtx ctx;
+  Node root; root.name = "<root>";
+  ctx.tree = &root;
+  G1Wires g1{ctx.issue_wires(254), ctx.issue_wires(254), ctx.issue_wires(254)};  // Inputs::allocate: G1Projective::new, then G2Projective::new
+  G2Wires g2 = pairing::g2_from_wires(ctx.issue_wires(1524));
+  body(ctx, g1, g2);
+  return ctx.cur.total;  // StreamingResult::gate_count.total_gate_count(): every gate of the execution pass, dead ones included
+}
+int pairing_csv() {
+  // g2_aff = (7 * G2::generator()).into_affine(): 7 Q = 2 (2 Q + Q) + Q in the pairing's own homogeneous projective coordinates (x / z, y / z)
+  const HFq2 gx = test_g2_generator_x(), gy = test_g2_generator_y();
+  HG2 r{gx, gy, HFq2{HFq::from_u64(1), HFq()}};
+  (void)h_double_in_place(r); (void)h_add_in_place(r, gx, gy); (void)h_double_in_place(r); (void)h_add_in_place(r, gx, gy);
+  const HFq2 zi = hfq2_inv(r.z), q7x = HFq2::mul(r.x, zi), q7y = HFq2::mul(r.y, zi);
+  // on the twist: y^2 = x^3 + b'
+  if (HFq::cmp(HFq2::sub(HFq2::sq(q7y), HFq2::add(HFq2::mul(HFq2::sq(q7x), q7x), PairingConst::coeff_b())).c0, HFq()) != 0) { std::fprintf(stderr, "7 G2 is not on the curve\n"); return 1; }
+  const std::vector<HEllCoeff> ell7 = h_ell_coeffs(q7x, q7y);
+  auto mont = [](uint64_t v) { return fq_as_montgomery_const(BigU(v)); };
+  const Fq12 f0 = fq12::one_constant();
+  std::printf("test_name,total_gates\n");
+  auto row = [](const char* name, uint64_t n) { std::printf("%s,%llu\n", name, (unsigned long long)n); };
+  row("fq_mul_montgomery", count_of([&](CircuitContext& c, const G1Wires&, const G2Wires&) {
+    (void)fq::mul_montgomery(c, constant_wires(mont(0xFFFFFFFFull), 254), constant_wires(mont(0xFFFFFFFFFFFFFFFFull), 254)); }));
+  row("mul_constant_by_fq_montgomery", count_of([&](CircuitContext& c, const G1Wires& g1, const G2Wires&) {
+    (void)fq2::mul_constant_by_fq_montgomery(c, HFq2{HFq::from_u64(123), HFq::from_u64(456)}, g1.x); }));
+  row("fq_mul_by_constant_montgomery", count_of([&](CircuitContext& c, const G1Wires& g1, const G2Wires&) { (void)fq::mul_by_constant_montgomery(c, g1.x, mont(123)); }));
+  row("test_double_in_place_montgomery", count_of([&](CircuitContext& c, const G1Wires&, const G2Wires& g2) { (void)pairing::double_in_place_circuit_montgomery(c, g2); }));
+  row("test_add_in_place_montgomery", count_of([&](CircuitContext& c, const G1Wires&, const G2Wires& g2) { (void)pairing::add_in_place_montgomery(c, g2, g2); }));
+  row("test_mul_by_char_montgomery", count_of([&](CircuitContext& c, const G1Wires&, const G2Wires& g2) { (void)pairing::mul_by_char_montgomery(c, g2); }));
+  row("test_ell_montgomery", count_of([&](CircuitContext& c, const G1Wires& g1, const G2Wires& g2) {
+    const std::vector<Fq6> coeffs = pairing::ell_coeffs_montgomery(c, g2);
+    (void)pairing::ell_montgomery(c, f0, coeffs[0], g1); }));
+  row("test_ell_by_constant_montgomery", count_of([&](CircuitContext& c, const G1Wires& g1, const G2Wires&) { (void)pairing::ell_eval_const(c, f0, ell7[0], g1); }));
+  row("test_ell_coeffs_evaluate_montgomery_fast", count_of([&](CircuitContext& c, const G1Wires&, const G2Wires& g2) { (void)pairing::ell_coeffs_montgomery(c, g2); }));
+  row("test_miller_loop_evaluate_montgomery_fast", count_of([&](CircuitContext& c, const G1Wires& g1, const G2Wires& g2) { (void)pairing::miller_loop_montgomery_fast(c, g1, g2); }));
+  row("test_miller_loop", count_of([&](CircuitContext& c, const G1Wires& g1, const G2Wires&) { (void)pairing::miller_loop_const_q(c, g1, q7x, q7y); }));
+  row("test_deserialized_compressed_g1", count_of([&](CircuitContext& c, const G1Wires& g1, const G2Wires&) {
+    const Wires& x = g1.x;
+    Wires x2 = fq::square_montgomery(c, x);
+    Wires x3 = fq::mul_montgomery(c, x2, x);
+    Wires y2 = fq::add(c, x3, constant_wires(mont(3), 254));  // Fq::add with the constant as WIRES (g1::Config::COEFF_B = 3), not add_constant
+    Wires y = fq::sqrt_montgomery(c, y2);
+    Wires neg_y = fq::neg(c, y);
+    (void)gadgets::select(c, y, neg_y, TRUE_WIRE); }));
+  row("test_deserialized_compressed_g2", count_of([&](CircuitContext& c, const G1Wires&, const G2Wires& g2) {
+    const Fq2& x = g2.x;
+    Fq2 x2 = fq2::square_montgomery(c, x);
+    Fq2 x3 = fq2::mul_montgomery(c, x2, x);
+    Fq2 y2 = fq2::add_constant(c, x3, PairingConst::coeff_b().as_montgomery_const());
+    Fq2 y = fq2::sqrt_general_montgomery(c, y2);
+    Fq2 neg_y = fq2::neg(c, y);
+    (void)gadgets::select(c, y.c[0], neg_y.c[0], TRUE_WIRE);
+    (void)gadgets::select(c, y.c[1], neg_y.c[1], TRUE_WIRE); }));
+  row("test_multi_miller_loop", count_of([&](CircuitContext& c, const G1Wires& g1, const G2Wires&) { (void)pairing::multi_miller_loop_const_q(c, {g1}, {{q7x, q7y}}); }));
+  row("test_multi_miller_loop_evaluate_montgomery_fast", count_of([&](CircuitContext& c, const G1Wires& g1, const G2Wires& g2) { (void)pairing::multi_miller_loop_montgomery_fast(c, {g1}, {g2}); }));
+  return 0;
+}
+}  // namespace
+
 int main(int argc, char** argv) {
-  if (argc < 2) { std::fprintf(stderr, "usage: gate_counts <circuit spec> [tree depth] [--json] [--verified true|false]\n"); return 2; }
+  if (argc < 2) { std::fprintf(stderr, "usage: gate_counts <circuit spec> [tree depth] [--json] [--verified true|false]\n       gate_counts --pairing-csv\n"); return 2; }
+  if (std::string(argv[1]) == "--pairing-csv") {
+    try { return pairing_csv(); } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
+  }
   int depth = 3;
   bool json = false;
   const char* verified = "null";

@@ -27,7 +27,7 @@ UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cyclotomic_sq
                   # the Fq inversions (binary extended Euclid, fp254impl.rs:333-690) enter as their own 4-iteration components: as ONE unit an
                   # inversion (11 M ciphertexts) — or the Fq12 inversion around it (21 M) — would set the size of every instance's device
                   # ciphertext block (340 MB x 512 instances); their chunks keep the largest block at an Fq12 multiplication's 5.4 M records
-                  "inverse_iteration", "inverse::divide_result_by_2^k::chunk", "inverse::divide_result_by_even_part::chunk"]
+                  "inverse::iteration_group", "inverse::divide_chains"]
 COMPRESSED = "--compressed" in sys.argv  # groth16_verify_compressed (groth16.rs:250-268): decompression of A, B, C in front of the verifier
 if COMPRESSED:  # the square roots are ladders of ~380 Fq multiplications each: four ladder steps (one fp254::exp_chunk component) are a unit
     UNITS += ["fp254::exp_chunk"]

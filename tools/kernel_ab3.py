@@ -18,7 +18,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 eng = gsv.Engine(0)
 print("library:", os.environ.get("GSV_ENGINE_SO", "libgsv_engine.so"), flush=True)
 SHAPES = (("wide   ", "fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"]), ("ladder ", "fq_sqrt", ["fp254::exp_chunk"]),
-          ("inverse", "fq_inverse", ["inverse_iteration", "inverse::divide_result_by_2^k::chunk", "inverse::divide_result_by_even_part::chunk"]))
+          ("inverse", "fq_inverse", ["inverse_iteration", "inverse::divide_result_by_2^k::chunk", "inverse::divide_result_by_even_part::chunk"]),
+          ("inv_grp", "fq_inverse", ["inverse::iteration_group", "inverse::divide_chains"]))  # round 5: the inversion as 3 long calls
 for name, spec, units in SHAPES:
     plan = gsv.Plan.from_circuit(spec, units, window_div=4)
     ref = None

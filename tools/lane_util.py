@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""AES-lane utilisation of a plan: how full are the AND passes of the kernel's wide steps?
+
+usage: lane_util.py <plan file (.gsvplan)> [<out.json>]
+
+For every program of the plan (weighted by the number of its calls) and NI = 1, 2, 4 instances per workgroup (BT = 1024 / NI threads per
+instance, kernels.hip) the step descriptors {and_off, and_cnt, xor_off, xor_cnt} give, without a GPU:
+  pass_fill   = sum(and_cnt) / sum(ceil(and_cnt / BT) * BT)     what VERDICT r4 item 4 asks for: a partial pass counted as a full one
+  wave_fill   = sum(and_cnt) / sum(ceil(and_cnt / 64) * 64)     what the LDS / VALU pipes see: an idle WAVE of a partial pass issues nothing,
+                                                                a partly filled wave issues everything
+  kernel_fill = the same with the kernel's own rule (kernels.hip run_step): whole passes of BT one-gate-per-lane, then a remainder of at most
+                2 * BT / 8 gates in the eight-lanes-per-gate form (same lookups per gate, so it counts as full), a larger remainder as one
+                partly filled one-gate-per-lane pass at wave granularity; narrow steps (and_cnt * 8 + xor_cnt <= BT) are all multi-lane
+plus the share of AND gates that sit in narrow steps / in multi-lane remainders, and steps per call."""
+import json
+import mmap
+import struct
+import sys
+
+import numpy as np
+
+HDR = struct.Struct("<8s6I3Q2Q")
+PROG = struct.Struct("<6Q8Q11Q10I")
+
+
+def pad16(n):
+    return (n + 15) & ~15
+
+
+def main():
+    path = sys.argv[1]
+    with open(path, "rb") as f:
+        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+    h = HDR.unpack_from(mm, 0)
+    n_prog, n_calls, rec_sizes, calls_off, table_off = h[1], h[2], h[9], h[10], h[11]
+    sd = rec_sizes & 0xFFFF
+    table = struct.unpack_from("<%dQ" % n_prog, mm, table_off)
+    # calls per program
+    calls = np.zeros(n_prog, np.int64)
+    pos = calls_off
+    for _ in range(n_calls):
+        prog, n_in, n_out, _ = struct.unpack_from("<4I", mm, pos)
+        calls[prog] += 1
+        pos += 16 + pad16(4 * n_in) + pad16(4 * n_out)
+    res = {"plan_file": path, "programs": int(n_prog), "calls": int(n_calls), "by_instances_per_workgroup": {}}
+    steps_all = []
+    for k in range(n_prog):
+        f = PROG.unpack_from(mm, table[k])
+        n_steps, and_terms = f[0], f[-1]
+        a = np.frombuffer(mm, dtype=np.uint32, count=n_steps * 4, offset=table[k] + pad16(PROG.size)).reshape(n_steps, 4)
+        steps_all.append((a[:, 1].astype(np.int64), a[:, 3].astype(np.int64), int(calls[k]), int(and_terms)))
+    for ni in (1, 2, 4):
+        bt = 1024 // ni
+        tot = dict(ands=0, pass_slots=0, wave_slots=0, kernel_slots=0, narrow_ands=0, multilane_rem_ands=0, steps=0, narrow_steps=0, and_steps=0)
+        split = {2: dict(ands=0, kernel_slots=0), 4: dict(ands=0, kernel_slots=0)}
+        for ac, xc, w, terms in steps_all:
+            if w == 0:
+                continue
+            has = ac > 0
+            narrow = has & ((((ac * 8 + 63) // 64) * 64 + xc) <= bt)
+            wide = has & ~narrow
+            rem = ac % bt
+            small = rem <= 2 * (bt // 8)
+            full = np.where(small, ac - rem, ac)
+            # kernel slots: narrow -> as many as gates; wide: full passes at wave granularity (only the last pass can be partial) + multi-lane remainder as gates
+            kslots = np.where(narrow, ac, ((full + 63) // 64) * 64 + np.where(small, rem, 0))
+            tot["ands"] += int(ac.sum()) * w
+            tot["pass_slots"] += int((((ac + bt - 1) // bt) * bt)[has].sum()) * w
+            tot["wave_slots"] += int((((ac + 63) // 64) * 64)[has].sum()) * w
+            tot["kernel_slots"] += int(kslots[has].sum()) * w
+            tot["narrow_ands"] += int(ac[narrow].sum()) * w
+            tot["multilane_rem_ands"] += int(np.where(small, rem, 0)[wide].sum()) * w
+            tot["steps"] += len(ac) * w
+            tot["narrow_steps"] += int(narrow.sum()) * w
+            tot["and_steps"] += int(has.sum()) * w
+            split[terms]["ands"] += int(ac.sum()) * w
+            split[terms]["kernel_slots"] += int(kslots[has].sum()) * w
+        e = {"threads_per_instance": bt, "and_gates": tot["ands"], "device_steps": tot["steps"], "steps_with_and_gates": tot["and_steps"], "narrow_steps": tot["narrow_steps"],
+             "pass_fill": tot["ands"] / tot["pass_slots"], "wave_fill": tot["ands"] / tot["wave_slots"], "kernel_fill": tot["ands"] / tot["kernel_slots"],
+             "and_share_in_narrow_steps": tot["narrow_ands"] / tot["ands"], "and_share_in_multilane_remainders": tot["multilane_rem_ands"] / tot["ands"],
+             "kernel_fill_two_wire_programs": split[2]["ands"] / max(1, split[2]["kernel_slots"]), "kernel_fill_four_wire_programs": split[4]["ands"] / max(1, split[4]["kernel_slots"]),
+             "and_share_two_wire_programs": split[2]["ands"] / tot["ands"]}
+        res["by_instances_per_workgroup"][str(ni)] = e
+        print("NI=%d (BT %4d): pass_fill %.4f  wave_fill %.4f  kernel_fill %.4f (two-wire programs %.4f, four-wire %.4f); ANDs in narrow steps %.2f %%, in multi-lane remainders %.2f %%; %d steps (%d narrow)"
+              % (ni, bt, e["pass_fill"], e["wave_fill"], e["kernel_fill"], e["kernel_fill_two_wire_programs"], e["kernel_fill_four_wire_programs"], 100 * e["and_share_in_narrow_steps"],
+                 100 * e["and_share_in_multilane_remainders"], e["device_steps"], e["narrow_steps"]))
+    if len(sys.argv) > 2:
+        json.dump(res, open(sys.argv[2], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
