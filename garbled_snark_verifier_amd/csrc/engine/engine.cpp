@@ -1788,6 +1788,8 @@ struct DrainSink {
 // program-order block while the garbler writes window k+1 into the other one of two blocks.
 struct PairState {
   hipStream_t stream = nullptr;                           // the evaluator's launches
+  hipStream_t gstream = nullptr;                          // CU-masked pairs: the garbler's launches (else they go to the engine's stream)
+  hipEvent_t ready = nullptr;                             // engine stream -> gstream hand-over at the start of a pass
   hipEvent_t garbled[2] = {nullptr, nullptr}, evaluated[2] = {nullptr, nullptr};
 };
 static int ensure_pair(gsv_session* s) {
@@ -1799,7 +1801,32 @@ static int ensure_pair(gsv_session* s) {
     // 5 ms for a one-thread kernel on the candidate — and the ones that queue up behind the engine's stream are kept alive until a
     // good one is found (the round-robin moves on), then destroyed.  No overlapping stream among eight: the last one serves (the pair
     // is still correct, window k is then evaluated after window k+1 has been garbled instead of beside it).
-    {
+    // Round 5: the two long launches get DISJOINT sets of CUs through CU-masked streams (hipExtStreamCreateWithCUMask): a masked stream
+    // owns a hardware queue of its own (the mask is a queue property), so the overlap no longer depends on which queue the runtime's
+    // round-robin picks, and neither launch's waiting workgroups — a window holds more calls than run at once, the rest spin on their
+    // dependency flags with a whole CU's LDS each — can sit on the CUs the other one needs (the 40 - 65 s run-to-run spread of round 4).
+    // Three quarters of the CUs garble (two AES blocks per AND), a quarter evaluates (one).  The mask bits alternate in blocks of eight,
+    // 3 : 1: whichever way the runtime maps bits to XCDs / shader engines, every XCD keeps CUs of both launches.  GSV_PAIR_CU_MASK=0, or a
+    // runtime that refuses the masks, falls back to the probed unmasked stream below.
+    if (!(getenv("GSV_PAIR_CU_MASK") && atoi(getenv("GSV_PAIR_CU_MASK")) == 0)) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, s->e->device) == hipSuccess && prop.multiProcessorCount >= 32) {
+        const uint32_t n_cu = uint32_t(prop.multiProcessorCount), words = (n_cu + 31) / 32;
+        std::vector<uint32_t> gm(words, 0), em(words, 0);
+        for (uint32_t i = 0; i < n_cu; ++i) (((i / 8) % 4 == 3) ? em : gm)[i / 32] |= 1u << (i % 32);
+        hipStream_t g = nullptr, e2 = nullptr;
+        if (hipExtStreamCreateWithCUMask(&g, words, gm.data()) == hipSuccess && hipExtStreamCreateWithCUMask(&e2, words, em.data()) == hipSuccess &&
+            hipEventCreateWithFlags(&ps->ready, hipEventDisableTiming) == hipSuccess) {
+          ps->gstream = g; ps->stream = e2;
+          if (getenv("GSV_DRAIN_DEBUG")) std::fprintf(stderr, "garble -> evaluate: CU-masked streams, %u CUs garble, %u evaluate\n", n_cu - n_cu / 4, n_cu / 4);
+        } else {
+          (void)hipGetLastError();
+          if (g) (void)hipStreamDestroy(g);
+          if (e2) (void)hipStreamDestroy(e2);
+        }
+      }
+    }
+    if (!ps->stream) {
       std::vector<hipStream_t> rejected;
       uint32_t* const word = static_cast<uint32_t*>(s->d_error) + 4;
       for (int attempt = 0; attempt < 8 && !ps->stream; ++attempt) {
@@ -1828,12 +1855,15 @@ static void destroy_pair(PairState* ps) {
   if (!ps) return;
   for (int b = 0; b < 2; ++b) { if (ps->garbled[b]) (void)hipEventDestroy(ps->garbled[b]); if (ps->evaluated[b]) (void)hipEventDestroy(ps->evaluated[b]); }
   if (ps->stream) (void)hipStreamDestroy(ps->stream);
+  if (ps->gstream) (void)hipStreamDestroy(ps->gstream);
+  if (ps->ready) (void)hipEventDestroy(ps->ready);
   delete ps;
 }
 
 // Follows the RUNNING window w through the completion counters its workgroups write into mapped host memory (kernels.hip, epilogue)
 // until calls [k0, k1) of the plan have completed for every instance group, or the window's launch itself has finished (*window_done).
-static int wait_calls_done(gsv_session* s, size_t w, uint32_t k0, uint32_t k1, bool* window_done) {
+static int wait_calls_done(gsv_session* s, size_t w, uint32_t k0, uint32_t k1, bool* window_done, hipStream_t launch_stream = nullptr) {
+  if (!launch_stream) launch_stream = s->e->stream;  // the stream the running window was launched on
   const Schedule::Window& win = s->sched.windows[w];
   const uint32_t n_wg = uint32_t((s->n_inst + s->ni - 1) / s->ni);
   const auto t0 = std::chrono::steady_clock::now();
@@ -1851,7 +1881,7 @@ static int wait_calls_done(gsv_session* s, size_t w, uint32_t k0, uint32_t k1, b
     bool all = true;
     for (uint32_t k = k0; k < k1 && all; ++k) all = __atomic_load_n(s->host_done + (k - win.call0), __ATOMIC_ACQUIRE) == n_wg;
     if (all) break;
-    const hipError_t q = hipStreamQuery(s->e->stream);
+    const hipError_t q = hipStreamQuery(launch_stream);
     if (q == hipSuccess) { *window_done = true; break; }
     if (q != hipErrorNotReady) {  // a failed launch / a lost device is neither "done" nor "running": the caller's error path must run
       (void)hipGetLastError();
@@ -2058,7 +2088,14 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   if (want_drain && T + 1 > gsv_drain::usable_cores()) (void)hipEventCreateWithFlags(&device_done_owner.ev, hipEventBlockingSync | hipEventDisableTiming);
   const hipEvent_t device_done = device_done_owner.ev;
   int rc = GSV_OK;
-  if (hipEventRecord(s->ev0, s->e->stream) != hipSuccess) { finish_workers(); close_files(); return fail(GSV_ERR_DEVICE, "hipEventRecord failed"); }
+  // The stream the garbler's windows are launched on: the engine's, or — a garble || evaluate pair with CU-masked streams (ensure_pair) —
+  // the pair's masked garbler stream, which first waits for whatever the engine's stream still holds (input staging, the memsets above).
+  hipStream_t gs = s->e->stream;
+  if (ev && s->pair->gstream) {
+    gs = s->pair->gstream;
+    if (hipEventRecord(s->pair->ready, s->e->stream) != hipSuccess || hipStreamWaitEvent(gs, s->pair->ready, 0) != hipSuccess) { finish_workers(); close_files(); return fail(GSV_ERR_DEVICE, "stream hand-over failed"); }
+  }
+  if (hipEventRecord(s->ev0, gs) != hipSuccess) { finish_workers(); close_files(); return fail(GSV_ERR_DEVICE, "hipEventRecord failed"); }
   for (uint64_t r0 = first; r0 < total && rc == GSV_OK; r0 += seg) {
     const uint64_t r1 = std::min(total, r0 + seg);
     uint64_t n_records, base;  // per instance, in this segment; stream index of its first record
@@ -2069,13 +2106,13 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
         // window w goes to block w & 1; the evaluator must be done with what that block held (window w - 2)
         const int b = int(w & 1);
         block = b ? s->ct_alt : s->CT;
-        if (w >= pw0 + 2 && hipStreamWaitEvent(s->e->stream, s->pair->evaluated[b], 0) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "hipStreamWaitEvent failed"); break; }
+        if (w >= pw0 + 2 && hipStreamWaitEvent(gs, s->pair->evaluated[b], 0) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "hipStreamWaitEvent failed"); break; }
       }
-      rc = launch_plan_window(s, w, gate_id_base, false, block);
+      rc = launch_plan_window(s, w, gate_id_base, false, block, gs);
       if (rc != GSV_OK) break;
       if (ev) {
         const int b = int(w & 1);
-        if (hipEventRecord(s->pair->garbled[b], s->e->stream) != hipSuccess || hipStreamWaitEvent(s->pair->stream, s->pair->garbled[b], 0) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "event hand-over failed"); break; }
+        if (hipEventRecord(s->pair->garbled[b], gs) != hipSuccess || hipStreamWaitEvent(s->pair->stream, s->pair->garbled[b], 0) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "event hand-over failed"); break; }
         rc = launch_plan_window(ev, w, gate_id_base, true, block, s->pair->stream);
         if (rc != GSV_OK) break;
         if (hipEventRecord(s->pair->evaluated[b], s->pair->stream) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "hipEventRecord failed"); break; }
@@ -2093,11 +2130,11 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
           const Schedule::Segment& sg = s->sched.segments[q];
           const bool last = q + 1 == win.seg1;
           const auto t0 = std::chrono::steady_clock::now();
-          if (!last) rc = wait_calls_done(s, w, sg.call0, sg.call1, &window_done);
+          if (!last) rc = wait_calls_done(s, w, sg.call0, sg.call1, &window_done, gs);
           if (rc != GSV_OK) break;
           if (last && !window_done) {
             // the last segment ends with the window: sleep on the stream (on a blocking-sync event when the workers own the cores)
-            const bool ok = device_done ? hipEventRecord(device_done, s->e->stream) == hipSuccess && hipEventSynchronize(device_done) == hipSuccess : hipStreamSynchronize(s->e->stream) == hipSuccess;
+            const bool ok = device_done ? hipEventRecord(device_done, gs) == hipSuccess && hipEventSynchronize(device_done) == hipSuccess : hipStreamSynchronize(gs) == hipSuccess;
             if (!ok) { rc = fail(GSV_ERR_DEVICE, "kernel failed"); break; }
             window_done = true;
           }
@@ -2115,7 +2152,7 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
         }
         if (rc != GSV_OK) break;
       }
-      if (hipStreamSynchronize(s->e->stream) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "kernel failed"); break; }
+      if (hipStreamSynchronize(gs) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "kernel failed"); break; }
       continue;
     } else {
       // ring slots are (replay % ct_cap): a segment starts at a multiple of ct_cap, so its replays sit in slots 0..n_rep-1
@@ -2143,7 +2180,7 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   if (s->ct_ring && rc != GSV_OK) {
     // a failed pass: calls of the running window may still wait for room in the ring — let them run out (the results are discarded)
     __atomic_store_n(s->host_ct_pos, ~0ull, __ATOMIC_RELEASE);
-    (void)hipStreamSynchronize(s->e->stream);
+    (void)hipStreamSynchronize(gs);
   }
   finish_workers();
   if (ev && hipStreamSynchronize(s->pair->stream) != hipSuccess && rc == GSV_OK) rc = fail(GSV_ERR_DEVICE, "evaluation kernel failed");
@@ -2153,7 +2190,7 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
                  (unsigned long long)drained_records, double(drained_records) * double(n_inst) * 16e-9 / tot, T, GROUP, depth, t_wait_drain, t_wait_device, t_gather);
   }
   if (rc == GSV_OK && s->plan) {
-    (void)hipEventRecord(s->ev1, s->e->stream);
+    (void)hipEventRecord(s->ev1, gs);  // (every window on gs has been synchronised: the output gather on the engine's stream follows safely)
     if (c1 == s->plan->calls.size()) {
       rc = gather_plan_outputs(s, false);
       if (rc == GSV_OK && ev) rc = gather_plan_outputs(ev, true);

@@ -550,11 +550,26 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         const uint32_t and_rem = and_cnt % BT;
         const uint32_t and_full = small_rem(and_cnt) ? and_cnt - and_rem : and_cnt;
         Rec qnext = r0;
+#ifdef GSV_LATE_ST
+        // Stores one pass late (garbling): the label and the ciphertext of pass k are held in registers and stored once the operands of
+        // pass k+1 have arrived, right in front of its AES — their acknowledgements then come back under that AES instead of being waited
+        // for at the top of pass k+1, where `s_waitcnt vmcnt(0)` (all the compiler can say across the loop) needs the next record and gets
+        // the stores' round trip with it.  The second half of the next record is prefetched with its first half.
+        constexpr bool LATE = !EVAL;
+        Label pend_c0{{0, 0, 0, 0}}, pend_ct{{0, 0, 0, 0}};
+        uint32_t pend_c = 0, pend_cti = 0;
+        u32x4 hinext = (LATE && tid < and_full) ? load_and_hi(and_off + tid) : u32x4{0u, 0u, 0u, 0u};
+#endif
         for (uint32_t i = tid; i < and_full; i += BT) {
           LdsBankedTable aes_pass = aes;
           asm volatile("" : "+s"(aes_pass.rkp));
           const Rec q = qnext;
+#ifdef GSV_LATE_ST
+          const u32x4 hi_now = hinext;
+          if (i + BT < and_full) { qnext = load_and_rec(and_off + i + BT); if (LATE) hinext = load_and_hi(and_off + i + BT); }
+#else
           if (i + BT < and_full) qnext = load_and_rec(and_off + i + BT);
+#endif
           const uint32_t cti = and_off + i;
 #if defined(GSV_BF_LD)
           // every load of the gate — the record's second half, five LDS reads, five wire-file reads — is issued before anything waits
@@ -568,6 +583,8 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           }
           if (BF) __builtin_amdgcn_sched_barrier(0);
           const AndOp o = decode_and(q, hi_q);
+#elif defined(GSV_LATE_ST)
+          const AndOp o = decode_and(q, LATE ? hi_now : load_and_hi(cti));
 #else
           const AndOp o = decode_and(q, load_and_hi(cti));
 #endif
@@ -593,6 +610,17 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
               b = lxor(b, lxor(wf.ld(o.b3), wf.ld(o.b4)));
             }
           }
+#ifdef GSV_LATE_ST
+          if (LATE) {
+            // make the compiler wait for this pass's operands HERE (an asm that takes them as inputs), in front of the stores: its own wait
+            // would otherwise sit at their first use inside the AES, behind the stores, and take the stores' round trip with it
+            asm volatile("" : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(b.w[0]), "+v"(b.w[1]), "+v"(b.w[2]), "+v"(b.w[3]), "+v"(pl.w[0]), "+v"(pl.w[1]), "+v"(pl.w[2]), "+v"(pl.w[3])::"memory");
+          }
+          if (LATE && i != tid) {  // the previous pass's results: this lane took part in it (passes fill from lane 0)
+            wf.st(pend_c, pend_c0);
+            __builtin_nontemporal_store(u32x4{pend_ct.w[0], pend_ct.w[1], pend_ct.w[2], pend_ct.w[3]}, &CT[ct_base + pend_cti]);
+          }
+#endif
           Label c0, ct{{0, 0, 0, 0}};
           uint32_t vc = 0;
           if (!EVAL) {
@@ -610,12 +638,21 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
             vc = (gate_eval_bit(t, va, vb) ^ vp) & 1u;
           }
           c0 = lxor(c0, pl);
+#ifdef GSV_LATE_ST
+          if (LATE) { pend_c0 = c0; pend_ct = ct; pend_c = o.c; pend_cti = cti; continue; }
+#endif
           if (!no_store || c0.w[0] == 0x12345678u) {
             wf.st(o.c, c0);
             if (EVAL) wf.st_bit(o.c, vc);
           }
           if (!EVAL && !no_store) __builtin_nontemporal_store(u32x4{ct.w[0], ct.w[1], ct.w[2], ct.w[3]}, &CT[ct_base + cti]);
         }
+#ifdef GSV_LATE_ST
+        if (LATE && tid < and_full) {  // the last pass this lane took part in
+          wf.st(pend_c, pend_c0);
+          __builtin_nontemporal_store(u32x4{pend_ct.w[0], pend_ct.w[1], pend_ct.w[2], pend_ct.w[3]}, &CT[ct_base + pend_cti]);
+        }
+#endif
         for (uint32_t g = and_full + tid / LPG; g < and_cnt; g += BT / LPG) {
           // the first remainder record was prefetched two steps ago when the step has no whole pass
           const Rec q = (and_full == 0 && g == tid / LPG) ? r0 : load_and_rec(and_off + g);

@@ -251,21 +251,21 @@ inline WireId equal_constant(CircuitContext& c, const Fq12& a, const Fq12Const& 
 // ------------------------------------------------------------------ square roots (fp254impl.rs:691-725, fq.rs:175-192,290-299, fq2.rs:396-446)
 namespace fq {
 // fp254impl.rs:691-725 (#[bn_component(offcircuit_args = "exp")]): left-to-right square-and-multiply over the exponent's bits
-constexpr size_t EXP_CHUNK = 4;
+inline size_t exp_chunk_bits() { static const size_t v = [] { const char* e = getenv("GSV_EXP_CHUNK"); const int n = e ? atoi(e) : 4; return size_t(n >= 1 && n <= 64 ? n : 4); }(); return v; }  // ladder steps per fp254::exp_chunk wrapper (experiments: GSV_EXP_CHUNK)
 inline Fq exp_by_constant_montgomery(CircuitContext& c, const Fq& a, const BigU& exp) {
   check_len(a);
   const std::string kb = exp.key_bytes();
   return component(c, KeyBuilder("fp254::exp_by_constant_montgomery").param("exp", kb.data(), kb.size()), a, N, [&exp](CircuitContext& cc, const Wires& x) -> Wires {
     if (exp.is_zero()) return constant_wires(BigU(1), x.size());  // (the plain constant 1, as in the reference)
     if (exp == BigU(1)) return x;
-    // The square-and-multiply ladder, EXP_CHUNK exponent bits at a time.  Each chunk is wrapped in a component of this
+    // The square-and-multiply ladder, exp_chunk_bits() (= 4) exponent bits at a time.  Each chunk is wrapped in a component of this
     // restatement's own ("fp254::exp_chunk", keyed by its bit pattern): a component boundary never changes the gate stream (a
     // wire is dead iff nothing reads it — the committed fixtures were produced before the wrapping existed), and it gives the
     // plan builder a unit of a few multiplications (<= 16 distinct programs per exponent) between the 380-multiplication ladder
     // and its single multiplications.
     Fq result = x;
     for (size_t hi = exp.bits() - 1; hi > 0;) {
-      const size_t n = std::min(EXP_CHUNK, hi);
+      const size_t n = std::min(exp_chunk_bits(), hi);
       std::string pat;
       for (size_t k = 0; k < n; ++k) pat.push_back(exp.bit(hi - 1 - k) ? '1' : '0');
       result = component(cc, KeyBuilder("fp254::exp_chunk").param("bits", pat.data(), pat.size()), concat(x, result), N, [&pat](CircuitContext& c3, const Wires& in) -> Wires {
