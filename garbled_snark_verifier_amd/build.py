@@ -83,8 +83,9 @@ def check_step_barrier_isa(asm=None):
     instantiation, so that a compiler bump cannot silently put the store-acknowledgement wait back:
       * each kernel holds exactly two `s_waitcnt lgkmcnt(0)` + `s_barrier` pairs (the step loop is unrolled by two: ping-pong
         record registers);
-      * in each of them the instruction right in front of the wait is the 16-byte record prefetch (global_load_dwordx4): the
-        prefetch crosses the barrier in flight and nothing waits for vector memory in between.  (Other lgkmcnt(0) + s_barrier
+      * in each of them the instruction in front of the wait — looking through scalar bookkeeping (SGPR spill reloads from VGPR lanes,
+        scalar ALU, s_setprio) — is the 16-byte record prefetch (global_load_dwordx4): the prefetch crosses the barrier in flight and
+        nothing waits for vector memory in between.  (Other lgkmcnt(0) + s_barrier
         pairs are the compiler's own __syncthreads of the prologue / replay epilogue.)
     Returns {kernel symbol: number of step barriers}; raises RuntimeError on a violation."""
     asm = asm if asm is not None else disassemble_kernels()
@@ -93,7 +94,14 @@ def check_step_barrier_isa(asm=None):
     if len(kernels) != 16:
         raise RuntimeError("expected 16 instantiations of run_program_kernel, found %d" % len(kernels))
     for name, ins in kernels.items():
-        n = sum(1 for i, t in enumerate(ins) if t == "s_waitcnt lgkmcnt(0)" and 0 < i < len(ins) - 1 and ins[i + 1] == "s_barrier" and ins[i - 1].startswith("global_load_dwordx4"))
+        def prefetch_in_front(i):
+            # the instruction in front of the wait, looking through scalar bookkeeping the compiler may put there (reloads of spilled
+            # SGPRs from VGPR lanes, scalar ALU): it must be the record prefetch, and nothing in between may wait for vector memory
+            j = i - 1
+            while j > 0 and (ins[j].startswith(("v_readlane_b32", "v_writelane_b32", "s_nop", "s_setprio")) or (ins[j].startswith("s_") and not ins[j].startswith(("s_waitcnt", "s_barrier", "s_cbranch", "s_branch", "s_endpgm")))):
+                j -= 1
+            return ins[j].startswith("global_load_dwordx4")
+        n = sum(1 for i, t in enumerate(ins) if t == "s_waitcnt lgkmcnt(0)" and 0 < i < len(ins) - 1 and ins[i + 1] == "s_barrier" and prefetch_in_front(i))
         if n != 2:
             raise RuntimeError("%s: found %d step barriers with the record prefetch issued right in front of them, expected 2" % (name, n))
         # (the one legitimate vmcnt wait in front of a barrier is the dataflow epilogue's agent-scope release: buffer_wbl2 ; s_waitcnt vmcnt(0))

@@ -25,6 +25,12 @@
 #include "kernel_api.h"
 #include "limits.h"
 
+// Issue priority inside a wide step (round 5): 1 = falls with the pass index (adopted: +2 % on the wide shape, +3 % on the ladders,
+// profiles/r05_kernel/kernel_ab_prio*.log), 2 / 3 = measured alternatives (loads first / the memory-bound rest first), 0 = off.
+#ifndef GSV_PASS_PRIO
+#define GSV_PASS_PRIO 1
+#endif
+
 namespace gsv {
 namespace dev {
 
@@ -560,7 +566,21 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         uint32_t pend_c = 0, pend_cti = 0;
         u32x4 hinext = (LATE && tid < and_full) ? load_and_hi(and_off + tid) : u32x4{0u, 0u, 0u, 0u};
 #endif
+#if GSV_PASS_PRIO
+        uint32_t pass_idx = 0;
+#endif
         for (uint32_t i = tid; i < and_full; i += BT) {
+#if GSV_PASS_PRIO
+          // Issue priority falls with the pass index: a wave that is AHEAD (the instruction arbiter prefers the oldest wave of a SIMD, i.e.
+          // the first instance group's) yields to the waves that are still in an earlier pass, so that the groups move through the step's
+          // passes together and no group is left to run its last pass alone, latency-bound, while the others wait at the barrier.
+#if GSV_PASS_PRIO == 2
+          __builtin_amdgcn_s_setprio(3);  // record decode + operand loads: few instructions, long latencies — out of the door first
+#else
+          if (pass_idx == 0) __builtin_amdgcn_s_setprio(3); else if (pass_idx == 1) __builtin_amdgcn_s_setprio(2); else if (pass_idx == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+          ++pass_idx;
+#endif
+#endif
           LdsBankedTable aes_pass = aes;
           asm volatile("" : "+s"(aes_pass.rkp));
           const Rec q = qnext;
@@ -621,6 +641,10 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
             __builtin_nontemporal_store(u32x4{pend_ct.w[0], pend_ct.w[1], pend_ct.w[2], pend_ct.w[3]}, &CT[ct_base + pend_cti]);
           }
 #endif
+#if GSV_PASS_PRIO == 2
+          if (pass_idx == 0) __builtin_amdgcn_s_setprio(2); else if (pass_idx == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+          ++pass_idx;
+#endif
           Label c0, ct{{0, 0, 0, 0}};
           uint32_t vc = 0;
           if (!EVAL) {
@@ -638,6 +662,9 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
             vc = (gate_eval_bit(t, va, vb) ^ vp) & 1u;
           }
           c0 = lxor(c0, pl);
+#if GSV_PASS_PRIO == 2
+          __builtin_amdgcn_s_setprio(3);  // the stores, then the next pass's loads
+#endif
 #ifdef GSV_LATE_ST
           if (LATE) { pend_c0 = c0; pend_ct = ct; pend_c = o.c; pend_cti = cti; continue; }
 #endif
@@ -653,6 +680,15 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           __builtin_nontemporal_store(u32x4{pend_ct.w[0], pend_ct.w[1], pend_ct.w[2], pend_ct.w[3]}, &CT[ct_base + pend_cti]);
         }
 #endif
+#if GSV_PASS_PRIO
+#if GSV_PASS_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);  // remainder, free gates, barrier: behind every wave that is still in a whole pass
+#elif GSV_PASS_PRIO == 2
+        __builtin_amdgcn_s_setprio(1);  // the multi-lane remainder (short AES work)
+#else
+        __builtin_amdgcn_s_setprio(3);  // variant 3: the memory-bound rest of the step first
+#endif
+#endif
         for (uint32_t g = and_full + tid / LPG; g < and_cnt; g += BT / LPG) {
           // the first remainder record was prefetched two steps ago when the step has no whole pass
           const Rec q = (and_full == 0 && g == tid / LPG) ? r0 : load_and_rec(and_off + g);
@@ -662,6 +698,9 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           } else {
 #endif
         // ---- free-gate batches (their label stores are the wave's youngest stores: no young ciphertext store)
+#if GSV_PASS_PRIO == 2
+        __builtin_amdgcn_s_setprio(3);
+#endif
         if (xor_cnt) { issue_xor_operands(0); load_xor_recs(uint32_t(XB) * BT, xrn); }
         for (uint32_t base = 0; base < xor_cnt; base += XB * BT) {
           finish_xor_batch(base);
