@@ -219,7 +219,18 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   // which instance of this workgroup: wave-uniform (BT is a multiple of 64), so say so — every per-instance base
   // address below then lives in SGPRs instead of costing a VGPR each
   const uint32_t sub = NI == 1 ? 0u : uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x / BT)));
-  const uint32_t tid = threadIdx.x - sub * BT;      // lane index inside the instance's thread group
+  // Lane index inside the instance's thread group; for the latency-bound (four-wire) programs ROTATED by one wave per group.  A
+  // workgroup's waves go to the four SIMDs cyclically, so with four groups of four waves, wave j of every group sits on the same SIMD: the
+  // partly filled pass of a narrow step (lanes 0 .. r of every group: a ladder step holds 137 AND gates per instance) loads the same two or
+  // three SIMDs in all four groups and leaves the rest idle.  With the rotation group g's lane 0 is its wave g, and the groups' waves land
+  // on different SIMDs: ladders +11 %, inversions +8 % at 1 024 instances (profiles/r05_kernel/kernel_ab_rot.log).  A pure relabelling of
+  // lanes in wave units: quad roles (tid & 7), the LDS bank (tid & 31) and wave uniformity are unchanged.  NOT for the wide (two-wire)
+  // programs: there the imbalance lets the less loaded SIMD's waves start the step's free gates under the others' last AES pass, and
+  // balancing the SIMDs costs 3 %.
+#ifndef GSV_ROTATE_GROUPS
+#define GSV_ROTATE_GROUPS 1
+#endif
+  const uint32_t tid = (GSV_ROTATE_GROUPS && NI > 1 && four_wire) ? (((threadIdx.x - sub * BT) + sub * 64u) & (BT - 1u)) : threadIdx.x - sub * BT;
   const LdsBankedTable aes{(tid & 31u) * 4u, (cst_u32*)c_rk};
   // narrow-step mode: LPG lanes per AND gate (garble: two blocks x 4 columns; evaluate: one block x 4 columns)
   constexpr uint32_t LPG = EVAL ? 4u : 8u;
@@ -504,13 +515,20 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         // latency (not record -> operands -> store back to back).  The records of batch 0 are issued BEFORE the AES
         // passes and land behind them.
         constexpr int XB = 2;
+#ifdef GSV_XOR_REV
+        // free gates are handed out from the TOP lane down: the waves that hold the partly filled last AND pass (the low lanes) get the
+        // fewest free gates, the waves without it the most
+        const uint32_t xl = four_wire ? tid : (BT - 1u) - tid;
+#else
+        const uint32_t xl = tid;
+#endif
         u32x4 xr[XB], xrn[XB];
         Label xa[XB];
         uint32_t xv[XB];  // evaluate: XOR of the operands' plaintext bits
         auto load_xor_recs = [&](uint32_t base, u32x4 (&r)[XB]) {
 #pragma unroll
           for (int j = 0; j < XB; ++j) {
-            const uint32_t g = base + uint32_t(j) * BT + tid;
+            const uint32_t g = base + uint32_t(j) * BT + xl;
             r[j] = u32x4{0, 0, 0, 0};
             if (g < xor_cnt) r[j] = xq[g];
           }
@@ -520,7 +538,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           for (int j = 0; j < XB; ++j) {
             const XorOp o = decode_xor(xr[j]);
             xa[j] = delta; xv[j] = 0;
-            if (!no_load && base + uint32_t(j) * BT + tid < xor_cnt) {
+            if (!no_load && base + uint32_t(j) * BT + xl < xor_cnt) {
               xa[j] = lxor(lxor(wf.ld(o.x1), wf.ld(o.x2)), lxor(wf.ld(o.x3), wf.ld(o.x4)));
               if (EVAL) xv[j] = wf.ld_bit(o.x1) ^ wf.ld_bit(o.x2) ^ wf.ld_bit(o.x3) ^ wf.ld_bit(o.x4);
             }
@@ -529,7 +547,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         auto finish_xor_batch = [&](uint32_t base) {
 #pragma unroll
           for (int j = 0; j < XB; ++j) {
-            if (base + uint32_t(j) * BT + tid < xor_cnt) {
+            if (base + uint32_t(j) * BT + xl < xor_cnt) {
               const XorOp o = decode_xor(xr[j]);
               Label c0 = xa[j];
               if (!EVAL) c0 = lxor_if(c0, delta, o.par);
