@@ -320,9 +320,10 @@ class Engine:
         # sessions (and plans loaded straight into this device) use the engine's stream and device: they go first, whoever still holds them
         # (a session kept alive by a reference cycle and collected after the engine was closed ran gsv_session_destroy on a freed engine)
         if getattr(self, "h", None) is not None and self.h:
-            for s in list(_live["session"]):
-                if getattr(s, "engine", None) is self:
-                    s.close()
+            for kind in ("session", "plan"):
+                for s in list(_live[kind]):
+                    if getattr(s, "engine", None) is self:
+                        s.close()
         if getattr(self, "h", None) is not None and _lib is not None and self.h and not sys.is_finalizing():
             _lib.gsv_engine_destroy(self.h)
         self.h = None

@@ -10,6 +10,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <chrono>
 #include <cstring>
@@ -175,10 +176,11 @@ struct gsv_session {
   uint64_t plan_max_block = 0;  // ciphertext records per instance of the device block: the largest WINDOW of the schedule
   uint64_t plan_max_segment = 0;  // ... of a gate-order buffer: the largest drain SEGMENT (schedule.hpp)
   bool ct_ring = false;              // the device block is a ring of plan_max_block records (schedule.hpp, SchedParams::ring_ct)
+  std::string ring_diag;  // ring mode: the longest interval between two publications of the host's position in the last pass, and where it went
   unsigned long long* host_ct_pos = nullptr;  // ring mode: the host's stream-position counter (page-locked, mapped into the device)
   unsigned long long* dev_ct_pos = nullptr;   // ... its device address
   hipStream_t aux_stream = nullptr;  // gather kernels and flag polls of the drain, beside the running window
-  uint32_t* host_done = nullptr;     // per call of the running window: workgroups that have finished it (mapped host memory, written by the device)
+  uint32_t* host_done = nullptr;     // per call of the plan: workgroups that have finished it in the current pass (mapped host memory, written by the device)
   uint32_t* dev_done = nullptr;      // ... its device address
   struct CallDev { DevProgram dp; };
   std::vector<CallDev> call_dev;
@@ -1325,10 +1327,9 @@ int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_i
     std::vector<dev::CallDesc> cds(n);
     std::vector<uint32_t> csrc, cdst, deps;
     {
-      // the device-written completion counters of a running window (one per call of the widest window), in mapped host memory
-      uint32_t widest = 0;
-      for (const Schedule::Window& w : sc.windows) widest = std::max(widest, w.call1 - w.call0);
-      HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->host_done), size_t(widest) * 4 + 64, hipHostMallocMapped | hipHostMallocCoherent));
+      // the device-written completion counters (one per call of the PLAN: windows enqueued back to back never share a counter), in mapped host memory
+      HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->host_done), n * 4 + 64, hipHostMallocMapped | hipHostMallocCoherent));
+      std::memset(s->host_done, 0, n * 4 + 64);
       HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&s->dev_done), s->host_done, 0));
     }
     for (const Schedule::Window& w : sc.windows) {
@@ -1341,7 +1342,7 @@ int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_i
         d.steps = s->call_dev[k].dp.steps; d.ands = s->call_dev[k].dp.ands; d.xors = s->call_dev[k].dp.xors;
         d.gid_off = c.gid_off; d.ct_off = s->plan_retain ? c.ct_off : s->ct_ring ? sc.ring_off[k] : c.ct_off - w.ct0;
         if (s->ct_ring) { d.ct_need = sc.ring_need[k]; d.ct_ready = sc.seg_end[k]; d.ct_pos = s->dev_ct_pos; }
-        d.done_host = s->dev_done + (k - w.call0);
+        d.done_host = s->dev_done + k;
         d.w_base = base; d.n_steps = g.n_steps; d.and_terms = g.and_terms;
         d.pre_off = uint32_t(csrc.size());
         if (base != 0)  // the call's own copies of the constant labels (FALSE, TRUE, the all-zero label) in front of its scratch region
@@ -1561,8 +1562,8 @@ static int launch_plan_window(gsv_session* s, size_t w, uint64_t gate_id_base, b
   ka.calls = static_cast<const dev::CallDesc*>(s->d_calls) + win.call0;
   ka.copy_src = static_cast<const uint32_t*>(s->d_copy_src); ka.copy_dst = static_cast<const uint32_t*>(s->d_copy_dst);
   ka.deps = static_cast<const uint32_t*>(s->d_deps); ka.flags = static_cast<uint32_t*>(s->d_flags); ka.error = static_cast<uint32_t*>(s->d_error);
-  if (s->host_done) {  // (launches of one session are serialised: the previous window has finished before the host gets here)
-    std::memset(s->host_done, 0, size_t(win.call1 - win.call0) * 4);
+  if (s->host_done) {  // (the counters of THIS window's calls: its launch of the previous pass has long finished — every pass ends synchronised)
+    std::memset(s->host_done + win.call0, 0, size_t(win.call1 - win.call0) * 4);
     __atomic_thread_fence(__ATOMIC_RELEASE);
   }
   ka.flag_stride = s->flag_stride; ka.epoch = ++s->epoch;
@@ -1584,8 +1585,9 @@ static int launch_plan_window(gsv_session* s, size_t w, uint64_t gate_id_base, b
 }
 // after a synchronisation: did a dependency wait give up?
 static int check_plan_error(gsv_session* s) {
-  uint32_t err = 0;
-  HIPCHK(hipMemcpy(&err, s->d_error, 4, hipMemcpyDeviceToHost));
+  uint32_t ew[16] = {0};
+  HIPCHK(hipMemcpy(ew, s->d_error, 64, hipMemcpyDeviceToHost));
+  const uint32_t err = ew[0];
   if (err == 2) {
     // which calls of the last window have not finished everywhere, and where the host's position stood (diagnostics)
     std::string open_calls;
@@ -1594,10 +1596,12 @@ static int check_plan_error(gsv_session* s) {
       const Schedule::Window& win = s->sched.windows.back();
       int shown = 0;
       for (uint32_t k = win.call0; k < win.call1 && shown < 12; ++k)
-        if (s->host_done[k - win.call0] != n_wg) { open_calls += " " + std::to_string(k) + "(" + std::to_string(s->host_done[k - win.call0]) + "/" + std::to_string(n_wg) + ", need " + std::to_string(s->sched.ring_need[k]) + ")"; ++shown; }
+        if (s->host_done[k] != n_wg) { open_calls += " " + std::to_string(k) + "(" + std::to_string(s->host_done[k]) + "/" + std::to_string(n_wg) + ", need " + std::to_string(s->sched.ring_need[k]) + ")"; ++shown; }
     }
     return fail(GSV_ERR_DEVICE, "a call waited for the host's stream position (ciphertext ring) and saw it stand still at " + std::to_string(s->host_ct_pos ? *s->host_ct_pos : 0) +
-                                    "; unfinished calls:" + open_calls + "; results are invalid");
+                                    "; unfinished calls:" + open_calls + "; the call that gave up: " + std::to_string(ew[8]) + " of the window (instance group " + std::to_string(ew[9]) + "), it wanted position " +
+                                    std::to_string((uint64_t(ew[11]) << 32) | ew[10]) + ", saw " + std::to_string((uint64_t(ew[13]) << 32) | ew[12]) + " unchanged for " +
+                                    std::to_string(double((uint64_t(ew[15]) << 32) | ew[14]) * 1e-8) + " s" + (s->ring_diag.empty() ? "" : "; host: " + s->ring_diag) + "; results are invalid");
   }
   if (err) return fail(GSV_ERR_DEVICE, "a call of the plan waited for a dependency that never completed (dispatch-order assumption of schedule.hpp violated); results are invalid");
   return GSV_OK;
@@ -1879,7 +1883,7 @@ static int wait_calls_done(gsv_session* s, size_t w, uint32_t k0, uint32_t k1, b
   uint32_t polls = 0;
   while (!*window_done && k0 < k1) {
     bool all = true;
-    for (uint32_t k = k0; k < k1 && all; ++k) all = __atomic_load_n(s->host_done + (k - win.call0), __ATOMIC_ACQUIRE) == n_wg;
+    for (uint32_t k = k0; k < k1 && all; ++k) all = __atomic_load_n(s->host_done + k, __ATOMIC_ACQUIRE) == n_wg;
     if (all) break;
     const hipError_t q = hipStreamQuery(launch_stream);
     if (q == hipSuccess) { *window_done = true; break; }
@@ -1890,7 +1894,7 @@ static int wait_calls_done(gsv_session* s, size_t w, uint32_t k0, uint32_t k1, b
     std::this_thread::sleep_for(std::chrono::microseconds(100));
     if ((++polls & 1023u) == 0) {  // every ~0.1 s: has any call of the window completed for another workgroup?
       uint64_t sum = 0;
-      for (uint32_t k = win.call0; k < win.call1; ++k) sum += __atomic_load_n(s->host_done + (k - win.call0), __ATOMIC_RELAXED);
+      for (uint32_t k = win.call0; k < win.call1; ++k) sum += __atomic_load_n(s->host_done + k, __ATOMIC_RELAXED);
       const auto now = std::chrono::steady_clock::now();
       if (sum != last_sum) { last_sum = sum; last_move = now; }
       else if (std::chrono::duration<double>(now - last_move).count() > deadline)
@@ -1900,7 +1904,7 @@ static int wait_calls_done(gsv_session* s, size_t w, uint32_t k0, uint32_t k1, b
       reported = true;
       std::string msg;
       for (uint32_t k = win.call0; k < win.call1; ++k)
-        if (s->host_done[k - win.call0] != n_wg) msg += " " + std::to_string(k) + "(" + std::to_string(s->host_done[k - win.call0]) + "/" + std::to_string(n_wg) + (s->ct_ring ? ",need " + std::to_string(s->sched.ring_need[k]) + ",ready " + std::to_string(s->sched.seg_end[k]) : "") + ")";
+        if (s->host_done[k] != n_wg) msg += " " + std::to_string(k) + "(" + std::to_string(s->host_done[k]) + "/" + std::to_string(n_wg) + (s->ct_ring ? ",need " + std::to_string(s->sched.ring_need[k]) + ",ready " + std::to_string(s->sched.seg_end[k]) : "") + ")";
       std::fprintf(stderr, "drain debug: waiting > 3 s for calls [%u, %u) of window %zu; host position %llu; unfinished:%s\n", k0, k1, w, s->host_ct_pos ? (unsigned long long)*s->host_ct_pos : 0ull, msg.substr(0, 1500).c_str());
     }
   }
@@ -2084,6 +2088,9 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
     t_wait_drain += secs(t0);
   };
   size_t n_pushed = 0;
+  auto t_last_pub = std::chrono::steady_clock::now();
+  double worst_gap = 0;
+  s->ring_diag.clear();
   struct BlockingEvent { hipEvent_t ev = nullptr; ~BlockingEvent() { if (ev) (void)hipEventDestroy(ev); } } device_done_owner;
   if (want_drain && T + 1 > gsv_drain::usable_cores()) (void)hipEventCreateWithFlags(&device_done_owner.ev, hipEventBlockingSync | hipEventDisableTiming);
   const hipEvent_t device_done = device_done_owner.ev;
@@ -2130,6 +2137,7 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
           const Schedule::Segment& sg = s->sched.segments[q];
           const bool last = q + 1 == win.seg1;
           const auto t0 = std::chrono::steady_clock::now();
+          const double drain_before = t_wait_drain;
           if (!last) rc = wait_calls_done(s, w, sg.call0, sg.call1, &window_done, gs);
           if (rc != GSV_OK) break;
           if (last && !window_done) {
@@ -2145,7 +2153,18 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
           if (rc != GSV_OK) break;
           if (hipStreamSynchronize(s->aux_stream) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "ciphertext gather failed"); break; }
           t_gather += secs(tg);
-          if (s->ct_ring) __atomic_store_n(s->host_ct_pos, (unsigned long long)(sg.ct0 + sg.n_ct), __ATOMIC_RELEASE);  // the calls whose blocks overlap this segment's may write now
+          if (s->ct_ring) {
+            __atomic_store_n(s->host_ct_pos, (unsigned long long)(sg.ct0 + sg.n_ct), __ATOMIC_RELEASE);  // the calls whose blocks overlap this segment's may write now
+            const double gap = secs(t_last_pub);
+            if (gap > worst_gap) {
+              worst_gap = gap;
+              char buf[256];
+              std::snprintf(buf, sizeof buf, "longest interval between two positions %.2f s, before segment %u (calls [%u, %u)): %.2f s waiting for its calls, %.2f s for a free gate-order buffer, %.2f s gathering", gap, q,
+                            sg.call0, sg.call1, std::chrono::duration<double>(tg - t0).count() - (t_wait_drain - drain_before), t_wait_drain - drain_before, secs(tg));
+              s->ring_diag = buf;
+            }
+            t_last_pub = std::chrono::steady_clock::now();
+          }
           drained_records += sg.n_ct;
           push_segment(sg.n_ct, sg.ct0, n_pushed % depth);
           ++n_pushed;
@@ -2294,24 +2313,66 @@ static int evaluate_streaming_impl(gsv_session* s, uint64_t gate_id_base, const 
   HIPCHK(hipSetDevice(s->e->device));
   const uint64_t seg_records = s->plan ? s->plan_max_segment : s->ct_cap * g.n_ct;  // per instance: stride of the gate-order buffer
   if (!s->ct_gate && seg_records) DEVALLOC(&s->ct_gate, n_inst * seg_records * 16, "the gate-order ciphertext buffer");
-  struct Pinned { void* p[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; ~Pinned() { for (void* q : p) if (q) (void)hipHostFree(q); for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); } } stage;
+  // The CBC-MAC of one instance is a serial chain (ciphertext_source.rs:36-107 folds it while reading), the chains of different instances
+  // are independent: with hashes asked for, the chunks are read CHUNK-major (every instance's chunk at one offset, then the next offset)
+  // and instance i's chunks are folded in order by worker i mod T, beside the uploads; a staging buffer is reused once its copy AND its MAC
+  // are done.  (The reference's evaluator runs its finalized cases under into_par_iter: cut_and_choose/evaluator.rs:118-181.)
+  const size_t T = hashes ? std::max<size_t>(1, std::min<size_t>(std::min<size_t>(n_inst, 16), gsv_drain::usable_cores() > 1 ? gsv_drain::usable_cores() - 1 : 1)) : 0;
+  const size_t NB = 2 + 2 * T;
+  struct Pinned { std::vector<void*> p; std::vector<hipEvent_t> ev; ~Pinned() { for (void* q : p) if (q) (void)hipHostFree(q); for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); } } stage;
   const uint64_t chunk = std::min<uint64_t>(std::max<uint64_t>(seg_records, 1), CT_STAGE_RECORDS);
-  for (int b = 0; b < 2; ++b) { HIPCHK(hipHostMalloc(&stage.p[b], size_t(chunk) * 16, hipHostMallocDefault)); HIPCHK(hipEventCreateWithFlags(&stage.ev[b], hipEventDisableTiming)); }
+  stage.p.assign(NB, nullptr); stage.ev.assign(NB, nullptr);
+  for (size_t k = 0; k < NB; ++k) { HIPCHK(hipHostMalloc(&stage.p[k], size_t(chunk) * 16, hipHostMallocDefault)); HIPCHK(hipEventCreateWithFlags(&stage.ev[k], hipEventDisableTiming)); }
   std::vector<CbcMacHost> macs(n_inst);
+  struct MacPool {  // declared after `stage` and `macs`: joined before either goes away
+    struct Job { size_t inst; const uint8_t* p; uint64_t n; size_t buf; };
+    std::vector<CbcMacHost>& macs;
+    std::vector<std::deque<Job>> q;
+    std::vector<char> busy;  // per staging buffer: a MAC job still reads it
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_free;
+    bool closed = false;
+    MacPool(std::vector<CbcMacHost>& m, size_t T, size_t NB) : macs(m), q(T), busy(NB, 0) {
+      for (size_t t = 0; t < T; ++t) th.emplace_back([this, t] {
+        for (;;) {
+          Job j;
+          { std::unique_lock<std::mutex> lk(mu); cv_job.wait(lk, [&] { return closed || !q[t].empty(); }); if (q[t].empty()) return; j = q[t].front(); q[t].pop_front(); }
+          macs[j.inst].update(j.p, j.n);
+          { std::lock_guard<std::mutex> lk(mu); busy[j.buf] = 0; }
+          cv_free.notify_all();
+        }
+      });
+    }
+    void push(size_t inst, const uint8_t* p, uint64_t n, size_t buf) {
+      { std::lock_guard<std::mutex> lk(mu); busy[buf] = 1; q[inst % q.size()].push_back(Job{inst, p, n, buf}); }
+      cv_job.notify_all();
+    }
+    void wait_free(size_t buf) { std::unique_lock<std::mutex> lk(mu); cv_free.wait(lk, [&] { return !busy[buf]; }); }
+    void finish() {  // every queued chunk folded, workers gone
+      { std::lock_guard<std::mutex> lk(mu); closed = true; }
+      cv_job.notify_all();
+      for (std::thread& t : th) t.join();
+      th.clear();
+    }
+    ~MacPool() { finish(); }
+  } pool(macs, T, NB);
   if (s->plan) HIPCHK(hipMemsetAsync(s->d_error, 0, 4, s->e->stream));
   HIPCHK(hipEventRecord(s->ev0, s->e->stream));
-  int rc = GSV_OK, b = 0;
-  // `n` records per instance starting at stream index `base` -> the gate-order buffer (in bounded, page-locked chunks; hashed as read)
-  auto upload = [&](uint64_t base, uint64_t n) -> int {
-    for (size_t i = 0; i < n_inst; ++i)
-      for (uint64_t off = 0; off < n; off += chunk, b ^= 1) {
+  int rc = GSV_OK;
+  size_t b = 0;
+  // `n` records per instance starting at stream index `base` -> the gate-order buffer through `st` (bounded page-locked chunks, hashed as read)
+  auto upload = [&](uint64_t base, uint64_t n, hipStream_t st) -> int {
+    for (uint64_t off = 0; off < n; off += chunk)
+      for (size_t i = 0; i < n_inst; ++i, b = (b + 1) % NB) {
         const uint64_t m = std::min(chunk, n - off);
-        HIPCHK(hipEventSynchronize(stage.ev[b]));  // the copy that last used this staging buffer has finished
+        if (hipEventSynchronize(stage.ev[b]) != hipSuccess) return fail(GSV_ERR_DEVICE, "event wait failed");  // the copy that last used this staging buffer has finished
+        if (T) pool.wait_free(b);  // ... and so has its MAC
         uint8_t* host = static_cast<uint8_t*>(stage.p[b]);
         if (read(i, base + off, host, m) != 0) return fail(GSV_ERR_EXHAUSTED, "Ciphertext source exhausted: instance " + std::to_string(i) + " ran dry at record " + std::to_string(base + off));
-        if (hashes) macs[i].update(host, m);
-        HIPCHK(hipMemcpyAsync(static_cast<uint8_t*>(s->ct_gate) + (i * seg_records + off) * 16, host, m * 16, hipMemcpyHostToDevice, s->e->stream));
-        HIPCHK(hipEventRecord(stage.ev[b], s->e->stream));
+        if (T) pool.push(i, host, m, b);
+        if (hipMemcpyAsync(static_cast<uint8_t*>(s->ct_gate) + (i * seg_records + off) * 16, host, m * 16, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(stage.ev[b], st) != hipSuccess)
+          return fail(GSV_ERR_DEVICE, "ciphertext upload failed");
       }
     return GSV_OK;
   };
@@ -2336,16 +2397,7 @@ static int evaluate_streaming_impl(gsv_session* s, uint64_t gate_id_base, const 
         if (rc != GSV_OK) break;
         if (window_done) { rc = fail(GSV_ERR_DEVICE, "internal: the window finished before its ciphertexts were uploaded"); break; }
         // uploads and the scatter go through the side stream (the main stream holds the running window)
-        for (size_t i = 0; i < n_inst && rc == GSV_OK; ++i)
-          for (uint64_t off = 0; off < sg.n_ct; off += chunk, b ^= 1) {
-            const uint64_t m = std::min(chunk, sg.n_ct - off);
-            if (hipEventSynchronize(stage.ev[b]) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "event wait failed"); break; }
-            uint8_t* host = static_cast<uint8_t*>(stage.p[b]);
-            if (read(i, sg.ct0 + off, host, m) != 0) { rc = fail(GSV_ERR_EXHAUSTED, "Ciphertext source exhausted: instance " + std::to_string(i) + " ran dry at record " + std::to_string(sg.ct0 + off)); break; }
-            if (hashes) macs[i].update(host, m);
-            if (hipMemcpyAsync(static_cast<uint8_t*>(s->ct_gate) + (i * seg_records + off) * 16, host, m * 16, hipMemcpyHostToDevice, s->aux_stream) != hipSuccess ||
-                hipEventRecord(stage.ev[b], s->aux_stream) != hipSuccess) { rc = fail(GSV_ERR_DEVICE, "ciphertext upload failed"); break; }
-          }
+        rc = upload(sg.ct0, sg.n_ct, s->aux_stream);
         if (rc == GSV_OK) rc = permute_plan_calls(s, w, sg.call0, sg.call1, sg.ct0, seg_records, 1, nullptr, nullptr, s->aux_stream);
         if (rc == GSV_OK && hipStreamSynchronize(s->aux_stream) != hipSuccess) rc = fail(GSV_ERR_DEVICE, "ciphertext scatter failed");
         if (rc == GSV_OK) __atomic_store_n(s->host_ct_pos, (unsigned long long)(sg.ct0 + sg.n_ct), __ATOMIC_RELEASE);
@@ -2364,7 +2416,7 @@ static int evaluate_streaming_impl(gsv_session* s, uint64_t gate_id_base, const 
       for (uint32_t q = win.seg0; q < win.seg1 && rc == GSV_OK; ++q) {
         const Schedule::Segment& sg = s->sched.segments[q];
         // (the stream orders this segment's uploads behind the scatter of the previous one, which read the same buffer)
-        rc = upload(sg.ct0, sg.n_ct);
+        rc = upload(sg.ct0, sg.n_ct, s->e->stream);
         if (rc == GSV_OK) rc = permute_plan_calls(s, w, sg.call0, sg.call1, sg.ct0, seg_records, 1, nullptr, nullptr, nullptr);
       }
       if (rc == GSV_OK) rc = launch_plan_window(s, w, gate_id_base, true);
@@ -2373,7 +2425,7 @@ static int evaluate_streaming_impl(gsv_session* s, uint64_t gate_id_base, const 
     const uint64_t n_ct = g.n_ct, total = s->replays, seg = s->ct_cap;
     for (uint64_t r0 = 0; r0 < total && rc == GSV_OK; r0 += seg) {
       const uint64_t r1 = std::min(total, r0 + seg);
-      rc = upload(r0 * n_ct, (r1 - r0) * n_ct);
+      rc = upload(r0 * n_ct, (r1 - r0) * n_ct, s->e->stream);
       if (rc != GSV_OK) break;
       if (gsvk_gather_segment(s->CT, s->ct_stride(), s->dp.ct_pos, n_ct, uint32_t(r1 - r0), uint32_t(n_inst), s->ct_gate, seg_records, 1, s->e->stream) != 0) { rc = fail(GSV_ERR_DEVICE, "ciphertext scatter launch failed"); break; }
       rc = launch(s, gate_id_base, true, r0, r1 - r0);
@@ -2382,6 +2434,7 @@ static int evaluate_streaming_impl(gsv_session* s, uint64_t gate_id_base, const 
   if (hipStreamSynchronize(s->e->stream) != hipSuccess && rc == GSV_OK) rc = fail(GSV_ERR_DEVICE, "kernel failed");
   if (rc != GSV_OK) return rc;
   if (s->plan) { HIPCHK(hipEventRecord(s->ev1, s->e->stream)); rc = gather_plan_outputs(s, true); if (rc) return rc; HIPCHK(hipStreamSynchronize(s->e->stream)); rc = check_plan_error(s); if (rc) return rc; }
+  pool.finish();
   if (hashes) for (size_t i = 0; i < n_inst; ++i) macs[i].digest(hashes + 16 * i);
   return GSV_OK;
 }

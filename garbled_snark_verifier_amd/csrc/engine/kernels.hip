@@ -295,6 +295,12 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         if (now != seen) { seen = now; t_start = wall_clock64(); continue; }
         if (wall_clock64() - t_start > ka.wait_ticks) {  // (the host publishes a position per drain segment: fractions of a second apart)
           __hip_atomic_store(ka.error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // who gave up, on what (diagnostics for engine.cpp, check_plan_error; whichever call writes last is reported)
+          const unsigned long long waited = wall_clock64() - t_start;
+          ka.error[8] = blockIdx.y; ka.error[9] = blockIdx.x;
+          ka.error[10] = uint32_t(want); ka.error[11] = uint32_t(want >> 32);
+          ka.error[12] = uint32_t(seen); ka.error[13] = uint32_t(seen >> 32);
+          ka.error[14] = uint32_t(waited); ka.error[15] = uint32_t(waited >> 32);
           break;
         }
       }

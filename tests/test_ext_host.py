@@ -7,7 +7,7 @@ headers (the restated reference layers above the seam).
 CPU (`not gpu`): the plan the external host builds through the ABI is, byte for byte, the plan the engine's built-in builder
 (gsv_plan_build_file) writes for the same circuit, units and window share — tools/plan_digest.py: same header, same program blocks,
 same calls, whatever order the compile workers appended the blocks in.
-GPU: BASELINE config 4 — the whole groth16_verify_compressed circuit (1 public input, 11 456 865 898 gates, 3 147 calls of 296 programs)
+GPU: BASELINE config 4 — the whole groth16_verify_compressed circuit (1 public input, 11 456 865 898 gates, 1 257 calls of 212 unit programs)
 recorded through the ABI, loaded, ONE instance garbled with nothing retained on the device through gsv_session_garble_streaming_sink
 into the host program's own CBC-MAC: MAC and output label == the oracle's flat-stream fixture."""
 import hashlib
@@ -123,7 +123,7 @@ def test_abi_misuse_is_refused(tmp_path):
 
 @pytest.mark.gpu
 def test_full_verifier_through_the_public_abi(ext_host, tmp_path):
-    """BASELINE config 4 from an external host: record -> plan file through gsv_plan_recorder_* (3 147 calls, 296 programs, 11.46 B
+    """BASELINE config 4 from an external host: record -> plan file through gsv_plan_recorder_* (1 257 calls, 212 unit programs, 11.46 B
     gates), gsv_plan_load, one instance garbled with retain_stream = 0 through gsv_session_garble_streaming_sink into the host's own
     CBC-MAC.  MAC and output label == the CPU oracle's flat-stream fixture; the plan file == the built-in builder's; build time and host
     RSS reported (profiles/r05_e2e/ext_host_verifier.json keeps one run)."""

@@ -807,6 +807,43 @@ def test_ciphertext_ring_whole_pass_in_one_window(engine, tmp_path, monkeypatch)
     plan.close()
 
 
+def test_ring_watchdog_names_a_stalled_host(engine, monkeypatch):
+    """The ring's wait is bounded by a PROGRESS watchdog (kernels.hip: the host's position unchanged for GSV_DEP_WAIT_SECONDS): a sink that
+    stops consuming stalls the host's drain, the device gives up instead of hanging, the pass fails with status GSV_ERR_DEVICE and the
+    message says who waited for what and where the host's time went (engine.cpp, check_plan_error) — and the same session garbles the
+    oracle's stream again afterwards."""
+    import time
+    import garbled_snark_verifier_amd as gsv
+    monkeypatch.setenv("GSV_CT_RING_RECORDS", "1000000")
+    plan = gsv.Plan.from_circuit("fq12_mix", FINE_UNITS)
+    n_in, n_ct = plan.info["n_inputs"], plan.info["n_ciphertexts"]
+    d, f, t, inp = gsv.labels_from_seed(101, n_in)
+    ref = o.garble("fq12_mix", 101)
+    st = gsv.Session(engine, plan, 1, retain_stream="ring", concurrent_calls=16, drain_segment_records=300_000)
+    assert st.schedule_info()["n_segments"] > 20
+    calls = {"n": 0}
+
+    def sleepy(inst, first, recs):
+        calls["n"] += 1
+        if calls["n"] == 3:
+            time.sleep(8.0)
+
+    monkeypatch.setenv("GSV_DEP_WAIT_SECONDS", "2")
+    st.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
+    with pytest.raises(gsv.GsvError, match=r"stand still.*gave up.*wanted position \d+.*host: longest interval between two positions [0-9.]+ s.*gate-order buffer"):
+        st.garble_to_sink(sleepy, threads=1, with_hashes=True)
+    monkeypatch.delenv("GSV_DEP_WAIT_SECONDS")
+    st.set_garble_inputs(d[None], np.stack([f, t])[None], inp[None])
+    got = np.zeros((n_ct, 16), np.uint8)
+
+    def handler(inst, first, recs):
+        got[first:first + recs.shape[0]] = recs
+
+    hashes = st.garble_to_sink(handler, threads=1, with_hashes=True)
+    assert hashes[0] == ref.ct_hash.tobytes() and (got == ref.ciphertexts).all() and (st.read_outputs()[0] == ref.output_label0).all()
+    st.close(); plan.close()
+
+
 def test_garble_and_evaluate_side_by_side_on_the_device(engine):
     """examples/groth16_garble.rs:171-230 / tests/garbler_evaluator_connection.rs:64-172: the garbler feeds the evaluator while it
     garbles.  gsv_session_garble_evaluate: window k of the garbler's device block is evaluated on a second stream while window k+1 is
