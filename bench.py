@@ -818,7 +818,7 @@ def run_verifier(args):
         n_launch = sum(win_per_slice[(args.warmup + j) % len(slices)] for j in range(K))
         g_rank = r["gates_per_instance"] * B
         achieved = g_rank * bytes_per_gate / stream_s / 1e9
-        # HBM traffic per launch comes from separate rocprofv3 --pmc passes (tools/profile_r04.sh; counters cannot be read from inside the
+        # HBM traffic per launch comes from separate rocprofv3 --pmc passes (tools/profile_r05.sh; counters cannot be read from inside the
         # process).  It is quoted only when it belongs to THIS build and THIS configuration: the traffic.json records the sha256 of the
         # libgsv_engine.so that was profiled, the batch and the circuit; anything else leaves `traffic` null.
         traffic, traffic_source = None, None
@@ -842,7 +842,7 @@ def run_verifier(args):
                     same_lib = bool(lib_sha) and tj.get("engine_library_sha256") == lib_sha
                     same_src = bool(src_sha) and tj.get("engine_source_sha256") == src_sha
                     if not (same_lib or same_src):
-                        traffic_source = "profiles/%s/traffic.json belongs to another engine build (library and source sha256 differ): not quoted; re-run tools/profile_r04.sh" % cand
+                        traffic_source = "profiles/%s/traffic.json belongs to another engine build (library and source sha256 differ): not quoted; re-run tools/profile_r05.sh" % cand
                         continue
                     traffic = float(tj["hbm_bytes_per_launch"])
                     traffic_source = ("profiles/%s/traffic.json (separate rocprofv3 --pmc passes of this workload with %s; NOT measured in this run)"
@@ -908,7 +908,7 @@ def run_verifier(args):
                          # (grid.y = its calls) for all instances of the GPU: `launches_timed` dispatches, what rocprofv3 --kernel-trace counts
                          "kernel": "run_program_kernel<false, %d, 0, FW>" % ni, "launches_timed": n_launch, "kernel_ms_avg": stream_s * 1e3 / max(1, n_launch),
                          "kernel_note": "one kernel, two instantiations: FW = true for the windows that hold a program in the four-wire record form (191 of a pass's 672), false for the others; "
-                                        "kernel_ms_avg is over all window launches = the dispatch-weighted mean of the two rows of profiles/r04_final/kernel_stats.csv",
+                                        "kernel_ms_avg is over all window launches = the dispatch-weighted mean of the two rows of profiles/r05_final/kernel_stats.csv",
                          "algorithmic_bytes_per_launch": g_rank * bytes_per_gate / max(1, n_launch), "bytes_per_gate": bytes_per_gate, "calls_timed": n_calls_timed,
                          "note": "algorithmic-bytes accounting of SURVEY.md §8(d); fusion and the LDS label window keep most of those bytes off HBM, the limit that binds is T-table AES issue (DESIGN.md §3)",
                          "binding_limit": "aes-issue", "aes_ceiling_gates_per_s": aes_and_per_s / f_nf, "aes_ceiling_frac": (g_rank / stream_s) / (aes_and_per_s / f_nf), "aes_ceiling_source": aes_src},

@@ -173,6 +173,24 @@ __device__ __forceinline__ uint32_t aes128_quad(const LdsBankedTable& T, const u
   const uint32_t m2 = T.lk<0, 2>(s) & 0x00ff0000u, m3 = T.lk<2, 3>(s) & 0xff000000u;
   return m0 ^ quad_from<GSV_QP_NEXT1>(m1) ^ quad_from<GSV_QP_NEXT2>(m2) ^ quad_from<GSV_QP_NEXT3>(m3) ^ rkc[10];
 }
+// TWO blocks in the same quad, interleaved (garbling hashes x and x ^ delta under one tweak): the lookups per block are the same, the two
+// dependency chains run in each other's latency shadow, and an AND gate takes FOUR lanes instead of eight.
+__device__ __forceinline__ void aes128_quad_x2(const LdsBankedTable& T, const uint32_t (&rkc)[11], uint32_t& s, uint32_t& z) {
+  s ^= rkc[0]; z ^= rkc[0];
+#pragma unroll
+  for (int r = 1; r < 10; ++r) {
+    const uint32_t u0 = T.lk<0, 0>(s), u1 = T.lk<0, 1>(s), u2 = T.lk<2, 2>(s), u3 = T.lk<2, 3>(s);
+    const uint32_t v0 = T.lk<0, 0>(z), v1 = T.lk<0, 1>(z), v2 = T.lk<2, 2>(z), v3 = T.lk<2, 3>(z);
+    const uint32_t odd = rkc[r] ^ quad_from<GSV_QP_NEXT1>(u1) ^ quad_from<GSV_QP_NEXT3>(u3);
+    const uint32_t odz = rkc[r] ^ quad_from<GSV_QP_NEXT1>(v1) ^ quad_from<GSV_QP_NEXT3>(v3);
+    s = __builtin_amdgcn_alignbit(odd, odd, 24) ^ (u0 ^ quad_from<GSV_QP_NEXT2>(u2));
+    z = __builtin_amdgcn_alignbit(odz, odz, 24) ^ (v0 ^ quad_from<GSV_QP_NEXT2>(v2));
+  }
+  const uint32_t m0 = T.lk<2, 0>(s) & 0x000000ffu, m1 = T.lk<0, 1>(s) & 0x0000ff00u, m2 = T.lk<0, 2>(s) & 0x00ff0000u, m3 = T.lk<2, 3>(s) & 0xff000000u;
+  const uint32_t n0 = T.lk<2, 0>(z) & 0x000000ffu, n1 = T.lk<0, 1>(z) & 0x0000ff00u, n2 = T.lk<0, 2>(z) & 0x00ff0000u, n3 = T.lk<2, 3>(z) & 0xff000000u;
+  s = m0 ^ quad_from<GSV_QP_NEXT1>(m1) ^ quad_from<GSV_QP_NEXT2>(m2) ^ quad_from<GSV_QP_NEXT3>(m3) ^ rkc[10];
+  z = n0 ^ quad_from<GSV_QP_NEXT1>(n1) ^ quad_from<GSV_QP_NEXT2>(n2) ^ quad_from<GSV_QP_NEXT3>(n3) ^ rkc[10];
+}
 __device__ __forceinline__ uint32_t tweak_word(uint64_t gate_id, uint32_t c) {  // column c of tweak_of(gate_id)
   const uint64_t t0 = gate_id ^ 0x123456789ABCDEF0ull, t1 = gate_id * 0xDEADBEEFCAFEBABEull;
   const uint64_t t = (c & 2u) ? t1 : t0;
@@ -234,6 +252,15 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   const LdsBankedTable aes{(tid & 31u) * 4u, (cst_u32*)c_rk};
   // narrow-step mode: LPG lanes per AND gate (garble: two blocks x 4 columns; evaluate: one block x 4 columns)
   constexpr uint32_t LPG = EVAL ? 4u : 8u;
+  // Second multi-lane form (garbling four-wire programs: the latency-bound ladders and inversions): both blocks of a gate interleaved in ONE
+  // quad (aes128_quad_x2), four lanes per gate.  At four instances per workgroup an instance has 256 lanes = 32 gates per eight-lane pass,
+  // and half of an inversion's steps hold 33..48 AND gates, a fifth of a ladder's 65..96: they took two passes, or one partly filled
+  // one-gate-per-lane pass at its ~5 us, and take one / two four-lane passes now.
+#ifndef GSV_DUAL_QUAD
+#define GSV_DUAL_QUAD 1
+#endif
+  constexpr bool DUAL = GSV_DUAL_QUAD && FW && !EVAL && HASH == 0;
+  constexpr uint32_t LPG2 = DUAL ? 4u : LPG;
   const uint32_t col = tid & 3u, blk = (tid >> 2) & 1u;
   uint32_t rkc[11];
 #pragma unroll
@@ -366,9 +393,26 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     // flight across the barrier by themselves.
     const uint32_t last_step = ka.n_steps - 1;
     // narrow step: its AND gates in the multi-lane form (LPG lanes each) and — from the next wave boundary — its free gates fit ONE pass
-    auto is_narrow = [&](const u32x4& d) -> bool { return HASH == 0 && !no_narrow && d.y != 0 && ((d.y * LPG + 63u) & ~63u) + d.w <= BT; };
-    // wide steps: is the AND remainder small enough for the multi-lane form?
-    auto small_rem = [&](uint32_t n_and) -> bool { return HASH == 0 && (n_and % BT) <= 2u * (BT / LPG); };
+    // (the value: lanes per gate of the pass — LPG, or LPG2 when the gates only fit at four lanes each; 0: not a narrow step)
+    auto narrow_lpg = [&](const u32x4& d) -> uint32_t {
+      if (HASH != 0 || no_narrow || d.y == 0) return 0u;
+      if (((d.y * LPG + 63u) & ~63u) + d.w <= BT) return LPG;
+      if (DUAL && four_wire && ((d.y * LPG2 + 63u) & ~63u) + d.w <= BT) return LPG2;
+      return 0u;
+    };
+    auto is_narrow = [&](const u32x4& d) -> bool { return narrow_lpg(d) != 0u; };
+    // wide steps: is the AND remainder small enough for a multi-lane form?  (lanes per gate of the remainder's passes; 0: one partly filled
+    // one-gate-per-lane pass)
+    auto rem_lpg = [&](uint32_t n_and) -> uint32_t {
+      if (HASH != 0) return 0u;
+      const uint32_t rem = n_and % BT;
+#ifndef GSV_DUAL_REM_PASSES
+#define GSV_DUAL_REM_PASSES 2
+#endif
+      if (DUAL && four_wire) return rem <= BT / LPG ? LPG : rem <= uint32_t(GSV_DUAL_REM_PASSES) * (BT / LPG2) ? LPG2 : rem <= 2u * (BT / LPG) ? LPG : 0u;
+      return rem <= 2u * (BT / LPG) ? LPG : 0u;
+    };
+    auto small_rem = [&](uint32_t n_and) -> bool { return rem_lpg(n_and) != 0u; };
     auto load_desc = [&](uint32_t s) -> u32x4 {
       u32x4 d = step_q[s < last_step ? s : last_step];  // wave-uniform address: a scalar (SMEM) load, two steps ahead of its use
       if (!inst_active) { d.y = 0; d.w = 0; }
@@ -386,12 +430,13 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     auto xor_lane0 = [&](uint32_t na) -> uint32_t { return (na + 63u) & ~63u; };
     auto rec_ptr = [&](const u32x4& d) -> const glb_u8* {
       const glb_u8* p = (const glb_u8*)ka.steps;
-      if (is_narrow(d)) {
-        const uint32_t na = d.y * LPG, x0 = xor_lane0(na);
-        if (tid < na) p = and_bytes + size_t(d.x + tid / LPG) * 32u;
+      const uint32_t nl = narrow_lpg(d);
+      if (nl) {
+        const uint32_t na = d.y * nl, x0 = xor_lane0(na);
+        if (tid < na) p = and_bytes + size_t(d.x + tid / nl) * 32u;
         else if (tid >= x0 && tid < x0 + d.w) p = xor_bytes + size_t(d.z + (tid - x0)) * 16u;
       } else if (d.y >= BT || !small_rem(d.y)) { if (tid < d.y) p = and_bytes + size_t(d.x + tid) * 32u; }  // wide: first one-per-lane pass
-      else if (tid / LPG < d.y) p = and_bytes + size_t(d.x + tid / LPG) * 32u;  // wide with only a small remainder: first multi-lane pass
+      else { const uint32_t rl = rem_lpg(d.y); if (tid / rl < d.y) p = and_bytes + size_t(d.x + tid / rl) * 32u; }  // wide with only a small remainder: first multi-lane pass
       return p;
     };
     auto load_rec = [&](const u32x4& d) -> Rec { return *(const glb_u128*)rec_ptr(d); };
@@ -475,6 +520,30 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         if (col == 0) wf.st_bit(o.c, (gate_eval_bit(t, va, vb) ^ vp) & 1u);
       }
     };
+    // The same with both blocks in one quad (garbling, four lanes per gate: aes128_quad_x2).
+    auto and_multilane_x2 = [&](const Rec& q, const u32x4& q_hi, uint32_t cti) {
+      const AndOp o = decode_and(q, q_hi);
+      const uint32_t t = o.t;
+      uint32_t a_c = dq, b_c = dq, p_c = 0;
+      if (!no_load) {
+        a_c = wf.ld_word(o.a1, col) ^ wf.ld_word(o.a2, col);
+        b_c = wf.ld_word(o.b1, col) ^ wf.ld_word(o.b2, col);
+        p_c = wf.ld_word(o.p, col);
+        if (four_wire) {
+          a_c ^= wf.ld_word(o.a3, col) ^ wf.ld_word(o.a4, col);
+          b_c ^= wf.ld_word(o.b3, col) ^ wf.ld_word(o.b4, col);
+        }
+      }
+      const uint32_t twc = tweak_word(o.gid, col);
+      uint32_t h = a_c ^ (alpha_a(t) ? dq : 0u) ^ twc;  // selected_a
+      uint32_t o2 = h ^ dq;                              // other_a
+      if (!no_aes) aes128_quad_x2(aes, rkc, h, o2);
+      const uint32_t c0_c = h ^ (alpha_c(t) ? dq : 0u) ^ p_c;
+      const uint32_t ct_c = h ^ o2 ^ b_c ^ (alpha_b(t) ? dq : 0u);
+      if (!no_store) wf.st_word(o.c, col, c0_c);
+      asm volatile("" ::: "memory");
+      if (!no_store) __builtin_nontemporal_store(ct_c, &CTw[(ct_base + cti) * 4u + col]);
+    };
     // decoded free-gate record (u32x4 = w0 | w1)
     struct XorOp { uint32_t x1, x2, x3, x4, c, par; };
     auto decode_xor = [&](const u32x4& r) -> XorOp {
@@ -498,9 +567,11 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       if (ka.step_clock && blockIdx.x == 0 && threadIdx.x == 0 && rep + 1 == ka.replays) ka.step_clock[s] = wall_clock64();  // older than this step's stores
       if (is_narrow(sd)) {
         // ------------------------------------------------------------------ narrow step: one pass
-        const uint32_t na = and_cnt * LPG, x0 = xor_lane0(na);
+        const uint32_t nl = narrow_lpg(sd);
+        const uint32_t na = and_cnt * nl, x0 = xor_lane0(na);
         if (tid < na) {
-          and_multilane(r0, load_and_hi(and_off + tid / LPG), and_off + tid / LPG);
+          if (!DUAL || nl == LPG) and_multilane(r0, load_and_hi(and_off + tid / LPG), and_off + tid / LPG);
+          else and_multilane_x2(r0, load_and_hi(and_off + tid / LPG2), and_off + tid / LPG2);
         } else if (tid >= x0 && tid < x0 + sd.w) {
           const XorOp o = decode_xor(r0);
           Label c0 = delta;
@@ -713,10 +784,17 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         __builtin_amdgcn_s_setprio(3);  // variant 3: the memory-bound rest of the step first
 #endif
 #endif
-        for (uint32_t g = and_full + tid / LPG; g < and_cnt; g += BT / LPG) {
-          // the first remainder record was prefetched two steps ago when the step has no whole pass
-          const Rec q = (and_full == 0 && g == tid / LPG) ? r0 : load_and_rec(and_off + g);
-          and_multilane(q, load_and_hi(and_off + g), and_off + g);
+        if (!DUAL || rem_lpg(and_cnt) != LPG2) {
+          for (uint32_t g = and_full + tid / LPG; g < and_cnt; g += BT / LPG) {
+            // the first remainder record was prefetched two steps ago when the step has no whole pass
+            const Rec q = (and_full == 0 && g == tid / LPG) ? r0 : load_and_rec(and_off + g);
+            and_multilane(q, load_and_hi(and_off + g), and_off + g);
+          }
+        } else {
+          for (uint32_t g = and_full + tid / LPG2; g < and_cnt; g += BT / LPG2) {
+            const Rec q = (and_full == 0 && g == tid / LPG2) ? r0 : load_and_rec(and_off + g);
+            and_multilane_x2(q, load_and_hi(and_off + g), and_off + g);
+          }
         }
 #ifdef GSV_SKEW_XOR
           } else {

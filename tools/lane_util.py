@@ -10,7 +10,8 @@ instance, kernels.hip) the step descriptors {and_off, and_cnt, xor_off, xor_cnt}
                                                                 a partly filled wave issues everything
   kernel_fill = the same with the kernel's own rule (kernels.hip run_step): whole passes of BT one-gate-per-lane, then a remainder of at most
                 2 * BT / 8 gates in the eight-lanes-per-gate form (same lookups per gate, so it counts as full), a larger remainder as one
-                partly filled one-gate-per-lane pass at wave granularity; narrow steps (and_cnt * 8 + xor_cnt <= BT) are all multi-lane
+                partly filled one-gate-per-lane pass at wave granularity; narrow steps (and_cnt * 8 + xor_cnt <= BT) are all multi-lane; four-wire
+                programs (round 5) also have a four-lanes-per-gate form: narrow up to and_cnt * 4 + xor_cnt <= BT, remainders up to 2 * BT / 4
 plus the share of AND gates that sit in narrow steps / in multi-lane remainders, and steps per call."""
 import json
 import mmap
@@ -58,9 +59,12 @@ def main():
                 continue
             has = ac > 0
             narrow = has & ((((ac * 8 + 63) // 64) * 64 + xc) <= bt)
-            wide = has & ~narrow
             rem = ac % bt
             small = rem <= 2 * (bt // 8)
+            if terms == 4:  # four-wire programs also have the four-lanes-per-gate form (two interleaved blocks per quad, kernels.hip aes128_quad_x2)
+                narrow = narrow | (has & ((((ac * 4 + 63) // 64) * 64 + xc) <= bt))
+                small = rem <= 2 * (bt // 4)
+            wide = has & ~narrow
             full = np.where(small, ac - rem, ac)
             # kernel slots: narrow -> as many as gates; wide: full passes at wave granularity (only the last pass can be partial) + multi-lane remainder as gates
             kslots = np.where(narrow, ac, ((full + 63) // 64) * 64 + np.where(small, rem, 0))
