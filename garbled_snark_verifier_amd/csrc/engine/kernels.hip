@@ -259,7 +259,8 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
 #ifndef GSV_DUAL_QUAD
 #define GSV_DUAL_QUAD 1
 #endif
-  constexpr bool DUAL = GSV_DUAL_QUAD && FW && !EVAL && HASH == 0;
+  constexpr bool DUAL = GSV_DUAL_QUAD && (FW || GSV_DUAL_QUAD == 2) && !EVAL && HASH == 0;  // (2: every garbling program — measured: wide -2.3 %, the Miller loop -2.6 % at 1 024 instances, profiles/r05_kernel/kernel_ab_dualall.log: not adopted)
+  const bool dual_prog = GSV_DUAL_QUAD == 2 || four_wire;
   constexpr uint32_t LPG2 = DUAL ? 4u : LPG;
   const uint32_t col = tid & 3u, blk = (tid >> 2) & 1u;
   uint32_t rkc[11];
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     auto narrow_lpg = [&](const u32x4& d) -> uint32_t {
       if (HASH != 0 || no_narrow || d.y == 0) return 0u;
       if (((d.y * LPG + 63u) & ~63u) + d.w <= BT) return LPG;
-      if (DUAL && four_wire && ((d.y * LPG2 + 63u) & ~63u) + d.w <= BT) return LPG2;
+      if (DUAL && dual_prog && ((d.y * LPG2 + 63u) & ~63u) + d.w <= BT) return LPG2;
       return 0u;
     };
     auto is_narrow = [&](const u32x4& d) -> bool { return narrow_lpg(d) != 0u; };
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
 #ifndef GSV_DUAL_REM_PASSES
 #define GSV_DUAL_REM_PASSES 2
 #endif
-      if (DUAL && four_wire) return rem <= BT / LPG ? LPG : rem <= uint32_t(GSV_DUAL_REM_PASSES) * (BT / LPG2) ? LPG2 : rem <= 2u * (BT / LPG) ? LPG : 0u;
+      if (DUAL && dual_prog) return rem <= BT / LPG ? LPG : rem <= uint32_t(GSV_DUAL_REM_PASSES) * (BT / LPG2) ? LPG2 : rem <= 2u * (BT / LPG) ? LPG : 0u;
       return rem <= 2u * (BT / LPG) ? LPG : 0u;
     };
     auto small_rem = [&](uint32_t n_and) -> bool { return rem_lpg(n_and) != 0u; };

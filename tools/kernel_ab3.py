@@ -20,6 +20,11 @@ print("library:", os.environ.get("GSV_ENGINE_SO", "libgsv_engine.so"), flush=Tru
 SHAPES = (("wide   ", "fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"]), ("ladder ", "fq_sqrt", ["fp254::exp_chunk"]),
           ("inverse", "fq_inverse", ["inverse_iteration", "inverse::divide_result_by_2^k::chunk", "inverse::divide_result_by_even_part::chunk"]),
           ("inv_grp", "fq_inverse", ["inverse::iteration_group", "inverse::divide_chains"]))  # round 5: the inversion as 3 long calls
+MILLER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::mul_by_034_montgomery", "pairing::ell_by_constant_montgomery", "pairing::double_in_place_circuit_montgomery",
+                "pairing::add_in_place_montgomery", "pairing::mul_by_char_montgomery"]
+if os.environ.get("AB_SHAPES"):  # e.g. AB_SHAPES=wide,miller — `miller`: the whole Miller loop with the verifier's units (doubling / addition steps and line evaluations: the MID-width two-wire programs)
+    want = os.environ["AB_SHAPES"].split(",")
+    SHAPES = tuple(x for x in SHAPES + (("miller ", "miller_loop", MILLER_UNITS),) if x[0].strip() in want)
 for name, spec, units in SHAPES:
     plan = gsv.Plan.from_circuit(spec, units, window_div=4)
     ref = None
