@@ -88,7 +88,7 @@ VERIFIER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cycl
 
 
 # The same circuit with the Fq12 multiplications and squarings entered one level finer, as their three fq6::mul_montgomery units (a component
-# boundary the reference does not have: stream-neutral): 3 751 calls instead of 3 147, more width for the call-level dataflow
+# boundary the reference does not have: stream-neutral): 1 861 calls instead of 1 257 (round 4, before the inversions became three long calls: 3 751 / 3 147), more width for the call-level dataflow
 # and 19 % more device steps.  ONE instance garbles 7.6 % faster, sixteen 8.7 % (profiles/r04_e2e/verifier_mixed_units.log); a full GPU pays
 # for the extra steps.  bench.py builds this plan for its small-batch legs (--small-batch-units fq6, the default) beside the Fq12-level one.
 SMALL_BATCH_UNITS = ["fq6::mul_montgomery"] + [u for u in VERIFIER_UNITS if u not in ("fq12::square_montgomery", "fq12::mul_montgomery")]
