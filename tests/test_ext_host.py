@@ -24,9 +24,7 @@ EXT_DIR = os.path.join(ROOT, "tests", "ext_host")
 EXT = os.path.join(EXT_DIR, "ext_host")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-VERIFIER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cyclotomic_square_montgomery", "fq12::mul_by_034_montgomery",
-                  "pairing::ell_by_constant_montgomery", "pairing::double_in_place_circuit_montgomery", "pairing::add_in_place_montgomery", "pairing::mul_by_char_montgomery",
-                  "bigint::multiplexer", "g1::add_montgomery", "inverse::iteration_group", "inverse::divide_chains", "fp254::exp_chunk"]
+from conftest import VERIFIER_PLAN_UNITS as VERIFIER_UNITS  # noqa: E402 - the headline circuit's units, shared with tests/test_gpu_parity.py
 
 
 @pytest.fixture(scope="module")
@@ -122,26 +120,22 @@ def test_abi_misuse_is_refused(tmp_path):
 
 
 @pytest.mark.gpu
-def test_full_verifier_through_the_public_abi(ext_host, tmp_path):
+def test_full_verifier_through_the_public_abi(ext_host, verifier_plan_file, tmp_path):
     """BASELINE config 4 from an external host: record -> plan file through gsv_plan_recorder_* (1 257 calls, 212 unit programs, 11.46 B
     gates), gsv_plan_load, one instance garbled with retain_stream = 0 through gsv_session_garble_streaming_sink into the host's own
-    CBC-MAC.  MAC and output label == the CPU oracle's flat-stream fixture; the plan file == the built-in builder's; build time and host
-    RSS reported (profiles/r05_e2e/ext_host_verifier.json keeps one run)."""
-    import garbled_snark_verifier_amd as gsv
+    CBC-MAC.  MAC and output label == the CPU oracle's flat-stream fixture; the plan file == the built-in builder's (the session's shared
+    file, conftest.verifier_plan_file); build time and host RSS reported (profiles/r05_e2e/ext_host_verifier.json keeps one run)."""
     import plan_digest
-    case = json.load(open(os.path.join(GOLDEN, "groth16_verify_compressed_1pub_golden.json")))
+    case = verifier_plan_file["case"]
     d = "/dev/shm" if os.path.isdir("/dev/shm") and os.statvfs("/dev/shm").f_bavail * os.statvfs("/dev/shm").f_frsize > 100e9 else str(tmp_path)
-    a, b = os.path.join(d, "gsv_ext_host_%d_abi.gsvplan" % os.getpid()), os.path.join(d, "gsv_ext_host_%d_builtin.gsvplan" % os.getpid())
+    a, b = os.path.join(d, "gsv_ext_host_%d_abi.gsvplan" % os.getpid()), verifier_plan_file["path"]
     try:
         j = run_ext(ext_host, case["circuit"], VERIFIER_UNITS, a, "--window-div", 4, "--garble", case["seed"])
         assert (j["n_gates"], j["n_ciphertexts"]) == (case["gates"], case["n_ciphertexts"]) == (11_456_865_898, 2_980_165_547)
         assert j["ct_hash"] == case["ct_hash"] == j["engine_ct_hash"] and j["sink_in_order"] and j["sink_records"] == case["n_ciphertexts"]
         out = bytes.fromhex(j["output_label0"])
         assert hashlib.sha256(out).hexdigest() == case["output_label0_sha256"] and out[:16].hex() == case["first_output_label0"]
-        import time
-        t0 = time.time()
-        gsv.Plan.build_file(case["circuit"], VERIFIER_UNITS, b, window_div=4)
-        j["builtin_build_s"] = time.time() - t0
+        j["builtin_build_s"] = verifier_plan_file["build_s"]
         da, db = plan_digest.digest(a, threads=16), plan_digest.digest(b, threads=16)
         j["plan_digest"], j["builtin_plan_digest"] = da["digest"], db["digest"]
         out_dir = os.path.join(ROOT, "gpurun_out")
@@ -150,6 +144,5 @@ def test_full_verifier_through_the_public_abi(ext_host, tmp_path):
         assert da == db
         assert j["build_s"] <= 2.0 * j["builtin_build_s"] + 10.0, j
     finally:
-        for f in (a, b):
-            if os.path.exists(f):
-                os.remove(f)
+        if os.path.exists(a):
+            os.remove(a)

@@ -1032,6 +1032,7 @@ def test_plan_recorder_through_the_c_abi(engine):
     s.close()
 
 
+@pytest.mark.slow
 def test_miller_loop_as_a_plan(engine):
     """multi_miller_loop_groth16_evaluate_montgomery_fast (pairing.rs:944-1007): 6,909,061,143 gates, 62 % of the verifier, as a
     plan; hash + output labels == the oracle's flat-stream fixture (tests/golden/miller_loop_golden.json, 8 minutes of oracle
@@ -1123,24 +1124,17 @@ VERIFIER_UNITS = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cycl
 
 
 @pytest.fixture(scope="module")
-def compressed_verifier_plan(engine):
-    """The plan of the reference's headline circuit, groth16_verify_compressed (groth16.rs:250-268), built ONCE for the tests below
-    the way bench.py gets it on a fresh machine: gsv_plan_build_file (warm-up recorders beside the driver, every program written to the
-    plan file by the worker that compiled it; one image per program, compiled for a quarter of the LDS window), then gsv_plan_load
-    streams the 41 GB of records into the GPU's memory — ~55 s and ~20 GB of host memory on the GPU box."""
-    import shutil
-    import tempfile
+def compressed_verifier_plan(engine, verifier_plan_file):
+    """The plan of the reference's headline circuit, groth16_verify_compressed (groth16.rs:250-268), for the tests below: the session's
+    plan file (conftest.verifier_plan_file: gsv_plan_build_file — warm-up recorders beside the driver, every program written to the file by
+    the worker that compiled it, one image per program for a quarter of the LDS window — the way bench.py gets it on a fresh machine),
+    streamed into the GPU's memory by gsv_plan_load (41.8 GB of records, a few seconds)."""
     import garbled_snark_verifier_amd as gsv
+    from conftest import VERIFIER_PLAN_UNITS
+    assert VERIFIER_UNITS + ["fp254::exp_chunk"] == VERIFIER_PLAN_UNITS
     # ONE public input: the reference's own benchmark configuration (examples/groth16_garble.rs:107-110, groth16_cut_and_choose.rs:116-119)
-    case = json.load(open(os.path.join(os.path.dirname(GOLDEN), "groth16_verify_compressed_1pub_golden.json")))
-    d = tempfile.mkdtemp(prefix="gsv_test_plan_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-    try:
-        path = os.path.join(d, "verifier.gsvplan")
-        gsv.Plan.build_file(case["circuit"], VERIFIER_UNITS + ["fp254::exp_chunk"], path, window_div=4)
-        plan = gsv.Plan.load(path, engine)
-    finally:
-        shutil.rmtree(d, ignore_errors=True)  # the records are in HBM now
-    yield case, plan
+    plan = gsv.Plan.load(verifier_plan_file["path"], engine)
+    yield verifier_plan_file["case"], plan
     plan.close()
 
 
@@ -1281,13 +1275,13 @@ def test_cc16_verifier_full_size_on_one_gpu(engine, compressed_verifier_plan):
     assert hashlib.sha256(table.tobytes()).hexdigest() == gold["table_sha256"]
 
 
-def test_verifier_garble_evaluate_and_generic_sink_at_full_size(engine, compressed_verifier_plan):
+def test_verifier_garble_evaluate_at_full_size(engine, compressed_verifier_plan):
     """The second phase of the reference's benchmark at verifier size (examples/groth16_garble.rs:171-230): two instances are garbled
     and — window by window, from the garbler's device block, nothing retained (retain_stream = 0) — evaluated at the same time, one with
     the valid proof's bits, one with A's sign flag flipped: decoded outputs (1, 0), active output labels = select(label0, bit), and
-    the garbler's commitment of instance 0 == the oracle's flat-stream fixture.  The commitment is computed by a PYTHON handler
-    behind the generic sink (gsv_session_garble_streaming_sink: every 16-byte record of the 48 GB stream passes through the callback
-    in gate order), chained through gsv_cbcmac_update."""
+    the garbler's commitment of instance 0 == the oracle's flat-stream fixture.  (The generic sink at this size — every record of the
+    48 GB stream through a host callback in gate order — is tests/test_ext_host.py's external host since round 5; at component size:
+    test_generic_ciphertext_sink_and_source.)"""
     import garbled_snark_verifier_amd as gsv
     case, plan = compressed_verifier_plan
     n_in = plan.info["n_inputs"]
@@ -1312,19 +1306,6 @@ def test_verifier_garble_evaluate_and_generic_sink_at_full_size(engine, compress
     assert case["expected_output"] == 1 and ob[:, 0].tolist() == [1, 0]
     assert (oa == np.where(ob[:, :, None] == 1, out0 ^ delta[:, None, :], out0)).all()
     es.close()
-    # the same garbler session again, its stream through a Python CiphertextHandler (instance 0 only is MAC'ed here: one serial chain)
-    gs.set_garble_inputs(delta, consts, inputs)
-    state = [np.zeros(16, np.uint8)]
-    seen = [0, 0]
-
-    def handler(inst, first, recs):
-        assert first == seen[inst]
-        seen[inst] += recs.shape[0]
-        if inst == 0:
-            state[0] = np.frombuffer(gsv.cbcmac(recs, state[0]), np.uint8).copy()
-
-    gs.garble_to_sink(handler, threads=2)
-    assert seen == [case["n_ciphertexts"]] * 2 and state[0].tobytes().hex() == case["ct_hash"]
     gs.close()
 
 
@@ -1376,6 +1357,7 @@ def test_plan_slices_and_plan_file_on_the_device(engine, tmp_path):
     plan.close()
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("fixture,units,gates", [
     ("groth16_verify_golden.json", VERIFIER_UNITS, 10_914_485_653),
 ])
