@@ -12,7 +12,11 @@ import garbled_snark_verifier_amd as gsv
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 eng = gsv.Engine(0)
-plan = gsv.Plan.from_circuit("fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"], window_div=4)
+# PMC_SHAPE: wide (default) | ladder (fq_sqrt as exp_chunk units) | inverse (fq_inverse as its three long calls) — tools/kernel_ab3.py's shapes
+SHAPES = {"wide": ("fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"]), "ladder": ("fq_sqrt", ["fp254::exp_chunk"]),
+          "inverse": ("fq_inverse", ["inverse::iteration_group", "inverse::divide_chains"])}
+spec, units = SHAPES[os.environ.get("PMC_SHAPE", "wide")]
+plan = gsv.Plan.from_circuit(spec, units, window_div=4)
 d, f, t, inp = gsv.labels_from_seed(3, plan.info["n_inputs"])
 sess = gsv.Session(eng, plan, B, retain_stream=False, concurrent_calls=1)
 for _ in range(3):
