@@ -38,6 +38,35 @@ class GsvError(RuntimeError):
 _live = {"session": weakref.WeakSet(), "plan": weakref.WeakSet(), "program": weakref.WeakSet(), "engine": weakref.WeakSet()}
 
 
+class _gc_paused:
+    """Cyclic garbage collection paused for the duration of a streaming call.  A streaming pass runs Python on OTHER threads (the sink /
+    source callbacks) and, in ring mode, its device calls wait for the host's progress.  If the collector fires on such a thread and
+    finalizes a forgotten Session / Plan / Program, `gsv_*_destroy` -> hipFree synchronises the WHOLE device: it waits for the running
+    window, which waits for the host's stream position, which waits for the callback that is stuck in hipFree — until the device's
+    watchdog ends the pass after GSV_DEP_WAIT_SECONDS with GSV_ERR_DEVICE (seen once in round 5's full GPU suite).  A host
+    must not destroy device objects while a ring pass runs; this keeps the collector from doing it behind the caller's back."""
+
+    _lock = __import__("threading").Lock()
+    _depth = 0
+    _was_enabled = False
+
+    def __enter__(self):
+        import gc
+        with _gc_paused._lock:
+            if _gc_paused._depth == 0:
+                _gc_paused._was_enabled = gc.isenabled()
+                gc.disable()
+            _gc_paused._depth += 1
+
+    def __exit__(self, *exc):
+        import gc
+        with _gc_paused._lock:
+            _gc_paused._depth -= 1
+            if _gc_paused._depth == 0 and _gc_paused._was_enabled:
+                gc.enable()
+        return False
+
+
 @atexit.register
 def _close_everything():
     for kind in ("session", "plan", "program", "engine"):
@@ -571,10 +600,12 @@ class Session:
         hashes (CBC-MAC, gate order) and, with `directory`, writes gc_<first_index+i>.bin files.  discard=True: garble
         only, the ciphertexts are dropped."""
         if discard:
-            _chk(lib().gsv_session_garble_streaming(self.h, gate_id_base, None, 0, 0, None))
+            with _gc_paused():
+                _chk(lib().gsv_session_garble_streaming(self.h, gate_id_base, None, 0, 0, None))
             return None
         out = np.zeros((self.n, 16), np.uint8)
-        _chk(lib().gsv_session_garble_streaming(self.h, gate_id_base, directory.encode() if directory else None, first_index, threads, _p(out)))
+        with _gc_paused():
+            _chk(lib().gsv_session_garble_streaming(self.h, gate_id_base, directory.encode() if directory else None, first_index, threads, _p(out)))
         return [bytes(out[i]) for i in range(self.n)]
 
     def garble_calls(self, first_call, n_calls, gate_id_base=0, directory=None, first_index=0, threads=0, discard=False):
@@ -582,10 +613,12 @@ class Session:
         CBC-MAC states continue from the previous slice; first_call == 0 starts a new pass.  Returns the MAC states after the
         slice (the commitments once the last slice has run), or None with discard=True."""
         if discard:
-            _chk(lib().gsv_session_garble_streaming_calls(self.h, gate_id_base, first_call, n_calls, None, 0, 0, None))
+            with _gc_paused():
+                _chk(lib().gsv_session_garble_streaming_calls(self.h, gate_id_base, first_call, n_calls, None, 0, 0, None))
             return None
         out = np.zeros((self.n, 16), np.uint8)
-        _chk(lib().gsv_session_garble_streaming_calls(self.h, gate_id_base, first_call, n_calls, directory.encode() if directory else None, first_index, threads, _p(out)))
+        with _gc_paused():
+            _chk(lib().gsv_session_garble_streaming_calls(self.h, gate_id_base, first_call, n_calls, directory.encode() if directory else None, first_index, threads, _p(out)))
         return [bytes(out[i]) for i in range(self.n)]
 
     def garble_to_sink(self, handler, gate_id_base=0, first_call=0, n_calls=0, threads=0, with_hashes=False):
@@ -605,7 +638,8 @@ class Session:
 
         cb = CT_SINK_FN(_cb)
         out = np.zeros((self.n, 16), np.uint8) if with_hashes else None
-        rc = lib().gsv_session_garble_streaming_sink(self.h, gate_id_base, first_call, n_calls, cb, None, threads, _p(out))
+        with _gc_paused():
+            rc = lib().gsv_session_garble_streaming_sink(self.h, gate_id_base, first_call, n_calls, cb, None, threads, _p(out))
         if failure:
             raise failure[0]
         _chk(rc)
@@ -615,7 +649,8 @@ class Session:
         """Garble this (plan, retain_stream=False) session while `evaluator` — a session of the same plan and options with its inputs
         set — evaluates every window straight from this session's device block (gsv_session_garble_evaluate)."""
         out = np.zeros((self.n, 16), np.uint8) if with_hashes else None
-        _chk(lib().gsv_session_garble_evaluate(self.h, evaluator.h, gate_id_base, threads, _p(out)))
+        with _gc_paused():
+            _chk(lib().gsv_session_garble_evaluate(self.h, evaluator.h, gate_id_base, threads, _p(out)))
         return [bytes(out[i]) for i in range(self.n)] if with_hashes else None
 
     def evaluate_streaming_indexed(self, directory, indexes, gate_id_base=0):
@@ -623,7 +658,8 @@ class Session:
         idx = np.ascontiguousarray(indexes, np.uint64)
         assert idx.size == self.n
         out = np.zeros((self.n, 16), np.uint8)
-        _chk(lib().gsv_session_evaluate_streaming_indexed(self.h, gate_id_base, directory.encode(), idx.ctypes.data_as(C.POINTER(C.c_uint64)), _p(out)))
+        with _gc_paused():
+            _chk(lib().gsv_session_evaluate_streaming_indexed(self.h, gate_id_base, directory.encode(), idx.ctypes.data_as(C.POINTER(C.c_uint64)), _p(out)))
         return [bytes(out[i]) for i in range(self.n)]
 
     def evaluate_from_source(self, source, gate_id_base=0):
@@ -647,7 +683,8 @@ class Session:
 
         cb = CT_SOURCE_FN(_cb)
         out = np.zeros((self.n, 16), np.uint8)
-        rc = lib().gsv_session_evaluate_streaming_source(self.h, gate_id_base, cb, None, _p(out))
+        with _gc_paused():
+            rc = lib().gsv_session_evaluate_streaming_source(self.h, gate_id_base, cb, None, _p(out))
         if failure:
             raise failure[0]
         _chk(rc)
@@ -682,7 +719,8 @@ class Session:
     def evaluate_streaming(self, directory, first_index=0, gate_id_base=0):
         """Evaluate with the ciphertexts read from gc_<first_index+i>.bin segment by segment; returns the files' CBC-MACs."""
         out = np.zeros((self.n, 16), np.uint8)
-        _chk(lib().gsv_session_evaluate_streaming(self.h, gate_id_base, directory.encode(), first_index, _p(out)))
+        with _gc_paused():
+            _chk(lib().gsv_session_evaluate_streaming(self.h, gate_id_base, directory.encode(), first_index, _p(out)))
         return [bytes(out[i]) for i in range(self.n)]
 
     def set_evaluate_inputs(self, const_active, input_active, input_bits):
