@@ -32,6 +32,24 @@ impl Default for GsvPlanSessionOpts {
     }
 }
 
+/// gsv_plan_schedule_info (include/gsv_engine.h): what a plan session's schedule looks like (windows, drain segments, the ciphertext ring).
+#[repr(C)]
+#[derive(Default, Debug, Clone, Copy)]
+pub struct GsvPlanScheduleInfo {
+    pub n_calls: u64,
+    pub n_windows: u64,
+    pub n_dependencies: u64,
+    pub max_width: u64,
+    pub scratch_slots: u64,
+    pub wire_file_slots: u64,
+    pub window_ct_records: u64,
+    pub critical_steps: u64,
+    pub total_steps: u64,
+    pub n_segments: u64,
+    pub segment_ct_records: u64,
+    pub ct_ring_records: u64,
+}
+
 /// gsv_compile_opts (include/gsv_engine.h): one image for a share of the LDS window, background compilation, records into a plan file.
 #[repr(C)]
 pub struct GsvCompileOpts {
@@ -109,6 +127,17 @@ extern "C" {
     pub fn gsv_session_read_ciphertexts(s: *mut GsvSession, instance: usize, first: u64, n: u64, out: *mut u8) -> c_int;
     pub fn gsv_session_ciphertext_hash(s: *mut GsvSession, instance: usize, hash: *mut u8) -> c_int;
     pub fn gsv_commit_labels(labels: *const u8, n: u64, out: *mut u8) -> c_int;
+    // labels, commitment helper, plan files and slices of a plan, schedule introspection, sample drains
+    pub fn gsv_labels_from_seed(seed: u64, n_inputs: usize, delta: *mut u8, false_label0: *mut u8, true_label0: *mut u8, input_label0: *mut u8) -> c_int;
+    pub fn gsv_cbcmac_update(state: *mut u8, records: *const u8, n_records: u64) -> c_int;
+    pub fn gsv_plan_save(p: *const GsvPlan, path: *const c_char) -> c_int;
+    pub fn gsv_plan_counts(p: *const GsvPlan, n_gates: *mut u64, n_ciphertexts: *mut u64, n_calls: *mut u64) -> c_int;
+    pub fn gsv_plan_call_info(p: *const GsvPlan, call: u64, gate_offset: *mut u64, n_gates: *mut u64, ct_offset: *mut u64, n_ciphertexts: *mut u64, n_steps: *mut u64) -> c_int;
+    pub fn gsv_session_plan_schedule_info(s: *const GsvSession, info: *mut GsvPlanScheduleInfo) -> c_int;
+    pub fn gsv_session_plan_window(s: *const GsvSession, window: u64, first_call: *mut u64, n_calls: *mut u64, max_width: *mut u64) -> c_int;
+    pub fn gsv_session_garble_streaming_calls(s: *mut GsvSession, gate_id_base: u64, first_call: u64, n_calls: u64, dir: *const c_char, first_index: u64, n_threads: c_int, hashes: *mut u8) -> c_int;
+    pub fn gsv_session_set_drain_instances(s: *mut GsvSession, n: usize) -> c_int;
+    pub fn gsv_session_instances_per_workgroup(s: *const GsvSession, out: *mut c_int) -> c_int;
 }
 
 pub fn chk(rc: c_int) {
