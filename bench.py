@@ -710,7 +710,7 @@ def run_verifier(args):
                         # folded into ONE serial CBC-MAC chain on one host core (the chain, ~1.1e8 blocks/s = 27 s, is nearly as long as the
                         # garbling).  The session's default: two launch windows (the scope in which the instance's call chains overlap), the
                         # stream taken off the device in 1 GB segments of the RUNNING window, eight gate-order buffers between the device and
-                        # the chain (engine.cpp, garble_streaming_range; tools/small_batch_commit.py: 30.4 s against round 3's 36.9 s)
+                        # the chain (engine.cpp, garble_streaming_range; tools/rounds_1-4/small_batch_commit.py: 30.4 s against round 3's 36.9 s)
                         wc = VerifierWork(gsv, engine, plan_sb, 1, [case["seed"]])
                         try:
                             dtc = wc.run_pass(commit=True)

@@ -1,6 +1,6 @@
 """Device rate of a plan as a function of the instance count and of the number of calls that may run side by side (diagnostic tool).
 
-  python tools/concurrency_rate.py <circuit spec> <units csv|coarse|fine> [instances csv] [concurrency csv]
+  python tools/rounds_1-4/concurrency_rate.py <circuit spec> <units csv|coarse|fine> [instances csv] [concurrency csv]
 
 Garbles with the ciphertexts kept on the device (retain) when they fit, else discarded window by window; prints gates/s and the
 schedule's shape (batches, widest batch, depth in device steps)."""
@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 import garbled_snark_verifier_amd as gsv  # noqa: E402
 
 COARSE = ["fq12::square_montgomery", "fq12::mul_montgomery", "fq12::cyclotomic_square_montgomery", "fq12::mul_by_034_montgomery", "pairing::ell_by_constant_montgomery",

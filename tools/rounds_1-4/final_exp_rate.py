@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Device rate on a REAL verifier component: final_exponentiation_montgomery (3,519,328,217 gates) as a 286-call plan,
-ciphertexts discarded (the HBM-resident rate; with the drain the run is PCIe-bound, see tools/e2e_streaming.py).  Diagnostic tool."""
+ciphertexts discarded (the HBM-resident rate; with the drain the run is PCIe-bound, see tools/rounds_1-4/e2e_streaming.py).  Diagnostic tool."""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import garbled_snark_verifier_amd as gsv
 

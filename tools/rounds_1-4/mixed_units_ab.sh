@@ -4,7 +4,7 @@ REST="pairing::double_in_place_circuit_montgomery,pairing::add_in_place_montgome
 export CR_REPS=1
 out=gpurun_out/r04_e2e/verifier_mixed_units.log
 echo "== M0: Fq12-level units (bench.py's plan)" > $out
-python tools/concurrency_rate.py $FIX "fq12::square_montgomery,fq12::mul_montgomery,fq12::cyclotomic_square_montgomery,fq12::mul_by_034_montgomery,pairing::ell_by_constant_montgomery,$REST" 1,16 0 >> $out 2>&1
+python tools/rounds_1-4/concurrency_rate.py $FIX "fq12::square_montgomery,fq12::mul_montgomery,fq12::cyclotomic_square_montgomery,fq12::mul_by_034_montgomery,pairing::ell_by_constant_montgomery,$REST" 1,16 0 >> $out 2>&1
 echo "== M1: fq12 mul/square as fq6::mul units" >> $out
-python tools/concurrency_rate.py $FIX "fq6::mul_montgomery,fq12::cyclotomic_square_montgomery,fq12::mul_by_034_montgomery,pairing::ell_by_constant_montgomery,$REST" 1,16 0 >> $out 2>&1
+python tools/rounds_1-4/concurrency_rate.py $FIX "fq6::mul_montgomery,fq12::cyclotomic_square_montgomery,fq12::mul_by_034_montgomery,pairing::ell_by_constant_montgomery,$REST" 1,16 0 >> $out 2>&1
 cat $out

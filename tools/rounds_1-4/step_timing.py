@@ -5,7 +5,7 @@ gates) replayed many times on one instance, optionally under GSV_DIAG ablations 
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import garbled_snark_verifier_amd as gsv
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/<dir>/pmc_counters.json (tools/profile_r02.sh: FETCH_SIZE and WRITE_SIZE of the run_program_kernel dispatches, separate
+"""profiles/<dir>/pmc_counters.json (tools/rounds_1-4/profile_r02.sh: FETCH_SIZE and WRITE_SIZE of the run_program_kernel dispatches, separate
 rocprofv3 --pmc passes) -> profiles/<dir>/traffic.json with HBM bytes per launch as MI355X_MICROARCH.md prescribes: both
 counters are in KiB; on gfx950 FETCH_SIZE reads half of the bytes of wide coalesced 16-byte-per-lane reads, so it is doubled
 before it is compared with a byte count (the kernel's reads are record streams and 16-byte label reads: the doubled figure is an
