@@ -217,7 +217,8 @@ def _gpu_evaluate_batch(circuit, engine, program, gc_dir):
     """Default evaluation backend of evaluate_from: EvaluateMode over FileSources on the GPU, ALL finalized instances in one session —
     one launch per window of the stream for the whole batch (gsv_session_evaluate_streaming_indexed).  The reference evaluates the
     cases side by side on a rayon pool (`into_par_iter`, cut_and_choose/evaluator.rs:354-475); a one-instance session per case would
-    use one CU of 256 and pay a session per case."""
+    use one CU of 256 and pay a session per case.  The files' CBC-MACs (the CiphertextMismatch check) are folded while reading, instance i on
+    worker i mod T of the engine's pool, beside the uploads (engine.cpp, evaluate_streaming_impl)."""
     from . import Engine, Plan, Program, Session
     eng = engine or Engine(0)
     prog = program or Program.from_circuit(circuit)
