@@ -25,11 +25,9 @@
 #include "kernel_api.h"
 #include "limits.h"
 
-// Issue priority inside a wide step (round 5): 1 = falls with the pass index (adopted: +2 % on the wide shape, +3 % on the ladders,
-// profiles/r05_kernel/kernel_ab_prio*.log), 2 / 3 = measured alternatives (loads first / the memory-bound rest first), 0 = off.
-#ifndef GSV_PASS_PRIO
-#define GSV_PASS_PRIO 1
-#endif
+// Kernel variants that were measured and rejected (branch-free operand loads, free gates first on odd waves, stores one pass late, free
+// gates from the top lane down, two other issue-priority schemes, the four-lane quad form for every program) live as a patch against this
+// file in profiles/r05_kernel/rejected_variants.patch, with their A/B logs beside it; this file holds the adopted code only.
 
 namespace gsv {
 namespace dev {
@@ -113,16 +111,6 @@ struct WireFile {
     u32x4 v;
     if (slot & GSV_SLOT_LDS_FLAG) v = *win(slot); else v = hbm[slot];
     return Label{{v.x, v.y, v.z, v.w}};
-  }
-  // Branch-free form of ld() (GSV_BF_LD builds): BOTH locations are read — the one that does not hold the label reads an all-zero label
-  // (window entry 0 / wire-file slot 2, program.hpp) — and the caller XORs the two.  No exec-mask juggling, no wait between the LDS read
-  // and the global load of one operand: all operand loads of a gate are in flight at once.
-  __device__ __forceinline__ void ld2(uint32_t slot, u32x4& l, u32x4& g) const {
-    const bool in_lds = (slot & GSV_SLOT_LDS_FLAG) != 0;
-    const uint32_t la = in_lds ? (slot << 4) + (win_base - (GSV_SLOT_LDS_FLAG << 4)) : win_base;
-    const uint32_t gs = in_lds ? 2u : slot;
-    l = *reinterpret_cast<lds_u128*>(uintptr_t(la));
-    g = hbm[gs];
   }
   __device__ __forceinline__ void st(uint32_t slot, const Label& l) const {
     const u32x4 v = {l.w[0], l.w[1], l.w[2], l.w[3]};
@@ -245,10 +233,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   // lanes in wave units: quad roles (tid & 7), the LDS bank (tid & 31) and wave uniformity are unchanged.  NOT for the wide (two-wire)
   // programs: there the imbalance lets the less loaded SIMD's waves start the step's free gates under the others' last AES pass, and
   // balancing the SIMDs costs 3 %.
-#ifndef GSV_ROTATE_GROUPS
-#define GSV_ROTATE_GROUPS 1
-#endif
-  const uint32_t tid = (GSV_ROTATE_GROUPS && NI > 1 && four_wire) ? (((threadIdx.x - sub * BT) + sub * 64u) & (BT - 1u)) : threadIdx.x - sub * BT;
+  const uint32_t tid = (NI > 1 && four_wire) ? (((threadIdx.x - sub * BT) + sub * 64u) & (BT - 1u)) : threadIdx.x - sub * BT;
   const LdsBankedTable aes{(tid & 31u) * 4u, (cst_u32*)c_rk};
   // narrow-step mode: LPG lanes per AND gate (garble: two blocks x 4 columns; evaluate: one block x 4 columns)
   constexpr uint32_t LPG = EVAL ? 4u : 8u;
@@ -256,11 +241,10 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
   // quad (aes128_quad_x2), four lanes per gate.  At four instances per workgroup an instance has 256 lanes = 32 gates per eight-lane pass,
   // and half of an inversion's steps hold 33..48 AND gates, a fifth of a ladder's 65..96: they took two passes, or one partly filled
   // one-gate-per-lane pass at its ~5 us, and take one / two four-lane passes now.
-#ifndef GSV_DUAL_QUAD
-#define GSV_DUAL_QUAD 1
-#endif
-  constexpr bool DUAL = GSV_DUAL_QUAD && (FW || GSV_DUAL_QUAD == 2) && !EVAL && HASH == 0;  // (2: every garbling program — measured: wide -2.3 %, the Miller loop -2.6 % at 1 024 instances, profiles/r05_kernel/kernel_ab_dualall.log: not adopted)
-  const bool dual_prog = GSV_DUAL_QUAD == 2 || four_wire;
+  // (compiled into every garbling instantiation it costs the wide programs 2.3 % and the Miller loop 2.6 % at 1 024 instances,
+  // profiles/r05_kernel/kernel_ab_dualall.log: it exists in the FW instantiations only)
+  constexpr bool DUAL = FW && !EVAL && HASH == 0;
+  const bool dual_prog = four_wire;
   constexpr uint32_t LPG2 = DUAL ? 4u : LPG;
   const uint32_t col = tid & 3u, blk = (tid >> 2) & 1u;
   uint32_t rkc[11];
@@ -407,10 +391,8 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     auto rem_lpg = [&](uint32_t n_and) -> uint32_t {
       if (HASH != 0) return 0u;
       const uint32_t rem = n_and % BT;
-#ifndef GSV_DUAL_REM_PASSES
-#define GSV_DUAL_REM_PASSES 2
-#endif
-      if (DUAL && dual_prog) return rem <= BT / LPG ? LPG : rem <= uint32_t(GSV_DUAL_REM_PASSES) * (BT / LPG2) ? LPG2 : rem <= 2u * (BT / LPG) ? LPG : 0u;
+      // (up to two four-lane passes; three: -3 %, profiles/r05_kernel/kernel_ab_dualrem.log)
+      if (DUAL && dual_prog) return rem <= BT / LPG ? LPG : rem <= 2u * (BT / LPG2) ? LPG2 : rem <= 2u * (BT / LPG) ? LPG : 0u;
       return rem <= 2u * (BT / LPG) ? LPG : 0u;
     };
     auto small_rem = [&](uint32_t n_and) -> bool { return rem_lpg(n_and) != 0u; };
@@ -593,13 +575,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         // latency (not record -> operands -> store back to back).  The records of batch 0 are issued BEFORE the AES
         // passes and land behind them.
         constexpr int XB = 2;
-#ifdef GSV_XOR_REV
-        // free gates are handed out from the TOP lane down: the waves that hold the partly filled last AND pass (the low lanes) get the
-        // fewest free gates, the waves without it the most
-        const uint32_t xl = four_wire ? tid : (BT - 1u) - tid;
-#else
         const uint32_t xl = tid;
-#endif
         u32x4 xr[XB], xrn[XB];
         Label xa[XB];
         uint32_t xv[XB];  // evaluate: XOR of the operands' plaintext bits
@@ -637,14 +613,6 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           }
         };
         load_xor_recs(0, xr);
-#ifdef GSV_SKEW_XOR
-        // Odd waves run the step's free gates BEFORE its AND passes, even waves after (the two are the same dependency level): the waves
-        // of a CU then do not all sit in their memory-bound phase / in their AES passes at the same time.
-        const bool xor_first = __builtin_amdgcn_readfirstlane(int((threadIdx.x >> 6) & 1u)) != 0;
-#pragma unroll 1
-        for (int ph = 0; ph < 2; ++ph) {
-          if ((ph == 0) != xor_first) {
-#endif
         // ---- AND-family gates: whole passes of BT gates in the one-gate-per-lane form (two interleaved AES blocks
         // per lane), then the remainder in the LPG-lanes-per-gate form: a partly filled one-gate-per-lane pass would
         // cost the full ~5 us AES latency for a handful of waves, the multi-lane form ~1 us per BT/LPG gates.
@@ -652,95 +620,30 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         const uint32_t and_rem = and_cnt % BT;
         const uint32_t and_full = small_rem(and_cnt) ? and_cnt - and_rem : and_cnt;
         Rec qnext = r0;
-#ifdef GSV_LATE_ST
-        // Stores one pass late (garbling): the label and the ciphertext of pass k are held in registers and stored once the operands of
-        // pass k+1 have arrived, right in front of its AES — their acknowledgements then come back under that AES instead of being waited
-        // for at the top of pass k+1, where `s_waitcnt vmcnt(0)` (all the compiler can say across the loop) needs the next record and gets
-        // the stores' round trip with it.  The second half of the next record is prefetched with its first half.
-        constexpr bool LATE = !EVAL;
-        Label pend_c0{{0, 0, 0, 0}}, pend_ct{{0, 0, 0, 0}};
-        uint32_t pend_c = 0, pend_cti = 0;
-        u32x4 hinext = (LATE && tid < and_full) ? load_and_hi(and_off + tid) : u32x4{0u, 0u, 0u, 0u};
-#endif
-#if GSV_PASS_PRIO
         uint32_t pass_idx = 0;
-#endif
         for (uint32_t i = tid; i < and_full; i += BT) {
-#if GSV_PASS_PRIO
           // Issue priority falls with the pass index: a wave that is AHEAD (the instruction arbiter prefers the oldest wave of a SIMD, i.e.
           // the first instance group's) yields to the waves that are still in an earlier pass, so that the groups move through the step's
           // passes together and no group is left to run its last pass alone, latency-bound, while the others wait at the barrier.
-#if GSV_PASS_PRIO == 2
-          __builtin_amdgcn_s_setprio(3);  // record decode + operand loads: few instructions, long latencies — out of the door first
-#else
           if (pass_idx == 0) __builtin_amdgcn_s_setprio(3); else if (pass_idx == 1) __builtin_amdgcn_s_setprio(2); else if (pass_idx == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
           ++pass_idx;
-#endif
-#endif
           LdsBankedTable aes_pass = aes;
           asm volatile("" : "+s"(aes_pass.rkp));
           const Rec q = qnext;
-#ifdef GSV_LATE_ST
-          const u32x4 hi_now = hinext;
-          if (i + BT < and_full) { qnext = load_and_rec(and_off + i + BT); if (LATE) hinext = load_and_hi(and_off + i + BT); }
-#else
           if (i + BT < and_full) qnext = load_and_rec(and_off + i + BT);
-#endif
           const uint32_t cti = and_off + i;
-#if defined(GSV_BF_LD)
-          // every load of the gate — the record's second half, five LDS reads, five wire-file reads — is issued before anything waits
-          // for one of them (the scheduling barrier keeps the compiler from sinking a use, and with it a wait, between them)
-          constexpr bool BF = !FW;  // (the four-wire instantiations keep the branching loads: with both forms they spill 31 VGPRs)
-          const u32x4 hi_q = load_and_hi(cti);
-          u32x4 l0, l1, l2, l3, l4, g0, g1, g2, g3, g4;
-          if (BF && !no_load) {
-            const AndOp os = decode_and(q, u32x4{0u, 0u, 0u, 0u});  // the slots of a two-wire record sit in its first half
-            wf.ld2(os.a1, l0, g0); wf.ld2(os.a2, l1, g1); wf.ld2(os.b1, l2, g2); wf.ld2(os.b2, l3, g3); wf.ld2(os.p, l4, g4);
-          }
-          if (BF) __builtin_amdgcn_sched_barrier(0);
-          const AndOp o = decode_and(q, hi_q);
-#elif defined(GSV_LATE_ST)
-          const AndOp o = decode_and(q, LATE ? hi_now : load_and_hi(cti));
-#else
           const AndOp o = decode_and(q, load_and_hi(cti));
-#endif
           const uint32_t t = o.t;
           Label a = delta, b = delta, pl{{0, 0, 0, 0}};
           if (!no_load) {
-#ifdef GSV_BF_LD
-            if (BF) {
-              const u32x4 av = (l0 ^ l1) ^ (g0 ^ g1), bv = (l2 ^ l3) ^ (g2 ^ g3), pv = l4 ^ g4;
-              a = Label{{av.x, av.y, av.z, av.w}}; b = Label{{bv.x, bv.y, bv.z, bv.w}}; pl = Label{{pv.x, pv.y, pv.z, pv.w}};
-            } else {
-              a = lxor(wf.ld(o.a1), wf.ld(o.a2));
-              b = lxor(wf.ld(o.b1), wf.ld(o.b2));
-              pl = wf.ld(o.p);
-            }
-#else
             a = lxor(wf.ld(o.a1), wf.ld(o.a2));
             b = lxor(wf.ld(o.b1), wf.ld(o.b2));
             pl = wf.ld(o.p);
-#endif
             if (four_wire) {
               a = lxor(a, lxor(wf.ld(o.a3), wf.ld(o.a4)));
               b = lxor(b, lxor(wf.ld(o.b3), wf.ld(o.b4)));
             }
           }
-#ifdef GSV_LATE_ST
-          if (LATE) {
-            // make the compiler wait for this pass's operands HERE (an asm that takes them as inputs), in front of the stores: its own wait
-            // would otherwise sit at their first use inside the AES, behind the stores, and take the stores' round trip with it
-            asm volatile("" : "+v"(a.w[0]), "+v"(a.w[1]), "+v"(a.w[2]), "+v"(a.w[3]), "+v"(b.w[0]), "+v"(b.w[1]), "+v"(b.w[2]), "+v"(b.w[3]), "+v"(pl.w[0]), "+v"(pl.w[1]), "+v"(pl.w[2]), "+v"(pl.w[3])::"memory");
-          }
-          if (LATE && i != tid) {  // the previous pass's results: this lane took part in it (passes fill from lane 0)
-            wf.st(pend_c, pend_c0);
-            __builtin_nontemporal_store(u32x4{pend_ct.w[0], pend_ct.w[1], pend_ct.w[2], pend_ct.w[3]}, &CT[ct_base + pend_cti]);
-          }
-#endif
-#if GSV_PASS_PRIO == 2
-          if (pass_idx == 0) __builtin_amdgcn_s_setprio(2); else if (pass_idx == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-          ++pass_idx;
-#endif
           Label c0, ct{{0, 0, 0, 0}};
           uint32_t vc = 0;
           if (!EVAL) {
@@ -758,33 +661,13 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
             vc = (gate_eval_bit(t, va, vb) ^ vp) & 1u;
           }
           c0 = lxor(c0, pl);
-#if GSV_PASS_PRIO == 2
-          __builtin_amdgcn_s_setprio(3);  // the stores, then the next pass's loads
-#endif
-#ifdef GSV_LATE_ST
-          if (LATE) { pend_c0 = c0; pend_ct = ct; pend_c = o.c; pend_cti = cti; continue; }
-#endif
           if (!no_store || c0.w[0] == 0x12345678u) {
             wf.st(o.c, c0);
             if (EVAL) wf.st_bit(o.c, vc);
           }
           if (!EVAL && !no_store) __builtin_nontemporal_store(u32x4{ct.w[0], ct.w[1], ct.w[2], ct.w[3]}, &CT[ct_base + cti]);
         }
-#ifdef GSV_LATE_ST
-        if (LATE && tid < and_full) {  // the last pass this lane took part in
-          wf.st(pend_c, pend_c0);
-          __builtin_nontemporal_store(u32x4{pend_ct.w[0], pend_ct.w[1], pend_ct.w[2], pend_ct.w[3]}, &CT[ct_base + pend_cti]);
-        }
-#endif
-#if GSV_PASS_PRIO
-#if GSV_PASS_PRIO == 1
         __builtin_amdgcn_s_setprio(0);  // remainder, free gates, barrier: behind every wave that is still in a whole pass
-#elif GSV_PASS_PRIO == 2
-        __builtin_amdgcn_s_setprio(1);  // the multi-lane remainder (short AES work)
-#else
-        __builtin_amdgcn_s_setprio(3);  // variant 3: the memory-bound rest of the step first
-#endif
-#endif
         if (!DUAL || rem_lpg(and_cnt) != LPG2) {
           for (uint32_t g = and_full + tid / LPG; g < and_cnt; g += BT / LPG) {
             // the first remainder record was prefetched two steps ago when the step has no whole pass
@@ -797,13 +680,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
             and_multilane_x2(q, load_and_hi(and_off + g), and_off + g);
           }
         }
-#ifdef GSV_SKEW_XOR
-          } else {
-#endif
         // ---- free-gate batches (their label stores are the wave's youngest stores: no young ciphertext store)
-#if GSV_PASS_PRIO == 2
-        __builtin_amdgcn_s_setprio(3);
-#endif
         if (xor_cnt) { issue_xor_operands(0); load_xor_recs(uint32_t(XB) * BT, xrn); }
         for (uint32_t base = 0; base < xor_cnt; base += XB * BT) {
           finish_xor_batch(base);
@@ -815,10 +692,6 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
             load_xor_recs(nb + XB * BT, xrn);
           }
         }
-#ifdef GSV_SKEW_XOR
-          }
-        }
-#endif
       }
       // keep r0's registers reserved through the step: were they handed to a store's data in between, the refill below would
       // have to wait for that store (vmcnt(0) in front of the prefetch) before it could overwrite them
