@@ -43,8 +43,10 @@ class _gc_paused:
     source callbacks) and, in ring mode, its device calls wait for the host's progress.  If the collector fires on such a thread and
     finalizes a forgotten Session / Plan / Program, `gsv_*_destroy` -> hipFree synchronises the WHOLE device: it waits for the running
     window, which waits for the host's stream position, which waits for the callback that is stuck in hipFree — until the device's
-    watchdog ends the pass after GSV_DEP_WAIT_SECONDS with GSV_ERR_DEVICE (seen once in round 5's full GPU suite).  A host
-    must not destroy device objects while a ring pass runs; this keeps the collector from doing it behind the caller's back."""
+    watchdog ends the pass after GSV_DEP_WAIT_SECONDS with GSV_ERR_DEVICE (seen once in round 5's full GPU suite).
+    Since round 6 the engine itself defers every release requested while a streaming pass is in flight (engine.cpp, ReleaseGate;
+    include/gsv_engine.h "Deferred release"), so a destroy from a callback is harmless whoever issues it; the pause stays as a second
+    layer (it also keeps collector pauses out of the callbacks, which sit on the drain's critical path)."""
 
     _lock = __import__("threading").Lock()
     _depth = 0
@@ -103,7 +105,7 @@ class _Gate(C.Structure):
 EXPORTS = [
     "gsv_last_error", "gsv_recorder_create", "gsv_recorder_destroy", "gsv_recorder_allocate_wire", "gsv_recorder_declare_input",
     "gsv_recorder_push_gates", "gsv_recorder_declare_outputs", "gsv_recorder_record_circuit", "gsv_recorder_counts", "gsv_program_compile", "gsv_program_destroy",
-    "gsv_program_get_info", "gsv_engine_create", "gsv_engine_destroy", "gsv_labels_from_seed", "gsv_session_create", "gsv_session_destroy",
+    "gsv_program_get_info", "gsv_engine_create", "gsv_engine_destroy", "gsv_deferred_release_count", "gsv_labels_from_seed", "gsv_session_create", "gsv_session_destroy",
     "gsv_session_set_garble_inputs", "gsv_session_garble", "gsv_session_set_evaluate_inputs", "gsv_session_upload_ciphertexts",
     "gsv_session_evaluate", "gsv_session_set_hasher", "gsv_session_sync", "gsv_session_last_kernel_ms", "gsv_session_read_outputs", "gsv_session_read_ciphertexts",
     "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_cbcmac_update_many", "gsv_commit_labels",
@@ -144,6 +146,8 @@ def lib():
         L.gsv_engine_create.argtypes = [C.c_int, C.POINTER(vp)]
         L.gsv_engine_destroy.argtypes = [vp]
         L.gsv_engine_destroy.restype = None
+        L.gsv_deferred_release_count.argtypes = []
+        L.gsv_deferred_release_count.restype = C.c_uint64
         L.gsv_labels_from_seed.argtypes = [C.c_uint64, C.c_size_t, u8p, u8p, u8p, u8p]
         L.gsv_session_create.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.c_uint64, C.POINTER(vp)]
         L.gsv_session_destroy.argtypes = [vp]

@@ -66,6 +66,45 @@ static int dev_alloc(void** p, size_t bytes, const char* what) {
   return fail(GSV_ERR_DEVICE, msg);
 }
 #define DEVALLOC(p, bytes, what) do { int _rc = dev_alloc(reinterpret_cast<void**>(p), (bytes), (what)); if (_rc) return _rc; } while (0)
+// ---- deferred release ---------------------------------------------------------------------------------------------------------------
+// hipFree / hipStreamDestroy synchronise the device.  While a streaming pass runs that is at best a stall of whoever destroys something
+// and at worst a deadlock: a ring pass waits for the host's stream position, which waits for a sink / source callback — and a host that
+// drops a session, plan, program or engine FROM that callback (a Rust `Drop` inside `CiphertextHandler::handle`, Python's collector on
+// the callback thread: profiles/r05_debug/) would wait in hipFree for that very pass until the device's watchdog ends it.  The destroy
+// entry points therefore never free while a streaming pass is in flight in this process: the request is queued and runs, in order, when
+// the last pass in flight has synchronised (the handle is invalid for the host from the moment destroy returns, as always).  Outside a
+// pass a destroy runs at once, under the gate's lock: a pass that starts meanwhile waits for it instead of being stalled by it.
+namespace {
+struct ReleaseGate {
+  std::recursive_mutex mu;                      // recursive: a queued plan destroy runs its programs' destroys
+  int active = 0;                               // streaming passes in flight (any session of this process)
+  std::vector<std::function<void()>> pending;   // destroy requests that arrived meanwhile, in arrival order
+  uint64_t n_deferred = 0;                      // statistics (gsv_deferred_release_count)
+};
+ReleaseGate& release_gate() { static ReleaseGate g; return g; }
+// First local of every streaming entry point: declared before anything else so that it is destroyed LAST — a session destroyed from
+// its own pass's callback is still alive while the entry point uses it.
+struct PassGuard {
+  PassGuard() { ReleaseGate& g = release_gate(); std::lock_guard<std::recursive_mutex> lk(g.mu); ++g.active; }
+  ~PassGuard() {
+    ReleaseGate& g = release_gate();
+    std::lock_guard<std::recursive_mutex> lk(g.mu);
+    if (--g.active != 0) return;
+    std::vector<std::function<void()>> run;
+    run.swap(g.pending);
+    for (auto& f : run) f();
+  }
+  PassGuard(const PassGuard&) = delete;
+  PassGuard& operator=(const PassGuard&) = delete;
+};
+void release_or_defer(std::function<void()> fn) {
+  ReleaseGate& g = release_gate();
+  std::lock_guard<std::recursive_mutex> lk(g.mu);
+  if (g.active > 0) { g.pending.push_back(std::move(fn)); ++g.n_deferred; return; }
+  fn();
+}
+}  // namespace
+
 // A stream that must make progress WHILE a window runs on the engine's stream (the drain's gathers and copies, the other half of a
 // garble -> evaluate pair).  The runtime multiplexes streams onto a few hardware queues per priority level, in order within a queue: a
 // side stream that lands on the main stream's queue would sit behind the running window — which, with a ciphertext ring, itself waits
@@ -117,6 +156,7 @@ struct gsv_program {
   // reads `prog` goes through program_ready() first.
   uint64_t decl_inputs = 0, decl_outputs = 0, decl_gates = 0;
   bool has_feedback = false, has_decl = false;
+  struct gsv_plan_recorder* for_recorder = nullptr;  // compiled with gsv_compile_opts.for_plan: registered there until either side is destroyed (g_recorder_link_mu)
   std::mutex cmu;
   std::condition_variable ccv;
   bool compiling = false;
@@ -166,6 +206,7 @@ struct gsv_session {
   size_t n_inst = 0;
   uint64_t replays = 1, ct_cap = 1;
   void *W = nullptr, *VB = nullptr, *CT = nullptr, *delta = nullptr, *out = nullptr, *out_bits = nullptr, *in_bits = nullptr, *step_clock = nullptr, *ct_stage = nullptr, *ct_gate = nullptr;
+  size_t ct_gate_bytes = 0;  // capacity of ct_gate and of every buffer of ct_gate_more (ensure_ct_gate)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint32_t ni = 1;  // instances per workgroup of this session's launches
   // plan sessions: `facade` stands in for the program (slots = wire-file stride, inputs / outputs in the global region)
@@ -293,9 +334,10 @@ int gsv_recorder_counts(const gsv_recorder* r, uint64_t* n_inputs, uint64_t* n_o
 
 // ---------------------------------------------------------------- program
 static int program_ready(const gsv_program* cp);
-void gsv_program_destroy(gsv_program* p) {
-  if (!p) return;
+static void unlink_from_recorder(gsv_program* p);
+static void program_destroy_now(gsv_program* p) {
   (void)program_ready(p);  // a background compilation still writes into it
+  unlink_from_recorder(p);  // its plan recorder must not wait on a destroyed program (gsv_plan_recorder_finish / _destroy)
   std::set<void*> freed;  // a half-window image loaded from a plan file is filed under both layouts
   for (auto& kv : p->dev) {
     (void)hipSetDevice(kv.first.first);
@@ -303,6 +345,10 @@ void gsv_program_destroy(gsv_program* p) {
       if (q && freed.insert(q).second) (void)hipFree(q);
   }
   delete p;
+}
+void gsv_program_destroy(gsv_program* p) {
+  if (!p) return;
+  release_or_defer([p] { program_destroy_now(p); });
 }
 int gsv_program_get_info(const gsv_program* p, gsv_program_info* info) {
   if (!p || !info) return fail(GSV_ERR_INVALID, "null argument");
@@ -338,12 +384,20 @@ int gsv_engine_create(int device, gsv_engine** out) {
   *out = e.release();
   return GSV_OK;
 }
-void gsv_engine_destroy(gsv_engine* e) {
-  if (!e) return;
+static void engine_destroy_now(gsv_engine* e) {
   (void)hipSetDevice(e->device);
   if (e->te) (void)hipFree(e->te);
   if (e->stream) (void)hipStreamDestroy(e->stream);
   delete e;
+}
+void gsv_engine_destroy(gsv_engine* e) {
+  if (!e) return;
+  release_or_defer([e] { engine_destroy_now(e); });
+}
+uint64_t gsv_deferred_release_count(void) {
+  ReleaseGate& g = release_gate();
+  std::lock_guard<std::recursive_mutex> lk(g.mu);
+  return g.n_deferred;
 }
 
 int gsv_labels_from_seed(uint64_t seed, size_t n_inputs, uint8_t delta[16], uint8_t false_label0[16], uint8_t true_label0[16], uint8_t* input_label0) {
@@ -449,8 +503,7 @@ int gsv_session_create(gsv_engine* e, const gsv_program* cp, size_t n_instances,
   *out = s.release();
   return GSV_OK;
 }
-void gsv_session_destroy(gsv_session* s) {
-  if (!s) return;
+static void session_destroy_now(gsv_session* s) {
   (void)hipSetDevice(s->e->device);
   (void)hipStreamSynchronize(s->e->stream);
   for (void* q : {s->W, s->VB, s->CT, s->delta, s->out, s->out_bits, s->in_bits, s->step_clock, s->ct_stage, s->ct_gate}) if (q) (void)hipFree(q);
@@ -467,6 +520,10 @@ void gsv_session_destroy(gsv_session* s) {
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   delete s;
 }
+void gsv_session_destroy(gsv_session* s) {
+  if (!s) return;
+  release_or_defer([s] { session_destroy_now(s); });
+}
 
 // ---------------------------------------------------------------- plans
 int gsv_plan_create(gsv_plan** out) {
@@ -476,8 +533,10 @@ int gsv_plan_create(gsv_plan** out) {
 }
 void gsv_plan_destroy(gsv_plan* p) {
   if (!p) return;
-  for (gsv_program* q : p->owned) gsv_program_destroy(q);
-  delete p;
+  release_or_defer([p] {
+    for (gsv_program* q : p->owned) program_destroy_now(q);
+    delete p;
+  });
 }
 int gsv_plan_add_call(gsv_plan* p, const gsv_program* prog, const uint32_t* in_globals, const uint32_t* out_globals) {
   if (!p || !prog || p->finished) return fail(GSV_ERR_INVALID, "bad argument / plan already finished");
@@ -752,6 +811,16 @@ struct gsv_plan_recorder {
     for (gsv_program* q : v) (void)program_ready(q);
   }
 };
+// program <-> plan recorder registration (gsv_compile_opts.for_plan): whichever side is destroyed first takes itself out of the other
+static std::mutex g_recorder_link_mu;
+static void unlink_from_recorder(gsv_program* p) {
+  std::lock_guard<std::mutex> lk(g_recorder_link_mu);
+  if (gsv_plan_recorder* r = p->for_recorder) {
+    std::lock_guard<std::mutex> lk2(r->mu);
+    r->compiled_for.erase(std::remove(r->compiled_for.begin(), r->compiled_for.end(), p), r->compiled_for.end());
+    p->for_recorder = nullptr;
+  }
+}
 int gsv_plan_recorder_create_opts(const gsv_plan_recorder_opts* o, gsv_plan_recorder** out) {
   if (!out) return fail(GSV_ERR_INVALID, "null out");
   if (o && o->struct_size != sizeof(gsv_plan_recorder_opts)) return fail(GSV_ERR_INVALID, "gsv_plan_recorder_opts.struct_size does not match this library");
@@ -775,6 +844,12 @@ int gsv_plan_recorder_create(gsv_plan_recorder** out) { return gsv_plan_recorder
 void gsv_plan_recorder_destroy(gsv_plan_recorder* r) {
   if (!r) return;
   r->wait_for_compilations();  // their jobs hold a pointer to this recorder's plan file
+  {
+    std::lock_guard<std::mutex> lk(g_recorder_link_mu);
+    std::lock_guard<std::mutex> lk2(r->mu);
+    for (gsv_program* q : r->compiled_for) q->for_recorder = nullptr;
+    r->compiled_for.clear();
+  }
   delete r;
 }
 int gsv_plan_recorder_allocate_wire(gsv_plan_recorder* r, uint16_t credits, uint64_t* wire_out) {
@@ -929,7 +1004,7 @@ static int compile_impl(gsv_recorder* r, const uint32_t* fb_out_idx, const uint3
     } catch (const std::exception& e) { return {GSV_ERR_CIRCUIT, e.what()};
     } catch (...) { return {GSV_ERR_CIRCUIT, "unknown exception"}; }
   };
-  if (pr) { std::lock_guard<std::mutex> lk(pr->mu); pr->compiled_for.push_back(q); }
+  if (pr) { std::lock_guard<std::mutex> lk0(g_recorder_link_mu); std::lock_guard<std::mutex> lk(pr->mu); pr->compiled_for.push_back(q); q->for_recorder = pr; }
   if (o && o->background) {
     q->compiling = true;
     abi_compile_pool().submit([q, work] {
@@ -940,7 +1015,7 @@ static int compile_impl(gsv_recorder* r, const uint32_t* fb_out_idx, const uint3
   } else {
     auto res = work();
     if (res.first) {
-      if (pr) { std::lock_guard<std::mutex> lk(pr->mu); pr->compiled_for.pop_back(); }
+      unlink_from_recorder(q);
       return fail(res.first, res.second);
     }
   }
@@ -1408,9 +1483,7 @@ int gsv_session_plan_window(const gsv_session* s, uint64_t window, uint64_t* fir
 }
 int gsv_session_set_drain_instances(gsv_session* s, size_t n) {
   if (!s || n > s->n_inst) return fail(GSV_ERR_INVALID, "null session / more instances than the session holds");
-  if (s->ct_gate && (n == 0 ? s->n_inst : n) > (s->drain_instances ? s->drain_instances : s->n_inst))
-    return fail(GSV_ERR_INVALID, "the session's gate-order buffers were sized for fewer instances: set this before the first streaming call");
-  s->drain_instances = n;
+  s->drain_instances = n;  // (the gate-order buffers are re-allocated by the next streaming call if they were sized for fewer: ensure_ct_gate)
   return GSV_OK;
 }
 int gsv_session_set_unchecked_slices(gsv_session* s, int on) {
@@ -1911,6 +1984,23 @@ static int wait_calls_done(gsv_session* s, size_t w, uint32_t k0, uint32_t k1, b
   return GSV_OK;
 }
 // the side stream and the device-written completion counters of a session whose stream leaves the device while a window runs
+// The gate-order buffers (ct_gate + the drain pipeline's further ones) hold `bytes` each — or are released and ct_gate re-allocated.  A
+// sample drain (gsv_session_set_drain_instances) sizes them for the sample; a later call over more instances (a full drain, or any
+// evaluate_streaming: the evaluator uploads EVERY instance's stream) must not write past them.
+static int ensure_ct_gate(gsv_session* s, size_t bytes) {
+  if (s->ct_gate && s->ct_gate_bytes >= bytes) return GSV_OK;
+  if (s->ct_gate || !s->ct_gate_more.empty()) {
+    HIPCHK(hipStreamSynchronize(s->e->stream));
+    if (s->aux_stream) HIPCHK(hipStreamSynchronize(s->aux_stream));
+    for (void* q : s->ct_gate_more) if (q) (void)hipFree(q);
+    s->ct_gate_more.clear();
+    if (s->ct_gate) (void)hipFree(s->ct_gate);
+    s->ct_gate = nullptr; s->ct_gate_bytes = 0;
+  }
+  DEVALLOC(&s->ct_gate, bytes, "the gate-order ciphertext buffer");
+  s->ct_gate_bytes = bytes;
+  return GSV_OK;
+}
 static int ensure_aux(gsv_session* s) {
   if (!s->aux_stream) HIPCHK(create_side_stream(&s->aux_stream));
   if (!s->host_done) return fail(GSV_ERR_INVALID, "internal: a plan session without completion counters");  // (allocated with its call descriptors)
@@ -1942,7 +2032,7 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   HIPCHK(hipSetDevice(s->e->device));
   const uint64_t seg_records = seg * n_ct;  // per instance
   if (want_drain) {
-    if (!s->ct_gate && seg_records) DEVALLOC(&s->ct_gate, n_inst * seg_records * 16, "the gate-order ciphertext buffer");
+    if (seg_records) { int grc = ensure_ct_gate(s, n_inst * size_t(seg_records) * 16); if (grc) return grc; }
     int rc = ensure_drain(s, T, seg_records, int(GROUP));
     if (rc) return rc;
   }
@@ -1991,7 +2081,7 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
     }
     while (1 + s->ct_gate_more.size() < want) {
       void* q = nullptr;
-      if (hipMalloc(&q, n_inst * size_t(seg_records) * 16) != hipSuccess) { (void)hipGetLastError(); break; }
+      if (hipMalloc(&q, s->ct_gate_bytes) != hipSuccess) { (void)hipGetLastError(); break; }  // (every buffer of the pipeline has ct_gate's capacity)
       s->ct_gate_more.push_back(q);
     }
     for (void* q : s->ct_gate_more) if (gate_bufs.size() < want) gate_bufs.push_back(q);
@@ -2227,6 +2317,7 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
 }
 static DrainSink mac_file_sink(uint8_t* hashes, const char* dir, uint64_t first_index) { DrainSink k; k.hashes = hashes; k.dir = dir; k.first_index = first_index; return k; }
 int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes) {
+  PassGuard pass_guard;  // destroys requested while this pass runs wait for its end (deferred release)
   if (!s) return fail(GSV_ERR_INVALID, "null argument");
   if (dir && !hashes) return fail(GSV_ERR_INVALID, "null hash buffer");
   return garble_streaming_range(s, gate_id_base, 0, s->plan ? s->plan->calls.size() : 1, mac_file_sink(hashes, dir, first_index), n_threads);
@@ -2242,6 +2333,7 @@ static int check_slice(gsv_session* s, uint64_t first_call, uint64_t n_calls) {
   return GSV_OK;
 }
 int gsv_session_garble_streaming_calls(gsv_session* s, uint64_t gate_id_base, uint64_t first_call, uint64_t n_calls, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes) {
+  PassGuard pass_guard;  // destroys requested while this pass runs wait for its end (deferred release)
   int rc = check_slice(s, first_call, n_calls);
   if (rc) return rc;
   if (dir && !hashes) return fail(GSV_ERR_INVALID, "null hash buffer");
@@ -2251,6 +2343,7 @@ int gsv_session_garble_streaming_calls(gsv_session* s, uint64_t gate_id_base, ui
 }
 // The generic CiphertextHandler: every drained run of records is handed to `sink` (gate order, per instance in stream order).
 int gsv_session_garble_streaming_sink(gsv_session* s, uint64_t gate_id_base, uint64_t first_call, uint64_t n_calls, gsv_ct_sink_fn sink, void* user, int n_threads, uint8_t* hashes) {
+  PassGuard pass_guard;  // destroys requested while this pass runs wait for its end (deferred release)
   if (!s || !sink) return fail(GSV_ERR_INVALID, "null argument");
   DrainSink k;
   k.hashes = hashes; k.fn = sink; k.user = user;
@@ -2265,6 +2358,7 @@ int gsv_session_garble_streaming_sink(gsv_session* s, uint64_t gate_id_base, uin
 // Garble and evaluate side by side on the device (examples/groth16_garble.rs:171-230: the garbler thread feeds the evaluator thread
 // through a channel; here window k of the garbler's device block is evaluated while window k+1 is garbled).
 int gsv_session_garble_evaluate(gsv_session* gs, gsv_session* es, uint64_t gate_id_base, int n_threads, uint8_t* hashes) {
+  PassGuard pass_guard;  // destroys requested while this pass runs wait for its end (deferred release)
   if (!gs || !es || gs == es) return fail(GSV_ERR_INVALID, "null / identical sessions");
   if (!gs->plan || gs->plan != es->plan || gs->e != es->e || gs->n_inst != es->n_inst || gs->ni != es->ni || gs->hasher != es->hasher)
     return fail(GSV_ERR_INVALID, "garbler and evaluator must be plan sessions of the same plan, engine, instance count and hasher");
@@ -2312,7 +2406,7 @@ static int evaluate_streaming_impl(gsv_session* s, uint64_t gate_id_base, const 
   const size_t n_inst = s->n_inst;
   HIPCHK(hipSetDevice(s->e->device));
   const uint64_t seg_records = s->plan ? s->plan_max_segment : s->ct_cap * g.n_ct;  // per instance: stride of the gate-order buffer
-  if (!s->ct_gate && seg_records) DEVALLOC(&s->ct_gate, n_inst * seg_records * 16, "the gate-order ciphertext buffer");
+  if (seg_records) { int grc = ensure_ct_gate(s, n_inst * size_t(seg_records) * 16); if (grc) return grc; }  // (a sample drain before may have sized it for fewer instances)
   // The CBC-MAC of one instance is a serial chain (ciphertext_source.rs:36-107 folds it while reading), the chains of different instances
   // are independent: with hashes asked for, the chunks are read CHUNK-major (every instance's chunk at one offset, then the next offset)
   // and instance i's chunks are folded in order by worker i mod T, beside the uploads; a staging buffer is reused once its copy AND its MAC
@@ -2457,12 +2551,17 @@ static int evaluate_from_files(gsv_session* s, uint64_t gate_id_base, const char
     return 0;
   }, hashes);
 }
-int gsv_session_evaluate_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, uint8_t* hashes) { return evaluate_from_files(s, gate_id_base, dir, nullptr, first_index, hashes); }
+int gsv_session_evaluate_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, uint8_t* hashes) {
+  PassGuard pass_guard;  // destroys requested while this pass runs wait for its end (deferred release)
+  return evaluate_from_files(s, gate_id_base, dir, nullptr, first_index, hashes);
+}
 int gsv_session_evaluate_streaming_indexed(gsv_session* s, uint64_t gate_id_base, const char* dir, const uint64_t* indexes, uint8_t* hashes) {
+  PassGuard pass_guard;  // destroys requested while this pass runs wait for its end (deferred release)
   if (!indexes) return fail(GSV_ERR_INVALID, "null index list");
   return evaluate_from_files(s, gate_id_base, dir, indexes, 0, hashes);
 }
 int gsv_session_evaluate_streaming_source(gsv_session* s, uint64_t gate_id_base, gsv_ct_source_fn source, void* user, uint8_t* hashes) {
+  PassGuard pass_guard;  // destroys requested while this pass runs wait for its end (deferred release)
   if (!s || !source) return fail(GSV_ERR_INVALID, "null argument");
   return evaluate_streaming_impl(s, gate_id_base, [&](size_t i, uint64_t first, uint8_t* dst, uint64_t n) -> int { return source(user, i, first, dst, n); }, hashes);
 }

@@ -208,6 +208,14 @@ int gsv_plan_from_circuit(const char* spec, const char* units_csv, gsv_plan** ou
 /* ---- engine --------------------------------------------------------------------------------- */
 int gsv_engine_create(int device, gsv_engine** out); /* fails with GSV_ERR_DEVICE if no HIP device */
 void gsv_engine_destroy(gsv_engine* e);
+/* Deferred release (round 6).  gsv_session_destroy, gsv_plan_destroy, gsv_program_destroy and gsv_engine_destroy may be called from ANY
+ * thread at ANY time — including from a gsv_ct_sink_fn / gsv_ct_source_fn callback in the middle of a streaming pass, which is where a
+ * Rust host's `Drop` or a garbage collector runs them (CircuitMode values are dropped wherever the host drops them, modes.rs:26-51).
+ * Freeing device memory synchronises the device, and a pass over a ciphertext ring waits for the host: so while any streaming pass
+ * (gsv_session_garble_streaming*, _sink, _garble_evaluate, gsv_session_evaluate_streaming*) is in flight in this process the destroy
+ * calls only queue the request; the queue runs, in order, when the last pass in flight has ended.  The handle is invalid for the host as
+ * soon as destroy returns, as always.  Returns how many requests have been deferred so far (tests, diagnostics). */
+uint64_t gsv_deferred_release_count(void);
 
 /* Seed -> labels exactly as GarbleMode::new + issue_garbled_wire draw them (garble_mode.rs:80-97,
  * 116-118): delta, false.label0, true.label0, then n_inputs input label0s.  Host-only helper for the

@@ -254,11 +254,26 @@ struct MacSink {  // CiphertextHandler::handle for ONE instance: AESAccumulating
   uint8_t state[16] = {0};
   uint64_t next_record = 0;
   bool in_order = true;
+  // --destroy-in-sink: what a host's `Drop` (or a garbage collector) does on the handler's thread in the middle of a pass — a second
+  // session and its plan are destroyed from INSIDE the callback (round 6: the engine defers the release to the end of the pass; before,
+  // hipFree waited for the ring pass, which waited for this callback: a 60 s stall ended by the device's watchdog)
+  gsv_session* victim_session = nullptr;
+  gsv_plan* victim_plan = nullptr;
+  uint64_t destroy_after = 0, deferred_before = 0, deferred_after = 0;
+  double destroy_s = 0;
 };
 static int mac_sink(void* user, size_t instance, uint64_t first, const uint8_t* records, uint64_t n) {
   MacSink& m = *static_cast<MacSink*>(user);
   if (instance != 0 || first != m.next_record) m.in_order = false;
   m.next_record = first + n;
+  if (m.victim_session && first + n >= m.destroy_after) {
+    const double t0 = now_s();
+    m.deferred_before = gsv_deferred_release_count();
+    gsv_session_destroy(m.victim_session); m.victim_session = nullptr;
+    gsv_plan_destroy(m.victim_plan); m.victim_plan = nullptr;
+    m.deferred_after = gsv_deferred_release_count();
+    m.destroy_s = now_s() - t0;
+  }
   return gsv_cbcmac_update(m.state, records, n);
 }
 static std::string hex(const uint8_t* b, size_t n) {
@@ -269,16 +284,18 @@ static std::string hex(const uint8_t* b, size_t n) {
 }
 
 int main(int argc, char** argv) {
-  if (argc < 4) { std::fprintf(stderr, "usage: ext_host <circuit spec> <units csv> <plan file> [--window-div N] [--warmup-threads N] [--garble SEED]\n"); return 2; }
+  if (argc < 4) { std::fprintf(stderr, "usage: ext_host <circuit spec> <units csv> <plan file> [--window-div N] [--warmup-threads N] [--garble SEED] [--ring] [--destroy-in-sink]\n"); return 2; }
   const std::string spec = argv[1], units_csv = argv[2], path = argv[3];
   uint32_t window_div = 4;
   int warm_threads = -1;
-  bool garble = false;
+  bool garble = false, ring = false, destroy_in_sink = false;
   uint64_t seed = 0;
   for (int i = 4; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--window-div") && i + 1 < argc) window_div = uint32_t(atoi(argv[++i]));
     else if (!std::strcmp(argv[i], "--warmup-threads") && i + 1 < argc) warm_threads = atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--garble") && i + 1 < argc) { garble = true; seed = std::strtoull(argv[++i], nullptr, 10); }
+    else if (!std::strcmp(argv[i], "--ring")) ring = true;                        // the whole pass as one launch over a ciphertext ring (GSV_STREAM_RING)
+    else if (!std::strcmp(argv[i], "--destroy-in-sink")) destroy_in_sink = true;  // destroy a second session + plan from the sink callback, mid-pass
     else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
   }
   try {
@@ -349,13 +366,19 @@ int main(int argc, char** argv) {
       chk(gsv_plan_load(path.c_str(), e, &plan), "gsv_plan_load");
       const double t_load = now_s() - t1;
       gsv_plan_session_opts so{};
-      so.retain_stream = 0;  // nothing retained: the stream leaves the device segment by segment of the running window
+      so.retain_stream = ring ? GSV_STREAM_RING : 0;  // nothing retained: the stream leaves the device segment by segment of the running window
+      if (ring) { so.max_concurrent_calls = 16; so.drain_segment_records = 300000; }
       gsv_session* s = nullptr;
       chk(gsv_session_create_plan_opts(e, plan, 1, &so, &s), "gsv_session_create_plan_opts");
+      MacSink sink;
+      if (destroy_in_sink) {
+        chk(gsv_plan_load(path.c_str(), e, &sink.victim_plan), "gsv_plan_load (second plan)");
+        chk(gsv_session_create_plan_opts(e, sink.victim_plan, 1, &so, &sink.victim_session), "gsv_session_create_plan_opts (second session)");
+        sink.destroy_after = n_ct / 3;
+      }
       std::vector<uint8_t> delta(16), consts(32), inputs(size_t(n_in) * 16);
       chk(gsv_labels_from_seed(seed, size_t(n_in), delta.data(), consts.data(), consts.data() + 16, inputs.data()), "gsv_labels_from_seed");
       chk(gsv_session_set_garble_inputs(s, delta.data(), consts.data(), inputs.data()), "gsv_session_set_garble_inputs");
-      MacSink sink;
       uint8_t engine_mac[16];
       const double t2 = now_s();
       chk(gsv_session_garble_streaming_sink(s, 0, 0, 0, mac_sink, &sink, 1, engine_mac), "gsv_session_garble_streaming_sink");
@@ -369,6 +392,11 @@ int main(int argc, char** argv) {
       std::snprintf(buf, sizeof buf, ", \"seed\": %llu, \"load_s\": %.2f, \"garble_s\": %.2f, \"sink_records\": %llu, \"sink_in_order\": %s", (unsigned long long)seed, t_load, t_garble,
                     (unsigned long long)sink.next_record, sink.in_order ? "true" : "false");
       extra = buf;
+      if (destroy_in_sink) {
+        std::snprintf(buf, sizeof buf, ", \"destroyed_in_sink\": %s, \"deferred_releases\": %llu, \"destroy_call_s\": %.4f, \"deferred_total_after_pass\": %llu",
+                      sink.victim_session ? "false" : "true", (unsigned long long)(sink.deferred_after - sink.deferred_before), sink.destroy_s, (unsigned long long)gsv_deferred_release_count());
+        extra += buf;
+      }
       extra += ", \"ct_hash\": \"" + hex(sink.state, 16) + "\", \"engine_ct_hash\": \"" + hex(engine_mac, 16) + "\", \"output_label0\": \"" + hex(out.data(), out.size()) + "\"";
     }
     getrusage(RUSAGE_SELF, &ru);

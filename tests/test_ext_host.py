@@ -34,8 +34,8 @@ def ext_host():
     return EXT
 
 
-def run_ext(exe, spec, units, path, *more):
-    r = subprocess.run([exe, spec, ",".join(units), path] + [str(x) for x in more], capture_output=True, text=True)
+def run_ext(exe, spec, units, path, *more, env=None):
+    r = subprocess.run([exe, spec, ",".join(units), path] + [str(x) for x in more], capture_output=True, text=True, env=dict(os.environ, **env) if env else None)
     assert r.returncode == 0, r.stderr
     return json.loads(r.stdout.strip().splitlines()[-1])
 
@@ -146,3 +146,25 @@ def test_full_verifier_through_the_public_abi(ext_host, verifier_plan_file, tmp_
     finally:
         if os.path.exists(a):
             os.remove(a)
+
+
+@pytest.mark.gpu
+def test_destroy_from_the_sink_callback_mid_pass(ext_host, tmp_path):
+    """A mode is dropped wherever the host drops it (src/circuit/modes.rs:26-51): the external host destroys a SECOND session and its plan
+    from inside its `CiphertextHandler` callback, a third of the way through a pass that runs as ONE launch over a ciphertext ring.  Until
+    round 5 that was a deadlock by construction (hipFree waits for the ring pass, the pass for the host's stream position, the position for
+    this callback) that the device's watchdog ended after GSV_DEP_WAIT_SECONDS with a failed pass.  Now the destroy calls return at once
+    (two deferred releases), the pass finishes in its normal time and MAC and output labels equal the run without the destroy and the CPU
+    oracle's flat stream."""
+    import oracle_lib as o
+    units = ["fq2::mul_montgomery", "fq2::square_montgomery", "fp254::mul_by_constant_montgomery", "bigint::mul_karatsuba", "fp254::montgomery_reduce"]
+    path = os.path.join(str(tmp_path), "mix.gsvplan")
+    env = {"GSV_CT_RING_RECORDS": "1000000", "GSV_DEP_WAIT_SECONDS": "20"}
+    plain = run_ext(ext_host, "fq12_mix", units, path, "--window-div", 1, "--garble", 77, "--ring", env=env)
+    j = run_ext(ext_host, "fq12_mix", units, path, "--window-div", 1, "--garble", 77, "--ring", "--destroy-in-sink", env=env)
+    ref = o.garble("fq12_mix", 77)
+    assert j["destroyed_in_sink"] is True and j["deferred_releases"] == 2 and j["destroy_call_s"] < 0.5, j
+    assert j["deferred_total_after_pass"] == 2, j
+    assert j["ct_hash"] == j["engine_ct_hash"] == plain["ct_hash"] == ref.ct_hash.tobytes().hex() and j["sink_in_order"]
+    assert bytes.fromhex(j["output_label0"]) == ref.output_label0.tobytes() == bytes.fromhex(plain["output_label0"])
+    assert j["garble_s"] < 3.0 * plain["garble_s"] + 2.0, (j["garble_s"], plain["garble_s"])  # (the stall it replaces: GSV_DEP_WAIT_SECONDS, then a failed pass)
