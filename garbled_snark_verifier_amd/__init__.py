@@ -105,7 +105,7 @@ class _Gate(C.Structure):
 EXPORTS = [
     "gsv_last_error", "gsv_recorder_create", "gsv_recorder_destroy", "gsv_recorder_allocate_wire", "gsv_recorder_declare_input",
     "gsv_recorder_push_gates", "gsv_recorder_declare_outputs", "gsv_recorder_record_circuit", "gsv_recorder_counts", "gsv_program_compile", "gsv_program_destroy",
-    "gsv_program_get_info", "gsv_engine_create", "gsv_engine_destroy", "gsv_deferred_release_count", "gsv_labels_from_seed", "gsv_session_create", "gsv_session_destroy",
+    "gsv_program_get_info", "gsv_engine_create", "gsv_engine_destroy", "gsv_deferred_release_count", "gsv_session_fallback_count", "gsv_plan_build_file_pair", "gsv_labels_from_seed", "gsv_session_create", "gsv_session_destroy",
     "gsv_session_set_garble_inputs", "gsv_session_garble", "gsv_session_set_evaluate_inputs", "gsv_session_upload_ciphertexts",
     "gsv_session_evaluate", "gsv_session_set_hasher", "gsv_session_sync", "gsv_session_last_kernel_ms", "gsv_session_read_outputs", "gsv_session_read_ciphertexts",
     "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_cbcmac_update_many", "gsv_commit_labels",
@@ -146,6 +146,8 @@ def lib():
         L.gsv_engine_create.argtypes = [C.c_int, C.POINTER(vp)]
         L.gsv_engine_destroy.argtypes = [vp]
         L.gsv_engine_destroy.restype = None
+        L.gsv_session_fallback_count.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.gsv_plan_build_file_pair.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]
         L.gsv_deferred_release_count.argtypes = []
         L.gsv_deferred_release_count.restype = C.c_uint64
         L.gsv_labels_from_seed.argtypes = [C.c_uint64, C.c_size_t, u8p, u8p, u8p, u8p]
@@ -426,6 +428,12 @@ class Plan:
                 else:
                     os.environ[k] = v
 
+    @staticmethod
+    def build_file_pair(spec, units, path_a, window_div_a, path_b, window_div_b):
+        """Two plan files from ONE recording of the circuit (gsv_plan_build_file_pair): every program compiled for both shares of the LDS
+        window.  Each file equals what build_file writes for its window_div."""
+        _chk(lib().gsv_plan_build_file_pair(spec.encode(), ",".join(units).encode(), os.fsencode(path_a), int(window_div_a), os.fsencode(path_b), int(window_div_b)))
+
     def _read_info(self):
         g, c, k = C.c_uint64(), C.c_uint64(), C.c_uint64()
         _chk(lib().gsv_plan_counts(self.h, C.byref(g), C.byref(c), C.byref(k)))
@@ -700,6 +708,12 @@ class Session:
         i = _PlanScheduleInfo()
         _chk(lib().gsv_session_plan_schedule_info(self.h, C.byref(i)))
         return {k: int(getattr(i, k)) for k in _SCHED_FIELDS}
+
+    def fallback_count(self):
+        """How often this plan session has fallen back to the safe schedule (one call per launch) after a dependency wait gave up."""
+        n = C.c_uint64()
+        _chk(lib().gsv_session_fallback_count(self.h, C.byref(n)))
+        return int(n.value)
 
     def windows(self):
         """[(first_call, n_calls, max_width)] of the schedule: slices handed to garble_calls start and end on these boundaries."""

@@ -232,6 +232,16 @@ struct gsv_session {
   Schedule sched;
   void *d_calls = nullptr, *d_copy_src = nullptr, *d_copy_dst = nullptr, *d_deps = nullptr, *d_flags = nullptr, *d_error = nullptr;
   uint32_t flag_stride = 0, epoch = 0;
+  // Safe-schedule fallback (round 6): the options the session was created with, the host's last inputs (re-staged when a pass is
+  // repeated) and what the big allocations hold, so that a second schedule can be installed into the same session.
+  gsv_plan_session_opts opts{};
+  bool safe_mode = false;                    // the schedule is the safe one: ONE call per launch, no dependency waits on the device
+  bool dep_fault = false;                    // the last pass ended with status 1 (a dependency wait gave up)
+  uint64_t n_fallbacks = 0;
+  size_t w_slots_cap = 0;                    // 16-byte slots per instance W / VB were allocated for
+  uint64_t ct_records_cap = 0;               // ciphertext records per instance CT was allocated for
+  std::vector<uint8_t> stash_delta, stash_consts, stash_inputs, stash_bits;
+  int stash_kind = 0;                        // 0 nothing, 1 garble inputs, 2 evaluate inputs
   size_t drain_instances = 0;               // streaming calls: only the first this-many instances' streams leave the device (0 = all)
   uint64_t next_call = 0;                   // streaming slices: the call the next slice must start with
   bool unchecked_slices = false;            // benchmarks may garble slices out of order (results are then meaningless)
@@ -584,8 +594,16 @@ static int plan_window_div(uint32_t* window_div) {
   if (const char* e = getenv("GSV_PLAN_WINDOW_DIV")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) *window_div = uint32_t(v); else return fail(GSV_ERR_INVALID, "GSV_PLAN_WINDOW_DIV must be 1, 2 or 4"); }
   return GSV_OK;
 }
-// sink: see PlanUnitCache::sink (gsv_plan_build_file); empty = the programs stay in memory
-static int plan_from_circuit_impl(const char* spec, const char* units_csv, const std::function<void(Program&)>& sink, gsv_plan** out) {
+// A dual build (gsv_plan_build_file_pair): the second image of every program — compiled from the same recording for 1 / window_div of the
+// LDS window, handed to `sink` — and the second plan.
+struct DualBuild {
+  uint32_t window_div = 1;
+  std::function<void(Program&)> sink;
+  gsv_plan** out = nullptr;
+};
+// sink: see PlanUnitCache::sink (gsv_plan_build_file); empty = the programs stay in memory.  window_div_override: 0 = GSV_PLAN_WINDOW_DIV.
+static int plan_from_circuit_impl(const char* spec, const char* units_csv, const std::function<void(Program&)>& sink, gsv_plan** out, uint32_t window_div_override = 0,
+                                  const DualBuild* dual = nullptr) {
   if (!spec || !units_csv || !out) return fail(GSV_ERR_INVALID, "null argument");
   GSV_TRY
   std::vector<std::string> names;
@@ -605,7 +623,14 @@ static int plan_from_circuit_impl(const char* spec, const char* units_csv, const
   // compilation for plans with hundreds of programs, at a smaller window when sessions have few instances).
   // GSV_PLAN_HALF_WINDOW=1 is the older spelling of GSV_PLAN_WINDOW_DIV=2.
   uint32_t window_div = 1;
-  { int rc = plan_window_div(&window_div); if (rc) return rc; }
+  if (window_div_override) window_div = window_div_override;
+  else { int rc = plan_window_div(&window_div); if (rc) return rc; }
+  if (dual) {
+    if (!sink || !dual->sink || !dual->out) return fail(GSV_ERR_INVALID, "internal: a dual build writes both plans to files");
+    CompileOptions ob = opt;
+    ob.lds_slots = std::min<uint32_t>(ob.lds_slots, LDS_WINDOW_SLOTS / dual->window_div);
+    mode.cache()->dual = true; mode.cache()->bg_opt_b = ob; mode.cache()->sink_b = dual->sink;
+  }
   // (a plan built straight into a file keeps ONE image per program and no trace: with GSV_PLAN_WINDOW_DIV=1 that image has the full LDS
   // window and serves one instance per workgroup only — the small-batch plan of bench.py: 3 % faster steps for 1 and 16 instances)
   const bool single_image = window_div > 1 || bool(sink);
@@ -633,25 +658,34 @@ static int plan_from_circuit_impl(const char* spec, const char* units_csv, const
                    100.0 * double(g.reads_hbm) / std::max<double>(1.0, double(g.reads_hbm + g.reads_lds)));
     }
   }
-  std::unique_ptr<gsv_plan> plan(new gsv_plan());
-  for (size_t k = 0; k < bp.programs.size(); ++k) {
-    gsv_program* q = new gsv_program();
-    plan->owned.push_back(q);
-    q->prog = std::move(bp.programs[k]);
-    q->window_div = window_div;
-    if (single_image) bp.traces[k] = Trace();
-    else q->src.reset(new ProgramSource{std::move(bp.traces[k]), bp.prog_inputs[k], bp.prog_outputs[k], {}, opt});
-    for (size_t i = 0; i < q->prog.input_slots.size(); ++i)
-      if (q->prog.input_slots[i] != SLOT_FIRST_INPUT + i) { gsv_plan_destroy(plan.release()); return fail(GSV_ERR_CIRCUIT, "internal: inputs are not slot-contiguous"); }
-  }
-  for (const BuiltPlan::Call& c : bp.calls) {
-    int rc = gsv_plan_add_call(plan.get(), plan->owned[size_t(c.program)], c.in_globals.data(), c.out_globals.data());
+  // the plan object over one set of images (a dual build makes two: same calls, same globals)
+  auto make_plan = [&](std::vector<Program>& programs, uint32_t wdiv, bool keep_traces, gsv_plan** dst) -> int {
+    std::unique_ptr<gsv_plan> plan(new gsv_plan());
+    for (size_t k = 0; k < programs.size(); ++k) {
+      gsv_program* q = new gsv_program();
+      plan->owned.push_back(q);
+      q->prog = std::move(programs[k]);
+      q->window_div = wdiv;
+      if (keep_traces) q->src.reset(new ProgramSource{std::move(bp.traces[k]), bp.prog_inputs[k], bp.prog_outputs[k], {}, opt});
+      for (size_t i = 0; i < q->prog.input_slots.size(); ++i)
+        if (q->prog.input_slots[i] != SLOT_FIRST_INPUT + i) { gsv_plan_destroy(plan.release()); return fail(GSV_ERR_CIRCUIT, "internal: inputs are not slot-contiguous"); }
+    }
+    for (const BuiltPlan::Call& c : bp.calls) {
+      int rc = gsv_plan_add_call(plan.get(), plan->owned[size_t(c.program)], c.in_globals.data(), c.out_globals.data());
+      if (rc) { gsv_plan_destroy(plan.release()); return rc; }
+    }
+    int rc = gsv_plan_finish(plan.get(), bp.n_inputs, bp.outputs.data(), bp.outputs.size());
     if (rc) { gsv_plan_destroy(plan.release()); return rc; }
-  }
-  int rc = gsv_plan_finish(plan.get(), bp.n_inputs, bp.outputs.data(), bp.outputs.size());
-  if (rc) { gsv_plan_destroy(plan.release()); return rc; }
-  if (plan->n_gates != mode.n_gates()) { gsv_plan_destroy(plan.release()); return fail(GSV_ERR_CIRCUIT, "internal: plan gate count differs from the recorded stream"); }
-  *out = plan.release();
+    if (plan->n_gates != mode.n_gates()) { gsv_plan_destroy(plan.release()); return fail(GSV_ERR_CIRCUIT, "internal: plan gate count differs from the recorded stream"); }
+    *dst = plan.release();
+    return GSV_OK;
+  };
+  gsv_plan* second = nullptr;
+  if (dual) { int rc = make_plan(bp.programs_b, dual->window_div, false, &second); if (rc) return rc; }
+  if (single_image) for (Trace& t : bp.traces) t = Trace();
+  int rc = make_plan(bp.programs, window_div, !single_image, out);
+  if (rc) { gsv_plan_destroy(second); return rc; }
+  if (dual) *dual->out = second;
   return GSV_OK;
   GSV_CATCH
 }
@@ -1068,21 +1102,14 @@ int gsv_plan_save(const gsv_plan* p, const char* path) {
 // Build a plan and write it to `path` without ever holding it: every program is appended to the file by the worker that compiled
 // it and its records are dropped (the verifier's plan is 41 GB of records; built in memory it peaks at ~54 GB of host RSS).
 // Load the file with gsv_plan_load (with an engine: streamed to the device).  One image per program: GSV_PLAN_WINDOW_DIV=2|4.
-int gsv_plan_build_file(const char* spec, const char* units_csv, const char* path) {
-  if (!spec || !units_csv || !path) return fail(GSV_ERR_INVALID, "null argument");
-  GSV_TRY
-  uint32_t window_div = 1;
-  { int rc = plan_window_div(&window_div); if (rc) return rc; }
-  PlanFileWriter w;
-  { int rc = w.open_file(path); if (rc) return rc; }
-  gsv_plan* plan = nullptr;
-  int rc = plan_from_circuit_impl(spec, units_csv, [&](Program& g) {
+static std::function<void(Program&)> spill_to(PlanFileWriter& w, uint32_t window_div) {
+  return [&w, window_div](Program& g) {
     g.file_off = w.append_program(g, window_div);
     g.spilled = true;
     std::vector<StepDesc>().swap(g.steps); std::vector<AndRec>().swap(g.ands); std::vector<XorRec>().swap(g.xors); std::vector<uint32_t>().swap(g.ct_pos);
-  }, &plan);
-  if (rc) return rc;
-  struct PlanOwner { gsv_plan* p; ~PlanOwner() { gsv_plan_destroy(p); } } po{plan};
+  };
+}
+static int finish_built_file(PlanFileWriter& w, const gsv_plan* plan) {
   std::vector<uint64_t> off;
   std::map<const gsv_program*, uint32_t> index;
   for (const gsv_program* q : plan->owned) {
@@ -1091,6 +1118,43 @@ int gsv_plan_build_file(const char* spec, const char* units_csv, const char* pat
     off.push_back(q->prog.file_off);
   }
   return w.finish(plan, off, index);
+}
+int gsv_plan_build_file(const char* spec, const char* units_csv, const char* path) {
+  if (!spec || !units_csv || !path) return fail(GSV_ERR_INVALID, "null argument");
+  GSV_TRY
+  uint32_t window_div = 1;
+  { int rc = plan_window_div(&window_div); if (rc) return rc; }
+  PlanFileWriter w;
+  { int rc = w.open_file(path); if (rc) return rc; }
+  gsv_plan* plan = nullptr;
+  int rc = plan_from_circuit_impl(spec, units_csv, spill_to(w, window_div), &plan, window_div);
+  if (rc) return rc;
+  struct PlanOwner { gsv_plan* p; ~PlanOwner() { gsv_plan_destroy(p); } } po{plan};
+  return finish_built_file(w, plan);
+  GSV_CATCH
+}
+// TWO plan files from ONE recording of the circuit: every program is compiled twice — for 1 / window_div_a and for 1 / window_div_b of the
+// LDS label window — by the worker that takes it off the recorder, and appended to both files.  A deployment that serves large batches
+// (four instances per workgroup: window_div 4) AND small ones (full window: window_div 1) builds both plans for the price of one
+// recording, which is the critical path of a build (bench.py: 94 s -> ~55 s to the first launch).  Each file is byte for byte what
+// gsv_plan_build_file writes for its window_div (tools/plan_digest.py; tests/test_ext_host.py).
+int gsv_plan_build_file_pair(const char* spec, const char* units_csv, const char* path_a, uint32_t window_div_a, const char* path_b, uint32_t window_div_b) {
+  if (!spec || !units_csv || !path_a || !path_b) return fail(GSV_ERR_INVALID, "null argument");
+  for (uint32_t d : {window_div_a, window_div_b}) if (d != 1 && d != 2 && d != 4) return fail(GSV_ERR_INVALID, "window_div must be 1, 2 or 4");
+  if (std::string(path_a) == path_b) return fail(GSV_ERR_INVALID, "the two plan files must differ");
+  GSV_TRY
+  PlanFileWriter wa, wb;
+  { int rc = wa.open_file(path_a); if (rc) return rc; }
+  { int rc = wb.open_file(path_b); if (rc) return rc; }
+  gsv_plan *plan_a = nullptr, *plan_b = nullptr;
+  DualBuild dual;
+  dual.window_div = window_div_b; dual.sink = spill_to(wb, window_div_b); dual.out = &plan_b;
+  int rc = plan_from_circuit_impl(spec, units_csv, spill_to(wa, window_div_a), &plan_a, window_div_a, &dual);
+  if (rc) return rc;
+  struct PlanOwner { gsv_plan* p; ~PlanOwner() { gsv_plan_destroy(p); } } oa{plan_a}, ob{plan_b};
+  rc = finish_built_file(wa, plan_a);
+  if (rc) return rc;
+  return finish_built_file(wb, plan_b);
   GSV_CATCH
 }
 
@@ -1257,6 +1321,7 @@ int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_ins
   return gsv_session_create_plan_opts(e, plan, n_instances, &o, out);
 }
 // The call-level schedule of a plan session (schedule.hpp) for `n_wg` workgroups per call on a device with `n_cus` CUs.
+static int install_schedule(gsv_session* s, const gsv_plan_session_opts& o, int n_cus, size_t free_b);
 static Schedule make_schedule(const gsv_plan* plan, uint32_t ni, size_t n_instances, int n_cus, size_t free_bytes, const gsv_plan_session_opts& o, uint64_t* max_call_ct) {
   std::vector<SchedCall> calls(plan->calls.size());
   uint64_t max_block = 0;
@@ -1368,9 +1433,38 @@ int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_i
   }
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  s->opts = o;
+  {
+    int rc = install_schedule(s.get(), o, prop.multiProcessorCount, free_b);
+    if (rc) return rc;
+  }
+  const Program& f = s->facade;
+  s->w_slots_cap = f.n_slots;
+  s->ct_records_cap = s->ct_stride();
+  DEVALLOC(&s->W, n_instances * size_t(f.n_slots) * 16, "the wire files");
+  HIPCHK(hipMalloc(&s->VB, n_instances * size_t(f.n_slots)));
+  HIPCHK(hipMemset(s->VB, 0, n_instances * size_t(f.n_slots)));
+  const size_t ct_bytes = n_instances * size_t(s->ct_stride()) * 16;
+  DEVALLOC(&s->CT, ct_bytes, "the ciphertext blocks");
+  HIPCHK(hipMalloc(&s->delta, n_instances * 16));
+  HIPCHK(hipMalloc(&s->out, n_instances * f.output_slots.size() * 16 + 16));
+  HIPCHK(hipMalloc(&s->out_bits, n_instances * f.output_slots.size() + 16));
+  HIPCHK(hipMalloc(&s->in_bits, n_instances * f.input_slots.size() + 16));
+  HIPCHK(hipEventCreate(&s->ev0));
+  HIPCHK(hipEventCreate(&s->ev1));
+  *out = s.release();
+  return GSV_OK;
+}
+// Everything of a plan session that depends on its SCHEDULE: the schedule itself, the wire-file layout (scratch regions in front of the
+// global wires), the ring's position counter, the completion counters, and the device tables of the window launches (call descriptors,
+// hand-over lists, dependency lists, completion flags).  Called by gsv_session_create_plan_opts and again, with the safe options, by
+// fall_back_to_safe_schedule (after drop_schedule).
+static int install_schedule(gsv_session* s, const gsv_plan_session_opts& o, int n_cus, size_t free_b) {
+  const gsv_plan* plan = s->plan;
+  const size_t n_instances = s->n_inst;
   uint64_t max_call_ct = 0;
   GSV_TRY
-  s->sched = make_schedule(plan, s->ni, n_instances, prop.multiProcessorCount, free_b, o, &max_call_ct);
+  s->sched = make_schedule(plan, s->ni, n_instances, n_cus, free_b, o, &max_call_ct);
   GSV_CATCH
   const Schedule& sc = s->sched;
   const uint32_t scratch = uint32_t((std::max<uint64_t>(sc.scratch_slots, SLOT_FIRST_INPUT) + 7) / 8 * 8);
@@ -1386,6 +1480,7 @@ int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_i
   }
   if (uint64_t(scratch) + plan->n_globals > 0xFFFFFFF0ull) return fail(GSV_ERR_CIRCUIT, "plan wire file too large");
   Program& f = s->facade;
+  f = Program();
   f.n_slots = scratch + plan->n_globals;
   f.n_gates = plan->n_gates; f.n_ct = plan->n_ct;
   for (uint32_t i = 0; i < plan->n_inputs; ++i) f.input_slots.push_back(scratch + i);
@@ -1435,8 +1530,12 @@ int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_i
         d.n_deps = uint32_t(deps.size()) - d.dep_off;
         if (csrc.size() > 0xFFFFFF00ull) return fail(GSV_ERR_CIRCUIT, "plan hand-over lists too large");
       }
-      s->flag_stride = std::max<uint32_t>(s->flag_stride, w.call1 - w.call0 + 1);  // + the group's progress counter (kernels.hip, watchdog)
+      s->flag_stride = std::max<uint32_t>(s->flag_stride, w.call1 - w.call0 + 2);  // + a slot nobody writes (fault injection below) + the group's progress counter (kernels.hip, watchdog)
     }
+    // GSV_FAULT_WITHHOLD_DEP=1 (tests): the first dependency of the first call that has one is pointed at the slot nobody writes — on
+    // the device exactly what a violated dispatch-order assumption looks like (a dependency that never completes).  Never for the safe schedule.
+    if (!s->safe_mode && getenv("GSV_FAULT_WITHHOLD_DEP") && atoi(getenv("GSV_FAULT_WITHHOLD_DEP")) == 1)
+      for (size_t k = 0; k < n; ++k) if (cds[k].n_deps) { deps[cds[k].dep_off] = s->flag_stride - 2; break; }
     const size_t n_wg = (n_instances + s->ni - 1) / s->ni;
     int rc;
     if ((rc = up(&s->d_calls, cds.data(), cds.size() * sizeof(dev::CallDesc))) || (rc = up(&s->d_copy_src, csrc.data(), csrc.size() * 4)) || (rc = up(&s->d_copy_dst, cdst.data(), cdst.size() * 4)) ||
@@ -1448,19 +1547,15 @@ int gsv_session_create_plan_opts(gsv_engine* e, const gsv_plan* plan, size_t n_i
     HIPCHK(hipMemset(s->d_error, 0, 64));
     if ((rc = up(&s->plan_out_slots, f.output_slots.data(), f.output_slots.size() * 4))) return rc;
   }
-  DEVALLOC(&s->W, n_instances * size_t(f.n_slots) * 16, "the wire files");
-  HIPCHK(hipMalloc(&s->VB, n_instances * size_t(f.n_slots)));
-  HIPCHK(hipMemset(s->VB, 0, n_instances * size_t(f.n_slots)));
-  const size_t ct_bytes = n_instances * size_t(s->ct_stride()) * 16;
-  DEVALLOC(&s->CT, ct_bytes, "the ciphertext blocks");
-  HIPCHK(hipMalloc(&s->delta, n_instances * 16));
-  HIPCHK(hipMalloc(&s->out, n_instances * f.output_slots.size() * 16 + 16));
-  HIPCHK(hipMalloc(&s->out_bits, n_instances * f.output_slots.size() + 16));
-  HIPCHK(hipMalloc(&s->in_bits, n_instances * f.input_slots.size() + 16));
-  HIPCHK(hipEventCreate(&s->ev0));
-  HIPCHK(hipEventCreate(&s->ev1));
-  *out = s.release();
   return GSV_OK;
+}
+// the schedule-dependent state of a session, released (the caller has synchronised the device's streams)
+static void drop_schedule(gsv_session* s) {
+  for (void** q : {&s->d_calls, &s->d_copy_src, &s->d_copy_dst, &s->d_deps, &s->d_flags, &s->d_error, &s->plan_out_slots}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+  if (s->host_done) (void)hipHostFree(s->host_done);
+  if (s->host_ct_pos) (void)hipHostFree(s->host_ct_pos);
+  s->host_done = nullptr; s->dev_done = nullptr; s->host_ct_pos = nullptr; s->dev_ct_pos = nullptr;
+  s->flag_stride = 0; s->next_call = 0;
 }
 int gsv_session_plan_schedule_info(const gsv_session* s, gsv_plan_schedule_info* info) {
   if (!s || !s->plan || !info) return fail(GSV_ERR_INVALID, "null argument / not a plan session");
@@ -1513,14 +1608,34 @@ static int stage_labels(gsv_session* s, const uint8_t* consts, const uint8_t* in
   return GSV_OK;
 }
 
-int gsv_session_set_garble_inputs(gsv_session* s, const uint8_t* delta, const uint8_t* const_label0, const uint8_t* input_label0) {
-  if (!s || !delta || !const_label0 || (!input_label0 && !s->prog().input_slots.empty())) return fail(GSV_ERR_INVALID, "null argument");
+// Plan sessions keep the host's last inputs: a pass that is repeated on the safe schedule (fall_back_to_safe_schedule) starts from them —
+// the wire file's input region is recycled by the plan's later calls, and the safe schedule lays the wire file out differently.
+static void stash_inputs(gsv_session* s, int kind, const uint8_t* delta, const uint8_t* consts, const uint8_t* inputs, const uint8_t* bits) {
+  if (!s->plan) return;
+  const size_t n_in = s->prog().input_slots.size();
+  s->stash_kind = kind;
+  if (delta) s->stash_delta.assign(delta, delta + s->n_inst * 16); else s->stash_delta.clear();
+  s->stash_consts.assign(consts, consts + s->n_inst * 32);
+  if (n_in) s->stash_inputs.assign(inputs, inputs + s->n_inst * n_in * 16); else s->stash_inputs.clear();
+  if (bits && n_in) s->stash_bits.assign(bits, bits + s->n_inst * n_in); else s->stash_bits.clear();
+}
+static int set_garble_inputs_impl(gsv_session* s, const uint8_t* delta, const uint8_t* const_label0, const uint8_t* input_label0) {
   HIPCHK(hipSetDevice(s->e->device));
   HIPCHK(hipMemcpy(s->delta, delta, s->n_inst * 16, hipMemcpyHostToDevice));
   return stage_labels(s, const_label0, input_label0);
 }
+int gsv_session_set_garble_inputs(gsv_session* s, const uint8_t* delta, const uint8_t* const_label0, const uint8_t* input_label0) {
+  if (!s || !delta || !const_label0 || (!input_label0 && !s->prog().input_slots.empty())) return fail(GSV_ERR_INVALID, "null argument");
+  stash_inputs(s, 1, delta, const_label0, input_label0, nullptr);
+  return set_garble_inputs_impl(s, delta, const_label0, input_label0);
+}
+static int set_evaluate_inputs_impl(gsv_session* s, const uint8_t* const_active, const uint8_t* input_active, const uint8_t* input_bits);
 int gsv_session_set_evaluate_inputs(gsv_session* s, const uint8_t* const_active, const uint8_t* input_active, const uint8_t* input_bits) {
   if (!s || !const_active || ((!input_active || !input_bits) && !s->prog().input_slots.empty())) return fail(GSV_ERR_INVALID, "null argument");
+  stash_inputs(s, 2, nullptr, const_active, input_active, input_bits);
+  return set_evaluate_inputs_impl(s, const_active, input_active, input_bits);
+}
+static int set_evaluate_inputs_impl(gsv_session* s, const uint8_t* const_active, const uint8_t* input_active, const uint8_t* input_bits) {
   HIPCHK(hipSetDevice(s->e->device));
   int rc = stage_labels(s, const_active, input_active);
   if (rc) return rc;
@@ -1676,6 +1791,7 @@ static int check_plan_error(gsv_session* s) {
                                     std::to_string((uint64_t(ew[11]) << 32) | ew[10]) + ", saw " + std::to_string((uint64_t(ew[13]) << 32) | ew[12]) + " unchanged for " +
                                     std::to_string(double((uint64_t(ew[15]) << 32) | ew[14]) * 1e-8) + " s" + (s->ring_diag.empty() ? "" : "; host: " + s->ring_diag) + "; results are invalid");
   }
+  s->dep_fault = err == 1;
   if (err) return fail(GSV_ERR_DEVICE, "a call of the plan waited for a dependency that never completed (dispatch-order assumption of schedule.hpp violated); results are invalid");
   return GSV_OK;
 }
@@ -2009,7 +2125,7 @@ static int ensure_aux(gsv_session* s) {
 
 // `ev`: an evaluator session over the same plan / schedule (plan sessions that do not retain the stream): every window is evaluated
 // straight from the garbler's device block while the next window is garbled.
-static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t c0, size_t c1, const DrainSink& sink, int n_threads, gsv_session* ev = nullptr) {
+static int garble_streaming_pass(gsv_session* s, uint64_t gate_id_base, size_t c0, size_t c1, const DrainSink& sink, int n_threads, gsv_session* ev) {
   if (!sink.any() && !ev) return garble_discard(s, gate_id_base, c0, c1);  // garble only (output labels, device-rate measurements of long plans / chains)
   const Program& g = s->prog();
   // program sessions: segments of one ring (ct_cap replays of n_ct records); plan sessions: one WINDOW of the schedule per segment
@@ -2314,6 +2430,71 @@ static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t 
   if (want_mac) for (size_t i = 0; i < n_inst; ++i) macs[i].digest(sink.hashes + 16 * i);
   s->garbled = true;
   return GSV_OK;
+}
+// A dependency wait gave up (status 1): the schedule's one assumption — a workgroup only waits for workgroups with a smaller linear index,
+// which the hardware dispatches first (include/gsv_engine.h, max_concurrent_calls) — did not hold on this device / driver.  The session
+// is switched, in place, to the SAFE schedule: one call per launch, in stream order, no dependency wait on the device at all (the stream
+// orders the launches) and no ciphertext ring.  Same plan images, same wire-file and ciphertext allocations (the safe schedule needs
+// less of both; re-allocated if not), the host's last inputs re-staged.  Slower (every call ends with a launch boundary), never wrong.
+static int fall_back_to_safe_schedule(gsv_session* s) {
+  if (!s->plan || s->safe_mode) return fail(GSV_ERR_DEVICE, "internal: no safe schedule to fall back to");
+  HIPCHK(hipSetDevice(s->e->device));
+  HIPCHK(hipDeviceSynchronize());
+  drop_schedule(s);
+  gsv_plan_session_opts o = s->opts;
+  o.max_concurrent_calls = 1;
+  o.max_window_calls = 1;
+  if (o.retain_stream == GSV_STREAM_RING) o.retain_stream = 0;
+  s->safe_mode = true;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, s->e->device));
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  int rc = install_schedule(s, o, prop.multiProcessorCount, free_b);
+  if (rc) return rc;
+  const Program& f = s->facade;
+  if (f.n_slots > s->w_slots_cap) {
+    (void)hipFree(s->W); (void)hipFree(s->VB); s->W = s->VB = nullptr;
+    DEVALLOC(&s->W, s->n_inst * size_t(f.n_slots) * 16, "the wire files");
+    HIPCHK(hipMalloc(&s->VB, s->n_inst * size_t(f.n_slots)));
+    s->w_slots_cap = f.n_slots;
+  }
+  HIPCHK(hipMemset(s->VB, 0, s->n_inst * size_t(f.n_slots)));
+  if (s->ct_stride() > s->ct_records_cap) {
+    (void)hipFree(s->CT); s->CT = nullptr;
+    if (s->ct_alt) { (void)hipFree(s->ct_alt); s->ct_alt = nullptr; }
+    DEVALLOC(&s->CT, s->n_inst * size_t(s->ct_stride()) * 16, "the ciphertext blocks");
+    s->ct_records_cap = s->ct_stride();
+  }
+  ++s->n_fallbacks;
+  s->dep_fault = false;
+  s->garbled = false;
+  std::fill(s->ct_uploaded.begin(), s->ct_uploaded.end(), 0);
+  if (s->stash_kind == 1) return set_garble_inputs_impl(s, s->stash_delta.data(), s->stash_consts.data(), s->stash_inputs.data());
+  if (s->stash_kind == 2) return set_evaluate_inputs_impl(s, s->stash_consts.data(), s->stash_inputs.data(), s->stash_bits.data());
+  return GSV_OK;
+}
+int gsv_session_fallback_count(const gsv_session* s, uint64_t* n) {
+  if (!s || !n) return fail(GSV_ERR_INVALID, "null argument");
+  *n = s->n_fallbacks;
+  return GSV_OK;
+}
+// A whole pass whose results the engine alone has seen (discarded, MAC'ed, written to gc files) is repeated on the safe schedule by
+// itself; a pass that fed a host callback or an evaluator session, or a slice of a pass, fails as before — the host has consumed a
+// prefix of a stream that is invalid, and a slice's call range follows the old schedule's windows — but leaves the session on the
+// safe schedule, so that the host's own repeat of the pass (from gsv_session_set_garble_inputs on) succeeds.
+static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t c0, size_t c1, const DrainSink& sink, int n_threads, gsv_session* ev = nullptr) {
+  int rc = garble_streaming_pass(s, gate_id_base, c0, c1, sink, n_threads, ev);
+  if (rc != GSV_ERR_DEVICE || !s->plan || !s->dep_fault || s->safe_mode) return rc;
+  const std::string first_error = g_err;
+  const bool whole = c0 == 0 && c1 == s->plan->calls.size();
+  int frc = fall_back_to_safe_schedule(s);
+  if (frc) return fail(GSV_ERR_DEVICE, first_error + "; the fall-back to the safe schedule failed too: " + g_err);
+  if (ev) { frc = fall_back_to_safe_schedule(ev); if (frc) return fail(GSV_ERR_DEVICE, first_error + "; the evaluator's fall-back to the safe schedule failed: " + g_err); }
+  if (!whole || sink.fn || ev)
+    return fail(GSV_ERR_DEVICE, first_error + "; the session now runs the safe schedule (one call per launch): repeat the pass from gsv_session_set_garble_inputs");
+  if (getenv("GSV_DRAIN_DEBUG") || getenv("GSV_PLAN_DEBUG")) std::fprintf(stderr, "plan session: %s -- repeating the pass on the safe schedule (one call per launch)\n", first_error.c_str());
+  return garble_streaming_pass(s, gate_id_base, 0, s->plan->calls.size(), sink, n_threads, nullptr);
 }
 static DrainSink mac_file_sink(uint8_t* hashes, const char* dir, uint64_t first_index) { DrainSink k; k.hashes = hashes; k.dir = dir; k.first_index = first_index; return k; }
 int gsv_session_garble_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, int n_threads, uint8_t* hashes) {

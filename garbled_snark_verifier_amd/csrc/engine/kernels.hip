@@ -29,11 +29,6 @@
 // gates from the top lane down, two other issue-priority schemes, the four-lane quad form for every program) live as a patch against this
 // file in profiles/r05_kernel/rejected_variants.patch, with their A/B logs beside it; this file holds the adopted code only.
 
-// Round 6 A/B: every operand load of a gate in flight at once through exec-masked inline assembly (WireFile::ld_issue).
-#ifndef GSV_ASM_LD
-#define GSV_ASM_LD 0
-#endif
-
 namespace gsv {
 namespace dev {
 
@@ -117,45 +112,6 @@ struct WireFile {
     if (slot & GSV_SLOT_LDS_FLAG) v = *win(slot); else v = hbm[slot];
     return Label{{v.x, v.y, v.z, v.w}};
   }
-#if GSV_ASM_LD
-  // ALL operand loads of a gate in flight at once, without a second register set and without reading both locations: the LDS read (lanes
-  // whose label sits in the window) and the global load (the other lanes) of one operand are issued back to back under complementary
-  // exec masks INTO THE SAME REGISTERS.  The hardware writes only the lanes that were active at issue, so the two results may land in
-  // either order; the compiler cannot know that (it sees two writers of one register and puts `s_waitcnt lgkmcnt(0)` between them: one LDS
-  // round trip per operand, under an LDS pipe that the other waves' AES lookups keep full), hence the inline assembly.  Nothing is
-  // waited for here: the caller issues every operand of the gate and then waits ONCE (GSV_LD_WAIT*: the loads are the wave's youngest
-  // vector-memory and LDS operations at that point, older ones return first anyway).
-  __device__ __forceinline__ void ld_issue(uint32_t slot, u32x4& v) const {
-    const uint32_t la = (slot << 4) + (win_base - (GSV_SLOT_LDS_FLAG << 4)), go = slot << 4;
-    uint64_t m, sv;
-    asm volatile("v_cmp_le_u32_e64 %[m], %[flag], %[slot]\n\t"
-                 "s_and_saveexec_b64 %[sv], %[m]\n\t"
-                 "ds_read_b128 %[v], %[la]\n\t"
-                 "s_andn2_b64 exec, %[sv], %[m]\n\t"
-                 "global_load_dwordx4 %[v], %[go], %[base]\n\t"
-                 "s_mov_b64 exec, %[sv]"
-                 : [v] "=&v"(v), [m] "=&s"(m), [sv] "=&s"(sv)
-                 : [flag] "s"(uint32_t(GSV_SLOT_LDS_FLAG)), [slot] "v"(slot), [la] "v"(la), [go] "v"(go), [base] "s"(hbm)
-                 : "memory", "scc");
-  }
-  __device__ __forceinline__ void ld_word_issue(uint32_t slot, uint32_t c, uint32_t& v) const {
-    const uint32_t la = (slot << 4) + (win_base - (GSV_SLOT_LDS_FLAG << 4)) + c * 4u, go = (slot << 4) + c * 4u;
-    uint64_t m, sv;
-    asm volatile("v_cmp_le_u32_e64 %[m], %[flag], %[slot]\n\t"
-                 "s_and_saveexec_b64 %[sv], %[m]\n\t"
-                 "ds_read_b32 %[v], %[la]\n\t"
-                 "s_andn2_b64 exec, %[sv], %[m]\n\t"
-                 "global_load_dword %[v], %[go], %[base]\n\t"
-                 "s_mov_b64 exec, %[sv]"
-                 : [v] "=&v"(v), [m] "=&s"(m), [sv] "=&s"(sv)
-                 : [flag] "s"(uint32_t(GSV_SLOT_LDS_FLAG)), [slot] "v"(slot), [la] "v"(la), [go] "v"(go), [base] "s"(hbm)
-                 : "memory", "scc");
-  }
-#define GSV_LD_WAIT4(a, b, c, d) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory")
-#define GSV_LD_WAIT5(a, b, c, d, e) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e)::"memory")
-#define GSV_LD_WAIT8(a, b, c, d, e, f, g, h) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h)::"memory")
-#define GSV_LD_WAIT9(a, b, c, d, e, f, g, h, i) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i)::"memory")
-#endif
   __device__ __forceinline__ void st(uint32_t slot, const Label& l) const {
     const u32x4 v = {l.w[0], l.w[1], l.w[2], l.w[3]};
     if (slot & GSV_SLOT_LDS_FLAG) *win(slot) = v; else hbm[slot] = v;
@@ -513,20 +469,6 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       uint32_t a_c = dq, b_c = dq, p_c = 0;
       GSV_PC_STAMP(1, o.c ^ o.t);  // the record's second half has arrived and is decoded
       if (!no_load) {
-#if GSV_ASM_LD
-        uint32_t w1, w2, w3, w4, w5;
-        wf.ld_word_issue(o.a1, col, w1); wf.ld_word_issue(o.a2, col, w2); wf.ld_word_issue(o.b1, col, w3); wf.ld_word_issue(o.b2, col, w4); wf.ld_word_issue(o.p, col, w5);
-        if (four_wire) {
-          uint32_t w6, w7, w8, w9;
-          wf.ld_word_issue(o.a3, col, w6); wf.ld_word_issue(o.a4, col, w7); wf.ld_word_issue(o.b3, col, w8); wf.ld_word_issue(o.b4, col, w9);
-          GSV_LD_WAIT9(w1, w2, w3, w4, w5, w6, w7, w8, w9);
-          a_c = w1 ^ w2 ^ w6 ^ w7; b_c = w3 ^ w4 ^ w8 ^ w9;
-        } else {
-          GSV_LD_WAIT5(w1, w2, w3, w4, w5);
-          a_c = w1 ^ w2; b_c = w3 ^ w4;
-        }
-        p_c = w5;
-#else
         a_c = wf.ld_word(o.a1, col) ^ wf.ld_word(o.a2, col);
         b_c = wf.ld_word(o.b1, col) ^ wf.ld_word(o.b2, col);
         p_c = wf.ld_word(o.p, col);
@@ -534,7 +476,6 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           a_c ^= wf.ld_word(o.a3, col) ^ wf.ld_word(o.a4, col);
           b_c ^= wf.ld_word(o.b3, col) ^ wf.ld_word(o.b4, col);
         }
-#endif
       }
       const uint32_t twc = tweak_word(o.gid, col);
       if (!EVAL) {
@@ -568,20 +509,6 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       const uint32_t t = o.t;
       uint32_t a_c = dq, b_c = dq, p_c = 0;
       if (!no_load) {
-#if GSV_ASM_LD
-        uint32_t w1, w2, w3, w4, w5;
-        wf.ld_word_issue(o.a1, col, w1); wf.ld_word_issue(o.a2, col, w2); wf.ld_word_issue(o.b1, col, w3); wf.ld_word_issue(o.b2, col, w4); wf.ld_word_issue(o.p, col, w5);
-        if (four_wire) {
-          uint32_t w6, w7, w8, w9;
-          wf.ld_word_issue(o.a3, col, w6); wf.ld_word_issue(o.a4, col, w7); wf.ld_word_issue(o.b3, col, w8); wf.ld_word_issue(o.b4, col, w9);
-          GSV_LD_WAIT9(w1, w2, w3, w4, w5, w6, w7, w8, w9);
-          a_c = w1 ^ w2 ^ w6 ^ w7; b_c = w3 ^ w4 ^ w8 ^ w9;
-        } else {
-          GSV_LD_WAIT5(w1, w2, w3, w4, w5);
-          a_c = w1 ^ w2; b_c = w3 ^ w4;
-        }
-        p_c = w5;
-#else
         a_c = wf.ld_word(o.a1, col) ^ wf.ld_word(o.a2, col);
         b_c = wf.ld_word(o.b1, col) ^ wf.ld_word(o.b2, col);
         p_c = wf.ld_word(o.p, col);
@@ -589,7 +516,6 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           a_c ^= wf.ld_word(o.a3, col) ^ wf.ld_word(o.a4, col);
           b_c ^= wf.ld_word(o.b3, col) ^ wf.ld_word(o.b4, col);
         }
-#endif
       }
       const uint32_t twc = tweak_word(o.gid, col);
       uint32_t h = a_c ^ (alpha_a(t) ? dq : 0u) ^ twc;  // selected_a
@@ -632,17 +558,7 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         } else if (tid >= x0 && tid < x0 + sd.w) {
           const XorOp o = decode_xor(r0);
           Label c0 = delta;
-#if GSV_ASM_LD
-          if (!no_load) {
-            u32x4 v1, v2, v3, v4;
-            wf.ld_issue(o.x1, v1); wf.ld_issue(o.x2, v2); wf.ld_issue(o.x3, v3); wf.ld_issue(o.x4, v4);
-            GSV_LD_WAIT4(v1, v2, v3, v4);
-            const u32x4 x = (v1 ^ v2) ^ (v3 ^ v4);
-            c0 = Label{{x.x, x.y, x.z, x.w}};
-          }
-#else
           if (!no_load) c0 = lxor(lxor(wf.ld(o.x1), wf.ld(o.x2)), lxor(wf.ld(o.x3), wf.ld(o.x4)));
-#endif
           if (!EVAL) c0 = lxor_if(c0, delta, o.par);
           if (!no_store || c0.w[0] == 0x12345678u) {
             wf.st(o.c, c0);
@@ -662,9 +578,6 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
         const uint32_t xl = tid;
         u32x4 xr[XB], xrn[XB];
         Label xa[XB];
-#if GSV_ASM_LD
-        u32x4 xo[XB][4];  // the four operands of each gate of the batch in flight (waited for in finish_xor_batch)
-#endif
         uint32_t xv[XB];  // evaluate: XOR of the operands' plaintext bits
         auto load_xor_recs = [&](uint32_t base, u32x4 (&r)[XB]) {
 #pragma unroll
@@ -679,30 +592,13 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           for (int j = 0; j < XB; ++j) {
             const XorOp o = decode_xor(xr[j]);
             xa[j] = delta; xv[j] = 0;
-#if GSV_ASM_LD
-            // issued by every lane of a wave that holds a gate of the batch (wave-uniform test; a lane without a gate holds an all-zero
-            // record = four reads of wire-file slot 0, never stored): finish_xor_batch waits for all of them with one s_waitcnt
-            if (!no_load && base + uint32_t(j) * BT + (xl & ~63u) < xor_cnt) {
-              wf.ld_issue(o.x1, xo[j][0]); wf.ld_issue(o.x2, xo[j][1]); wf.ld_issue(o.x3, xo[j][2]); wf.ld_issue(o.x4, xo[j][3]);
-              if (EVAL && base + uint32_t(j) * BT + xl < xor_cnt) xv[j] = wf.ld_bit(o.x1) ^ wf.ld_bit(o.x2) ^ wf.ld_bit(o.x3) ^ wf.ld_bit(o.x4);
-            }
-#else
             if (!no_load && base + uint32_t(j) * BT + xl < xor_cnt) {
               xa[j] = lxor(lxor(wf.ld(o.x1), wf.ld(o.x2)), lxor(wf.ld(o.x3), wf.ld(o.x4)));
               if (EVAL) xv[j] = wf.ld_bit(o.x1) ^ wf.ld_bit(o.x2) ^ wf.ld_bit(o.x3) ^ wf.ld_bit(o.x4);
             }
-#endif
           }
         };
         auto finish_xor_batch = [&](uint32_t base) {
-#if GSV_ASM_LD
-          if (!no_load) {
-            static_assert(XB == 2, "the wait below names the operands of two gates");
-            GSV_LD_WAIT8(xo[0][0], xo[0][1], xo[0][2], xo[0][3], xo[1][0], xo[1][1], xo[1][2], xo[1][3]);
-#pragma unroll
-            for (int j = 0; j < XB; ++j) { const u32x4 x = (xo[j][0] ^ xo[j][1]) ^ (xo[j][2] ^ xo[j][3]); xa[j] = Label{{x.x, x.y, x.z, x.w}}; }
-          }
-#endif
 #pragma unroll
           for (int j = 0; j < XB; ++j) {
             if (base + uint32_t(j) * BT + xl < xor_cnt) {
@@ -740,20 +636,6 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           const uint32_t t = o.t;
           Label a = delta, b = delta, pl{{0, 0, 0, 0}};
           if (!no_load) {
-#if GSV_ASM_LD
-            u32x4 va1, va2, vb1, vb2, vpl;
-            wf.ld_issue(o.a1, va1); wf.ld_issue(o.a2, va2); wf.ld_issue(o.b1, vb1); wf.ld_issue(o.b2, vb2); wf.ld_issue(o.p, vpl);
-            if (four_wire) {
-              u32x4 va3, va4, vb3, vb4;
-              wf.ld_issue(o.a3, va3); wf.ld_issue(o.a4, va4); wf.ld_issue(o.b3, vb3); wf.ld_issue(o.b4, vb4);
-              GSV_LD_WAIT9(va1, va2, vb1, vb2, vpl, va3, va4, vb3, vb4);
-              va1 ^= va3 ^ va4; vb1 ^= vb3 ^ vb4;
-            } else {
-              GSV_LD_WAIT5(va1, va2, vb1, vb2, vpl);
-            }
-            const u32x4 av = va1 ^ va2, bv = vb1 ^ vb2;
-            a = Label{{av.x, av.y, av.z, av.w}}; b = Label{{bv.x, bv.y, bv.z, bv.w}}; pl = Label{{vpl.x, vpl.y, vpl.z, vpl.w}};
-#else
             a = lxor(wf.ld(o.a1), wf.ld(o.a2));
             b = lxor(wf.ld(o.b1), wf.ld(o.b2));
             pl = wf.ld(o.p);
@@ -761,7 +643,6 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
               a = lxor(a, lxor(wf.ld(o.a3), wf.ld(o.a4)));
               b = lxor(b, lxor(wf.ld(o.b3), wf.ld(o.b4)));
             }
-#endif
           }
           Label c0, ct{{0, 0, 0, 0}};
           uint32_t vc = 0;
@@ -800,24 +681,15 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
           }
         }
         // ---- free-gate batches (their label stores are the wave's youngest stores: no young ciphertext store)
-#if GSV_ASM_LD
-        if (xor_cnt) { load_xor_recs(uint32_t(XB) * BT, xrn); issue_xor_operands(0); }  // (records first: finish_xor_batch waits with vmcnt(0) for the operands, which must be the youngest loads)
-#else
         if (xor_cnt) { issue_xor_operands(0); load_xor_recs(uint32_t(XB) * BT, xrn); }
-#endif
         for (uint32_t base = 0; base < xor_cnt; base += XB * BT) {
           finish_xor_batch(base);
           const uint32_t nb = base + XB * BT;
 #pragma unroll
           for (int j = 0; j < XB; ++j) xr[j] = xrn[j];
           if (nb < xor_cnt) {
-#if GSV_ASM_LD
-            load_xor_recs(nb + XB * BT, xrn);
-            issue_xor_operands(nb);
-#else
             issue_xor_operands(nb);
             load_xor_recs(nb + XB * BT, xrn);
-#endif
           }
         }
       }

@@ -42,6 +42,7 @@ struct PlanUnit {  // one compiled (component key, output liveness) pair
   int external = -1;  // >= 0: the program was compiled by the caller (C ABI plan recorder); trace / inputs / outputs are empty
   size_t n_ext_outputs = 0;
   std::unique_ptr<Program> compiled;  // set by the background compiler (PlanRecordMode::compile_in_background) before finish_plan
+  std::unique_ptr<Program> compiled_b;  // ... and the SECOND image of a dual build (PlanUnitCache::dual): the same trace compiled with bg_opt_b
 };
 
 inline size_t plan_compile_threads() {  // GSV_COMPILE_THREADS, default: the hardware's, at most 16
@@ -115,6 +116,12 @@ struct PlanUnitCache {
   std::function<void(Program&)> sink;
   CompileOptions bg_opt;
   bool bg_drop = false;
+  // Dual build (round 6, gsv_plan_build_file_pair): ONE recording of the circuit feeds TWO compilations of every program — e.g. the image
+  // for a quarter of the LDS window (four instances per workgroup) and the one for the full window (small batches).  Recording is the
+  // critical path of a build (the driver's walk is serial; the compile pool keeps up), so the second plan costs compile time only.
+  bool dual = false;
+  CompileOptions bg_opt_b;
+  std::function<void(Program&)> sink_b;
   std::unique_ptr<CompilePool> pool;  // set by compile_in_background; declared last: destroyed (its workers joined) before what the jobs use
 };
 
@@ -247,8 +254,12 @@ class PlanRecordMode final : public CircuitMode, public UnitHook {
         PlanUnitCache* ucp = &uc;  // outlives the pool it owns
         uc.pool->submit([pu, opt, drop, ucp] {
           pu->compiled.reset(new Program(compile_program(pu->trace, pu->inputs, pu->outputs, {}, opt)));
-          if (drop) pu->trace = Trace();
           if (ucp->sink) ucp->sink(*pu->compiled);
+          if (ucp->dual) {
+            pu->compiled_b.reset(new Program(compile_program(pu->trace, pu->inputs, pu->outputs, {}, ucp->bg_opt_b)));
+            if (ucp->sink_b) ucp->sink_b(*pu->compiled_b);
+          }
+          if (drop) pu->trace = Trace();
         });
       }
     } catch (...) {
@@ -464,6 +475,7 @@ inline void parallel_for_programs(size_t n, Fn&& fn) {
 struct BuiltPlan {
   struct Call { int program; std::vector<uint32_t> in_globals, out_globals; };  // program < 0: external program -1 - program
   std::vector<Program> programs;
+  std::vector<Program> programs_b;  // dual build: the second image of every program (same order), else empty
   std::vector<Trace> traces;  // kept per program so that the half-window variants can be compiled later
   std::vector<std::vector<uint32_t>> prog_inputs, prog_outputs;
   std::vector<Call> calls;
@@ -479,6 +491,7 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
   m.close_glue();
   m.wait_for_compilations();
   BuiltPlan bp;
+  const bool dual = m.cache()->dual;
   const uint32_t nw = m.n_ssa();
   constexpr int32_t SEG_INPUT = -1, SEG_NONE = -2;
   std::vector<int32_t> def_seg(nw, SEG_NONE);
@@ -542,6 +555,7 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
   std::vector<uint8_t> done;
   auto add_program = [&](Trace&& t, std::vector<uint32_t> in, std::vector<uint32_t> out) -> int {
     bp.programs.emplace_back();  // compiled below, all programs in parallel (units may have been compiled while recording)
+    if (dual) bp.programs_b.emplace_back();
     done.push_back(0);
     bp.traces.push_back(std::move(t));
     bp.prog_inputs.push_back(std::move(in));
@@ -562,7 +576,11 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
           // later calls of the unit reuse the program index, so the trace can move (178 constant-specialised line
           // functions of the Miller loop would otherwise exist twice)
           unit_program[size_t(s.unit)] = add_program(std::move(u.trace), u.inputs, u.outputs);
-          if (u.compiled) { bp.programs.back() = std::move(*u.compiled); u.compiled.reset(); done.back() = 1; }
+          if (u.compiled && (!dual || u.compiled_b)) {
+            bp.programs.back() = std::move(*u.compiled); u.compiled.reset();
+            if (dual) { bp.programs_b.back() = std::move(*u.compiled_b); u.compiled_b.reset(); }
+            done.back() = 1;
+          }
         }
         call.program = unit_program[size_t(s.unit)];
       }
@@ -616,9 +634,15 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
   if (getenv("GSV_PLAN_DEBUG")) std::fprintf(stderr, "plan: %zu segments, %u wires cross calls, %u global ids after recycling (%u inputs pinned)\n", m.segments.size(), bp.n_crossing_wires, next_global, bp.n_inputs);
   for (uint32_t w : outputs) bp.outputs.push_back(w == 0 ? PLAN_WIRE_FALSE : w == 1 ? PLAN_WIRE_TRUE : global_of[w]);
   const std::function<void(Program&)>& sink = m.cache()->sink;
+  const std::function<void(Program&)>& sink_b = m.cache()->sink_b;
+  const CompileOptions opt_b = m.cache()->bg_opt_b;
   parallel_for_programs(bp.programs.size(), [&](size_t i) {
     if (done[i]) return;
     bp.programs[i] = compile_program(bp.traces[i], bp.prog_inputs[i], bp.prog_outputs[i], {}, opt);
+    if (dual) {
+      bp.programs_b[i] = compile_program(bp.traces[i], bp.prog_inputs[i], bp.prog_outputs[i], {}, opt_b);
+      if (sink_b) sink_b(bp.programs_b[i]);
+    }
     if (sink) { bp.traces[i] = Trace(); sink(bp.programs[i]); }
   });
   return bp;

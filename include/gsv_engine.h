@@ -192,6 +192,11 @@ int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out);
  * ~25 GB instead of ~54 GB).  One image per program: GSV_PLAN_WINDOW_DIV=2|4 as below, or 1 = the full window, for sessions with one
  * instance per workgroup only (small batches: 3 % faster steps).  Then gsv_plan_load(path, engine). */
 int gsv_plan_build_file(const char* circuit_spec, const char* units_csv, const char* path);
+/* TWO plan files from ONE recording of the circuit (round 6): every program is compiled for 1 / window_div_a AND for 1 / window_div_b of
+ * the LDS label window (each 1, 2 or 4) by the worker that takes it off the recorder and appended to both files.  Recording is the
+ * critical path of a build, so a deployment that serves large batches (window_div 4) and small ones (window_div 1) gets both plans
+ * for the time of one.  Each file is byte for byte what gsv_plan_build_file writes for its window_div. */
+int gsv_plan_build_file_pair(const char* circuit_spec, const char* units_csv, const char* path_a, uint32_t window_div_a, const char* path_b, uint32_t window_div_b);
 
 /* Call operands naming the constant wires instead of a global wire. */
 #define GSV_PLAN_WIRE_FALSE 0xFFFFFFFEu
@@ -251,9 +256,17 @@ int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_ins
  *                         ASSUMPTION for values > 1: a workgroup that waits for a dependency only waits for workgroups with a smaller
  *                         linear index, which the hardware dispatches first (in-order workgroup dispatch — true of every AMD GPU to
  *                         date, but not an architectural guarantee).  A wait that sees no call of its instance group complete for
- *                         GSV_DEP_WAIT_SECONDS (default 60) sets an error flag instead of hanging: the next gsv_session_sync /
- *                         read_outputs / streaming call fails with GSV_ERR_DEVICE and the pass's gc files are removed.
- *                         max_concurrent_calls = 1 is the safe mode: every call depends on its predecessor only.
+ *                         GSV_DEP_WAIT_SECONDS (default 60) sets an error flag instead of hanging.  A STREAMING pass that ends that
+ *                         way (gsv_session_garble_streaming*, _sink, _garble_evaluate) switches the session, in place, to the SAFE
+ *                         schedule — one call per launch in stream order, no dependency wait on the device, no ciphertext ring; same
+ *                         images and allocations, the host's last inputs re-staged — and, when the engine alone has seen the pass's
+ *                         results (discarded / CBC-MAC / gc files, the whole plan in one call), repeats the pass by itself and
+ *                         returns its result (gsv_session_fallback_count tells).  A pass that fed a host callback or an evaluator
+ *                         session, and a slice of a pass, still fail with GSV_ERR_DEVICE (the host has consumed an invalid prefix;
+ *                         gc files are removed) but the session is on the safe schedule afterwards: repeating the pass from
+ *                         gsv_session_set_garble_inputs succeeds.  gsv_session_garble / _evaluate (asynchronous, whole stream
+ *                         retained) report the flag at the next gsv_session_sync / read_outputs as before.
+ *                         max_concurrent_calls = 1 keeps every call dependent on its predecessor only.
  *   window_ct_records     ciphertext records per instance of one window = ONE launch = the device block of a session that does not
  *                         retain the stream; independent call chains only overlap inside a window, so windows want to be large;
  *                         0 = 40 % of the free device memory, at most 48 GB over all instances (one instance of the verifier: one window).
@@ -291,6 +304,8 @@ typedef struct gsv_plan_schedule_info {
   uint64_t ct_ring_records;                 /* 0, or the size of the device's ciphertext ring (records per instance): see window_ct_records */
 } gsv_plan_schedule_info;
 int gsv_session_plan_schedule_info(const gsv_session* s, gsv_plan_schedule_info* info);
+/* How often this session has fallen back to the safe schedule (0 or 1: see max_concurrent_calls above). */
+int gsv_session_fallback_count(const gsv_session* s, uint64_t* n);
 /* Window `window` of the session's schedule: calls [first_call, first_call + n_calls) of the plan.  Slices handed to
  * gsv_session_garble_streaming_calls start and end on window boundaries. */
 int gsv_session_plan_window(const gsv_session* s, uint64_t window, uint64_t* first_call, uint64_t* n_calls, uint64_t* max_width);

@@ -73,6 +73,30 @@ def test_abi_route_plan_equals_the_builtin_builders(ext_host, tmp_path, window_d
     assert not [f for f in os.listdir(str(tmp_path)) if ".tmp." in f]
 
 
+@pytest.mark.parametrize("divs", [(4, 1), (2, 4)])
+def test_plan_file_pair_equals_separately_built_files(tmp_path, divs):
+    """gsv_plan_build_file_pair: ONE recording of the circuit feeds TWO compilations of every program (two shares of the LDS window) and
+    two plan files — each, byte for byte (program blocks, calls, header; tools/plan_digest.py), what gsv_plan_build_file writes for its
+    window_div alone.  bench.py builds its headline plan (window_div 4) and its small-batch plan (window_div 1) this way."""
+    import garbled_snark_verifier_amd as gsv
+    import plan_digest
+    d = str(tmp_path)
+    for spec, units in [("fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"]), ("driver_mix", ["test::inner", "bigint::add"]), ("g1_mux_add", ["bigint::multiplexer", "g1::add_montgomery"]),
+                        ("fq_mul", ["no::such_unit"])]:
+        pa, pb = os.path.join(d, "pair_a.gsvplan"), os.path.join(d, "pair_b.gsvplan")
+        gsv.Plan.build_file_pair(spec, units, pa, divs[0], pb, divs[1])
+        for path, div in ((pa, divs[0]), (pb, divs[1])):
+            ref = os.path.join(d, "single.gsvplan")
+            gsv.Plan.build_file(spec, units, ref, window_div=div)
+            da, dr = plan_digest.digest(path), plan_digest.digest(ref)
+            assert da == dr and da["unreferenced_bytes"] == 0, (spec, div, da, dr)
+    with pytest.raises(gsv.GsvError):
+        gsv.Plan.build_file_pair("fq_mul", ["x::y"], os.path.join(d, "same"), 4, os.path.join(d, "same"), 1)
+    with pytest.raises(gsv.GsvError):
+        gsv.Plan.build_file_pair("fq_mul", ["x::y"], os.path.join(d, "p"), 3, os.path.join(d, "q"), 1)
+    assert not [f for f in os.listdir(d) if ".tmp." in f]
+
+
 def test_abi_misuse_is_refused(tmp_path):
     """struct_size guards both option structs; a spilled program cannot be run; a finished plan recorder takes no more units."""
     import ctypes as C

@@ -945,6 +945,53 @@ def test_destroy_inside_a_sink_callback_is_deferred(engine, monkeypatch):
     again.close(); small.close(); small2.close(); st.close(); plan.close()
 
 
+def test_forced_dependency_fault_falls_back_to_the_safe_schedule(engine, tmp_path, monkeypatch):
+    """The schedule's one assumption (a workgroup only waits for workgroups the hardware dispatched before it) is not an architectural
+    guarantee.  GSV_FAULT_WITHHOLD_DEP=1 points one dependency of the window at a completion flag nobody writes: on the device exactly
+    what a violated assumption looks like.  The waiting call's progress watchdog gives up (GSV_DEP_WAIT_SECONDS), the pass ends with
+    status 1 — and instead of failing (rounds 1-5) the engine installs the SAFE schedule into the same session (one call per launch, stream
+    order, no device-side wait), re-stages the host's inputs and repeats the pass: MACs, gc files and output labels are the oracle's.
+    A pass through a host callback cannot be repeated behind the host's back (it has seen an invalid prefix): it fails, names the
+    remedy, and the host's repeat succeeds on the safe schedule."""
+    import garbled_snark_verifier_amd as gsv
+    monkeypatch.setenv("GSV_FAULT_WITHHOLD_DEP", "1")
+    monkeypatch.setenv("GSV_DEP_WAIT_SECONDS", "2")
+    plan = gsv.Plan.from_circuit("fq12_mix", FINE_UNITS)
+    seeds = [201, 202]
+    B, n_in = len(seeds), plan.info["n_inputs"]
+    labs = [gsv.labels_from_seed(s, n_in) for s in seeds]
+    delta = np.stack([x[0] for x in labs]); consts = np.stack([np.stack([x[1], x[2]]) for x in labs]); inputs = np.stack([x[3] for x in labs])
+    refs = [o.garble("fq12_mix", s) for s in seeds]
+    gc = str(tmp_path)
+    for kw in (dict(retain_stream=False, concurrent_calls=16), dict(retain_stream="ring", concurrent_calls=16, drain_segment_records=300_000)):
+        if kw["retain_stream"] == "ring":
+            monkeypatch.setenv("GSV_CT_RING_RECORDS", "1000000")
+        sess = gsv.Session(engine, plan, B, **kw)
+        before = sess.schedule_info()
+        assert before["n_windows"] < before["n_calls"] and sess.fallback_count() == 0
+        sess.set_garble_inputs(delta, consts, inputs)
+        hashes = sess.garble_streaming(directory=gc, first_index=40)
+        after = sess.schedule_info()
+        assert sess.fallback_count() == 1 and after["n_windows"] == after["n_calls"] and after["ct_ring_records"] == 0 and after["n_dependencies"] == 0
+        assert hashes == [r.ct_hash.tobytes() for r in refs] and (sess.read_outputs() == np.stack([r.output_label0 for r in refs])).all()
+        for i in range(B):
+            assert open(os.path.join(gc, gsv.gc_file_name(40 + i)), "rb").read() == refs[i].ciphertexts.tobytes()
+        # the safe schedule stays: further passes (also the discarding form) run on it without another fault
+        sess.set_garble_inputs(delta, consts, inputs)
+        sess.garble_streaming(discard=True)
+        assert sess.fallback_count() == 1 and (sess.read_outputs() == np.stack([r.output_label0 for r in refs])).all()
+        sess.close()
+    # through a sink: the failing pass is reported, the host repeats it
+    sess = gsv.Session(engine, plan, B, retain_stream=False, concurrent_calls=16)
+    sess.set_garble_inputs(delta, consts, inputs)
+    with pytest.raises(gsv.GsvError, match="safe schedule"):
+        sess.garble_to_sink(lambda *a: None, with_hashes=True)
+    assert sess.fallback_count() == 1
+    sess.set_garble_inputs(delta, consts, inputs)
+    assert sess.garble_to_sink(lambda *a: None, with_hashes=True) == [r.ct_hash.tobytes() for r in refs]
+    sess.close(); plan.close()
+
+
 def test_garble_and_evaluate_side_by_side_on_the_device(engine):
     """examples/groth16_garble.rs:171-230 / tests/garbler_evaluator_connection.rs:64-172: the garbler feeds the evaluator while it
     garbles.  gsv_session_garble_evaluate: window k of the garbler's device block is evaluated on a second stream while window k+1 is
