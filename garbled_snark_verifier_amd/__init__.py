@@ -147,7 +147,7 @@ def lib():
         L.gsv_engine_destroy.argtypes = [vp]
         L.gsv_engine_destroy.restype = None
         L.gsv_session_fallback_count.argtypes = [vp, C.POINTER(C.c_uint64)]
-        L.gsv_plan_build_file_pair.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32]
+        L.gsv_plan_build_file_pair.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_uint32]
         L.gsv_deferred_release_count.argtypes = []
         L.gsv_deferred_release_count.restype = C.c_uint64
         L.gsv_labels_from_seed.argtypes = [C.c_uint64, C.c_size_t, u8p, u8p, u8p, u8p]
@@ -429,10 +429,11 @@ class Plan:
                     os.environ[k] = v
 
     @staticmethod
-    def build_file_pair(spec, units, path_a, window_div_a, path_b, window_div_b):
-        """Two plan files from ONE recording of the circuit (gsv_plan_build_file_pair): every program compiled for both shares of the LDS
-        window.  Each file equals what build_file writes for its window_div."""
-        _chk(lib().gsv_plan_build_file_pair(spec.encode(), ",".join(units).encode(), os.fsencode(path_a), int(window_div_a), os.fsencode(path_b), int(window_div_b)))
+    def build_file_pair(spec, units_a, path_a, window_div_a, path_b, window_div_b, units_b=None):
+        """Two plan files from ONE build (gsv_plan_build_file_pair): the units both plans share are recorded once and compiled for both
+        shares of the LDS window (units_b None: the same units).  Each file equals what build_file writes for its units and window_div."""
+        _chk(lib().gsv_plan_build_file_pair(spec.encode(), ",".join(units_a).encode(), os.fsencode(path_a), int(window_div_a),
+                                            ",".join(units_b).encode() if units_b is not None else None, os.fsencode(path_b), int(window_div_b)))
 
     def _read_info(self):
         g, c, k = C.c_uint64(), C.c_uint64(), C.c_uint64()

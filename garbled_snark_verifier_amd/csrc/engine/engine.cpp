@@ -597,6 +597,7 @@ static int plan_window_div(uint32_t* window_div) {
 // A dual build (gsv_plan_build_file_pair): the second image of every program — compiled from the same recording for 1 / window_div of the
 // LDS window, handed to `sink` — and the second plan.
 struct DualBuild {
+  const char* units_csv = nullptr;  // the second plan's units; null or equal to the first plan's: one recorder serves both plans
   uint32_t window_div = 1;
   std::function<void(Program&)> sink;
   gsv_plan** out = nullptr;
@@ -606,14 +607,17 @@ static int plan_from_circuit_impl(const char* spec, const char* units_csv, const
                                   const DualBuild* dual = nullptr) {
   if (!spec || !units_csv || !out) return fail(GSV_ERR_INVALID, "null argument");
   GSV_TRY
-  std::vector<std::string> names;
-  {
+  auto split_csv = [](const char* csv) {
+    std::vector<std::string> v;
     std::string cur;
-    for (const char* q = units_csv;; ++q) {
-      if (*q == ',' || *q == 0) { if (!cur.empty()) names.push_back(cur); cur.clear(); if (!*q) break; }
+    for (const char* q = csv;; ++q) {
+      if (*q == ',' || *q == 0) { if (!cur.empty()) v.push_back(cur); cur.clear(); if (!*q) break; }
       else cur.push_back(*q);
     }
-  }
+    return v;
+  };
+  const std::vector<std::string> names = split_csv(units_csv);
+  const bool two_recorders = dual && dual->units_csv && split_csv(dual->units_csv) != names;
   NamedCircuit nc = make_circuit(spec);
   PlanRecordMode mode(names);
   CompileOptions opt;
@@ -630,6 +634,7 @@ static int plan_from_circuit_impl(const char* spec, const char* units_csv, const
     CompileOptions ob = opt;
     ob.lds_slots = std::min<uint32_t>(ob.lds_slots, LDS_WINDOW_SLOTS / dual->window_div);
     mode.cache()->dual = true; mode.cache()->bg_opt_b = ob; mode.cache()->sink_b = dual->sink;
+    if (two_recorders) { mode.cache()->names_a = names; mode.cache()->names_b = split_csv(dual->units_csv); }
   }
   // (a plan built straight into a file keeps ONE image per program and no trace: with GSV_PLAN_WINDOW_DIV=1 that image has the full LDS
   // window and serves one instance per workgroup only — the small-batch plan of bench.py: 3 % faster steps for 1 and 16 instances)
@@ -642,11 +647,32 @@ static int plan_from_circuit_impl(const char* spec, const char* units_csv, const
   const auto t0 = std::chrono::steady_clock::now();
   auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
   size_t n_recorders = 0;
+  // Two plans with different units: the second plan's driver walks the circuit on a thread of its own, over the SAME unit cache — the
+  // units the plans share (the verifier: its 182 constant line functions, 3.3 B of the 3.5 B gates a build records) are recorded once,
+  // by whoever gets there first (the other waits for them), and compiled for both plans.
+  std::unique_ptr<PlanRecordMode> mode_b;
+  std::vector<uint32_t> in_ssa_b, out_ssa_b;
+  std::thread walk_b;
+  std::exception_ptr walk_b_err;
+  if (two_recorders) {
+    mode_b.reset(new PlanRecordMode(split_csv(dual->units_csv), mode.cache()));
+    walk_b = std::thread([&] {
+      try {
+        size_t nr = 0;
+        record_plan(*mode_b, nc.n_inputs, nc.fn, std::vector<NamedCircuit::Warmup>(), in_ssa_b, out_ssa_b, &nr);
+      } catch (...) { walk_b_err = std::current_exception(); }
+    });
+  }
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } walk_b_joiner{walk_b};
   record_plan(mode, nc.n_inputs, nc.fn, nc.warmups, in_ssa, out_ssa, &n_recorders);
+  if (walk_b.joinable()) walk_b.join();
+  if (walk_b_err) std::rethrow_exception(walk_b_err);
   if (dbg) std::fprintf(stderr, "plan: recorded at %.1f s (%zu units, %zu glue classes, %zu warm-ups on %zu threads)\n", since(), mode.units.size(), mode.glue_classes.size(), nc.warmups.size(), n_recorders);
   mode.wait_for_compilations();
   if (dbg) std::fprintf(stderr, "plan: background compilations finished at %.1f s\n", since());
-  BuiltPlan bp = finish_plan(mode, in_ssa, out_ssa, opt);
+  BuiltPlan bp = finish_plan(mode, in_ssa, out_ssa, opt, dual && !two_recorders ? 2 : 0);
+  BuiltPlan bp_second;
+  if (two_recorders) bp_second = finish_plan(*mode_b, in_ssa_b, out_ssa_b, opt, 1);
   if (dbg) std::fprintf(stderr, "plan: all programs compiled at %.1f s\n", since());
   if (dbg) {  // per program: how often it is called, its size and shape (latency-bound programs carry four-wire records)
     std::vector<size_t> n_calls(bp.programs.size(), 0);
@@ -659,7 +685,7 @@ static int plan_from_circuit_impl(const char* spec, const char* units_csv, const
     }
   }
   // the plan object over one set of images (a dual build makes two: same calls, same globals)
-  auto make_plan = [&](std::vector<Program>& programs, uint32_t wdiv, bool keep_traces, gsv_plan** dst) -> int {
+  auto make_plan = [&](BuiltPlan& bp, const PlanRecordMode& mode, std::vector<Program>& programs, uint32_t wdiv, bool keep_traces, gsv_plan** dst) -> int {
     std::unique_ptr<gsv_plan> plan(new gsv_plan());
     for (size_t k = 0; k < programs.size(); ++k) {
       gsv_program* q = new gsv_program();
@@ -681,9 +707,9 @@ static int plan_from_circuit_impl(const char* spec, const char* units_csv, const
     return GSV_OK;
   };
   gsv_plan* second = nullptr;
-  if (dual) { int rc = make_plan(bp.programs_b, dual->window_div, false, &second); if (rc) return rc; }
+  if (dual) { int rc = two_recorders ? make_plan(bp_second, *mode_b, bp_second.programs, dual->window_div, false, &second) : make_plan(bp, mode, bp.programs_b, dual->window_div, false, &second); if (rc) return rc; }
   if (single_image) for (Trace& t : bp.traces) t = Trace();
-  int rc = make_plan(bp.programs, window_div, !single_image, out);
+  int rc = make_plan(bp, mode, bp.programs, window_div, !single_image, out);
   if (rc) { gsv_plan_destroy(second); return rc; }
   if (dual) *dual->out = second;
   return GSV_OK;
@@ -1138,7 +1164,8 @@ int gsv_plan_build_file(const char* spec, const char* units_csv, const char* pat
 // (four instances per workgroup: window_div 4) AND small ones (full window: window_div 1) builds both plans for the price of one
 // recording, which is the critical path of a build (bench.py: 94 s -> ~55 s to the first launch).  Each file is byte for byte what
 // gsv_plan_build_file writes for its window_div (tools/plan_digest.py; tests/test_ext_host.py).
-int gsv_plan_build_file_pair(const char* spec, const char* units_csv, const char* path_a, uint32_t window_div_a, const char* path_b, uint32_t window_div_b) {
+int gsv_plan_build_file_pair(const char* spec, const char* units_csv_a, const char* path_a, uint32_t window_div_a, const char* units_csv_b, const char* path_b, uint32_t window_div_b) {
+  const char* units_csv = units_csv_a;
   if (!spec || !units_csv || !path_a || !path_b) return fail(GSV_ERR_INVALID, "null argument");
   for (uint32_t d : {window_div_a, window_div_b}) if (d != 1 && d != 2 && d != 4) return fail(GSV_ERR_INVALID, "window_div must be 1, 2 or 4");
   if (std::string(path_a) == path_b) return fail(GSV_ERR_INVALID, "the two plan files must differ");
@@ -1148,7 +1175,7 @@ int gsv_plan_build_file_pair(const char* spec, const char* units_csv, const char
   { int rc = wb.open_file(path_b); if (rc) return rc; }
   gsv_plan *plan_a = nullptr, *plan_b = nullptr;
   DualBuild dual;
-  dual.window_div = window_div_b; dual.sink = spill_to(wb, window_div_b); dual.out = &plan_b;
+  dual.units_csv = units_csv_b; dual.window_div = window_div_b; dual.sink = spill_to(wb, window_div_b); dual.out = &plan_b;
   int rc = plan_from_circuit_impl(spec, units_csv, spill_to(wa, window_div_a), &plan_a, window_div_a, &dual);
   if (rc) return rc;
   struct PlanOwner { gsv_plan* p; ~PlanOwner() { gsv_plan_destroy(p); } } oa{plan_a}, ob{plan_b};

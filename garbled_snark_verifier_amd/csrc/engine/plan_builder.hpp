@@ -122,6 +122,15 @@ struct PlanUnitCache {
   bool dual = false;
   CompileOptions bg_opt_b;
   std::function<void(Program&)> sink_b;
+  // The two plans of a dual build may cut the circuit into DIFFERENT units (bench.py: Fq12-level units for full batches, Fq6-level for
+  // small ones): two recorders with their own unit names share this cache, a unit is recorded once whoever meets it first, and it is
+  // compiled for plan A / plan B only if its component is a unit of that plan (both lists empty: every unit for both).
+  std::vector<std::string> names_a, names_b;
+  static bool names_match(const std::vector<std::string>& names, const std::string& key) {
+    for (const std::string& n : names)
+      if (key.size() > n.size() && key.compare(0, n.size(), n) == 0 && (key[n.size()] == '#' || key[n.size()] == '|')) return true;
+    return false;
+  }
   std::unique_ptr<CompilePool> pool;  // set by compile_in_background; declared last: destroyed (its workers joined) before what the jobs use
 };
 
@@ -252,10 +261,14 @@ class PlanRecordMode final : public CircuitMode, public UnitHook {
         const CompileOptions opt = uc.bg_opt;
         const bool drop = uc.bg_drop;
         PlanUnitCache* ucp = &uc;  // outlives the pool it owns
-        uc.pool->submit([pu, opt, drop, ucp] {
-          pu->compiled.reset(new Program(compile_program(pu->trace, pu->inputs, pu->outputs, {}, opt)));
-          if (ucp->sink) ucp->sink(*pu->compiled);
-          if (ucp->dual) {
+        const bool split = uc.dual && !(uc.names_a.empty() && uc.names_b.empty());
+        const bool need_a = !split || PlanUnitCache::names_match(uc.names_a, key), need_b = uc.dual && (!split || PlanUnitCache::names_match(uc.names_b, key));
+        uc.pool->submit([pu, opt, drop, ucp, need_a, need_b] {
+          if (need_a) {
+            pu->compiled.reset(new Program(compile_program(pu->trace, pu->inputs, pu->outputs, {}, opt)));
+            if (ucp->sink) ucp->sink(*pu->compiled);
+          }
+          if (need_b) {
             pu->compiled_b.reset(new Program(compile_program(pu->trace, pu->inputs, pu->outputs, {}, ucp->bg_opt_b)));
             if (ucp->sink_b) ucp->sink_b(*pu->compiled_b);
           }
@@ -487,11 +500,14 @@ struct BuiltPlan {
 };
 
 // inputs / outputs: global SSA ids of the circuit's inputs / outputs as PlanRecordMode handed them out.
-inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inputs, const std::vector<uint32_t>& outputs, const CompileOptions& opt = CompileOptions()) {
+// which (dual builds, PlanUnitCache::dual): 0 = the first plan's images (or a plain build), 1 = the SECOND plan's images (compiled_b,
+// bg_opt_b, sink_b — they land in BuiltPlan::programs), 2 = both plans from this one recorder (programs and programs_b).
+inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inputs, const std::vector<uint32_t>& outputs, const CompileOptions& opt = CompileOptions(), int which = 0) {
   m.close_glue();
   m.wait_for_compilations();
   BuiltPlan bp;
-  const bool dual = m.cache()->dual;
+  if (which != 0 && !m.cache()->dual) gsv_panic("internal: finish_plan asked for the second image of a build that is not dual");
+  const bool dual = which == 2;
   const uint32_t nw = m.n_ssa();
   constexpr int32_t SEG_INPUT = -1, SEG_NONE = -2;
   std::vector<int32_t> def_seg(nw, SEG_NONE);
@@ -575,8 +591,11 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
         if (unit_program[size_t(s.unit)] < 0) {
           // later calls of the unit reuse the program index, so the trace can move (178 constant-specialised line
           // functions of the Miller loop would otherwise exist twice)
-          unit_program[size_t(s.unit)] = add_program(std::move(u.trace), u.inputs, u.outputs);
-          if (u.compiled && (!dual || u.compiled_b)) {
+          // (a dual build's cache is shared by two recorders: the trace stays where it is — it has been dropped after the compilations anyway)
+          unit_program[size_t(s.unit)] = m.cache()->dual ? add_program(Trace(u.trace), u.inputs, u.outputs) : add_program(std::move(u.trace), u.inputs, u.outputs);
+          if (which == 1) {
+            if (u.compiled_b) { bp.programs.back() = std::move(*u.compiled_b); u.compiled_b.reset(); done.back() = 1; }
+          } else if (u.compiled && (!dual || u.compiled_b)) {
             bp.programs.back() = std::move(*u.compiled); u.compiled.reset();
             if (dual) { bp.programs_b.back() = std::move(*u.compiled_b); u.compiled_b.reset(); }
             done.back() = 1;
@@ -638,6 +657,11 @@ inline BuiltPlan finish_plan(PlanRecordMode& m, const std::vector<uint32_t>& inp
   const CompileOptions opt_b = m.cache()->bg_opt_b;
   parallel_for_programs(bp.programs.size(), [&](size_t i) {
     if (done[i]) return;
+    if (which == 1) {
+      bp.programs[i] = compile_program(bp.traces[i], bp.prog_inputs[i], bp.prog_outputs[i], {}, opt_b);
+      if (sink_b) { bp.traces[i] = Trace(); sink_b(bp.programs[i]); }
+      return;
+    }
     bp.programs[i] = compile_program(bp.traces[i], bp.prog_inputs[i], bp.prog_outputs[i], {}, opt);
     if (dual) {
       bp.programs_b[i] = compile_program(bp.traces[i], bp.prog_inputs[i], bp.prog_outputs[i], {}, opt_b);

@@ -192,11 +192,14 @@ int gsv_plan_load(const char* path, gsv_engine* e, gsv_plan** out);
  * ~25 GB instead of ~54 GB).  One image per program: GSV_PLAN_WINDOW_DIV=2|4 as below, or 1 = the full window, for sessions with one
  * instance per workgroup only (small batches: 3 % faster steps).  Then gsv_plan_load(path, engine). */
 int gsv_plan_build_file(const char* circuit_spec, const char* units_csv, const char* path);
-/* TWO plan files from ONE recording of the circuit (round 6): every program is compiled for 1 / window_div_a AND for 1 / window_div_b of
- * the LDS label window (each 1, 2 or 4) by the worker that takes it off the recorder and appended to both files.  Recording is the
- * critical path of a build, so a deployment that serves large batches (window_div 4) and small ones (window_div 1) gets both plans
- * for the time of one.  Each file is byte for byte what gsv_plan_build_file writes for its window_div. */
-int gsv_plan_build_file_pair(const char* circuit_spec, const char* units_csv, const char* path_a, uint32_t window_div_a, const char* path_b, uint32_t window_div_b);
+/* TWO plan files from ONE build (round 6): plan A = (units_csv_a, 1 / window_div_a of the LDS label window), plan B likewise (window_div 1,
+ * 2 or 4; units_csv_b NULL = plan A's units).  The units the two plans share are recorded ONCE — the verifier's 182 constant line
+ * functions are 3.3 B of the 3.5 B gates a build records, whichever granularity the Fq12 arithmetic around them is cut at — and compiled
+ * for both plans by the worker that takes them off the recorder; with different unit lists the second plan's driver walks the circuit
+ * on a thread of its own over the same unit cache.  Recording is the critical path of a build, so a deployment that serves full batches
+ * (Fq12-level units, window_div 4) and small ones (Fq6-level units, window_div 1) gets both plans for about the time of one.  Each
+ * file is byte for byte what gsv_plan_build_file writes for its units and window_div. */
+int gsv_plan_build_file_pair(const char* circuit_spec, const char* units_csv_a, const char* path_a, uint32_t window_div_a, const char* units_csv_b, const char* path_b, uint32_t window_div_b);
 
 /* Call operands naming the constant wires instead of a global wire. */
 #define GSV_PLAN_WIRE_FALSE 0xFFFFFFFEu
