@@ -384,6 +384,66 @@ def cpu_quota_cores():
         return None
 
 
+def mac_threads_for_rank(requested, local_world, quota=None, visible=None):
+    """Host MAC workers of ONE rank's drain.  A lone rank leaves it to the engine (0: up to 32 workers, one per chain group).  The ranks of a
+    node share the host: each takes its share of the container's CPU quota (or of the visible CPUs), at least one — eight ranks with 32
+    workers each on a 16-core quota would spend the quota on context switches instead of CBC-MAC chains."""
+    if requested:
+        return int(requested)
+    if local_world <= 1:
+        return 0
+    cores = quota if quota is not None else cpu_quota_cores()
+    if cores is None:
+        cores = float(visible if visible is not None else (os.cpu_count() or 1))
+    return max(1, int(cores // local_world))
+
+
+def dry_run(args):
+    """`--dry-run`: what `--gpus N` of this workload will ask of every rank — device memory, host memory, host cores — and what it is expected
+    to deliver, from the plan's known sizes and this host's CPU quota.  No GPU, no process group: run it on the login shell of an 8-GPU node
+    before the job.  The numbers marked `measured` come from one-GPU runs (profiles/r05_final/bench_driver_command.json)."""
+    world = max(1, args.gpus)
+    quota = cpu_quota_cores()
+    visible = os.cpu_count() or 1
+    cores = quota if quota is not None else float(visible)
+    gates, n_ct = 11_456_865_898, 2_980_165_547           # the restated circuit, one public input (tests/golden/groth16_verify_compressed_1pub_golden.json)
+    f_nf = n_ct / gates
+    image_gb = {"headline (Fq12-level units, quarter LDS window)": 41.8, "small-batch (Fq6-level units, full window)": 41.6}
+    hbm_gb, pcie_gbs = 288.0, 54.4                         # MI355X; measured D2H rate of the drain (54-57 GB/s in 16 MiB chunks)
+    mac_core = {"aes-ni, 4 chains": 4.5e8, "vaes, 16 chains": 1.7e9}  # measured CBC-MAC blocks/s of one host core
+    threads = mac_threads_for_rank(args.mac_threads, world, quota, visible)
+    cc16 = args.workload == "cc16"
+    total = 16 if cc16 else args.instances * world
+    per_rank = [len(range(r, total, world)) for r in range(world)] if cc16 else [args.instances] * world
+    B = max(per_rank)
+    wire_mb, ring_gb_one = (19.1, 3.2) if not cc16 else (23.3, 3.2)
+    if cc16:
+        ct_block_gb = min(0.4 * (hbm_gb - 41.6), 48.0)    # the window block of a session that does not retain the stream (engine.cpp make_schedule)
+        dev_gb = 41.6 + B * wire_mb / 1e3 + ct_block_gb + 3 * B * 1.07  # + three gate-order buffers of <= 1 GB per instance
+        one_instance_s, sixteen_s = 29.8, 32.1             # measured: one / sixteen instances with commitments on one GPU
+        job_s = one_instance_s + (sixteen_s - one_instance_s) * (B - 1) / 15.0
+        expected = {"seconds_per_job": round(job_s, 1), "gates_per_s": gates * total / job_s,
+                    "why": "an instance is ~7.3 M dependent device steps (~27 s) however many GPUs there are: sixteen instances on ONE GPU take %.1f s, %d per GPU ~%.1f s — config 5 as stated is flat in N" % (sixteen_s, B, job_s)}
+    else:
+        dev_gb = 41.8 + B * wire_mb / 1e3 + B * 88.3 / 1e3
+        per_gpu = 1.05e11                                  # measured: 1 024 instances per GPU, ciphertexts into HBM
+        pcie_bound = pcie_gbs * 1e9 / 16 / f_nf
+        mac_bound = {k: cores * v / f_nf for k, v in mac_core.items()}
+        expected = {"value_gates_per_s": per_gpu * world, "scaling": "weak: no collective and no host work in the timed region (one barrier per step): linear in N",
+                    "with_commitment_gates_per_s": {k: min(world * pcie_bound, v) for k, v in mac_bound.items()},
+                    "with_commitment_bound": {k: ("pcie (%.3g per GPU)" % pcie_bound if world * pcie_bound <= v else "host MAC: %.0f cores x %.2g blocks/s" % (cores, mac_core[k])) for k, v in mac_bound.items()},
+                    "host_bound_from_n_gpus": {k: int(v // pcie_bound) + 1 for k, v in mac_bound.items()}}
+    out = {"dry_run": True, "workload": args.workload, "n_gpus": world, "instances_total": total, "instances_per_rank": per_rank,
+           "host": {"cpu_quota_cores": quota, "visible_cpus": visible, "mac_workers_per_rank": threads if threads else "engine default (<= 32)", "mac_workers_total": (threads or 32) * world},
+           "per_rank": {"device_memory_gb": round(dev_gb, 1), "of_hbm_gb": hbm_gb, "plan_image_gb": image_gb, "wire_file_mb_per_instance": wire_mb,
+                        "host_rss_gb": {"rank that builds the plan file (local rank 0, once per machine)": 17.0, "ranks that load it": 2.0},
+                        "plan_file": "one file per node in /dev/shm (41.8 GB, page cache shared): local rank 0 builds (~50 s), the others gsv_plan_load it into their GPU (5-11 s)",
+                        "pinned_host_buffers_gb": round((threads or 32) * 2 * (16 if B >= 128 else 4 if B > cores else 1) * 16 / 1024.0, 2)},
+           "exchange": "one all-gather of %d commit records x 48 952 B (RCCL over xGMI), nothing else" % total,
+           "expected": expected}
+    print(json.dumps(out), flush=True)
+
+
 _CPU_WORKER = """
 import json, os, sys
 sys.path.insert(0, %r)
@@ -639,7 +699,7 @@ def run_verifier(args):
             try:
                 si = e2e.sess.schedule_info()
                 quota = cpu_quota_cores()
-                dt = e2e.run_pass(commit=True, threads=args.mac_threads)
+                dt = e2e.run_pass(commit=True, threads=mac_threads_for_rank(args.mac_threads, local_world))
                 out = e2e.sess.read_outputs()
                 ok = fixture_ok(e2e.ct_hashes[0], out[0])
                 cc_ok = [e2e.ct_hashes[1 + k].hex() == cc_gold["ct_hashes"][k] and out[1 + k][0].tobytes().hex() == cc_gold["first_output_label0"][k] for k in range(n_cc)]
@@ -787,6 +847,8 @@ def run_verifier(args):
     slices = work.slices(ci[:, 1], args.slices)
     work_windows = work.sess.windows()
     sched = work.sess.schedule_info()
+    forms = plan.call_record_forms()
+    n_fw_windows = sum(1 for (c0, nc, _w) in work.sess.windows() if any(f == 4 for f in forms[c0:c0 + nc]))
     if rank == 0:
         log("bench.py: %d instances, %d per workgroup; %d windows in %d slices; per instance: wire file %.1f MB, ciphertext window %.1f MB"
             % (B, ni, sched["n_windows"], len(slices), sched["wire_file_slots"] * 16 / 1e6, sched["window_ct_records"] * 16 / 1e6))
@@ -815,7 +877,7 @@ def run_verifier(args):
             work.sess.set_drain_instances(n_chk)
             work.sess.set_unchecked_slices(False)
             t0 = time.perf_counter()
-            dt = work.run_pass(commit=True, threads=args.mac_threads)
+            dt = work.run_pass(commit=True, threads=mac_threads_for_rank(args.mac_threads, local_world))
             out = work.sess.read_outputs()
             ok0 = fixture_ok(work.ct_hashes[0], out[0])
             oks = [ok0] + [work.ct_hashes[1 + k].hex() == head_gold["ct_hashes"][k] and out[1 + k][0].tobytes().hex() == head_gold["first_output_label0"][k] for k in range(n_chk - 1)]
@@ -926,8 +988,10 @@ def run_verifier(args):
                          # one step = the window launches of one slice, all of the same kernel over different component programs; a launch = one WINDOW of the schedule
                          # (grid.y = its calls) for all instances of the GPU: `launches_timed` dispatches, what rocprofv3 --kernel-trace counts
                          "kernel": "run_program_kernel<false, %d, 0, FW>" % ni, "launches_timed": n_launch, "kernel_ms_avg": stream_s * 1e3 / max(1, n_launch),
-                         "kernel_note": "one kernel, two instantiations: FW = true for the windows that hold a program in the four-wire record form (191 of a pass's 672), false for the others; "
-                                        "kernel_ms_avg is over all window launches = the dispatch-weighted mean of the two rows of profiles/r05_final/kernel_stats.csv",
+                         "kernel_note": "one kernel, two instantiations: FW = true for the windows that hold a program in the four-wire record form (%d of a pass's %d), false for the others; "
+                                        "kernel_ms_avg is over all window launches = the dispatch-weighted mean of the two rows of profiles/<round>_final/kernel_stats.csv" % (n_fw_windows, sched["n_windows"]),
+                         # what `frac` is a fraction OF: the contract's algorithmic bytes, which fusion and the LDS window mostly keep off HBM — not HBM traffic
+                         "frac_of": "algorithmic bytes (SURVEY.md §8d: 64 + 16 f_nf per reference gate) / HBM peak — NOT HBM traffic: see hbm_measured_frac (counters) and aes_ceiling_frac (what binds)",
                          "algorithmic_bytes_per_launch": g_rank * bytes_per_gate / max(1, n_launch), "bytes_per_gate": bytes_per_gate, "calls_timed": n_calls_timed,
                          "note": "algorithmic-bytes accounting of SURVEY.md §8(d); fusion and the LDS label window keep most of those bytes off HBM, the limit that binds is T-table AES issue (DESIGN.md §3)",
                          "binding_limit": "aes-issue", "aes_ceiling_gates_per_s": aes_and_per_s / f_nf, "aes_ceiling_frac": (g_rank / stream_s) / (aes_and_per_s / f_nf), "aes_ceiling_source": aes_src},
@@ -982,7 +1046,8 @@ def run_cc16(args):
     for it in range(args.warmup + args.steps):
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.perf_counter()
-        tab, _ = sharding.cut_and_choose_commit(case["circuit"], gold["master_seed"], total, rank, world, engine=engine, program=plan, device="cuda" if world > 1 else None)
+        tab, _ = sharding.cut_and_choose_commit(case["circuit"], gold["master_seed"], total, rank, world, engine=engine, program=plan, device="cuda" if world > 1 else None,
+                                                threads=mac_threads_for_rank(args.mac_threads, local_world))
         torch.cuda.synchronize(); dist.barrier()
         dt = dist.max_float(time.perf_counter() - t0)
         if it >= args.warmup:
@@ -1122,7 +1187,11 @@ def main():
     ap.add_argument("--replays", type=int, default=0, help="synthetic: chain links per instance (0 = enough for 11.17 B gates)")
     ap.add_argument("--ct-ring", type=int, default=2, help="synthetic: replays of ciphertexts kept per instance in HBM")
     ap.add_argument("--component", default="fq12_sqmul", choices=["fq12_sqmul", "fq12_mul"], help="synthetic: link of the chain")
+    ap.add_argument("--dry-run", action="store_true", help="print the per-rank device / host memory and CPU budget of `--gpus N` of this workload and what it is expected to deliver; no GPU needed")
     args = ap.parse_args()
+    if args.dry_run:
+        dry_run(args)
+        return
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None:
         # No launcher: start the ranks ourselves, as fresh processes, before anything here has touched a GPU (no exec from a GPU process).

@@ -105,7 +105,7 @@ class _Gate(C.Structure):
 EXPORTS = [
     "gsv_last_error", "gsv_recorder_create", "gsv_recorder_destroy", "gsv_recorder_allocate_wire", "gsv_recorder_declare_input",
     "gsv_recorder_push_gates", "gsv_recorder_declare_outputs", "gsv_recorder_record_circuit", "gsv_recorder_counts", "gsv_program_compile", "gsv_program_destroy",
-    "gsv_program_get_info", "gsv_engine_create", "gsv_engine_destroy", "gsv_deferred_release_count", "gsv_session_fallback_count", "gsv_plan_build_file_pair", "gsv_labels_from_seed", "gsv_session_create", "gsv_session_destroy",
+    "gsv_program_get_info", "gsv_engine_create", "gsv_engine_destroy", "gsv_deferred_release_count", "gsv_session_fallback_count", "gsv_plan_build_file_pair", "gsv_plan_call_record_form", "gsv_labels_from_seed", "gsv_session_create", "gsv_session_destroy",
     "gsv_session_set_garble_inputs", "gsv_session_garble", "gsv_session_set_evaluate_inputs", "gsv_session_upload_ciphertexts",
     "gsv_session_evaluate", "gsv_session_set_hasher", "gsv_session_sync", "gsv_session_last_kernel_ms", "gsv_session_read_outputs", "gsv_session_read_ciphertexts",
     "gsv_session_ciphertext_hash", "gsv_cbcmac_update", "gsv_cbcmac_update_many", "gsv_commit_labels",
@@ -147,6 +147,7 @@ def lib():
         L.gsv_engine_destroy.argtypes = [vp]
         L.gsv_engine_destroy.restype = None
         L.gsv_session_fallback_count.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.gsv_plan_call_record_form.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint32)]
         L.gsv_plan_build_file_pair.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_uint32]
         L.gsv_deferred_release_count.argtypes = []
         L.gsv_deferred_release_count.restype = C.c_uint64
@@ -480,6 +481,15 @@ class Plan:
         for k in range(n):
             _chk(lib().gsv_plan_call_info(self.h, k, *[C.byref(x) for x in v]))
             out[k] = [x.value for x in v]
+        return out
+
+    def call_record_forms(self):
+        """Per call: wires per AND input of its program's records (2 or 4); a window with a four-wire program runs the FW kernel."""
+        v = C.c_uint32()
+        out = []
+        for k in range(self.info["n_calls"]):
+            _chk(lib().gsv_plan_call_record_form(self.h, k, C.byref(v)))
+            out.append(int(v.value))
         return out
 
     def add_call(self, program, in_globals, out_globals):

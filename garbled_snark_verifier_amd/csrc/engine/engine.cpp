@@ -2590,6 +2590,12 @@ int gsv_plan_call_info(const gsv_plan* p, uint64_t call, uint64_t* gate_offset, 
   if (n_steps) *n_steps = c.prog->prog.n_steps;
   return GSV_OK;
 }
+int gsv_plan_call_record_form(const gsv_plan* p, uint64_t call, uint32_t* and_terms) {
+  if (!p || !and_terms || call >= p->calls.size()) return fail(GSV_ERR_INVALID, "null argument / call index out of range");
+  { int rc = program_ready(p->calls[size_t(call)].prog); if (rc) return rc; }
+  *and_terms = p->calls[size_t(call)].prog->prog.and_terms;
+  return GSV_OK;
+}
 int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base) {
   if (!s) return fail(GSV_ERR_INVALID, "null session");
   // EvaluateMode panics with "Ciphertext source exhausted at gate .." when the source runs dry (evaluate_mode.rs:139-142).

@@ -121,7 +121,7 @@ def all_gather_records(local, total, rank, world, device=None):
     return out.cpu()[torch.from_numpy(np.argsort(idx, kind="stable"))]
 
 
-def garble_and_commit(circuit, seeds, indexes, engine=None, program=None, replays=1, gc_dir=None, session_kw=None):
+def garble_and_commit(circuit, seeds, indexes, engine=None, program=None, replays=1, gc_dir=None, session_kw=None, threads=0):
     """Garbler::create + commit (garbler.rs:191-257) for the given (index, seed) pairs in ONE session: returns the
     [len(seeds), record_len] commit records; with gc_dir the ciphertext streams go to gc_<index>.bin
     (ciphertext_repository.rs:94-127).  Indexes must be consecutive when gc_dir is used.  `program` may be a Plan (the
@@ -141,24 +141,25 @@ def garble_and_commit(circuit, seeds, indexes, engine=None, program=None, replay
     sess.set_garble_inputs(delta, consts, inputs)
     if gc_dir is not None:
         assert list(indexes) == list(range(indexes[0], indexes[0] + B)), "gc files are numbered first_index + i"
-    hashes = sess.garble_streaming(directory=gc_dir, first_index=int(indexes[0]) if B else 0)
+    hashes = sess.garble_streaming(directory=gc_dir, first_index=int(indexes[0]) if B else 0, threads=threads)  # threads: host MAC workers (0 = the engine's default)
     outs = sess.read_outputs()
     recs = np.stack([commit_record(indexes[i], hashes[i], outs[i], delta[i], consts[i, 0], consts[i, 1], inputs[i]) for i in range(B)])
     sess.close()
     return recs
 
 
-def cut_and_choose_commit(circuit, master_seed, total, rank, world, engine=None, program=None, garble=None, device=None, session_kw=None):
+def cut_and_choose_commit(circuit, master_seed, total, rank, world, engine=None, program=None, garble=None, device=None, session_kw=None, threads=0):
     """BASELINE config 5 / `Garbler::create` -> `commit` (garbler.rs:191-257) across ranks: `total` seeds are drawn from one master
     seed (:201-203), instance i goes to rank i mod world (the reference: one instance per pinned core, mod.rs:131-186), every rank
     garbles its instances WITH the ciphertext commitment (AESAccumulatingHash over the whole stream, :219-222) and builds their
     GarbledInstanceCommit records, and ONE all-gather leaves every rank with the [total, record_len] table ordered by instance
     index.  Nothing else is exchanged.  `garble(circuit, seeds, indexes) -> records` replaces the GPU garbler in the CPU tests.
+    `threads`: host MAC workers of this rank's drain — the ranks of a node share the host's cores (bench.mac_threads_for_rank).
     Returns (table as a uint8 numpy array, seeds)."""
     seeds = instance_seeds(master_seed, total)
     mine = shard_instances(total, rank, world)
     if garble is None:
-        garble = lambda c, sd, idx: garble_and_commit(c, sd, idx, engine=engine, program=program, session_kw=session_kw)  # noqa: E731
+        garble = lambda c, sd, idx: garble_and_commit(c, sd, idx, engine=engine, program=program, session_kw=session_kw, threads=threads)  # noqa: E731
     n_out, n_in = (program.info["n_outputs"], program.info["n_inputs"]) if program is not None else (None, None)
     if mine:
         local = np.ascontiguousarray(garble(circuit, [int(seeds[i]) for i in mine], mine), np.uint8)

@@ -174,6 +174,9 @@ int gsv_plan_recorder_finish(gsv_plan_recorder* r, const uint64_t* output_wires,
 /* Per-call facts of a finished plan: gate ids / ciphertext records consumed by the calls before `call`, and the call's own
  * gate, ciphertext and device-step counts.  Any pointer may be NULL. */
 int gsv_plan_call_info(const gsv_plan* p, uint64_t call, uint64_t* gate_offset, uint64_t* n_gates, uint64_t* ct_offset, uint64_t* n_ciphertexts, uint64_t* n_steps);
+/* Record form of the call's program: 2 = up to two wires per AND input (throughput-bound programs), 4 = up to four (latency-bound programs:
+ * fewer dependent steps).  A window launch that holds a four-wire program runs the FW instantiation of the kernel. */
+int gsv_plan_call_record_form(const gsv_plan* p, uint64_t call, uint32_t* and_terms);
 /* Wire file of a plan session, in 16-byte slots per instance: the global region (wires that cross calls; ids are recycled once
  * their last reader has run) behind the largest program's own slots. */
 int gsv_plan_wire_file(const gsv_plan* p, uint64_t* n_global_wires, uint64_t* max_program_slots);

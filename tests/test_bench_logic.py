@@ -3,6 +3,7 @@ barriers, the per-pass all-gather of commit records and the max-over-ranks elaps
 session is replaced by the test-only host interpreter (tests/hostsim) running a small plan, so the records that travel are
 real: they are compared with records built from the CPU oracle's garbling of the same seeds.  Also: plan files
 (gsv_plan_save / gsv_plan_load) round-trip without a device, and bench.py refuses a WORLD_SIZE that contradicts --gpus."""
+import json
 import os
 import socket
 import subprocess
@@ -218,3 +219,28 @@ def test_traffic_counters_are_bound_to_the_engine_sources():
     finals = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.endswith("_final") and os.path.exists(os.path.join(ROOT, "profiles", d, "traffic.json")))
     tj = json.load(open(os.path.join(ROOT, "profiles", finals[-1], "traffic.json")))
     assert len(tj["engine_library_sha256"]) == 64 and len(tj["engine_source_sha256"]) == 64 and tj["hbm_bytes_per_launch"] > 0
+
+
+def test_mac_workers_are_shared_among_the_ranks_of_a_node():
+    """A lone rank leaves the drain's worker count to the engine; the ranks of a node split the container's CPU quota (or the visible CPUs)."""
+    import bench
+    assert bench.mac_threads_for_rank(0, 1, quota=16.0) == 0
+    assert bench.mac_threads_for_rank(5, 8, quota=16.0) == 5        # an explicit --mac-threads wins
+    assert bench.mac_threads_for_rank(0, 8, quota=16.0) == 2
+    assert bench.mac_threads_for_rank(0, 8, quota=4.0) == 1         # never zero workers
+    assert bench.mac_threads_for_rank(0, 4, quota=None, visible=96) == 24
+
+
+def test_dry_run_prints_the_per_rank_budget():
+    """`bench.py --gpus 8 --workload cc16 --dry-run` (no GPU, no process group): two instances per rank, device memory well inside 288 GB,
+    one all-gather, and the honest expectation — config 5 as stated is flat in N; the weak-scaling headline is linear and its
+    with-commitment form becomes host-bound once N GPUs' PCIe streams outrun the quota's CBC-MAC capacity."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "cc16", "--dry-run"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["dry_run"] and j["instances_per_rank"] == [2] * 8 and j["per_rank"]["device_memory_gb"] < 200 and "all-gather of 16 commit records" in j["exchange"]
+    assert 25 < j["expected"]["seconds_per_job"] < 35 and "flat in N" in j["expected"]["why"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], capture_output=True, text=True)
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["instances_total"] == 8192 and j["per_rank"]["device_memory_gb"] < 288 and j["expected"]["value_gates_per_s"] > 8e11
+    assert set(j["expected"]["host_bound_from_n_gpus"]) == {"aes-ni, 4 chains", "vaes, 16 chains"}

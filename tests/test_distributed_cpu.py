@@ -212,6 +212,66 @@ def test_cc16_ranks_agree_on_a_failed_plan_load_world8(bad_rank, tmp_path):
     assert "plan" in res[0][1] and "failed on a rank" in res[0][1]
 
 
+def _plan_sharing_worker(rank, world, port, tmpdir, q):
+    """bench.get_plan with the REAL plan builder and loader on a small circuit: local rank 0 builds the plan file (gsv_plan_build_file),
+    every rank loads it (gsv_plan_load; without a device the loader makes a host copy instead of streaming into a GPU — the file path,
+    the barriers and the agreement logic are the ones the 8-GPU run takes)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(world)
+    os.environ["GSV_COMPILE_THREADS"] = "1"
+    import argparse
+    import bench
+    import garbled_snark_verifier_amd as gsv
+    builds = []
+
+    class CountingPlan:
+        @staticmethod
+        def build_file(circuit, units, path, window_div=4):
+            builds.append(rank)
+            gsv.Plan.build_file(circuit, units, path, window_div=window_div)
+
+        @staticmethod
+        def load(path, engine):
+            return gsv.Plan.load(path, None)
+
+    class Gsv:
+        Plan = CountingPlan
+
+    d = bench.Dist(world, "gloo", "cpu")
+    args = argparse.Namespace(no_plan_cache=False, plan_cache=tmpdir)
+    plan, info, _ = bench.get_plan(Gsv, None, args, "fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"], rank, rank, world, d, lambda m: None)
+    forms = plan.call_record_forms()
+    q.put((rank, len(builds), info["how"], info["cache_file"], dict(plan.info), forms, bench.mac_threads_for_rank(0, world, quota=16.0)))
+    plan.close()
+    d.barrier()
+    d.close()
+
+
+def test_plan_file_is_built_once_and_shared_by_eight_ranks(tmp_path):
+    """What `bench.py --gpus 8` does before its first launch: ONE plan file per node — local rank 0 builds it, the other seven load the same
+    file (page cache) — with the real builder and loader.  Every rank ends up with the same plan; exactly one build happened; every rank
+    takes an eighth of a 16-core quota for its MAC workers."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_plan_sharing_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: rest for r, *rest in (q.get(timeout=600) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sum(res[r][0] for r in range(world)) == 1 and res[0][0] == 1
+    assert res[0][1] == "built to file, loaded" and all(res[r][1] == "loaded" for r in range(1, world))
+    assert len({res[r][2] for r in range(world)}) == 1 and os.path.exists(res[0][2])
+    assert all(res[r][3] == res[0][3] and res[r][4] == res[0][4] for r in range(world)) and res[0][3]["n_calls"] > 1
+    assert all(res[r][5] == 2 for r in range(world))
+
+
 def test_instance_seeds_are_drawn_as_the_reference_draws_them():
     """Garbler::create draws `rng.gen::<u64>()` per instance (cut_and_choose/garbler.rs:201-203) on the caller's RNG — the reference's
     own test: ChaCha20Rng::seed_from_u64(1234) (cut_and_choose/tests.rs:102).  sharding.instance_seeds (the product's ChaCha stream,
