@@ -25,7 +25,7 @@ def _all_sources():
     srcs = []
     for root, _, files in os.walk(CSRC):
         for f in files:
-            if f.endswith((".hpp", ".h", ".hip", ".cpp")):
+            if f.endswith((".hpp", ".h", ".hip", ".cpp", ".ipp")):
                 srcs.append(os.path.join(root, f))
     srcs.append(os.path.join(os.path.dirname(HERE), "include", "gsv_engine.h"))
     return srcs

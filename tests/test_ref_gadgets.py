@@ -47,3 +47,53 @@ def test_counts_of_the_independent_restatement():
     g, _ = R.emit("fq_mul")
     assert len(g) == 414_284 and sum(1 for x in g if x[0] < 8) == 102_093
     assert sum(1 for x in g if x[3]) > 0  # Karatsuba truncations / dropped carries: dead gates exist and are counted
+
+
+# ---- round 6: the building blocks ABOVE the Fq6 level, gate by gate, in numpy form (tests/ref_stream_compare.py).  Until round 5 the bodies
+# of these gadgets (csrc/gadgets/bn254_ext.hpp, bn254_pairing.hpp, bn254_groth16.hpp) were checked against the Rust only through call-sequence
+# hashes, gate COUNTS and Execute-mode arithmetic.
+def _compare_streams(spec, cap):
+    import ref_stream_compare as S
+    exp = S.restated_stream(spec)
+    t, a, b, c, ins, outs = S.product_stream(spec, cap)
+    got = S.canonical_np(t, a, b, c, ins, outs[:len(exp[4])], dead_marker=0xFFFFFFFF)
+    assert len(got[0]) == len(exp[0]), "gate count: product %d, independent restatement %d" % (len(got[0]), len(exp[0]))
+    j = S.first_difference(got, exp)
+    if j is not None:
+        raise AssertionError("gate %d differs: product (type %d, a %d, b %d, dead %d), independent restatement (type %d, a %d, b %d, dead %d)"
+                             % ((j,) + tuple(int(x[j]) for x in got[:4]) + tuple(int(x[j]) for x in exp[:4])))
+    assert (got[4] == exp[4]).all(), "circuit outputs differ"
+    return len(got[0]), int(got[3].sum())
+
+
+def test_numpy_stream_comparison_agrees_with_the_tuple_form():
+    """The vectorised canonical form (round 6) against the list-of-tuples one on a circuit both can hold: same types, same operand
+    definitions, same derived deadness."""
+    import ref_stream_compare as S
+    n_in, fn = R.CIRCUITS["fq_mul"]
+    c = S.ArrayCtx(n_in)
+    outs = fn(c, list(c.inputs))
+    t, a, b, cc, calls = c.arrays()
+    ct, ra, rb, dead, ro = S.canonical_np(t, a, b, cc, c.inputs, outs, extra_reads=calls)
+    exp, exp_out = R.emit("fq_mul")
+    enc = lambda r: -1 - r[1] if r[0] == "c" else -(3 + r[1]) if r[0] == "i" else r[1]  # noqa: E731
+    assert len(exp) == len(ct) == 414_284
+    assert [int(x) for x in ct] == [g[0] for g in exp] and [int(x) for x in ra] == [enc(g[1]) for g in exp] and [int(x) for x in rb] == [enc(g[2]) for g in exp]
+    assert [bool(x) for x in dead] == [g[3] for g in exp] and [int(x) for x in ro] == [enc(r) for r in exp_out]
+
+
+MID = [("fq12_conjugate", 1 << 20), ("fq12_frobenius:1", 1 << 24), ("fq12_frobenius:2", 1 << 24), ("fq12_frobenius:3", 1 << 24), ("g2_mul_by_char", 1 << 23)]
+BIG = [("fq2_inverse", 1 << 25), ("g1_to_affine", 1 << 25), ("fq12_inverse", 1 << 26), ("fq_sqrt", 160_000_000), ("fq2_sqrt", 500_000_000)]
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("spec,cap", MID + BIG)
+def test_building_blocks_above_fq6_gate_by_gate(spec, cap):
+    """Frobenius maps (fq12.rs:430-442 over fq6.rs:489-515 / fq2.rs:374-384, with the `mul_by_constant` shortcuts for coefficients 0 and R),
+    conjugation, `mul_by_char` (pairing.rs:475-501), the tower inversions (fq2.rs:356-372, fq6.rs:450-487, fq12.rs:413-428 over the binary
+    extended Euclid of fp254impl.rs:333-690), projective -> affine (groth16.rs:26-48), the square-root ladder (fq.rs:290-299 over
+    fp254impl.rs:691-725: 251 squarings + 108 multiplications) and `Fq2::sqrt_general` (fq2.rs:425-446: norm, three exponentiations, one
+    inversion, `is_qnr`, select): product recorder trace == independent Python restatement, gate for gate, derived deadness included.
+    This round's log: profiles/r06_parity/ref_gadgets_above_fq6.log."""
+    n, n_dead = _compare_streams(spec, cap)
+    print("%s: %d gates (%d dead) identical" % (spec, n, n_dead))
