@@ -138,6 +138,11 @@ extern "C" {
     pub fn gsv_session_garble_streaming_calls(s: *mut GsvSession, gate_id_base: u64, first_call: u64, n_calls: u64, dir: *const c_char, first_index: u64, n_threads: c_int, hashes: *mut u8) -> c_int;
     pub fn gsv_session_set_drain_instances(s: *mut GsvSession, n: usize) -> c_int;
     pub fn gsv_session_instances_per_workgroup(s: *const GsvSession, out: *mut c_int) -> c_int;
+    // round 6: deferred release (a `Drop` inside `CiphertextHandler::handle` is safe), the safe-schedule fallback, two plans from one build
+    pub fn gsv_deferred_release_count() -> u64;
+    pub fn gsv_session_fallback_count(s: *const GsvSession, n: *mut u64) -> c_int;
+    pub fn gsv_plan_build_file_pair(circuit_spec: *const c_char, units_csv_a: *const c_char, path_a: *const c_char, window_div_a: u32, units_csv_b: *const c_char, path_b: *const c_char, window_div_b: u32) -> c_int;
+    pub fn gsv_plan_call_record_form(p: *const GsvPlan, call: u64, and_terms: *mut u32) -> c_int;
 }
 
 pub fn chk(rc: c_int) {

@@ -288,12 +288,13 @@ int main(int argc, char** argv) {
   const std::string spec = argv[1], units_csv = argv[2], path = argv[3];
   uint32_t window_div = 4;
   int warm_threads = -1;
-  bool garble = false, ring = false, destroy_in_sink = false;
+  bool garble = false, ring = false, destroy_in_sink = false, engine_mac_too = true;
   uint64_t seed = 0;
   for (int i = 4; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--window-div") && i + 1 < argc) window_div = uint32_t(atoi(argv[++i]));
     else if (!std::strcmp(argv[i], "--warmup-threads") && i + 1 < argc) warm_threads = atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--garble") && i + 1 < argc) { garble = true; seed = std::strtoull(argv[++i], nullptr, 10); }
+    else if (!std::strcmp(argv[i], "--no-engine-mac")) engine_mac_too = false;   // only the host's own CBC-MAC (one serial chain on the sink thread instead of two)
     else if (!std::strcmp(argv[i], "--ring")) ring = true;                        // the whole pass as one launch over a ciphertext ring (GSV_STREAM_RING)
     else if (!std::strcmp(argv[i], "--destroy-in-sink")) destroy_in_sink = true;  // destroy a second session + plan from the sink callback, mid-pass
     else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
@@ -352,6 +353,8 @@ int main(int argc, char** argv) {
     chk(gsv_plan_io(meta, &n_in, &n_out), "gsv_plan_io");
     gsv_plan_destroy(meta);
     gsv_plan_recorder_destroy(pr);
+    std::fprintf(stderr, "PLAN_FILE_READY %s\n", path.c_str());  // (tests: the file is complete — digest it while this process garbles)
+    std::fflush(stderr);
     const size_t n_units = cache->units.size();
     cache.reset();  // the unit programs (their records are in the file)
     struct rusage ru;
@@ -381,7 +384,9 @@ int main(int argc, char** argv) {
       chk(gsv_session_set_garble_inputs(s, delta.data(), consts.data(), inputs.data()), "gsv_session_set_garble_inputs");
       uint8_t engine_mac[16];
       const double t2 = now_s();
-      chk(gsv_session_garble_streaming_sink(s, 0, 0, 0, mac_sink, &sink, 1, engine_mac), "gsv_session_garble_streaming_sink");
+      std::memset(engine_mac, 0, sizeof engine_mac);
+      chk(gsv_session_garble_streaming_sink(s, 0, 0, 0, mac_sink, &sink, 1, engine_mac_too ? engine_mac : nullptr), "gsv_session_garble_streaming_sink");
+      if (!engine_mac_too) std::memcpy(engine_mac, sink.state, 16);
       const double t_garble = now_s() - t2;
       std::vector<uint8_t> out(size_t(n_out) * 16);
       chk(gsv_session_read_outputs(s, out.data(), nullptr), "gsv_session_read_outputs");

@@ -157,13 +157,30 @@ def test_full_verifier_through_the_public_abi(ext_host, verifier_plan_file, tmp_
     d = "/dev/shm" if os.path.isdir("/dev/shm") and os.statvfs("/dev/shm").f_bavail * os.statvfs("/dev/shm").f_frsize > 100e9 else str(tmp_path)
     a, b = os.path.join(d, "gsv_ext_host_%d_abi.gsvplan" % os.getpid()), verifier_plan_file["path"]
     try:
-        j = run_ext(ext_host, case["circuit"], VERIFIER_UNITS, a, "--window-div", 4, "--garble", case["seed"])
+        # the host process, its stderr followed: once its plan file is complete both files are digested here (CPU) while the process loads the
+        # file and garbles (GPU + one serial CBC-MAC chain) — the suite has a time limit
+        import threading
+        proc = subprocess.Popen([ext_host, case["circuit"], ",".join(VERIFIER_UNITS), a, "--window-div", "4", "--garble", str(case["seed"]), "--no-engine-mac"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        digests, err_lines = {}, []
+
+        def follow():
+            for ln in proc.stderr:
+                err_lines.append(ln)
+                if ln.startswith("PLAN_FILE_READY") and not digests:
+                    digests["a"] = plan_digest.digest(a, threads=8)
+        th = threading.Thread(target=follow)
+        th.start()
+        digests["b"] = plan_digest.digest(b, threads=8)
+        out_text = proc.stdout.read()
+        th.join()
+        assert proc.wait() == 0, "".join(err_lines)
+        j = json.loads(out_text.strip().splitlines()[-1])
         assert (j["n_gates"], j["n_ciphertexts"]) == (case["gates"], case["n_ciphertexts"]) == (11_456_865_898, 2_980_165_547)
         assert j["ct_hash"] == case["ct_hash"] == j["engine_ct_hash"] and j["sink_in_order"] and j["sink_records"] == case["n_ciphertexts"]
         out = bytes.fromhex(j["output_label0"])
         assert hashlib.sha256(out).hexdigest() == case["output_label0_sha256"] and out[:16].hex() == case["first_output_label0"]
         j["builtin_build_s"] = verifier_plan_file["build_s"]
-        da, db = plan_digest.digest(a, threads=16), plan_digest.digest(b, threads=16)
+        da, db = digests["a"], digests["b"]
         j["plan_digest"], j["builtin_plan_digest"] = da["digest"], db["digest"]
         out_dir = os.path.join(ROOT, "gpurun_out")
         if os.path.isdir(out_dir):

@@ -1350,7 +1350,7 @@ def test_verifier_lockstep_two_instances_per_workgroup(engine, compressed_verifi
     for B, ni in ((1024, 4), (512, 2)):
         sess = gsv.Session(engine, plan, B, retain_stream=False, concurrent_calls=1)  # sequential schedule: the same windows for every batch size
         assert sess.instances_per_workgroup == ni
-        sl = bench.session_slices(sess.windows(), ci[:, 1], 100)[0]  # decompression ladders: thousands of narrow steps (~30 M ciphertexts per instance)
+        sl = bench.session_slices(sess.windows(), ci[:, 1], 400)[0]  # decompression ladders: thousands of narrow steps (~7.5 M ciphertexts per instance: 1 024 x 120 MB over PCIe per run)
         assert (first, n) in ((None, None), sl[:2])
         first, n = sl[:2]
         for _ in range(2):
@@ -1374,18 +1374,21 @@ def test_verifier_lockstep_two_instances_per_workgroup(engine, compressed_verifi
     par.close()
 
 
-def test_verifier_whole_pass_four_per_workgroup_ciphertexts(engine, compressed_verifier_plan):
-    """The bench's TIMED configuration over a WHOLE pass with its ciphertexts checked: 1 024 instances of the verifier, four per workgroup
+def test_verifier_whole_pass_four_per_workgroup_ciphertexts(engine, compressed_verifier_plan, monkeypatch):
+    """The bench's TIMED kernel configuration over a WHOLE pass with its ciphertexts checked: the verifier at four instances per workgroup
     (run_program_kernel<false, 4, 0, *>, the default schedule's windows), every instance garbled, the streams of instances 0..7 — all four
     workgroup positions, two workgroups — drained and CBC-MAC'ed (gsv_session_set_drain_instances).  Instance 0 carries the
     single-instance fixture's seed, instances 1..7 seeds of the cut-and-choose fixture: MAC over all 2 980 165 547 ciphertexts and the
     output label of each == the CPU oracle's flat stream (examples/groth16_garble.rs:255-263 compares exactly this hash).  The other
-    1 016 instances carry the fixture's seed as well: their output labels must equal instance 0's."""
+    instances carry the fixture's seed as well: their output labels must equal instance 0's.  262 instances (66 workgroups, the last one
+    RAGGED: two of its four groups idle through every barrier) since round 6 — bench.py itself checks the 1 024-instance batch after its
+    timed steps in every run (`headline_ciphertext_check`), and the suite has to fit the driver's time limit (113 s -> ~40 s)."""
     import garbled_snark_verifier_amd as gsv
     case, plan = compressed_verifier_plan
     gold = json.load(open(os.path.join(os.path.dirname(GOLDEN), "cc16_verifier_golden.json")))
     assert gold["gates"] == case["gates"] == plan.info["n_gates"]
-    B, n_in = 1024, plan.info["n_inputs"]
+    monkeypatch.setenv("GSV_INSTANCES_PER_WG", "4")
+    B, n_in = 262, plan.info["n_inputs"]
     seeds = [case["seed"]] + [int(x) for x in gold["seeds"][:7]] + [case["seed"]] * (B - 8)
     labs = {sd: gsv.labels_from_seed(sd, n_in) for sd in set(seeds)}
     delta = np.stack([labs[sd][0] for sd in seeds]); consts = np.stack([np.stack([labs[sd][1], labs[sd][2]]) for sd in seeds]); inputs = np.stack([labs[sd][3] for sd in seeds])
@@ -1402,6 +1405,8 @@ def test_verifier_whole_pass_four_per_workgroup_ciphertexts(engine, compressed_v
     sess.close()
 
 
+@pytest.mark.slow  # (round 6: opt-in, `-m "gpu and slow"` — the valid / tampered evaluation at full size stays in the default set as test_verifier_garble_evaluate_at_full_size,
+                   #  which evaluates the same two proofs WHILE they are garbled; gsv_session_evaluate over a retained stream is covered at component size by every _evaluate_and_check)
 def test_compressed_verifier_evaluates_valid_and_tampered_proof(engine, compressed_verifier_plan):
     """BASELINE config 4, evaluator side (EvaluateMode over the whole circuit, evaluate_mode.rs:123-158): two instances of the
     verifier are garbled with their 49 GB ciphertext streams retained in HBM and evaluated — one with the valid proof's input bits,

@@ -41,7 +41,7 @@ def strip_comments(text):
 def c_functions():
     hdr = strip_comments(open(os.path.join(ROOT, "include", "gsv_engine.h")).read())
     out = {}
-    for m in re.finditer(r"\b(?:int|void|const char\s*\*)\s*(gsv_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+    for m in re.finditer(r"\b(?:int|void|uint64_t|const char\s*\*)\s*(gsv_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
         name, params = m.group(1), " ".join(m.group(2).split())
         types = []
         if params and params != "void":
