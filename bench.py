@@ -639,7 +639,6 @@ def run_verifier(args):
         plan_info["how"] = "built to file together with the small-batch plan (gsv_plan_build_file_pair), loaded"
         plan_info["build_s"] = small_build["pair_build_s"]
         plan_info["seconds"] += small_build["pair_build_s"]
-    aes_and_per_s, aes_src = measure_aes_ceiling(log) if rank == 0 else (AES_CEILING_AND_PER_S_R02, "not measured on this rank")
     if small_build["thread"] is not None:
         # the builder's threads (compile pool + warm-up recorders) stay below the CPU quota: a cgroup that runs out of quota throttles ALL its
         # threads — the one that launches the timed windows too — for the rest of the period
@@ -693,6 +692,8 @@ def run_verifier(args):
 
     t_first_launch = time.time() - T_START
     r = timed_steps(work, slices, args.warmup, args.steps, dist, sync, args.time_budget, T_START)
+    # (the T-table ceiling of this box: a child process of a few seconds, behind the timed steps since round 6)
+    aes_and_per_s, aes_src = measure_aes_ceiling(log) if rank == 0 else (AES_CEILING_AND_PER_S_R02, "not measured on this rank")
     label_match = None
     if rank == 0 and (args.warmup + r["steps_run"]) >= len(slices) and r["commit_table"] is not None:
         # the last completed pass's output label of instance 0 (fixture seed), as gathered in its commit record: commit(label0) of output 0
@@ -967,7 +968,7 @@ def run_verifier(args):
                               "1": None if "1" not in rbi_ or "seconds" not in rbi_["1"] else ready + rbi_["1"]["seconds"],
                               "1_with_commitment": None if "with_commitment" not in rbi_.get("1", {}) else ready + rbi_["1"]["with_commitment"]["seconds"],
                               "16": None if "16" not in rbi_ or "seconds" not in rbi_["16"] else ready + rbi_["16"]["seconds"],
-                              "note": "plan file build (beside the headline plan's build when the file did not exist) + load into HBM + one whole pass; reference: ~350 s for one instance on one core"}
+                              "note": "plan file build (behind the timed steps, with fewer threads than the CPU quota has cores, when the file did not exist) + load into HBM + one whole pass; reference: ~350 s for one instance on one core"}
         except Exception as e:  # noqa: BLE001
             cold_start = {"error": repr(e)}
         result.update({
