@@ -429,13 +429,7 @@ inline Program compile_program(const Trace& t, const std::vector<uint32_t>& inpu
     }
     for (size_t i = n; i-- > 0;)  // the fused list is in stream order: producers precede their readers
       for (int k = 0; k < fi; ++k) { const uint32_t w = ins(i)[k]; if (w != DEAD_WIRE && prod[w] != NONE) height[prod[w]] = std::max(height[prod[w]], height[i] + 1); }
-    const int sched_key = getenv("GSV_SCHED_KEY") ? atoi(getenv("GSV_SCHED_KEY")) : 0;  // experiment: 1 = stream order only, 2 = height in coarse buckets then stream order
-    const uint32_t bucket = getenv("GSV_SCHED_BUCKET") ? uint32_t(std::max(1, atoi(getenv("GSV_SCHED_BUCKET")))) : 64u;
-    auto key = [&](uint32_t i) -> uint64_t {
-      if (sched_key == 1) return uint64_t(0xFFFFFFFFu - i);
-      if (sched_key == 2) return (uint64_t(height[i] / bucket) << 32) | (0xFFFFFFFFu - i);
-      return (uint64_t(height[i]) << 32) | (0xFFFFFFFFu - i);  // longest path first, then stream order
-    };
+    auto key = [&](uint32_t i) -> uint64_t { return (uint64_t(height[i]) << 32) | (0xFFFFFFFFu - i); };  // longest path first, then stream order
     std::priority_queue<uint64_t> ready[2];
     for (size_t i = 0; i < n; ++i) if (pending[i] == 0) ready[is_and(i) ? 0 : 1].push(key(uint32_t(i)));
     const uint32_t cap[2] = {opt.and_cap ? opt.and_cap : 0xFFFFFFFFu, opt.xor_cap ? opt.xor_cap : 0xFFFFFFFFu};
