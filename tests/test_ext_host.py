@@ -147,15 +147,16 @@ def test_abi_misuse_is_refused(tmp_path):
 
 
 @pytest.mark.gpu
-def test_full_verifier_through_the_public_abi(ext_host, verifier_plan_file, tmp_path):
+def test_full_verifier_through_the_public_abi(ext_host, request, tmp_path):
     """BASELINE config 4 from an external host: record -> plan file through gsv_plan_recorder_* (1 257 calls, 212 unit programs, 11.46 B
     gates), gsv_plan_load, one instance garbled with retain_stream = 0 through gsv_session_garble_streaming_sink into the host's own
     CBC-MAC.  MAC and output label == the CPU oracle's flat-stream fixture; the plan file == the built-in builder's (the session's shared
     file, conftest.verifier_plan_file); build time and host RSS reported (profiles/r05_e2e/ext_host_verifier.json keeps one run)."""
     import plan_digest
-    case = verifier_plan_file["case"]
+    from conftest import HERE
+    case = json.load(open(os.path.join(HERE, "golden", "groth16_verify_compressed_1pub_golden.json")))
     d = "/dev/shm" if os.path.isdir("/dev/shm") and os.statvfs("/dev/shm").f_bavail * os.statvfs("/dev/shm").f_frsize > 100e9 else str(tmp_path)
-    a, b = os.path.join(d, "gsv_ext_host_%d_abi.gsvplan" % os.getpid()), verifier_plan_file["path"]
+    a = os.path.join(d, "gsv_ext_host_%d_abi.gsvplan" % os.getpid())
     try:
         # the host process, its stderr followed: once its plan file is complete both files are digested here (CPU) while the process loads the
         # file and garbles (GPU + one serial CBC-MAC chain) — the suite has a time limit
@@ -170,6 +171,10 @@ def test_full_verifier_through_the_public_abi(ext_host, verifier_plan_file, tmp_
                     digests["a"] = plan_digest.digest(a, threads=8)
         th = threading.Thread(target=follow)
         th.start()
+        # the session's built-in plan file (conftest.verifier_plan_file) is built NOW, beside the host process's own build through the ABI
+        # (both CPU-bound: ~85 s side by side instead of 50 + 52 s one after the other)
+        verifier_plan_file = request.getfixturevalue("verifier_plan_file")
+        b = verifier_plan_file["path"]
         digests["b"] = plan_digest.digest(b, threads=8)
         out_text = proc.stdout.read()
         th.join()
@@ -186,7 +191,7 @@ def test_full_verifier_through_the_public_abi(ext_host, verifier_plan_file, tmp_
         if os.path.isdir(out_dir):
             json.dump(j, open(os.path.join(out_dir, "ext_host_verifier.json"), "w"), indent=1)
         assert da == db
-        assert j["build_s"] <= 2.0 * j["builtin_build_s"] + 10.0, j
+        assert j["build_s"] <= 2.0 * j["builtin_build_s"] + 10.0, j  # (both built side by side since round 6)
     finally:
         if os.path.exists(a):
             os.remove(a)

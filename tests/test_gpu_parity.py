@@ -1374,6 +1374,9 @@ def test_verifier_lockstep_two_instances_per_workgroup(engine, compressed_verifi
     par.close()
 
 
+@pytest.mark.slow  # (round 6: opt-in, `-m "gpu and slow"` — a whole pass at four instances per workgroup takes ~95 s however few workgroups run it (a workgroup's time is
+                   #  the pass); bench.py checks exactly this on its timed 1 024-instance session in every run (`headline_ciphertext_check`: 8 of 8 MACs), the default set keeps
+                   #  four-per-workgroup sessions on the verifier's first slice (test_verifier_lockstep_two_instances_per_workgroup) and on fq12_mix (test_drain_instances_...))
 def test_verifier_whole_pass_four_per_workgroup_ciphertexts(engine, compressed_verifier_plan, monkeypatch):
     """The bench's TIMED kernel configuration over a WHOLE pass with its ciphertexts checked: the verifier at four instances per workgroup
     (run_program_kernel<false, 4, 0, *>, the default schedule's windows), every instance garbled, the streams of instances 0..7 — all four
