@@ -452,6 +452,7 @@ static int launch_plan_window(gsv_session* s, size_t w, uint64_t gate_id_base, b
   ka.n_steps = 0; ka.n_slots = f.n_slots; ka.replays = 1; ka.rep_base = 0; ka.ct_cap_replays = 1;
   ka.n_instances = uint32_t(s->n_inst); ka.hasher = uint32_t(s->hasher); ka.instances_per_wg = s->ni;
   for (uint32_t k = win.call0; k < win.call1 && !ka.any_four_wire; ++k) ka.any_four_wire = s->call_prog(k).and_terms == 4;
+  if (const char* dg = getenv("GSV_DIAG")) ka.diag = uint32_t(atoi(dg));  // timing experiments (libgsv_engine_diag.so only): outputs are wrong when set
   int lrc = gsvk_launch_batch(&ka, uint32_t(s->n_inst), win.call1 - win.call0, eval ? 1 : 0, stream);
   if (lrc != 0) return fail(GSV_ERR_DEVICE, std::string("kernel launch failed: ") + hipGetErrorString(hipError_t(lrc)));
   return GSV_OK;

@@ -29,6 +29,12 @@
 // gates from the top lane down, two other issue-priority schemes, the four-lane quad form for every program) live as a patch against this
 // file in profiles/r05_kernel/rejected_variants.patch, with their A/B logs beside it; this file holds the adopted code only.
 
+// Round 6 A/B: per-group step barriers at NI > 1 (an arrival counter per instance group in LDS instead of the workgroup-wide s_barrier): the
+// groups of a workgroup run independent instances and need not pass their steps together.  2 = with a start skew between the groups.
+#ifndef GSV_GROUP_BAR
+#define GSV_GROUP_BAR 0
+#endif
+
 namespace gsv {
 namespace dev {
 
@@ -329,6 +335,14 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     }
     __syncthreads();
   }
+#if GSV_GROUP_BAR
+  uint32_t bar_target = 0;  // arrivals of this group's waves so far (per-group step barrier)
+  if (threadIdx.x < uint32_t(NI)) *reinterpret_cast<lds_u32*>(uintptr_t(GSV_LDS_BYTES + 4u * threadIdx.x)) = 0u;
+  __syncthreads();
+#if GSV_GROUP_BAR == 2
+  for (uint32_t k = 0; k < sub * 3u; ++k) __builtin_amdgcn_s_sleep(127);  // start skew: ~3.4 us per sleep (127 x 64 clocks), ~10 us per group index = a fraction of a wide step
+#endif
+#endif
   cst_u128* const step_q = (cst_u128*)ka.steps;
   // Timing ablations (GSV_DIAG, kernel_api.h) exist only in a library built with -DGSV_DIAG_BUILD (build.py --diag): as run-time
   // flags they cost the production loop a dozen register initialisations and several branches per gate.
@@ -699,7 +713,20 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       if (!no_refill) r0 = load_rec(n2sd);  // stays in flight across the barrier and the whole next step
       GSV_PC_STAMP(5, and_cnt);  // the refill has been issued (ordered by the asm's memory clobber; no dependency on its data)
       if (no_barrier) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if GSV_GROUP_BAR
+      else if (NI > 1) {
+        // arrive: this wave's LDS stores are done (lgkmcnt), its wire-file stores are issued (the group's waves share the CU's L1, as above)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lds_u32* const ctr = reinterpret_cast<lds_u32*>(uintptr_t(GSV_LDS_BYTES + 4u * sub));
+        bar_target += BT / 64u;
+        if ((threadIdx.x & 63u) == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (int32_t(uint32_t(__builtin_amdgcn_readfirstlane(int(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)))) - bar_target) < 0) __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");
+      }
       else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+      else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 #ifdef GSV_DIAG_BUILD
       if (phase_clock) {
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pc_t[6]) : : "memory");
@@ -844,7 +871,7 @@ int gsvk_upload_round_keys(const uint32_t rk[44]) {
 int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, int evaluate, hipStream_t stream) { return gsvk_launch_batch(ka, n_instances, 1, evaluate, stream); }
 int gsvk_launch_batch(const gsv::dev::KernelArgs* ka, uint32_t n_instances, uint32_t n_calls, int evaluate, hipStream_t stream) {
   if (n_calls == 0 || n_calls > 65535u || (n_calls > 1 && !ka->calls) || (ka->calls && (!ka->flags || !ka->error))) return int(hipErrorInvalidValue);
-  const size_t lds = GSV_LDS_BYTES;
+  const size_t lds = GSV_LDS_BYTES + (GSV_GROUP_BAR ? 16u : 0u);
   // The opt-in to 160 KiB of dynamic LDS is a per-device function attribute: done once per device (an engine per GPU may live
   // in one process, and sessions may be driven from several host threads).
   {
