@@ -96,17 +96,35 @@ def check_step_barrier_isa(asm=None):
     for name, ins in kernels.items():
         def prefetch_in_front(i):
             # the instruction in front of the wait, looking through scalar bookkeeping the compiler may put there (reloads of spilled
-            # SGPRs from VGPR lanes, scalar ALU): it must be the record prefetch, and nothing in between may wait for vector memory
+            # SGPRs from VGPR lanes, scalar ALU, and — since the FW instantiations choose between two barrier forms — scalar branches and
+            # the other form's own scalar instructions): it must be the record prefetch, and nothing in between may wait for vector memory
             j = i - 1
-            while j > 0 and (ins[j].startswith(("v_readlane_b32", "v_writelane_b32", "s_nop", "s_setprio")) or (ins[j].startswith("s_") and not ins[j].startswith(("s_waitcnt", "s_barrier", "s_cbranch", "s_branch", "s_endpgm")))):
+            while j > 0 and (ins[j].startswith(("v_readlane_b32", "v_writelane_b32", "s_nop", "s_setprio")) or (ins[j].startswith("s_") and "vmcnt" not in ins[j] and not ins[j].startswith("s_endpgm"))):
                 j -= 1
             return ins[j].startswith("global_load_dwordx4")
+        grouped = "ELb1EEE" in name and ("ELi2ELi0" in name or "ELi4ELi0" in name)  # FW instantiations with several instances per workgroup: per-group barrier
         n = sum(1 for i, t in enumerate(ins) if t == "s_waitcnt lgkmcnt(0)" and 0 < i < len(ins) - 1 and ins[i + 1] == "s_barrier" and prefetch_in_front(i))
-        if n != 2:
-            raise RuntimeError("%s: found %d step barriers with the record prefetch issued right in front of them, expected 2" % (name, n))
+        if n != (0 if grouped else 2):
+            raise RuntimeError("%s: found %d step barriers with the record prefetch issued right in front of them, expected %d" % (name, n, 0 if grouped else 2))
         # (the one legitimate vmcnt wait in front of a barrier is the dataflow epilogue's agent-scope release: buffer_wbl2 ; s_waitcnt vmcnt(0))
         if any(t.startswith("s_waitcnt vmcnt") and i + 1 < len(ins) and ins[i + 1] == "s_barrier" and not (i and ins[i - 1].startswith("buffer_wbl2")) for i, t in enumerate(ins)):
             raise RuntimeError("%s: a barrier waits for vector memory" % name)
+        # Per-group step barrier (round 6: FW instantiations with several instances per workgroup): the arrive is `s_waitcnt lgkmcnt(0)`,
+        # lane 0's `ds_add_u32`, then a poll loop over `ds_read_b32` — all on VGPRs of its own.  Exactly two of them (the step loop is
+        # unrolled by two), each reached from the record prefetch without a vector-memory wait (a barrier that waited for the step's store
+        # acknowledgements would cost ~1 us per step), and the poll loop holds no vector-memory wait either.
+        arrives = [i for i, t in enumerate(ins) if t.startswith("ds_add_u32")]
+        if grouped:
+            if len(arrives) != 2:
+                raise RuntimeError("%s: found %d per-group barrier arrivals (ds_add_u32), expected 2" % (name, len(arrives)))
+            for i in arrives:
+                if not (ins[i - 1] == "s_mov_b64 exec, 1" and prefetch_in_front(i)):
+                    raise RuntimeError("%s: a per-group barrier is not reached from the record prefetch without a vector-memory wait" % name)
+                loop = ins[i + 1:i + 12]
+                if not any(t.startswith("ds_read_b32") for t in loop) or any("vmcnt" in t for t in loop):
+                    raise RuntimeError("%s: unexpected per-group barrier poll loop: %r" % (name, loop))
+        elif arrives:
+            raise RuntimeError("%s: a per-group barrier in an instantiation that should not have one" % name)
         out[name] = n
     return out
 

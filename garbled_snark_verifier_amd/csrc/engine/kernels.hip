@@ -29,12 +29,6 @@
 // gates from the top lane down, two other issue-priority schemes, the four-lane quad form for every program) live as a patch against this
 // file in profiles/r05_kernel/rejected_variants.patch, with their A/B logs beside it; this file holds the adopted code only.
 
-// Round 6 A/B: per-group step barriers at NI > 1 (an arrival counter per instance group in LDS instead of the workgroup-wide s_barrier): the
-// groups of a workgroup run independent instances and need not pass their steps together.  2 = with a start skew between the groups.
-#ifndef GSV_GROUP_BAR
-#define GSV_GROUP_BAR 0
-#endif
-
 namespace gsv {
 namespace dev {
 
@@ -55,6 +49,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 //                 * Te1 = rotl8(Te0), Te3 = rotl8(Te2): one v_alignbit for half of the lookups, none in the last round.
 //   [64 KiB, +90 KiB)      label window: GSV_LDS_SLOTS x 16 B, the short-lived wires chosen by the compiler
 //   [.., +5.6 KiB)         plaintext bits of window wires (evaluate mode)
+//   [.., +16 B)            arrival counters of the per-group step barrier, one per instance group (FW instantiations)
 //   [.., +176 B)           the 44 round-key words (read with a wave-uniform address = LDS broadcast; keeping them
 //                          in SGPRs instead spilled ~60 SGPRs and put v_readlane/v_writelane into every step)
 #define GSV_SLOT_LDS_FLAG (1u << 20)
@@ -335,14 +330,22 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
     }
     __syncthreads();
   }
-#if GSV_GROUP_BAR
-  uint32_t bar_target = 0;  // arrivals of this group's waves so far (per-group step barrier)
-  if (threadIdx.x < uint32_t(NI)) *reinterpret_cast<lds_u32*>(uintptr_t(GSV_LDS_BYTES + 4u * threadIdx.x)) = 0u;
-  __syncthreads();
-#if GSV_GROUP_BAR == 2
-  for (uint32_t k = 0; k < sub * 3u; ++k) __builtin_amdgcn_s_sleep(127);  // start skew: ~3.4 us per sleep (127 x 64 clocks), ~10 us per group index = a fraction of a wide step
-#endif
-#endif
+  // Per-GROUP step barrier (round 6) for the latency-bound (four-wire) programs at several instances per workgroup: the instance groups of a
+  // workgroup garble independent instances and need not pass their steps together — an arrival counter per group in LDS, polled by the
+  // group's own waves, replaces the workgroup-wide s_barrier, so a group whose waves are done with a narrow step starts the next one without
+  // waiting for the slowest wave of the other three groups.  Ladders +7.1 %, inversions +2.0 % at 1 024 instances; the wide (two-wire)
+  // programs lose 0.5 % to the polling (profiles/r06_kernel/kernel_ab_gbar.log): the launches without a four-wire program (two thirds of a
+  // pass) keep s_barrier, the FW instantiations use the group barrier for every call of their windows (one barrier form per instantiation:
+  // the compiler's output — and build.py's ISA check of it — stays simple).  Round 2 had measured +-0 for the same idea at two groups per
+  // workgroup on the programs of that time; a start skew between the groups adds nothing (gbar2 in the same log).
+  constexpr bool group_barrier = FW && NI > 1;
+  uint32_t bar_target = 0;  // arrivals of this group's waves so far
+  uint32_t bar_addr = GSV_LDS_GROUP_BAR_BASE + 4u * sub, bar_one = 1u, bar_val = 0u;  // the barrier's own VGPRs (see the step barrier below)
+  if (group_barrier) {
+    asm volatile("" : "+v"(bar_addr), "+v"(bar_one), "+v"(bar_val));
+    if (threadIdx.x < uint32_t(NI)) *reinterpret_cast<lds_u32*>(uintptr_t(GSV_LDS_GROUP_BAR_BASE + 4u * threadIdx.x)) = 0u;
+    __syncthreads();
+  }
   cst_u128* const step_q = (cst_u128*)ka.steps;
   // Timing ablations (GSV_DIAG, kernel_api.h) exist only in a library built with -DGSV_DIAG_BUILD (build.py --diag): as run-time
   // flags they cost the production loop a dozen register initialisations and several branches per gate.
@@ -713,20 +716,34 @@ __global__ __launch_bounds__(GSV_BLOCK_THREADS) void run_program_kernel(KernelAr
       if (!no_refill) r0 = load_rec(n2sd);  // stays in flight across the barrier and the whole next step
       GSV_PC_STAMP(5, and_cnt);  // the refill has been issued (ordered by the asm's memory clobber; no dependency on its data)
       if (no_barrier) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if GSV_GROUP_BAR
-      else if (NI > 1) {
-        // arrive: this wave's LDS stores are done (lgkmcnt), its wire-file stores are issued (the group's waves share the CU's L1, as above)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        lds_u32* const ctr = reinterpret_cast<lds_u32*>(uintptr_t(GSV_LDS_BYTES + 4u * sub));
+      else if (group_barrier) {
+        // arrive (lane 0 adds one to the group's counter) once this wave's LDS stores are done — its wire-file stores are issued, and the
+        // group's waves share the CU's L1 as above — then poll until all of the group's waves have arrived.  Inline assembly over three
+        // VGPRs that nothing else touches: written in C++ the counter's address and value land in registers that the step's stores have just
+        // used as sources, and the compiler waits for those stores' acknowledgements (s_waitcnt vmcnt) in front of every barrier.
         bar_target += BT / 64u;
-        if ((threadIdx.x & 63u) == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (int32_t(uint32_t(__builtin_amdgcn_readfirstlane(int(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)))) - bar_target) < 0) __builtin_amdgcn_s_sleep(2);
-        asm volatile("" ::: "memory");
+        uint64_t sv;
+        uint32_t tmp;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                     "s_mov_b64 %[sv], exec\n\t"
+                     "s_mov_b64 exec, 1\n\t"
+                     "ds_add_u32 %[addr], %[one]\n\t"
+                     "s_mov_b64 exec, %[sv]\n"
+                     ".Lgsv_gbar_poll%=:\n\t"
+                     "ds_read_b32 %[val], %[addr]\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "v_readfirstlane_b32 %[tmp], %[val]\n\t"
+                     "s_sub_i32 %[tmp], %[tmp], %[target]\n\t"
+                     "s_cmp_lt_i32 %[tmp], 0\n\t"
+                     "s_cbranch_scc0 .Lgsv_gbar_done%=\n\t"
+                     "s_sleep 2\n\t"
+                     "s_branch .Lgsv_gbar_poll%=\n"
+                     ".Lgsv_gbar_done%=:"
+                     : [val] "+v"(bar_val), [sv] "=&s"(sv), [tmp] "=&s"(tmp)
+                     : [addr] "v"(bar_addr), [one] "v"(bar_one), [target] "s"(bar_target)
+                     : "memory", "scc");
       }
       else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-      else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 #ifdef GSV_DIAG_BUILD
       if (phase_clock) {
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pc_t[6]) : : "memory");
@@ -871,7 +888,7 @@ int gsvk_upload_round_keys(const uint32_t rk[44]) {
 int gsvk_launch_program(const gsv::dev::KernelArgs* ka, uint32_t n_instances, int evaluate, hipStream_t stream) { return gsvk_launch_batch(ka, n_instances, 1, evaluate, stream); }
 int gsvk_launch_batch(const gsv::dev::KernelArgs* ka, uint32_t n_instances, uint32_t n_calls, int evaluate, hipStream_t stream) {
   if (n_calls == 0 || n_calls > 65535u || (n_calls > 1 && !ka->calls) || (ka->calls && (!ka->flags || !ka->error))) return int(hipErrorInvalidValue);
-  const size_t lds = GSV_LDS_BYTES + (GSV_GROUP_BAR ? 16u : 0u);
+  const size_t lds = GSV_LDS_BYTES;
   // The opt-in to 160 KiB of dynamic LDS is a per-device function attribute: done once per device (an engine per GPU may live
   // in one process, and sessions may be driven from several host threads).
   {
