@@ -402,7 +402,11 @@ def test_step_barrier_isa_check():
     from garbled_snark_verifier_amd import build
     asm = build.disassemble_kernels()
     res = build.check_step_barrier_isa(asm)
-    assert len(res) == 16 and set(res.values()) == {2}  # (garble / evaluate x 1, 2, 4 instances per workgroup + the two Blake3 kernels) x (two-wire only / four-wire capable)
+    # (garble / evaluate x 1, 2, 4 instances per workgroup + the two Blake3 kernels) x (two-wire only / four-wire capable); the four-wire capable
+    # instantiations with several instances per workgroup use the per-GROUP barrier since round 6 (two LDS arrival counters' worth of
+    # `ds_add_u32` instead of the two `s_barrier`s, equally free of vector-memory waits: checked by the same function)
+    assert len(res) == 16 and sorted(res.values()) == [0] * 4 + [2] * 12
+    assert all((v == 0) == ("ELb1EEE" in k and ("ELi2ELi0" in k or "ELi4ELi0" in k)) for k, v in res.items())
     lines = asm.splitlines()
     k = next(i for i, l in enumerate(lines) if "s_waitcnt lgkmcnt(0)" in l and "s_barrier" in lines[i + 1] and "global_load_dwordx4" in lines[i - 1])
     # something scheduled between the prefetch and the barrier
@@ -416,6 +420,11 @@ def test_step_barrier_isa_check():
     probe = build.check_workgroup_release_model()
     st, ba, ld = (next(i for i, t in enumerate(probe) if t.startswith(x)) for x in ("global_store", "s_barrier", "global_load"))
     assert st < ba < ld and not any("vmcnt" in t or t.startswith("buffer_") for t in probe[st:ld])
+    # a per-group barrier that waits for the step's stores (what the compiler made of the C++ form: profiles/r06_kernel/) trips the check too
+    g = next(i for i, l in enumerate(lines) if "s_mov_b64 exec, 1" in l and "ds_add_u32" in lines[i + 1])
+    bad = lines[:g - 1] + ["\ts_waitcnt vmcnt(1)    // doctored"] + lines[g - 1:]
+    with pytest.raises(RuntimeError, match="per-group barrier"):
+        build.check_step_barrier_isa("\n".join(bad))
     # the correctness precondition itself — the kernels object is NOT built for threadgroup-split mode — is what build() enforces
     # (the instruction-adjacency properties above are performance properties: build() only warns about them)
     assert build.check_not_tgsplit() is True

@@ -54,7 +54,7 @@ def audit():
             bm = re.match(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", t)
             if bm and bm.group(1) in labpos and labpos[bm.group(1)] <= k:
                 loops.append((labpos[bm.group(1)], k))
-        bars = [k for k, t in enumerate(ins) if t.startswith("s_barrier")]
+        bars = [k for k, t in enumerate(ins) if t.startswith(("s_barrier", "ds_add_u32"))]  # (ds_add_u32: the arrive of the per-group step barrier, FW instantiations at NI > 1)
         cand = sorted([(a, b) for a, b in loops if sum(1 for x in bars if a <= x <= b) >= 2], key=lambda ab: ab[1] - ab[0])  # the smallest such loop: the step loop (the replay loop around it is larger)
         a, b = cand[0] if cand else (0, -1)
         cnt = lambda seg: {"ins": len(seg), "readlane": sum(1 for t in seg if t.startswith("v_readlane")), "writelane": sum(1 for t in seg if t.startswith("v_writelane")),
