@@ -82,11 +82,11 @@ def test_plan_file_pair_equals_separately_built_files(tmp_path, divs):
     import garbled_snark_verifier_amd as gsv
     import plan_digest
     d = str(tmp_path)
-    for spec, units in [("fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"]), ("fq_mul", ["no::such_unit"])]:
+    for spec, units, variants in [("fq12_mix", ["fq12::mul_montgomery", "fq12::square_montgomery"], [["fq6::mul_montgomery", "fq2::square_montgomery"]]), ("fq_mul", ["no::such_unit"], [None])]:
         pa, pb = os.path.join(d, "pair_a.gsvplan"), os.path.join(d, "pair_b.gsvplan")
-        # the same units for both plans (one recorder), and — fq12_mix — plan B cut at Fq6 level (two recorders over one unit cache: what
-        # bench.py's headline / small-batch pair is)
-        for units_b in [None] + ([["fq6::mul_montgomery", "fq2::square_montgomery"]] if spec == "fq12_mix" else []):
+        # fq12_mix: plan B cut at Fq6 level (two recorders over one unit cache: what bench.py's headline / small-batch pair would be);
+        # fq_mul: the same (empty) unit set for both plans (one recorder, every program compiled twice)
+        for units_b in variants:
             gsv.Plan.build_file_pair(spec, units, pa, divs[0], pb, divs[1], units_b=units_b)
             for path, div, un in ((pa, divs[0], units), (pb, divs[1], units_b or units)):
                 ref = os.path.join(d, "single.gsvplan")
