@@ -100,6 +100,9 @@ impl<CTH: CiphertextHandler> GpuGarbleMode<CTH> {
         let mut out = vec![0u8; outputs.len() * 16];
         chk(unsafe { gsv_session_read_outputs(sess, out.as_mut_ptr(), std::ptr::null_mut()) });
         self.results = out.chunks_exact(16).map(|b| S::from_bytes(b.try_into().unwrap())).collect();
+        // (round 6: these calls are safe from ANY thread at ANY time — also from inside a CiphertextHandler of another mode that is in the
+        //  middle of its pass: the engine queues releases while a streaming pass is in flight and runs them when it has ended,
+        //  include/gsv_engine.h "Deferred release"; tests/ext_host/ext_host.cpp --destroy-in-sink is the compiled twin)
         unsafe {
             gsv_session_destroy(sess);
             if !plan.is_null() { gsv_plan_destroy(plan) }
