@@ -2,6 +2,8 @@
 # Round 6: A/B of the COMPILER's step schedule on the kernel_ab3 shapes (one box, one library): "base" = ASAP levels, else
 # "<key>:<and_cap>:<xor_cap>:<bucket>" = width-capped list scheduling with GSV_SCHED_KEY (0 longest path first, 1 stream order,
 # 2 longest path in buckets of <bucket> levels then stream order).  A parity subset against the oracle runs under every setting.
+# GSV_SCHED_KEY exists only with profiles/r06_kernel/sched_key_experiment.patch applied to csrc/engine/program.hpp (the experiment was not
+# adopted); without it every <key> behaves like 0.
 # usage: sched_ab_r06.sh <tag> <config> [<config> ...]
 TAG=$1; shift
 mkdir -p gpurun_out/r06_kernel
