@@ -630,7 +630,7 @@ int gsv_session_fallback_count(const gsv_session* s, uint64_t* n) {
 // safe schedule, so that the host's own repeat of the pass (from gsv_session_set_garble_inputs on) succeeds.
 static int garble_streaming_range(gsv_session* s, uint64_t gate_id_base, size_t c0, size_t c1, const DrainSink& sink, int n_threads, gsv_session* ev = nullptr) {
   int rc = garble_streaming_pass(s, gate_id_base, c0, c1, sink, n_threads, ev);
-  if (rc != GSV_ERR_DEVICE || !s->plan || !s->dep_fault || s->safe_mode) return rc;
+  if (rc != GSV_ERR_DEVICE || !s->plan || !(s->dep_fault || (ev && ev->dep_fault)) || s->safe_mode) return rc;
   const std::string first_error = g_err;
   const bool whole = c0 == 0 && c1 == s->plan->calls.size();
   int frc = fall_back_to_safe_schedule(s);

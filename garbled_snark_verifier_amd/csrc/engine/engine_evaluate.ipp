@@ -16,7 +16,7 @@ int gsv_session_evaluate(gsv_session* s, uint64_t gate_id_base) {
 // page-locked 16 MiB staging buffer: a window may be gigabytes), are folded into the per-instance CBC-MAC as FileSource does while
 // reading (ciphertext_source.rs:36-107), uploaded, scattered to the program-order positions the kernel reads, and evaluated.
 //   read(instance, first_record, dst, n) -> 0, or non-zero when the source runs dry ("Ciphertext source exhausted", evaluate_mode.rs:139-142)
-static int evaluate_streaming_impl(gsv_session* s, uint64_t gate_id_base, const std::function<int(size_t, uint64_t, uint8_t*, uint64_t)>& read, uint8_t* hashes) {
+static int evaluate_streaming_pass(gsv_session* s, uint64_t gate_id_base, const std::function<int(size_t, uint64_t, uint8_t*, uint64_t)>& read, uint8_t* hashes) {
   const Program& g = s->prog();
   // plan sessions: one window of the schedule per launch, its ciphertexts uploaded SEGMENT by segment (schedule.hpp: a gate-order buffer
   // holds the largest segment, the program-order device block the largest window); program sessions: one ring per launch
@@ -149,6 +149,18 @@ static int evaluate_streaming_impl(gsv_session* s, uint64_t gate_id_base, const 
   if (hashes) for (size_t i = 0; i < n_inst; ++i) macs[i].digest(hashes + 16 * i);
   return GSV_OK;
 }
+// The evaluator's side of the safe-schedule fallback (engine_drain.ipp, fall_back_to_safe_schedule): a pass that ended with a dependency wait
+// giving up switches the session to one call per launch; a source that can be read again from the start (gc files) is then evaluated
+// again at once, any other source gets the error with the remedy (its records have been consumed) and the host's repeat succeeds.
+static int evaluate_streaming_impl(gsv_session* s, uint64_t gate_id_base, const std::function<int(size_t, uint64_t, uint8_t*, uint64_t)>& read, uint8_t* hashes, bool rereadable = false) {
+  int rc = evaluate_streaming_pass(s, gate_id_base, read, hashes);
+  if (rc != GSV_ERR_DEVICE || !s->plan || !s->dep_fault || s->safe_mode) return rc;
+  const std::string first_error = g_err;
+  if (fall_back_to_safe_schedule(s)) return fail(GSV_ERR_DEVICE, first_error + "; the fall-back to the safe schedule failed too: " + g_err);
+  if (!rereadable) return fail(GSV_ERR_DEVICE, first_error + "; the session now runs the safe schedule (one call per launch): repeat the pass from gsv_session_set_evaluate_inputs");
+  if (getenv("GSV_DRAIN_DEBUG") || getenv("GSV_PLAN_DEBUG")) std::fprintf(stderr, "plan session: %s -- repeating the evaluation on the safe schedule (one call per launch)\n", first_error.c_str());
+  return evaluate_streaming_pass(s, gate_id_base, read, hashes);
+}
 // FileSource: instance i reads <dir>/gc_<indexes[i]>.bin (indexes == NULL: first_index + i)
 static int evaluate_from_files(gsv_session* s, uint64_t gate_id_base, const char* dir, const uint64_t* indexes, uint64_t first_index, uint8_t* hashes) {
   if (!s || !dir) return fail(GSV_ERR_INVALID, "null argument");
@@ -166,7 +178,7 @@ static int evaluate_from_files(gsv_session* s, uint64_t gate_id_base, const char
     if (n && std::fread(dst, 16, n, files[i]) != n) return 1;
     pos[i] += n;
     return 0;
-  }, hashes);
+  }, hashes, /*rereadable=*/true);
 }
 int gsv_session_evaluate_streaming(gsv_session* s, uint64_t gate_id_base, const char* dir, uint64_t first_index, uint8_t* hashes) {
   PassGuard pass_guard;  // destroys requested while this pass runs wait for its end (deferred release)

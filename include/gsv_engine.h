@@ -270,7 +270,9 @@ int gsv_session_create_plan_ex(gsv_engine* e, const gsv_plan* plan, size_t n_ins
  *                         returns its result (gsv_session_fallback_count tells).  A pass that fed a host callback or an evaluator
  *                         session, and a slice of a pass, still fail with GSV_ERR_DEVICE (the host has consumed an invalid prefix;
  *                         gc files are removed) but the session is on the safe schedule afterwards: repeating the pass from
- *                         gsv_session_set_garble_inputs succeeds.  gsv_session_garble / _evaluate (asynchronous, whole stream
+ *                         gsv_session_set_garble_inputs succeeds.  The streaming evaluator likewise: a pass over gc files is repeated
+ *                         by the engine, a pass over a host source fails once and succeeds when repeated from
+ *                         gsv_session_set_evaluate_inputs.  gsv_session_garble / _evaluate (asynchronous, whole stream
  *                         retained) report the flag at the next gsv_session_sync / read_outputs as before.
  *                         max_concurrent_calls = 1 keeps every call dependent on its predecessor only.
  *   window_ct_records     ciphertext records per instance of one window = ONE launch = the device block of a session that does not

@@ -989,7 +989,43 @@ def test_forced_dependency_fault_falls_back_to_the_safe_schedule(engine, tmp_pat
     assert sess.fallback_count() == 1
     sess.set_garble_inputs(delta, consts, inputs)
     assert sess.garble_to_sink(lambda *a: None, with_hashes=True) == [r.ct_hash.tobytes() for r in refs]
-    sess.close(); plan.close()
+    sess.close()
+    # the evaluator: from the gc files the engine repeats the pass by itself, from a host source the host does
+    bits = np.random.default_rng(3).integers(0, 2, size=(B, n_in)).astype(np.uint8)
+    active = np.where(bits[:, :, None] == 1, inputs ^ delta[:, None, :], inputs)
+    ca = np.stack([consts[:, 0], consts[:, 1] ^ delta], axis=1)
+
+    def check_eval(es, fh):
+        oa, ob = es.read_outputs(with_bits=True)
+        for i in range(B):
+            eb, _, _ = o.execute("fq12_mix", bits[i])
+            assert fh[i] == refs[i].ct_hash.tobytes() and (ob[i] == eb).all()
+            assert (oa[i] == np.where(ob[i][:, None] == 1, refs[i].output_label0 ^ delta[i][None, :], refs[i].output_label0)).all()
+
+    es = gsv.Session(engine, plan, B, retain_stream=False, concurrent_calls=16)
+    es.set_evaluate_inputs(ca, active, bits)
+    check_eval(es, es.evaluate_streaming(gc, first_index=40))
+    assert es.fallback_count() == 1
+    es.close()
+    es = gsv.Session(engine, plan, B, retain_stream=False, concurrent_calls=16)
+    es.set_evaluate_inputs(ca, active, bits)
+    src = lambda inst, first, n: refs[inst].ciphertexts[first:first + n]  # noqa: E731
+    with pytest.raises(gsv.GsvError, match="safe schedule"):
+        es.evaluate_from_source(src)
+    es.set_evaluate_inputs(ca, active, bits)
+    check_eval(es, es.evaluate_from_source(src))
+    es.close()
+    # a garble || evaluate pair: both sessions are switched, the host repeats the pair
+    kw = dict(retain_stream=False, concurrent_calls=16, window_ct_records=4_000_000)
+    gs, es = gsv.Session(engine, plan, B, **kw), gsv.Session(engine, plan, B, **kw)
+    gs.set_garble_inputs(delta, consts, inputs); es.set_evaluate_inputs(ca, active, bits)
+    with pytest.raises(gsv.GsvError, match="safe schedule"):
+        gs.garble_evaluate(es, with_hashes=True)
+    assert gs.fallback_count() == 1 and es.fallback_count() == 1
+    gs.set_garble_inputs(delta, consts, inputs); es.set_evaluate_inputs(ca, active, bits)
+    check_eval(es, gs.garble_evaluate(es, with_hashes=True))
+    gs.close(); es.close()
+    plan.close()
 
 
 def test_garble_and_evaluate_side_by_side_on_the_device(engine):
