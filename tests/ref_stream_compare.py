@@ -106,8 +106,13 @@ def _circuits():
     }
 
 
+def _lookup(name):
+    ext = _circuits()
+    return ext[name] if name in ext else R.CIRCUITS[name]
+
+
 def restated_stream(name):
-    n_in, fn = _circuits()[name]
+    n_in, fn = _lookup(name)
     c = ArrayCtx(n_in)
     outs = _flat(fn(c, list(c.inputs)))
     t, a, b, cc, calls = c.arrays()
@@ -118,7 +123,7 @@ def product_stream(name, cap):
     """The product recorder's trace of the named circuit (tests/hostsim: RecordMode under the two-pass driver), canonical form."""
     import ctypes as C
     import hostsim_lib as h
-    n_in = _circuits()[name][0]
+    n_in = _lookup(name)[0]
     t = np.zeros(cap, np.uint8)
     a, b, c = (np.zeros(cap, np.uint32) for _ in range(3))
     n, nw = C.c_uint64(), C.c_uint32()
