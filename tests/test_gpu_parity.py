@@ -955,7 +955,7 @@ def test_forced_dependency_fault_falls_back_to_the_safe_schedule(engine, tmp_pat
     remedy, and the host's repeat succeeds on the safe schedule."""
     import garbled_snark_verifier_amd as gsv
     monkeypatch.setenv("GSV_FAULT_WITHHOLD_DEP", "1")
-    monkeypatch.setenv("GSV_DEP_WAIT_SECONDS", "2")
+    monkeypatch.setenv("GSV_DEP_WAIT_SECONDS", "0.5")  # (progress based: no call of the instance group completed for that long; fq12_mix's calls take milliseconds)
     plan = gsv.Plan.from_circuit("fq12_mix", FINE_UNITS)
     seeds = [201, 202]
     B, n_in = len(seeds), plan.info["n_inputs"]
