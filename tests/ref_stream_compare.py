@@ -89,6 +89,68 @@ def _fq12(ws): return [[_fq2(ws, 3 * h + k) for k in range(3)] for h in range(2)
 def _flat(x): return [x] if isinstance(x, int) else [w for y in x for w in _flat(y)]
 
 
+# ---- g1.rs:309-368 scalar_mul_by_constant_base_montgomery with its REAL constant tables: the table entries are arkworks' Jacobian coordinates
+# after `p += base` / `b + b` (ark-ec 0.5.0, Cargo.lock:145-147, short Weierstrass `Projective`), so the restatement needs arkworks' formulas.
+# They are restated here from the published algorithms arkworks implements (EFD "add-2007-bl" and, for a = 0, "dbl-2009-l") with arkworks'
+# special cases (zero = (1, 1, 0); adding to zero copies the other operand; adding a point to itself doubles) — not from csrc/gadgets.
+def _jac_double(p):
+    P_ = R.P
+    x, y, z = p
+    if z == 0:
+        return p
+    a = x * x % P_; b = y * y % P_; c = b * b % P_
+    d = 2 * ((x + b) * (x + b) - a - c) % P_
+    e = 3 * a % P_; f = e * e % P_
+    x3 = (f - 2 * d) % P_
+    return (x3, (e * (d - x3) - 8 * c) % P_, 2 * y * z % P_)
+
+
+def _jac_add(p, q):
+    P_ = R.P
+    if p[2] == 0:
+        return q
+    if q[2] == 0:
+        return p
+    x1, y1, z1 = p; x2, y2, z2 = q
+    z1z1 = z1 * z1 % P_; z2z2 = z2 * z2 % P_
+    u1 = x1 * z2z2 % P_; u2 = x2 * z1z1 % P_
+    s1 = y1 * z2 * z2z2 % P_; s2 = y2 * z1 * z1z1 % P_
+    if u1 == u2 and s1 == s2:
+        return _jac_double(p)
+    h = (u2 - u1) % P_; i = 4 * h * h % P_; j = -h * i % P_
+    r = 2 * (s2 - s1) % P_; v = u1 * i % P_
+    x3 = (r * r + j - 2 * v) % P_
+    return (x3, (r * (v - x3) + 2 * s1 * j) % P_, 2 * z1 * z2 * h % P_)
+
+
+def g1_scalar_mul_const_base(c, s, base_affine, W):  # g1.rs:309-368 (#[component(offcircuit_args = "base")])
+    mont = lambda v: v * R.R_MOD_P % R.P  # noqa: E731 - G1Projective::as_montgomery: every coordinate times R
+    c._call(s)
+    n = 1 << W
+    base = (base_affine[0], base_affine[1], 1)
+    bases, p = [], (1, 1, 0)  # ark_bn254::G1Projective::default() = zero
+    for _ in range(n):
+        bases.append(p)
+        p = _jac_add(p, base)
+    to_add, index = [], 0
+    while index < R.N_BITS:
+        w = min(W, R.N_BITS - index)
+        sel = s[index:index + w]
+        table = [[R.const_wires(mont(q[k])) for q in bases[:1 << w]] for k in range(3)]
+        to_add.append([R.bigint_multiplexer(c, table[k], sel) for k in range(3)])  # g1::multiplexer: x, y, z (g1.rs:276-306)
+        index += W
+        nb = []
+        for q in bases:
+            for _ in range(w):
+                q = _jac_add(q, q)
+            nb.append(q)
+        bases = nb
+    acc = to_add[0]
+    for a in to_add[1:]:
+        acc = R.g1_add(c, acc, a)
+    return acc
+
+
 def _circuits():
     import ref_verifier_count as V  # (wraps ref_gadgets' functions with a memo that is a pass-through for any context but its own CountCtx)
     p2a = getattr(V.projective_to_affine, "__wrapped__", V.projective_to_affine)
@@ -101,6 +163,7 @@ def _circuits():
         "fq12_conjugate": (3048, lambda c, i: V.fq12_conjugate(c, _fq12(i))),                             # fq12.rs:444-447
         "g2_mul_by_char": (1524, lambda c, i: V.mul_by_char(c, [_fq2(i, 0), _fq2(i, 1), _fq2(i, 2)])),    # pairing.rs:475-501
         "g1_to_affine": (762, lambda c, i: p2a(c, [_fq(i, 0), _fq(i, 1), _fq(i, 2)])),                    # groth16.rs:26-48
+        "g1_scalar_mul:10": (254, lambda c, i: g1_scalar_mul_const_base(c, i, (1, 2), 10)),                # g1.rs:309-368 with the generator as base: the MSM's window tables, 225 M gates
         "fq_sqrt": (254, lambda c, i: V.fq_sqrt(c, i)),                                                   # fq.rs:290-299 -> fp254impl.rs:691-725, 149 M gates
         "fq2_sqrt": (508, lambda c, i: V.fq2_sqrt_general(c, _fq2(i, 0))),                                # fq2.rs:425-446, 471 M gates
     }

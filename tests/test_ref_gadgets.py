@@ -80,7 +80,7 @@ def test_numpy_stream_comparison_agrees_with_the_tuple_form():
 
 
 MID = [("fq12_conjugate", 1 << 20), ("fq12_frobenius:1", 1 << 24), ("fq12_frobenius:2", 1 << 24), ("fq12_frobenius:3", 1 << 24), ("g2_mul_by_char", 1 << 23)]
-BIG = [("fq2_inverse", 1 << 25), ("g1_to_affine", 1 << 25), ("fq12_inverse", 1 << 26), ("fq_sqrt", 160_000_000), ("fq2_sqrt", 500_000_000)]
+BIG = [("fq2_inverse", 1 << 25), ("g1_to_affine", 1 << 25), ("fq12_inverse", 1 << 26), ("fq_sqrt", 160_000_000), ("fq2_sqrt", 500_000_000), ("g1_scalar_mul:10", 240_000_000)]
 
 
 @pytest.mark.slow
