@@ -89,8 +89,10 @@ def test_building_blocks_above_fq6_gate_by_gate(spec, cap):
     """Frobenius maps (fq12.rs:430-442 over fq6.rs:489-515 / fq2.rs:374-384, with the `mul_by_constant` shortcuts for coefficients 0 and R),
     conjugation, `mul_by_char` (pairing.rs:475-501), the tower inversions (fq2.rs:356-372, fq6.rs:450-487, fq12.rs:413-428 over the binary
     extended Euclid of fp254impl.rs:333-690), projective -> affine (groth16.rs:26-48), the square-root ladder (fq.rs:290-299 over
-    fp254impl.rs:691-725: 251 squarings + 108 multiplications) and `Fq2::sqrt_general` (fq2.rs:425-446: norm, three exponentiations, one
-    inversion, `is_qnr`, select): product recorder trace == independent Python restatement, gate for gate, derived deadness included.
+    fp254impl.rs:691-725: 251 squarings + 108 multiplications), `Fq2::sqrt_general` (fq2.rs:425-446: norm, three exponentiations, one
+    inversion, `is_qnr`, select) and the MSM's window `scalar_mul_by_constant_base::<10>` (g1.rs:309-368) with its real table constants
+    (arkworks' Jacobian coordinates, restated from the published formulas in ref_stream_compare.py): product recorder trace == independent
+    Python restatement, gate for gate, derived deadness included.
     This round's log: profiles/r06_parity/ref_gadgets_above_fq6.log."""
     n, n_dead = _compare_streams(spec, cap)
     print("%s: %d gates (%d dead) identical" % (spec, n, n_dead))
