@@ -21,7 +21,7 @@ def pytest_collection_modifyitems(config, items):
     import os
     if "slow" in (config.getoption("-m") or "") or os.environ.get("GSV_SLOW_TESTS") == "1":
         return
-    skip = pytest.mark.skip(reason="slow: run with `-m slow` / `-m 'gpu and slow'` (or GSV_SLOW_TESTS=1); the last round.s log: profiles/r06_parity/slow_set.log")
+    skip = pytest.mark.skip(reason="slow: run with `-m slow` / `-m 'gpu and slow'` (or GSV_SLOW_TESTS=1); the last round's log: profiles/r06_parity/slow_set.log")
     for item in items:
         if "slow" in item.keywords:
             item.add_marker(skip)
