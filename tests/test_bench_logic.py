@@ -244,3 +244,14 @@ def test_dry_run_prints_the_per_rank_budget():
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["instances_total"] == 8192 and j["per_rank"]["device_memory_gb"] < 288 and j["expected"]["value_gates_per_s"] > 8e11
     assert set(j["expected"]["host_bound_from_n_gpus"]) == {"aes-ni, 4 chains", "vaes, 16 chains"}
+
+
+def test_bench_reexports_its_support_module():
+    """bench.py keeps the driver's contract (the workloads, `main`); what they share lives in bench_support.py and stays reachable as
+    `bench.<name>` (tools/ and the tests use it that way)."""
+    import bench
+    import bench_support
+    for name in ("plan_slices", "session_slices", "instance_seeds", "Dist", "timed_steps", "VerifierWork", "get_plan", "mac_threads_for_rank", "dry_run", "cpu_baseline",
+                 "VERIFIER_UNITS", "SMALL_BATCH_UNITS", "FIXTURE", "garble_then_evaluate", "cc16_one_gpu", "measure_aes_ceiling", "_plan_cache_path", "T_START"):
+        assert getattr(bench, name) is getattr(bench_support, name), name
+    assert all(hasattr(bench, f) for f in ("run_verifier", "run_cc16", "run_synthetic", "main"))
